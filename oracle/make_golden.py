@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE ONLY -- generate ``tests/golden/*.npz`` by running the REAL
+reference (``/root/reference/masr``, imported unmodified through ``oracle/shims``)
+on CPU.  Run in the build container:  ``python -m oracle.make_golden``.
+
+Fixtures (all inputs are either stored or re-derivable from seeds):
+* ``testwav.npz``      int16 PCM of the reference's only fixture ``dataset/test.wav``
+                       + reference ``AudioFeaturizer.featurize`` output (fbank itself comes
+                       from the oracle restatement: torchaudio is absent -> unpinned).
+* ``conformer_v512.npz``  reference ConformerModel (configs/conformer.yml, streaming=True,
+                       synthetic weights seed 0, V=512): get_encoder_out probs, encoder output,
+                       chunk-16 masked encoder output, and a 5-step get_encoder_out_chunk run.
+* ``conformer_v4233.npz`` same model family at V=4233: per-frame top-4 (index, prob).
+* ``predictor.npz``    reference MASRPredictor(use_gpu=False) on TorchScript export of the
+                       synthetic model: predict(test.wav) and every predict_stream partial.
+* ``greedy.npz``       reference greedy_decoder / greedy_decoder_chunk outputs on seeded probs.
+"""
+import json
+import os
+import tempfile
+import wave
+
+import numpy as np
+import torch
+import yaml
+
+from oracle import shims, weights
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+REF = shims.REFERENCE_ROOT
+
+
+def build_reference_conformer(sd, vocab_size, tmp):
+    from masr.model_utils.conformer.model import ConformerModel
+    cfg = yaml.safe_load(open(os.path.join(REF, 'configs', 'conformer.yml'), encoding='utf-8'))
+    p = os.path.join(tmp, 'mean_istd.json')
+    json.dump({'mean': sd['encoder.global_cmvn.mean'].tolist(), 'istd': sd['encoder.global_cmvn.istd'].tolist(),
+               'feature_method': 'fbank'}, open(p, 'w'))
+    torch.manual_seed(0)
+    m = ConformerModel(input_dim=80, vocab_size=vocab_size, mean_istd_path=p, streaming=True,
+                       encoder_conf=cfg['encoder_conf'], decoder_conf=cfg['decoder_conf'], **cfg['model_conf'])
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith('decoder.') for k in missing)
+    return m.eval(), cfg, p
+
+
+def golden_inputs():
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn(3, 331, 80, generator=g) * 3 + 13
+    lens = torch.tensor([331, 200, 97])
+    feats = feats * (torch.arange(331)[None, :, None] < lens[:, None, None])   # collate_fn zero padding
+    return feats, lens
+
+
+def main():
+    shims.install()
+    os.makedirs(OUT, exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    torch.set_grad_enabled(False)
+
+    # ---- test.wav ---------------------------------------------------------
+    w = wave.open(os.path.join(REF, 'dataset', 'test.wav'))
+    pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16).copy()
+    from masr.data_utils.audio import AudioSegment
+    from masr.data_utils.featurizer.audio_featurizer import AudioFeaturizer
+    seg = AudioSegment.from_ndarray(pcm, 16000)
+    feat = AudioFeaturizer(feature_method='fbank', n_mels=80, sample_rate=16000, use_dB_normalization=True,
+                           target_dB=-20).featurize(seg)
+    i16 = seg.to('int16')
+    np.savez_compressed(os.path.join(OUT, 'testwav.npz'), pcm=pcm, norm_i16=i16, fbank=feat.astype(np.float32))
+
+    # ---- conformer V=512 ----------------------------------------------------
+    feats, lens = golden_inputs()
+    sd = weights.conformer_state_dict(0, 512)
+    m, cfg, _ = build_reference_conformer(sd, 512, tmp)
+    probs = m.get_encoder_out(feats, lens)
+    enc, _ = m.encoder(feats, lens, -1, -1)
+    enc16, _ = m.encoder(feats, lens, 16, -1)
+    att = torch.zeros(0, 0, 0, 0)
+    cnn = torch.zeros(0, 0, 0, 0)
+    off = 0
+    chunk_probs = []
+    for cur in range(0, 331 - 67 + 1, 64):
+        r, att, cnn = m.get_encoder_out_chunk(feats[:1, cur:cur + 67], off, -16, att, cnn)
+        off += r.shape[1]
+        chunk_probs.append(r[0].numpy())
+    np.savez_compressed(os.path.join(OUT, 'conformer_v512.npz'), probs=probs.numpy(), enc=enc.numpy(),
+                        enc16=enc16.numpy(), chunk_probs=np.stack(chunk_probs), att_tail=att[:, :, -16:].numpy(),
+                        att_shape=np.array(att.shape), cnn=cnn.numpy())
+
+    # ---- conformer V=4233: top-4 ---------------------------------------------
+    sd = weights.conformer_state_dict(0, 4233)
+    m, cfg, mean_istd = build_reference_conformer(sd, 4233, tmp)
+    probs = m.get_encoder_out(feats, lens)
+    top = torch.topk(probs, 4, dim=-1)
+    np.savez_compressed(os.path.join(OUT, 'conformer_v4233.npz'), top_p=top.values.numpy(),
+                        top_i=top.indices.numpy().astype(np.int32))
+
+    # ---- MASRPredictor facade on the TorchScript export ---------------------------
+    from masr.predict import MASRPredictor
+    vocab = weights.synthetic_vocab(4233)
+    vpath = os.path.join(tmp, 'vocabulary.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in vocab:
+            f.write(f'{t}\t1\n')
+    mdir = os.path.join(tmp, 'models', 'conformer_streaming_fbank')
+    os.makedirs(mdir)
+    torch.jit.save(m.export(), os.path.join(mdir, 'inference.pt'))
+    cfg['dataset_conf']['dataset_vocab'] = vpath
+    cfg['dataset_conf']['mean_istd_path'] = mean_istd
+    cfg['decoder'] = 'ctc_greedy'
+    pred = MASRPredictor(configs=cfg, model_path=os.path.join(mdir, 'inference.pt'), use_gpu=False)
+    off_res = pred.predict(audio_data=pcm.copy())
+    texts, scores, valid = [], [], []
+    n = len(pcm)
+    step = 8000
+    for s in range(0, n, step):
+        chunk = pcm[s:s + step].tobytes()
+        r = pred.predict_stream(audio_data=chunk, is_end=(s + step >= n))
+        valid.append(r is not None and r['text'] is not None)
+        texts.append('' if not valid[-1] else r['text'])
+        scores.append(0.0 if not valid[-1] else float(r['score']))
+    pred.reset_stream()
+    np.savez_compressed(os.path.join(OUT, 'predictor.npz'), offline_text=np.array(off_res['text']),
+                        offline_score=np.array(off_res['score'], np.float64), stream_text=np.array(texts),
+                        stream_score=np.array(scores, np.float64), stream_valid=np.array(valid))
+
+    # ---- greedy decoders --------------------------------------------------------
+    from masr.decoders.ctc_greedy_decoder import greedy_decoder, greedy_decoder_chunk
+    rng = np.random.default_rng(7)
+    v6 = ['<blank>', '<unk>', 'a', 'b', '<space>', '<eos>']
+    p = rng.dirichlet(np.ones(6) * 0.3, size=40).astype(np.float32)
+    s, t = greedy_decoder(p, v6)
+    a = b = None
+    cs, ct = [], []
+    for k in range(0, 40, 8):
+        sc, tx, a, b = greedy_decoder_chunk(p[k:k + 8], v6, a, b)
+        cs.append(sc)
+        ct.append(tx)
+    np.savez_compressed(os.path.join(OUT, 'greedy.npz'), probs=p, score=np.array(s, np.float64), text=np.array(t),
+                        chunk_scores=np.array(cs, np.float64), chunk_texts=np.array(ct))
+    print('golden fixtures written to', OUT)
+    for f in sorted(os.listdir(OUT)):
+        print(' ', f, os.path.getsize(os.path.join(OUT, f)))
+    print('offline:', off_res, 'stream:', texts[-1], scores[-1])
+
+
+if __name__ == '__main__':
+    main()
