@@ -1,0 +1,159 @@
+"""bench.py -- audio-seconds/sec of the offline hot path (BASELINE config 2) on N MI355X GPUs.
+
+A "step" is one pass of PCM -> fbank -> Conformer encoder -> CTC greedy over one batch of
+32 x 10 s synthetic 16 kHz utterances per GPU, inputs resident in HBM (weak scaling: every rank
+owns its own batch; for N > 1 the hypotheses are all-gathered over RCCL inside the step).
+Prints ONE JSON line on rank 0 (contract in the task statement; extra keys: roofline, cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 32
+N_SAMPLES = 160000          # 10 s @ 16 kHz
+VOCAB = 4233
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return min(n, 64)
+
+
+def cpu_baseline(sample_utts=4, reps=2):
+    """The CPU oracle (restatement of the reference's PyTorch CPU path, pinned bit-identical to the
+    reference modules) timed on this host: featurize + get_encoder_out + greedy on a bounded sample."""
+    from masr_amd.utils import synthetic
+    from oracle import conformer as oc, decoders as od, fbank as ofb
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f'cpu_baseline: {cores} threads')
+    sd = synthetic.conformer_state_dict(0, VOCAB)
+    vocab = synthetic.synthetic_vocab(VOCAB)
+    pcm = synthetic.synthetic_pcm(sample_utts, N_SAMPLES, seed=1234)
+    times = []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        feats = np.stack([ofb.featurize_pcm16(pcm[i])[0] for i in range(sample_utts)])
+        with torch.no_grad():
+            probs = oc.get_encoder_out(sd, torch.from_numpy(feats), torch.full((sample_utts,), feats.shape[1])).numpy()
+        od.greedy_decoder_batch(list(probs), vocab)
+        dt = time.perf_counter() - t0
+        log(f'cpu_baseline rep {r}: {dt:.2f} s for {sample_utts} x 10 s')
+        if r > 0:
+            times.append(dt)
+        if dt > 60 and r >= 1:
+            break
+    med = float(np.median(times))
+    return {'value': sample_utts * 10.0 / med, 'unit': 'audio-seconds/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{sample_utts} x 10 s utterances (batched get_encoder_out path, trainer.py:632), '
+                      f'median of {reps}, torch threads={cores}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-kind', type=int, default=2, help='kernel class timed with HIP events (2 = FFN W1 GEMM)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))   # RCCL
+    n_gpus = world if world > 1 else 1
+
+    from masr_amd.engine import HipEngine, subsampled_len
+    from masr_amd.utils import synthetic
+    sd = synthetic.conformer_state_dict(0, VOCAB)
+    eng = HipEngine(sd, vocab_size=VOCAB, device=local)
+    pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234 + rank)).cuda()
+    n = torch.full((BATCH,), N_SAMPLES, dtype=torch.int32, device='cuda')
+    Tp = subsampled_len(1 + (N_SAMPLES - 400) // 160)
+    out = (torch.empty(BATCH, Tp, dtype=torch.int32, device='cuda'), torch.empty(BATCH, dtype=torch.int32, device='cuda'),
+           torch.empty(BATCH, dtype=torch.float32, device='cuda'))
+    gathered = torch.empty(world * BATCH, Tp, dtype=torch.int32, device='cuda') if world > 1 else None
+
+    def step():
+        eng.transcribe_batch(pcm, n, out=out)
+        if world > 1:   # the only exchange step: hypotheses (token ids, -1 padded), ~32 KB per rank
+            dist.all_gather_into_tensor(gathered, out[0])
+
+    log(f'rank {rank}: engine ready, warmup {args.warmup}')
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    eng.profile_select(args.profile_kind)
+    eng.profile_read(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    log(f'rank {rank}: timed region done: {dt * 1e3 / args.steps:.2f} ms/step')
+    prof_ms, prof_n, prof_flops = eng.profile_read(reset=True)
+    eng.profile_select(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        audio_s = n_gpus * BATCH * (N_SAMPLES / 16000.0) * args.steps
+        roofline = None
+        if prof_n > 0 and prof_ms > 0:
+            achieved = prof_flops / (prof_ms * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<128,128> (FFN w_1: [B*T\',256]x[256,2048], SiLU epilogue)',
+                        'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                        'launches': int(prof_n), 'avg_us': round(prof_ms * 1e3 / prof_n, 2),
+                        'flops_per_launch': prof_flops / prof_n}
+        res = {'metric': 'audio-seconds/sec (RTF^-1), conformer_streaming_fbank b32x10s, PCM->fbank->encoder->ctc_greedy',
+               'value': round(audio_s / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': n_gpus, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 3), 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'configs[1]: conformer.yml streaming fbank, batch=32 synthetic 16 kHz 10 s '
+                                      'utterances per GPU, ctc_greedy, random-init weights V=4233',
+                          'global_batch': n_gpus * BATCH, 'audio_seconds_per_step': n_gpus * BATCH * 10.0,
+                          'parallelism': f'dp{n_gpus}', 'algorithmic_gflop_per_step_per_gpu': 742.0},
+               'roofline': roofline}
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,142 @@
+/*
+ * libmasr_hip.so -- C ABI of the MI355X (gfx950) MASR inference hot path.
+ *
+ * The reference (yeyupiaoling/MASR) has no FFI of its own: its boundary is three Python call
+ * sites.  This header is the C-ABI a binding for that path would use; the
+ * Python mirror of the reference classes lives in masr_amd/ and calls these functions via ctypes.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; masr_last_error() gives the message
+ *  - all *_dev pointers are DEVICE pointers owned by the caller (e.g. torch tensors); the library
+ *    never frees them, launches on the caller's hipStream_t (passed as void*) and never
+ *    synchronises unless stated
+ *  - host pointers are plain arrays read during the call
+ *  - an engine is bound to one GPU and is not thread-safe (one engine per rank)
+ *  - all arithmetic is fp32 ("f32" MFMA v_mfma_f32_32x32x2_f32), like the reference's CPU path
+ */
+#ifndef MASR_HIP_H
+#define MASR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct masr_engine masr_engine;
+
+/* Model hyper-parameters = the YAML `encoder_conf` block (reference configs/conformer.yml:1-16)
+ * + vocabulary size (masr/trainer.py:174-203 builds the model from exactly these). */
+typedef struct masr_config {
+    int32_t model_kind;      /* 0 = conformer                                                   */
+    int32_t d_model;         /* encoder_conf.output_size        (256)                           */
+    int32_t heads;           /* encoder_conf.attention_heads    (4)                             */
+    int32_t d_ff;            /* encoder_conf.linear_units       (2048)                          */
+    int32_t num_blocks;      /* encoder_conf.num_blocks         (12)                            */
+    int32_t cnn_kernel;      /* encoder_conf.cnn_module_kernel  (15)                            */
+    int32_t n_mels;          /* preprocess_conf.n_mels          (80)                            */
+    int32_t vocab_size;      /* len(vocabulary.txt)                                             */
+    int32_t causal;          /* `streaming: True` => causal conv + dynamic-chunk masks (model.py:37-42) */
+    int32_t max_pos;         /* positional table length (reference max_len = 5000, embedding.py:14)  */
+    int32_t device_id;
+    int32_t reserved[5];
+} masr_config;
+
+const char* masr_last_error(void);
+int masr_version(void);
+
+/* Lifecycle.  Replaces InferencePredictor.__init__'s torch.jit.load + .to(device)
+ * (masr/infer_utils/inference_predictor.py:31-41). */
+int masr_create(const masr_config* cfg, masr_engine** out);
+void masr_destroy(masr_engine* e);
+
+/* Weight upload keyed by the reference state_dict names (produced by
+ * masr/trainer.py:308,684-689).  `host` is fp32, `shape` has `ndim` entries.  Names outside
+ * `encoder.*` / `ctc.*` are ignored (attention decoder, unused by get_encoder_out*).
+ * The optional name "__pos_table__" [max_pos, d_model] overrides the built-in sin/cos table
+ * (conformer/embedding.py:31-37) so that it is bit-identical to torch's. */
+int masr_load_tensor(masr_engine* e, const char* name, const float* host, const int64_t* shape, int32_t ndim);
+/* Builds the derived device tensors (fused QKV, GLU-permuted pointwise_conv1, channels-last conv
+ * weights, per-layer positional keys W_pos*PE) -- call once after all tensors are loaded. */
+int masr_finalize(masr_engine* e, void* stream);
+
+/* Feature front-end.  Replaces AudioFeaturizer.featurize
+ * (masr/data_utils/featurizer/audio_featurizer.py:37-69,120-138) for a padded batch of 16 kHz
+ * audio: per-utterance RMS-dB normalisation + int16 truncation + Kaldi fbank.  Works on an engine
+ * without weights (tables are built by masr_create).
+ *   samples_dev  [B, n_max] int16 PCM (sample_format 0; AudioSegment scales by 1/32768,
+ *                audio.py:532-546) or float32 samples in [-1,1] scale (sample_format 1)
+ *   n_samples_dev [B] int32
+ *   feats_dev    [B, T_max, n_mels] f32, T_max = 1 + (n_max - 400) / 160; frames >= T_b are zero
+ *   n_frames_dev [B] int32 (out, may be NULL)
+ *   norm_pcm_dev [B, n_max] int16 (out, may be NULL): the normalised int16 samples (audio.py:549-574)
+ *   gain_dev     [B] f32 (out, may be NULL): linear gain 10^(gain_dB/20) applied by normalize()
+ *                (audio.py:256-264) -- lets the host mirror the reference's in-place mutation */
+int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev,
+                     int32_t B, int32_t n_max, int32_t use_db_normalization, float target_db, float* feats_dev,
+                     int32_t* n_frames_dev, int16_t* norm_pcm_dev, float* gain_dev, void* stream);
+
+/* Full-context encoder.  Replaces ConformerEncoder.forward called from
+ * ConformerModel.get_encoder_out (masr/model_utils/conformer/model.py:152-167, encoder.py:305-346).
+ *   feats_dev [B, T, n_mels] f32 (zero padded), feat_lens_dev [B] int32 (frames)
+ *   decoding_chunk_size: -1 = full attention (get_encoder_out), >0 = chunk mask (encoder.forward(..., c, -1))
+ *   enc_out_dev [B, T', d_model] f32, T' = ((T-1)/2-1)/2 */
+int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat_lens_dev, int32_t B, int32_t T,
+                     int32_t decoding_chunk_size, float* enc_out_dev, void* stream);
+
+/* CTC head.  Replaces CTCLoss.softmax (masr/model_utils/loss/ctc.py:62-70): probs = softmax(Linear).
+ *   enc_dev [M, d_model] -> probs_dev [M, V] ; optional per-frame argmax / max-prob outputs */
+int masr_ctc_probs(masr_engine* e, const float* enc_dev, int32_t M, float* probs_dev, int32_t* argmax_dev,
+                   float* maxprob_dev, void* stream);
+/* Same head without materialising probs for the caller: per-frame (argmax, max prob) only --
+ * all that greedy_decoder (masr/decoders/ctc_greedy_decoder.py:20-21) reads from probs. */
+int masr_ctc_greedy_frames(masr_engine* e, const float* enc_dev, int32_t M, int32_t* argmax_dev, float* maxprob_dev,
+                           void* stream);
+/* Best-path collapse + score.  Replaces the list logic of greedy_decoder
+ * (ctc_greedy_decoder.py:20-30): tokens_dev [B, Tp] (-1 padded), n_tokens_dev [B],
+ * score_dev [B] = fp32 sequential mean of the non-blank max-probs (caller multiplies by 100).
+ * n_frames_dev [B] (may be NULL = all Tp frames, the reference's batch behaviour trainer.py:340). */
+int masr_ctc_collapse(masr_engine* e, const int32_t* argmax_dev, const float* maxprob_dev, const int32_t* n_frames_dev,
+                      int32_t B, int32_t Tp, int32_t blank, int32_t* tokens_dev, int32_t* n_tokens_dev,
+                      float* score_dev, void* stream);
+/* Stand-alone argmax/max-prob over host-provided probabilities already on the device
+ * (greedy_decoder's np.argmax, ctc_greedy_decoder.py:20). */
+int masr_argmax_rows(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t* argmax_dev,
+                     float* maxprob_dev, void* stream);
+
+/* One call for the whole offline hot path (MASRPredictor.predict semantics, masr/predict.py:167-192,
+ * batched like MASRTrainer.evaluate, trainer.py:632): PCM -> fbank -> encoder -> CTC greedy.
+ * decode_all_frames != 0 reproduces the reference batch quirk of decoding padded frames. */
+int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t* n_samples_dev, int32_t B,
+                          int32_t n_max, int32_t use_db_normalization, float target_db, int32_t decode_all_frames,
+                          int32_t* tokens_dev, int32_t* n_tokens_dev, float* score_dev, void* stream);
+
+/* Streaming.  Replaces InferencePredictor.predict_chunk_conformer / reset_stream
+ * (inference_predictor.py:80-102) -> ConformerEncoder.forward_chunk (encoder.py:348-420) with
+ * required_cache_size < 0 (keep all history, predict.py:312-313).  Stream state (attention KV
+ * cache, conv cache, offset) lives in the engine; `n` streams advance in lock-step per call.
+ *   stream_ids [n] host int32, feats_dev [n, Tc, n_mels] (Tc <= 67), probs_dev [n, Tc', V] */
+int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id);
+int masr_stream_reset(masr_engine* e, int32_t stream_id);
+int masr_stream_close(masr_engine* e, int32_t stream_id);
+int masr_stream_offset(masr_engine* e, int32_t stream_id, int32_t* offset);
+int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, const float* feats_dev, int32_t Tc,
+                      float* probs_dev, int32_t* argmax_dev, float* maxprob_dev, void* stream);
+/* Read back a stream's caches in the reference layout (for parity tests):
+ * att [L, H, t, 2*dk], cnn [L, 1, d, kernel-1] -- device pointers, t = current offset. */
+int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, float* cnn_dev, void* stream);
+
+/* Single kernels, exposed for unit tests and profiling. */
+int masr_op_layernorm(masr_engine* e, const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,
+                      int32_t M, float eps, void* stream);
+int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
+                 float* c_dev, int32_t M, int32_t N, int32_t K, int32_t act, float alpha, void* stream);
+
+/* Profiling: time every launch of one kernel class with HIP events on the launch stream.
+ * kind: 0 none, 1 gemm (all), 2 ffn-w1 gemm, 3 conv2 gemm, 4 attention, 5 fbank.
+ * masr_profile_read synchronises the events and returns total ms / launch count / flops since reset. */
+int masr_profile_select(masr_engine* e, int32_t kind);
+int masr_profile_read(masr_engine* e, double* total_ms, int64_t* launches, double* flops, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

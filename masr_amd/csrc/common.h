@@ -1,0 +1,79 @@
+// Shared declarations for the MI355X (gfx950) MASR inference kernels.
+// Everything here is internal to libmasr_hip.so; the public C ABI is include/masr_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace masr {
+
+// ---- GEMM: C[M,N] = epilogue(A[M,K] * W[N,K]^T) on v_mfma_f32_32x32x2_f32 ----------------
+enum GemmAct { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+enum GemmAMode { A_PLAIN = 0, A_CONV2 = 1 };
+enum GemmEpi { EPI_STD = 0, EPI_GLU = 1 };
+
+struct GemmArgs {
+    const float* A;      // [M, lda] row-major (A_PLAIN) or conv1 activations [B,T1,F1,C] (A_CONV2)
+    const float* W;      // [N, K] row-major (K contiguous) -- torch Linear.weight layout
+    const float* bias;   // [N] or nullptr
+    float* C;            // [M, ldc]
+    const float* R;      // residual [M, ldr] or nullptr (may alias C)
+    const int* lens;     // optional per-sequence feature lengths for row masking (see mask_tp)
+    int M, N, K;
+    int lda, ldc, ldr;
+    int act;             // GemmAct (EPI_STD only)
+    float alpha;         // out = R + alpha * act(acc + bias)
+    int mask_tp;         // >0: row r -> (b = r / mask_tp, t = r % mask_tp); rows with 4*t >= lens[b] give act(..)=0
+    // A_CONV2 geometry: row m -> (b, t2, f2) with m = (b*T2 + t2)*F2 + f2 ; k -> (kh, kw*C + c)
+    int T1, F1, T2, F2, Cc;
+};
+
+void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s);
+
+// ---- elementwise / reductions ------------------------------------------------------------
+// LayerNorm over rows of width 256.  If seq_t > 0 the output row is remapped to
+// b*(seq_t+pad)+pad+t (conv-module padded layout) and rows with 4*t >= lens[b] are zeroed.
+void launch_layernorm(const float* x, const float* w, const float* b, float* y, int M, float eps,
+                      int seq_t, int pad, const int* lens, hipStream_t s);
+// CMVN + Conv2d(1->C,3x3,s2) + ReLU, output channels-last [B,T1,F1,C]
+void launch_conv1(const float* feats, const float* mean, const float* istd, const float* w9c, const float* bias,
+                  float* out, int B, int T, int F, int C, hipStream_t s);
+// depthwise causal conv (k taps) + LayerNorm(C=256) + SiLU on padded layout [nseq, pad+Tq, 256] -> [nseq*Tq, 256]
+void launch_dwconv_ln_silu(const float* g, const float* wkc, const float* bias, const float* lnw, const float* lnb,
+                           float* out, int nseq, int Tq, int ktaps, float eps, hipStream_t s);
+// softmax over V per row (in place) + argmax / max prob
+void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs, int* idx, float* maxp, hipStream_t s);
+// CTC collapse per utterance
+void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank,
+                         int* tokens, int* ntok, float* score, hipStream_t s);
+void launch_argmax_rows(const float* probs, int M, int V, int* idx, float* maxp, hipStream_t s);
+void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, hipStream_t s);
+void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s);
+void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hipStream_t s);
+
+// ---- attention ---------------------------------------------------------------------------
+struct AttSeq {            // one per sequence, device memory
+    const float* q;        // first query row of this sequence (row stride q_stride)
+    const float* k;        // first key row   (row stride kv_stride)
+    const float* v;        // first value row (row stride kv_stride)
+    float* out;            // first output row (row stride 256)
+    int nq, nk;            // number of query rows / key rows
+    int klen;              // keys j >= klen are masked (padding)
+    int pos0;              // positional index of key 0
+    int q_abs0;            // absolute index of query 0 (for the chunk mask)
+    int pad_;
+};
+void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q_stride, int kv_stride,
+                      const float* ptab /*[max_pos,256]*/, const float* bias_u, const float* bias_v,
+                      int chunk_size, hipStream_t s);
+void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, hipStream_t s);
+
+// ---- features ------------------------------------------------------------------------------
+void launch_fbank(const void* pcm, int sample_format /*0 int16, 1 float32*/, const int* nsamp, int B, int n_max,
+                  int use_db, float target_db, const float* window, const float* melw, const int* mel_lo,
+                  const int* mel_hi, const float* tw256, const float* tw512, float* feats, int T_max,
+                  float* gain_scratch, int16_t* norm_out, hipStream_t s);
+
+}  // namespace masr

@@ -1,0 +1,348 @@
+// HBM-bound kernels of the Conformer path: LayerNorm, CMVN+conv1, depthwise-conv+LN+SiLU,
+// CTC softmax/argmax and CTC collapse.  All are written for wave64 and 16-byte coalesced access.
+#include "common.h"
+
+namespace masr {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm(256), eps inside sqrt (torch.nn.LayerNorm; reference conformer/encoder.py:63-72).
+// One wave per row, float4 per lane, two-pass variance in registers.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* y, int M, float eps,
+                                                           int seq_t, int pad, const int* __restrict__ lens) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    size_t orow = row;
+    bool zero = false;
+    if (seq_t > 0) {
+        const int bb = row / seq_t, t = row - bb * seq_t;
+        orow = (size_t)bb * (seq_t + pad) + pad + t;
+        if (lens && 4 * t >= lens[bb]) zero = true;
+    }
+    f32x4 o;
+    if (zero) {
+        o = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * 256 + lane * 4);
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+        const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + lane * 4);
+        o[0] = d0 * rstd * ww[0] + bb[0];
+        o[1] = d1 * rstd * ww[1] + bb[1];
+        o[2] = d2 * rstd * ww[2] + bb[2];
+        o[3] = d3 * rstd * ww[3] + bb[3];
+    }
+    *reinterpret_cast<f32x4*>(y + orow * 256 + lane * 4) = o;
+}
+
+void launch_layernorm(const float* x, const float* w, const float* b, float* y, int M, float eps, int seq_t, int pad,
+                      const int* lens, hipStream_t s) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(layernorm256_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, y, M, eps, seq_t, pad, lens);
+}
+
+// ------------------------------------------------------------------------------------------
+// GlobalCMVN (utils/cmvn.py:21-32) + Conv2d(1->256, 3x3, stride 2) + ReLU
+// (conformer/subsampling.py:86-87).  One workgroup per (b, t1) output row, thread = out channel;
+// the 3 x F input rows are normalised once into LDS and broadcast-read.
+// Output is channels-last [B, T1, F1, C] so that the conv2 implicit GEMM reads contiguous K.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ feats, const float* __restrict__ mean,
+                                                    const float* __restrict__ istd, const float* __restrict__ w9c,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int T,
+                                                    int F, int T1, int F1, int C) {
+    extern __shared__ float sm[];  // [3][F]
+    const int bt = blockIdx.x;
+    const int b = bt / T1, t1 = bt % T1;
+    for (int i = threadIdx.x; i < 3 * F; i += blockDim.x) {
+        const int kh = i / F, f = i % F;
+        const float v = feats[((size_t)b * T + 2 * t1 + kh) * F + f];
+        sm[i] = (v - mean[f]) * istd[f];
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    float w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = w9c[i * C + c];
+    const float bv = bias[c];
+    float* o = out + ((size_t)bt * F1) * C + c;
+    for (int f1 = 0; f1 < F1; ++f1) {
+        float acc = bv;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc = fmaf(w[kh * 3 + kw], sm[kh * F + 2 * f1 + kw], acc);
+        o[(size_t)f1 * C] = fmaxf(acc, 0.f);
+    }
+}
+
+void launch_conv1(const float* feats, const float* mean, const float* istd, const float* w9c, const float* bias,
+                  float* out, int B, int T, int F, int C, hipStream_t s) {
+    const int T1 = (T - 1) / 2, F1 = (F - 1) / 2;
+    if (B * T1 <= 0) return;
+    hipLaunchKernelGGL(conv1_kernel, dim3(B * T1), dim3(256), 3 * F * sizeof(float), s, feats, mean, istd, w9c, bias,
+                       out, T, F, T1, F1, C);
+}
+
+// ------------------------------------------------------------------------------------------
+// Depthwise causal Conv1d(k taps, groups=C) + LayerNorm(C) + SiLU
+// (conformer/convolution.py:121-126).  Input is the GLU output in the padded layout
+// [nseq, pad + Tq, 256] with pad = k-1 history rows in front of every sequence (zero rows or the
+// streaming cnn cache pushed through pointwise_conv1+GLU, exactly as the reference does by
+// concatenating before pointwise_conv1, convolution.py:101-108).  Output [nseq*Tq, 256].
+// Workgroup = 16 output rows of one sequence; thread = channel for the sliding-window conv,
+// then the tile is transposed through LDS so that each wave normalises whole rows.
+// ------------------------------------------------------------------------------------------
+static constexpr int DW_TT = 16;
+template <int KT>
+__global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const float* __restrict__ g, const float* __restrict__ wkc,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ lnw,
+                                                             const float* __restrict__ lnb, float* __restrict__ out,
+                                                             int Tq, float eps) {
+    __shared__ __align__(16) float tile[DW_TT][256 + 4];
+    const int tiles = (Tq + DW_TT - 1) / DW_TT;
+    const int seq = blockIdx.x / tiles;
+    const int t0 = (blockIdx.x % tiles) * DW_TT;
+    const int c = threadIdx.x;
+    constexpr int pad = KT - 1;
+    // padded row (t0 + j) of this sequence <-> input time t0 + j - pad
+    const float* gin = g + ((size_t)seq * (pad + Tq) + t0) * 256 + c;
+    float w[KT], win[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) w[j] = wkc[j * 256 + c];
+    const float bv = bias[c];
+    const int nrows = min(DW_TT, Tq - t0);
+    win[0] = 0.f;
+#pragma unroll
+    for (int j = 0; j < KT - 1; ++j) win[j + 1] = gin[(size_t)j * 256];
+    for (int r = 0; r < nrows; ++r) {
+#pragma unroll
+        for (int j = 0; j < KT - 1; ++j) win[j] = win[j + 1];
+        win[KT - 1] = gin[(size_t)(pad + r) * 256];
+        float acc = bv;                       // out[t] = b + sum_j w[j] * gpad[t + j]
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc = fmaf(w[j], win[j], acc);
+        tile[r][c] = acc;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(lnw + lane * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
+    for (int r = wave; r < nrows; r += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[r][lane * 4]);
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+        const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        f32x4 o;
+        o[0] = d0 * rstd * ww[0] + bb[0];
+        o[1] = d1 * rstd * ww[1] + bb[1];
+        o[2] = d2 * rstd * ww[2] + bb[2];
+        o[3] = d3 * rstd * ww[3] + bb[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = o[i] / (1.0f + expf(-o[i]));
+        *reinterpret_cast<f32x4*>(out + ((size_t)seq * Tq + t0 + r) * 256 + lane * 4) = o;
+    }
+}
+
+void launch_dwconv_ln_silu(const float* g, const float* wkc, const float* bias, const float* lnw, const float* lnb,
+                           float* out, int nseq, int Tq, int ktaps, float eps, hipStream_t s) {
+    if (nseq * Tq <= 0) return;
+    const int tiles = (Tq + DW_TT - 1) / DW_TT;
+    const dim3 grid(nseq * tiles), blk(256);
+    if (ktaps == 15) hipLaunchKernelGGL(dwconv_ln_silu_kernel<15>, grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
+    else if (ktaps == 7) hipLaunchKernelGGL(dwconv_ln_silu_kernel<7>, grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
+    else if (ktaps == 31) hipLaunchKernelGGL(dwconv_ln_silu_kernel<31>, grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
+}
+
+// ------------------------------------------------------------------------------------------
+// CTC head tail: softmax over V (loss/ctc.py:62-70) + per-frame argmax / max prob
+// (ctc_greedy_decoder.py:20-21).  One workgroup per frame; the row lives in registers.
+// argmax is taken on the logits with first-index tie breaking (numpy argmax semantics).
+// ------------------------------------------------------------------------------------------
+static constexpr int SM_MAXPT = 32;  // supports V <= 8192
+__global__ __launch_bounds__(256) void softmax_argmax_kernel(float* logits, int V, int ldv, int write_probs,
+                                                             int* __restrict__ idx, float* __restrict__ maxp) {
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    __shared__ float red_s[4];
+    const int row = blockIdx.x;
+    float* x = logits + (size_t)row * ldv;
+    float v[SM_MAXPT];
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < SM_MAXPT; ++i) {
+        const int j = threadIdx.x + i * 256;
+        v[i] = j < V ? x[j] : -INFINITY;
+        if (v[i] > m) { m = v[i]; mi = j; }
+    }
+    // block argmax (value desc, index asc)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red_v[wave] = m; red_i[wave] = mi; }
+    __syncthreads();
+    m = red_v[0]; mi = red_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (red_v[w] > m || (red_v[w] == m && red_i[w] < mi)) { m = red_v[w]; mi = red_i[w]; }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXPT; ++i) {
+        v[i] = expf(v[i] - m);   // exp(-inf) = 0 for the tail
+        sum += v[i];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red_s[wave] = sum;
+    __syncthreads();
+    sum = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+    const float inv = 1.0f / sum;
+    if (write_probs) {
+#pragma unroll
+        for (int i = 0; i < SM_MAXPT; ++i) {
+            const int j = threadIdx.x + i * 256;
+            if (j < V) x[j] = v[i] / sum;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (idx) idx[row] = mi;
+        if (maxp) maxp[row] = inv;   // exp(0) / sum
+    }
+}
+
+void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs, int* idx, float* maxp,
+                           hipStream_t s) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(M), dim3(256), 0, s, logits, V, ldv, write_probs, idx, maxp);
+}
+
+// ------------------------------------------------------------------------------------------
+// CTC best-path collapse (ctc_greedy_decoder.py:20-30): drop repeats, drop blanks; the score is
+// the SEQUENTIAL fp32 sum (python sum over np.float32) of the max-probs of all non-blank frames,
+// divided by their count.  T' <= ~1250, one lane per utterance is plenty.
+// ------------------------------------------------------------------------------------------
+__global__ void ctc_collapse_kernel(const int* __restrict__ idx, const float* __restrict__ maxp,
+                                    const int* __restrict__ nframes, int B, int Tp, int blank, int* tokens, int* ntok,
+                                    float* score) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = nframes ? min(nframes[b], Tp) : Tp;
+    int prev = -1, cnt = 0, nb = 0;
+    float acc = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const int id = idx[(size_t)b * Tp + t];
+        if (id != blank) {
+            acc = acc + maxp[(size_t)b * Tp + t];
+            ++nb;
+            if (id != prev) tokens[(size_t)b * Tp + cnt++] = id;
+        }
+        prev = id;
+    }
+    for (int t = cnt; t < Tp; ++t) tokens[(size_t)b * Tp + t] = -1;
+    ntok[b] = cnt;
+    score[b] = nb > 0 ? acc / (float)nb : 0.f;
+}
+
+void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank, int* tokens,
+                         int* ntok, float* score, hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, s, idx, maxp, nframes, B, Tp, blank,
+                       tokens, ntok, score);
+}
+
+// argmax / max over rows of an existing probability matrix (np.argmax semantics: first maximum)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ p, int V, int* __restrict__ idx,
+                                                          float* __restrict__ maxp) {
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    const float* x = p + (size_t)blockIdx.x * V;
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int j = threadIdx.x; j < V; j += 256) {
+        const float v = x[j];
+        if (v > m) { m = v; mi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { red_v[threadIdx.x >> 6] = m; red_i[threadIdx.x >> 6] = mi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = red_v[0]; mi = red_i[0];
+        for (int w = 1; w < 4; ++w)
+            if (red_v[w] > m || (red_v[w] == m && red_i[w] < mi)) { m = red_v[w]; mi = red_i[w]; }
+        idx[blockIdx.x] = mi;
+        if (maxp) maxp[blockIdx.x] = m;
+    }
+}
+
+void launch_argmax_rows(const float* probs, int M, int V, int* idx, float* maxp, hipStream_t s) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, s, probs, V, idx, maxp);
+}
+
+// samples -> fbank frames (snip_edges) -> encoder frames (two 3x3/stride-2 convs)
+__global__ void frame_counts_kernel(const int* __restrict__ nsamp, int B, int* nfr, int* nenc) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = nsamp[b];
+    const int T = n >= 400 ? 1 + (n - 400) / 160 : 0;
+    if (nfr) nfr[b] = T;
+    if (nenc) nenc[b] = T >= 7 ? ((T - 1) / 2 - 1) / 2 : 0;
+}
+
+void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(frame_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, nsamp, B, nfr, nenc);
+}
+
+// stream caches -> reference layouts (encoder.py:404-419): att [L,H,t,2dk], cnn [L,1,d,pad]
+__global__ void export_att_kernel(const float* __restrict__ cache, float* __restrict__ out, int H, int cap, int t,
+                                  int dk) {
+    const int l = blockIdx.z, h = blockIdx.y, j = blockIdx.x;
+    const int d = H * dk;
+    const float* row = cache + ((size_t)l * cap + j) * 2 * d;
+    float* o = out + (((size_t)l * H + h) * t + j) * 2 * dk;
+    for (int i = threadIdx.x; i < 2 * dk; i += blockDim.x) o[i] = i < dk ? row[h * dk + i] : row[d + h * dk + (i - dk)];
+}
+void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s) {
+    hipLaunchKernelGGL(export_att_kernel, dim3(t, H, L), dim3(128), 0, s, cache, out, H, cap, t, dk);
+}
+__global__ void export_cnn_kernel(const float* __restrict__ cache, float* __restrict__ out, int pad, int d) {
+    const int l = blockIdx.x;
+    for (int i = threadIdx.x; i < pad * d; i += blockDim.x) {
+        const int c = i / pad, j = i % pad;
+        out[(size_t)l * pad * d + i] = cache[((size_t)l * pad + j) * d + c];
+    }
+}
+void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hipStream_t s) {
+    hipLaunchKernelGGL(export_cnn_kernel, dim3(L), dim3(256), 0, s, cache, out, pad, d);
+}
+
+}  // namespace masr

@@ -1,0 +1,819 @@
+// libmasr_hip.so -- engine: weight store, workspace, orchestration of the Conformer hot path and
+// the C ABI declared in include/masr_hip.h.  Host-side only; every kernel lives in the sibling
+// .hip files and is launched on the caller's stream.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/masr_hip.h"
+#include "common.h"
+
+using namespace masr;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+    g_err = m;
+    return 1;
+}
+#define HIPCHK(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" +     \
+                        std::to_string(__LINE__) + ")");                                                \
+    } while (0)
+#define CHK(expr)              \
+    do {                       \
+        int _r = (expr);       \
+        if (_r) return _r;     \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return 0;
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        bytes = 0;
+        size_t want = n + n / 8 + 256;
+        HIPCHK(hipMalloc(&p, want));
+        bytes = want;
+        return 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct LayerW {
+    float *ln_ffm_w, *ln_ffm_b, *ffm_w1, *ffm_b1, *ffm_w2, *ffm_b2;
+    float *ln_mha_w, *ln_mha_b, *wqkv, *bqkv, *wo, *bo, *pos_u, *pos_v, *wpos, *ptab;
+    float *ln_conv_w, *ln_conv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *cln_w, *cln_b, *pw2_w, *pw2_b;
+    float *ln_ff_w, *ln_ff_b, *ff_w1, *ff_b1, *ff_w2, *ff_b2;
+    float *ln_fin_w, *ln_fin_b;
+};
+
+struct HostTensor {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+};
+
+struct Stream {
+    bool open = false;
+    int offset = 0;
+    int cap = 0;
+    DevBuf att;  // [L][cap][2*d]  (k | v per row)
+    DevBuf cnn;  // [L][kernel-1][d]
+};
+
+enum ProfKind { PROF_NONE = 0, PROF_GEMM = 1, PROF_FFN1 = 2, PROF_CONV2 = 3, PROF_ATT = 4, PROF_FBANK = 5 };
+
+}  // namespace
+
+struct masr_engine {
+    masr_config cfg;
+    bool finalized = false;
+    std::map<std::string, HostTensor> host;
+    std::vector<void*> owned;   // device weight allocations
+    // weights
+    float *cmvn_mean = nullptr, *cmvn_istd = nullptr, *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr,
+          *conv2_b = nullptr, *embed_w = nullptr, *embed_b = nullptr, *after_w = nullptr, *after_b = nullptr,
+          *ctc_w = nullptr, *ctc_b = nullptr, *pe = nullptr;
+    std::vector<LayerW> layers;
+    // fbank tables
+    float *window = nullptr, *melw = nullptr, *tw256 = nullptr, *tw512 = nullptr;
+    int *mel_lo = nullptr, *mel_hi = nullptr;
+    // workspace
+    DevBuf x1, x2, x, ln, hid, qkv, att, lnpad, glu, dwo, logits, feats, enc, idx, maxp, attseq, gain, nframes, lens;
+    // streams
+    std::vector<Stream> streams;
+    // profiling
+    int prof_kind = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    double prof_flops = 0.0;
+};
+
+namespace {
+
+template <class T>
+int upload(masr_engine* e, const std::vector<T>& v, T** out) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    e->owned.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return 0;
+}
+
+int get(masr_engine* e, const std::string& name, std::vector<int64_t> shape, const HostTensor** out) {
+    auto it = e->host.find(name);
+    if (it == e->host.end()) return fail("missing tensor: " + name);
+    int64_t want = 1, have = 1;
+    for (auto s : shape) want *= s;
+    for (auto s : it->second.shape) have *= s;
+    if (want != have)
+        return fail("tensor " + name + ": expected " + std::to_string(want) + " elements, got " + std::to_string(have));
+    *out = &it->second;
+    return 0;
+}
+
+int up(masr_engine* e, const std::string& name, std::vector<int64_t> shape, float** out) {
+    const HostTensor* t;
+    CHK(get(e, name, shape, &t));
+    return upload(e, t->v, out);
+}
+
+// ---- profiling helpers ------------------------------------------------------------------------------
+struct ProfScope {
+    masr_engine* e;
+    hipStream_t s;
+    bool on;
+    ProfScope(masr_engine* e_, hipStream_t s_, int kind, double flops) : e(e_), s(s_) {
+        on = e->prof_kind != 0 && (e->prof_kind == kind || (e->prof_kind == PROF_GEMM && (kind == PROF_FFN1 || kind == PROF_CONV2)));
+        if (!on) return;
+        if (e->prof_used == e->prof_events.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            e->prof_events.push_back({a, b});
+        }
+        hipEventRecord(e->prof_events[e->prof_used].first, s);
+        e->prof_flops += flops;
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(e->prof_events[e->prof_used].second, s);
+        e->prof_used++;
+    }
+};
+
+void gemm(masr_engine* e, hipStream_t s, const float* A, int lda, const float* W, const float* bias, float* C, int ldc,
+          int M, int N, int K, int act, float alpha, const float* R, int ldr, int kind = PROF_GEMM,
+          const int* lens = nullptr, int mask_tp = 0) {
+    GemmArgs a{};
+    a.A = A; a.W = W; a.bias = bias; a.C = C; a.R = R; a.lens = lens;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr;
+    a.act = act; a.alpha = alpha; a.mask_tp = mask_tp;
+    ProfScope ps(e, s, kind, 2.0 * M * (double)N * K);
+    launch_gemm(a, A_PLAIN, EPI_STD, s);
+}
+
+}  // namespace
+
+namespace {
+// fbank tables (float32 arithmetic mirrors torchaudio's get_mel_banks / povey window); they do not
+// depend on the model, so a weight-less engine can already run the feature front-end.
+int build_fbank_tables(masr_engine* e) {
+    {
+        std::vector<float> win(400), tw256(256), tw512(2 * 257), melw((size_t)80 * 257, 0.f);
+        std::vector<int> lo(80), hi(80);
+        for (int i = 0; i < 400; ++i) {
+            const double hann = 0.5 - 0.5 * cos(2.0 * M_PI * i / 399.0);
+            win[i] = (float)pow(hann, 0.85);
+        }
+        for (int k = 0; k < 128; ++k) {
+            tw256[2 * k] = (float)cos(-2.0 * M_PI * k / 256.0);
+            tw256[2 * k + 1] = (float)sin(-2.0 * M_PI * k / 256.0);
+        }
+        for (int k = 0; k <= 256; ++k) {
+            tw512[2 * k] = (float)cos(-2.0 * M_PI * k / 512.0);
+            tw512[2 * k + 1] = (float)sin(-2.0 * M_PI * k / 512.0);
+        }
+        const double mel_low = 1127.0 * log(1.0 + 20.0 / 700.0), mel_high = 1127.0 * log(1.0 + 8000.0 / 700.0);
+        const float delta = (float)((mel_high - mel_low) / 81.0), mlow = (float)mel_low;
+        for (int m = 0; m < 80; ++m) {
+            const float left = mlow + (float)m * delta, center = mlow + ((float)m + 1.0f) * delta,
+                        right = mlow + ((float)m + 2.0f) * delta;
+            lo[m] = 257;
+            hi[m] = 0;
+            for (int k = 0; k < 256; ++k) {
+                const float freq = 31.25f * (float)k;
+                const float mel = 1127.0f * logf(1.0f + freq / 700.0f);
+                const float upv = (mel - left) / (center - left), down = (right - mel) / (right - center);
+                const float wv = fmaxf(0.f, fminf(upv, down));
+                melw[(size_t)m * 257 + k] = wv;
+                if (wv > 0.f) {
+                    lo[m] = std::min(lo[m], k);
+                    hi[m] = std::max(hi[m], k + 1);
+                }
+            }
+            if (lo[m] > hi[m]) lo[m] = hi[m] = 0;
+        }
+        CHK(upload(e, win, &e->window));
+        CHK(upload(e, tw256, &e->tw256));
+        CHK(upload(e, tw512, &e->tw512));
+        CHK(upload(e, melw, &e->melw));
+        CHK(upload(e, lo, &e->mel_lo));
+        CHK(upload(e, hi, &e->mel_hi));
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+const char* masr_last_error(void) { return g_err.c_str(); }
+int masr_version(void) { return 1; }
+
+int masr_create(const masr_config* cfg, masr_engine** out) {
+    if (!cfg || !out) return fail("null argument");
+    if (cfg->model_kind != 0) return fail("only model_kind 0 (conformer) is implemented");
+    if (cfg->d_model != 256 || cfg->heads != 4) return fail("kernels are specialised for d_model=256, heads=4");
+    if (cfg->n_mels != 80) return fail("n_mels must be 80");
+    if (cfg->d_ff % 128 || cfg->cnn_kernel != 15) return fail("unsupported d_ff / cnn_module_kernel");
+    if (!cfg->causal) return fail("only the streaming-trained (causal conv) conformer is implemented");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail("no HIP device");
+    HIPCHK(hipSetDevice(cfg->device_id));
+    masr_engine* e = new masr_engine();
+    e->cfg = *cfg;
+    if (e->cfg.max_pos <= 0) e->cfg.max_pos = 5000;
+    if (build_fbank_tables(e)) {
+        masr_destroy(e);
+        return 1;
+    }
+    *out = e;
+    return 0;
+}
+
+void masr_destroy(masr_engine* e) {
+    if (!e) return;
+    for (void* p : e->owned) (void)hipFree(p);
+    DevBuf* bufs[] = {&e->x1, &e->x2, &e->x, &e->ln, &e->hid, &e->qkv, &e->att, &e->lnpad, &e->glu, &e->dwo,
+                      &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& s : e->streams) {
+        s.att.release();
+        s.cnn.release();
+    }
+    for (auto& ev : e->prof_events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    delete e;
+}
+
+int masr_load_tensor(masr_engine* e, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
+    if (!e || !name || !host) return fail("null argument");
+    std::string n(name);
+    if (n.rfind("encoder.", 0) != 0 && n.rfind("ctc.", 0) != 0 && n != "__pos_table__") return 0;
+    HostTensor t;
+    int64_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) {
+        t.shape.push_back(shape[i]);
+        cnt *= shape[i];
+    }
+    t.v.assign(host, host + cnt);
+    e->host[n] = std::move(t);
+    e->finalized = false;
+    return 0;
+}
+
+int masr_finalize(masr_engine* e, void* stream) {
+    if (!e) return fail("null engine");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(e->cfg.device_id));
+    const int d = e->cfg.d_model, dff = e->cfg.d_ff, L = e->cfg.num_blocks, V = e->cfg.vocab_size, F = e->cfg.n_mels;
+    const int F1 = (F - 1) / 2, F2 = (F1 - 1) / 2, K = e->cfg.cnn_kernel, H = e->cfg.heads, dk = d / H;
+    const HostTensor* t;
+    CHK(up(e, "encoder.global_cmvn.mean", {F}, &e->cmvn_mean));
+    CHK(up(e, "encoder.global_cmvn.istd", {F}, &e->cmvn_istd));
+    {   // conv1 [d,1,3,3] -> [9][d]
+        CHK(get(e, "encoder.embed.conv.0.weight", {d, 1, 3, 3}, &t));
+        std::vector<float> w(9 * d);
+        for (int c = 0; c < d; ++c)
+            for (int k = 0; k < 9; ++k) w[k * d + c] = t->v[c * 9 + k];
+        CHK(upload(e, w, &e->conv1_w));
+        CHK(up(e, "encoder.embed.conv.0.bias", {d}, &e->conv1_b));
+    }
+    {   // conv2 [co,ci,3,3] -> [co][(kh*3+kw)*d + ci]
+        CHK(get(e, "encoder.embed.conv.2.weight", {d, d, 3, 3}, &t));
+        std::vector<float> w((size_t)d * 9 * d);
+        for (int co = 0; co < d; ++co)
+            for (int ci = 0; ci < d; ++ci)
+                for (int k = 0; k < 9; ++k) w[(size_t)co * 9 * d + k * d + ci] = t->v[((size_t)co * d + ci) * 9 + k];
+        CHK(upload(e, w, &e->conv2_w));
+        CHK(up(e, "encoder.embed.conv.2.bias", {d}, &e->conv2_b));
+    }
+    {   // embed.out.0 [d][c*F2+f] -> [d][f*d + c]   (subsampling.py:110 flattens channel-major)
+        CHK(get(e, "encoder.embed.out.0.weight", {d, (int64_t)d * F2}, &t));
+        std::vector<float> w((size_t)d * d * F2);
+        for (int o = 0; o < d; ++o)
+            for (int c = 0; c < d; ++c)
+                for (int f = 0; f < F2; ++f) w[(size_t)o * d * F2 + f * d + c] = t->v[(size_t)o * d * F2 + c * F2 + f];
+        CHK(upload(e, w, &e->embed_w));
+        CHK(up(e, "encoder.embed.out.0.bias", {d}, &e->embed_b));
+    }
+    {   // positional table (conformer/embedding.py:31-37)
+        auto it = e->host.find("__pos_table__");
+        if (it != e->host.end()) {
+            if ((int64_t)it->second.v.size() != (int64_t)e->cfg.max_pos * d) return fail("__pos_table__ has wrong size");
+            CHK(upload(e, it->second.v, &e->pe));
+        } else {
+            std::vector<float> pe((size_t)e->cfg.max_pos * d);
+            for (int i = 0; i < d; i += 2) {
+                const float div = expf((float)i * (float)(-(log(10000.0) / d)));
+                for (int p = 0; p < e->cfg.max_pos; ++p) {
+                    pe[(size_t)p * d + i] = sinf((float)p * div);
+                    pe[(size_t)p * d + i + 1] = cosf((float)p * div);
+                }
+            }
+            CHK(upload(e, pe, &e->pe));
+        }
+    }
+    e->layers.assign(L, LayerW{});
+    for (int i = 0; i < L; ++i) {
+        LayerW& w = e->layers[i];
+        const std::string p = "encoder.encoders." + std::to_string(i) + ".";
+        auto ln = [&](const std::string& n, float** ww, float** bb) -> int {
+            CHK(up(e, p + n + ".weight", {d}, ww));
+            return up(e, p + n + ".bias", {d}, bb);
+        };
+        CHK(ln("norm_ff_macaron", &w.ln_ffm_w, &w.ln_ffm_b));
+        CHK(ln("norm_mha", &w.ln_mha_w, &w.ln_mha_b));
+        CHK(ln("norm_conv", &w.ln_conv_w, &w.ln_conv_b));
+        CHK(ln("norm_ff", &w.ln_ff_w, &w.ln_ff_b));
+        CHK(ln("norm_final", &w.ln_fin_w, &w.ln_fin_b));
+        CHK(ln("conv_module.norm", &w.cln_w, &w.cln_b));
+        CHK(up(e, p + "feed_forward_macaron.w_1.weight", {dff, d}, &w.ffm_w1));
+        CHK(up(e, p + "feed_forward_macaron.w_1.bias", {dff}, &w.ffm_b1));
+        CHK(up(e, p + "feed_forward_macaron.w_2.weight", {d, dff}, &w.ffm_w2));
+        CHK(up(e, p + "feed_forward_macaron.w_2.bias", {d}, &w.ffm_b2));
+        CHK(up(e, p + "feed_forward.w_1.weight", {dff, d}, &w.ff_w1));
+        CHK(up(e, p + "feed_forward.w_1.bias", {dff}, &w.ff_b1));
+        CHK(up(e, p + "feed_forward.w_2.weight", {d, dff}, &w.ff_w2));
+        CHK(up(e, p + "feed_forward.w_2.bias", {d}, &w.ff_b2));
+        {   // fused QKV projection [3d, d]
+            std::vector<float> wq((size_t)3 * d * d), bq(3 * d);
+            const char* nm[3] = {"linear_q", "linear_k", "linear_v"};
+            for (int j = 0; j < 3; ++j) {
+                CHK(get(e, p + "self_attn." + nm[j] + ".weight", {d, d}, &t));
+                memcpy(&wq[(size_t)j * d * d], t->v.data(), sizeof(float) * d * d);
+                CHK(get(e, p + "self_attn." + nm[j] + ".bias", {d}, &t));
+                memcpy(&bq[j * d], t->v.data(), sizeof(float) * d);
+            }
+            CHK(upload(e, wq, &w.wqkv));
+            CHK(upload(e, bq, &w.bqkv));
+        }
+        CHK(up(e, p + "self_attn.linear_out.weight", {d, d}, &w.wo));
+        CHK(up(e, p + "self_attn.linear_out.bias", {d}, &w.bo));
+        CHK(up(e, p + "self_attn.linear_pos.weight", {d, d}, &w.wpos));
+        CHK(up(e, p + "self_attn.pos_bias_u", {H, dk}, &w.pos_u));
+        CHK(up(e, p + "self_attn.pos_bias_v", {H, dk}, &w.pos_v));
+        {   // pointwise_conv1 [2d, d, 1]: permute rows so that every wave's two 32-column MFMA tiles hold
+            // (value, gate) of the same 32 channels (GLU epilogue, gemm_f32.hip)
+            CHK(get(e, p + "conv_module.pointwise_conv1.weight", {2 * d, d, 1}, &t));
+            const HostTensor* tb;
+            CHK(get(e, p + "conv_module.pointwise_conv1.bias", {2 * d}, &tb));
+            std::vector<float> wp((size_t)2 * d * d), bp(2 * d);
+            for (int pr = 0; pr < 2 * d; ++pr) {
+                const int j = pr / 128, q = pr % 128, wv = q / 64, n = (q % 64) / 32, ii = q % 32;
+                const int ch = j * 64 + wv * 32 + ii;
+                const int src = ch + n * d;
+                memcpy(&wp[(size_t)pr * d], &t->v[(size_t)src * d], sizeof(float) * d);
+                bp[pr] = tb->v[src];
+            }
+            CHK(upload(e, wp, &w.pw1_w));
+            CHK(upload(e, bp, &w.pw1_b));
+        }
+        {   // depthwise [d,1,K] -> [K][d]
+            CHK(get(e, p + "conv_module.depthwise_conv.weight", {d, 1, K}, &t));
+            std::vector<float> wd((size_t)K * d);
+            for (int c = 0; c < d; ++c)
+                for (int j = 0; j < K; ++j) wd[(size_t)j * d + c] = t->v[(size_t)c * K + j];
+            CHK(upload(e, wd, &w.dw_w));
+            CHK(up(e, p + "conv_module.depthwise_conv.bias", {d}, &w.dw_b));
+        }
+        CHK(up(e, p + "conv_module.pointwise_conv2.weight", {d, d, 1}, &w.pw2_w));
+        CHK(up(e, p + "conv_module.pointwise_conv2.bias", {d}, &w.pw2_b));
+        {   // positional keys p_j = W_pos * PE(j) for every position, once (attention.py:229-231)
+            void* pt = nullptr;
+            HIPCHK(hipMalloc(&pt, (size_t)e->cfg.max_pos * d * sizeof(float)));
+            e->owned.push_back(pt);
+            w.ptab = (float*)pt;
+            gemm(e, s, e->pe, d, w.wpos, nullptr, w.ptab, d, e->cfg.max_pos, d, d, ACT_NONE, 1.f, nullptr, 0, PROF_NONE);
+        }
+    }
+    CHK(up(e, "encoder.after_norm.weight", {d}, &e->after_w));
+    CHK(up(e, "encoder.after_norm.bias", {d}, &e->after_b));
+    CHK(up(e, "ctc.ctc_lo.weight", {V, d}, &e->ctc_w));
+    CHK(up(e, "ctc.ctc_lo.bias", {V}, &e->ctc_b));
+
+    HIPCHK(hipStreamSynchronize(s));
+    e->host.clear();
+    e->finalized = true;
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Encoder orchestration
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct EncodeCtx {
+    int nseq;        // sequences (utterances or streams)
+    int Tq;          // encoder frames per sequence in this call
+    const int* lens; // device feature lengths for pad masking, or nullptr (streaming)
+};
+
+int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb, const float* w1, const float* b1,
+        const float* w2, const float* b2) {
+    const int d = e->cfg.d_model, dff = e->cfg.d_ff;
+    float* x = e->x.as<float>();
+    launch_layernorm(x, lnw, lnb, e->ln.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
+    gemm(e, s, e->ln.as<float>(), d, w1, b1, e->hid.as<float>(), dff, M, dff, d, ACT_SILU, 1.f, nullptr, 0, PROF_FFN1);
+    gemm(e, s, e->hid.as<float>(), dff, w2, b2, x, d, M, d, dff, ACT_NONE, 0.5f, x, d);
+    return 0;
+}
+
+// feats [nseq, T, 80] -> x [nseq*Tq, d] (embed incl. x*sqrt(d))
+int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, int* Tq_out) {
+    const int d = e->cfg.d_model, F = e->cfg.n_mels, F1 = (F - 1) / 2, F2 = (F1 - 1) / 2;
+    const int T1 = (T - 1) / 2, Tq = (T1 - 1) / 2;
+    if (T < 7 || Tq <= 0) return fail("input too short for Conv2dSubsampling4 (need >= 7 frames)");
+    const int M = nseq * Tq;
+    CHK(e->x1.ensure((size_t)nseq * T1 * F1 * d * sizeof(float)));
+    CHK(e->x2.ensure((size_t)M * F2 * d * sizeof(float)));
+    CHK(e->x.ensure((size_t)M * d * sizeof(float)));
+    launch_conv1(feats, e->cmvn_mean, e->cmvn_istd, e->conv1_w, e->conv1_b, e->x1.as<float>(), nseq, T, F, d, s);
+    {
+        GemmArgs a{};
+        a.A = e->x1.as<float>(); a.W = e->conv2_w; a.bias = e->conv2_b; a.C = e->x2.as<float>();
+        a.M = M * F2; a.N = d; a.K = 9 * d; a.ldc = d; a.act = ACT_RELU; a.alpha = 1.f;
+        a.T1 = T1; a.F1 = F1; a.T2 = Tq; a.F2 = F2; a.Cc = d;
+        ProfScope ps(e, s, PROF_CONV2, 2.0 * a.M * (double)a.N * a.K);
+        launch_gemm(a, A_CONV2, EPI_STD, s);
+    }
+    gemm(e, s, e->x2.as<float>(), F2 * d, e->embed_w, e->embed_b, e->x.as<float>(), d, M, d, F2 * d, ACT_NONE,
+         sqrtf((float)d), nullptr, 0);
+    *Tq_out = Tq;
+    return 0;
+}
+
+int ensure_layer_ws(masr_engine* e, int nseq, int Tq) {
+    const int d = e->cfg.d_model, dff = e->cfg.d_ff, pad = e->cfg.cnn_kernel - 1;
+    const size_t M = (size_t)nseq * Tq;
+    CHK(e->ln.ensure(M * d * sizeof(float)));
+    CHK(e->hid.ensure(M * dff * sizeof(float)));
+    CHK(e->qkv.ensure(M * 3 * d * sizeof(float)));
+    CHK(e->att.ensure(M * d * sizeof(float)));
+    CHK(e->lnpad.ensure((size_t)nseq * (Tq + pad) * d * sizeof(float)));
+    CHK(e->glu.ensure((size_t)nseq * (Tq + pad) * d * sizeof(float)));
+    CHK(e->dwo.ensure(M * d * sizeof(float)));
+    return 0;
+}
+
+// conv module on x (in place residual); lnpad rows [0,pad) of every sequence must already hold the
+// history (zeros or cnn cache)
+int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c) {
+    const int d = e->cfg.d_model, K = e->cfg.cnn_kernel, pad = K - 1;
+    const int M = c.nseq * c.Tq, Mp = c.nseq * (c.Tq + pad);
+    float* x = e->x.as<float>();
+    launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, c.Tq, pad, c.lens, s);
+    {
+        GemmArgs a{};
+        a.A = e->lnpad.as<float>(); a.lda = d; a.W = w.pw1_w; a.bias = w.pw1_b; a.C = e->glu.as<float>(); a.ldc = d;
+        a.M = Mp; a.N = 2 * d; a.K = d; a.alpha = 1.f;
+        ProfScope ps(e, s, PROF_GEMM, 2.0 * a.M * (double)a.N * a.K);
+        launch_gemm(a, A_PLAIN, EPI_GLU, s);
+    }
+    launch_dwconv_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), c.nseq, c.Tq, K,
+                          1e-5f, s);
+    gemm(e, s, e->dwo.as<float>(), d, w.pw2_w, w.pw2_b, x, d, M, d, d, ACT_NONE, 1.f, x, d, PROF_GEMM, c.lens,
+         c.lens ? c.Tq : 0);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat_lens_dev, int32_t B, int32_t T,
+                     int32_t decoding_chunk_size, float* enc_out_dev, void* stream) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (B <= 0) return fail("empty batch");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = e->cfg.d_model, H = e->cfg.heads, pad = e->cfg.cnn_kernel - 1;
+    int Tq = 0;
+    CHK(embed(e, s, feats_dev, B, T, &Tq));
+    if (Tq >= e->cfg.max_pos) return fail("sequence longer than max_pos");   // embedding.py:48-50 assert
+    const int M = B * Tq;
+    CHK(ensure_layer_ws(e, B, Tq));
+    CHK(e->attseq.ensure(sizeof(AttSeq) * B));
+    HIPCHK(hipMemsetAsync(e->lnpad.p, 0, (size_t)B * (Tq + pad) * d * sizeof(float), s));
+    float* x = e->x.as<float>();
+    EncodeCtx ctx{B, Tq, feat_lens_dev};
+    launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), feat_lens_dev, B, Tq, s);
+    for (const LayerW& w : e->layers) {
+        CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
+        launch_layernorm(x, w.ln_mha_w, w.ln_mha_b, e->ln.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
+        gemm(e, s, e->ln.as<float>(), d, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M, 3 * d, d, ACT_NONE, 1.f, nullptr, 0);
+        {
+            ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
+            launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v,
+                             decoding_chunk_size > 0 ? decoding_chunk_size : 0, s);
+        }
+        gemm(e, s, e->att.as<float>(), d, w.wo, w.bo, x, d, M, d, d, ACT_NONE, 1.f, x, d);
+        CHK(conv_module(e, s, w, ctx));
+        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
+        launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
+    }
+    launch_layernorm(x, e->after_w, e->after_b, enc_out_dev, M, 1e-5f, 0, 0, nullptr, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int ctc_head(masr_engine* e, const float* enc_dev, int M, float* probs_dev, int write_probs, int32_t* argmax_dev,
+                    float* maxprob_dev, hipStream_t s) {
+    const int d = e->cfg.d_model, V = e->cfg.vocab_size;
+    float* logits = probs_dev;
+    if (!logits) {
+        CHK(e->logits.ensure((size_t)M * V * sizeof(float)));
+        logits = e->logits.as<float>();
+    }
+    gemm(e, s, enc_dev, d, e->ctc_w, e->ctc_b, logits, V, M, V, d, ACT_NONE, 1.f, nullptr, 0);
+    launch_softmax_argmax(logits, M, V, V, write_probs, argmax_dev, maxprob_dev, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int masr_ctc_probs(masr_engine* e, const float* enc_dev, int32_t M, float* probs_dev, int32_t* argmax_dev,
+                   float* maxprob_dev, void* stream) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (!probs_dev) return fail("probs_dev is null");
+    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+    return ctc_head(e, enc_dev, M, probs_dev, 1, argmax_dev, maxprob_dev, (hipStream_t)stream);
+}
+
+int masr_ctc_greedy_frames(masr_engine* e, const float* enc_dev, int32_t M, int32_t* argmax_dev, float* maxprob_dev,
+                           void* stream) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+    return ctc_head(e, enc_dev, M, nullptr, 0, argmax_dev, maxprob_dev, (hipStream_t)stream);
+}
+
+int masr_ctc_collapse(masr_engine* e, const int32_t* argmax_dev, const float* maxprob_dev, const int32_t* n_frames_dev,
+                      int32_t B, int32_t Tp, int32_t blank, int32_t* tokens_dev, int32_t* n_tokens_dev,
+                      float* score_dev, void* stream) {
+    if (!e) return fail("null engine");
+    launch_ctc_collapse(argmax_dev, maxprob_dev, n_frames_dev, B, Tp, blank, tokens_dev, n_tokens_dev, score_dev,
+                        (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int masr_argmax_rows(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t* argmax_dev,
+                     float* maxprob_dev, void* stream) {
+    if (!e) return fail("null engine");
+    if (V > 8192) return fail("V > 8192 not supported");
+    launch_argmax_rows(probs_dev, M, V, argmax_dev, maxprob_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev,
+                     int32_t B, int32_t n_max, int32_t use_db_normalization, float target_db, float* feats_dev,
+                     int32_t* n_frames_dev, int16_t* norm_pcm_dev, float* gain_dev, void* stream) {
+    if (!e) return fail("null engine");
+    if (sample_format != 0 && sample_format != 1) return fail("sample_format must be 0 (int16) or 1 (float32)");
+    hipStream_t s = (hipStream_t)stream;
+    const int T_max = n_max >= 400 ? 1 + (n_max - 400) / 160 : 0;
+    float* gain = gain_dev;
+    if (!gain) {
+        CHK(e->gain.ensure(sizeof(float) * B));
+        gain = e->gain.as<float>();
+    }
+    {
+        ProfScope ps(e, s, PROF_FBANK, 0.0);
+        launch_fbank(samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, target_db, e->window,
+                     e->melw, e->mel_lo, e->mel_hi, e->tw256, e->tw512, feats_dev, T_max, gain, norm_pcm_dev, s);
+    }
+    if (n_frames_dev) launch_frame_counts(n_samples_dev, B, n_frames_dev, nullptr, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t* n_samples_dev, int32_t B,
+                          int32_t n_max, int32_t use_db_normalization, float target_db, int32_t decode_all_frames,
+                          int32_t* tokens_dev, int32_t* n_tokens_dev, float* score_dev, void* stream) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (n_max < 400) return fail("n_max < 400 samples: no frame");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = e->cfg.d_model, F = e->cfg.n_mels;
+    const int T = 1 + (n_max - 400) / 160, T1 = (T - 1) / 2, Tq = (T1 - 1) / 2;
+    if (Tq <= 0) return fail("utterances too short");
+    CHK(e->feats.ensure((size_t)B * T * F * sizeof(float)));
+    CHK(e->nframes.ensure(sizeof(int) * 2 * B));
+    CHK(e->enc.ensure((size_t)B * Tq * d * sizeof(float)));
+    CHK(e->idx.ensure(sizeof(int) * B * Tq));
+    CHK(e->maxp.ensure(sizeof(float) * B * Tq));
+    int* nfr = e->nframes.as<int>();
+    int* nenc = nfr + B;
+    CHK(masr_fbank_batch(e, pcm_dev, 0, n_samples_dev, B, n_max, use_db_normalization, target_db,
+                         e->feats.as<float>(), nullptr, nullptr, nullptr, stream));
+    launch_frame_counts(n_samples_dev, B, nfr, nenc, s);
+    CHK(masr_encode_full(e, e->feats.as<float>(), nfr, B, T, -1, e->enc.as<float>(), stream));
+    CHK(masr_ctc_greedy_frames(e, e->enc.as<float>(), B * Tq, e->idx.as<int>(), e->maxp.as<float>(), stream));
+    CHK(masr_ctc_collapse(e, e->idx.as<int>(), e->maxp.as<float>(), decode_all_frames ? nullptr : nenc, B, Tq, 0,
+                          tokens_dev, n_tokens_dev, score_dev, stream));
+    return 0;
+}
+
+// ---- streaming -----------------------------------------------------------------------------------------
+
+int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (max_frames_out <= 0 || max_frames_out > e->cfg.max_pos) max_frames_out = e->cfg.max_pos;
+    int id = -1;
+    for (size_t i = 0; i < e->streams.size(); ++i)
+        if (!e->streams[i].open) { id = (int)i; break; }
+    if (id < 0) {
+        e->streams.emplace_back();
+        id = (int)e->streams.size() - 1;
+    }
+    Stream& st = e->streams[id];
+    const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
+    st.cap = max_frames_out;
+    CHK(st.att.ensure((size_t)L * st.cap * 2 * d * sizeof(float)));
+    CHK(st.cnn.ensure((size_t)L * pad * d * sizeof(float)));
+    HIPCHK(hipMemset(st.cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
+    st.offset = 0;
+    st.open = true;
+    *stream_id = id;
+    return 0;
+}
+
+static int stream_of(masr_engine* e, int id, Stream** out) {
+    if (!e) return fail("null engine");
+    if (id < 0 || id >= (int)e->streams.size() || !e->streams[id].open) return fail("bad stream id");
+    *out = &e->streams[id];
+    return 0;
+}
+
+int masr_stream_reset(masr_engine* e, int32_t stream_id) {
+    Stream* st;
+    CHK(stream_of(e, stream_id, &st));
+    const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(st->cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
+    st->offset = 0;
+    return 0;
+}
+
+int masr_stream_close(masr_engine* e, int32_t stream_id) {
+    Stream* st;
+    CHK(stream_of(e, stream_id, &st));
+    HIPCHK(hipDeviceSynchronize());
+    st->att.release();
+    st->cnn.release();
+    st->open = false;
+    return 0;
+}
+
+int masr_stream_offset(masr_engine* e, int32_t stream_id, int32_t* offset) {
+    Stream* st;
+    CHK(stream_of(e, stream_id, &st));
+    *offset = st->offset;
+    return 0;
+}
+
+int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, const float* feats_dev, int32_t Tc,
+                      float* probs_dev, int32_t* argmax_dev, float* maxprob_dev, void* stream) {
+    if (!e || !e->finalized) return fail("engine not finalized");
+    if (n <= 0) return fail("no streams");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = e->cfg.d_model, H = e->cfg.heads, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
+    std::vector<Stream*> st(n);
+    for (int i = 0; i < n; ++i) CHK(stream_of(e, stream_ids[i], &st[i]));
+    int Tq = 0;
+    CHK(embed(e, s, feats_dev, n, Tc, &Tq));
+    for (int i = 0; i < n; ++i)
+        if (st[i]->offset + Tq > st[i]->cap) return fail("stream exceeds its max_frames_out / max_pos");
+    const int M = n * Tq;
+    CHK(ensure_layer_ws(e, n, Tq));
+    CHK(e->attseq.ensure(sizeof(AttSeq) * (size_t)n * L));
+    // descriptors for all layers in one H2D copy
+    std::vector<AttSeq> hs((size_t)n * L);
+    for (int l = 0; l < L; ++l)
+        for (int i = 0; i < n; ++i) {
+            AttSeq& a = hs[(size_t)l * n + i];
+            float* cache = st[i]->att.as<float>() + (size_t)l * st[i]->cap * 2 * d;
+            a.q = e->qkv.as<float>() + (size_t)i * Tq * 3 * d;
+            a.k = cache;
+            a.v = cache + d;
+            a.out = e->att.as<float>() + (size_t)i * Tq * d;
+            a.nq = Tq;
+            a.nk = st[i]->offset + Tq;
+            a.klen = a.nk;
+            a.pos0 = 0;          // offset - cache_t1 == 0 with keep-all history (encoder.py:395)
+            a.q_abs0 = st[i]->offset;
+            a.pad_ = 0;
+        }
+    HIPCHK(hipMemcpyAsync(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // hs is a stack-lifetime host buffer
+    float* x = e->x.as<float>();
+    EncodeCtx ctx{n, Tq, nullptr};
+    for (int l = 0; l < L; ++l) {
+        const LayerW& w = e->layers[l];
+        CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
+        launch_layernorm(x, w.ln_mha_w, w.ln_mha_b, e->ln.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
+        gemm(e, s, e->ln.as<float>(), d, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M, 3 * d, d, ACT_NONE, 1.f, nullptr, 0);
+        for (int i = 0; i < n; ++i) {   // append this chunk's k|v rows to the stream's cache
+            float* cache = st[i]->att.as<float>() + ((size_t)l * st[i]->cap + st[i]->offset) * 2 * d;
+            HIPCHK(hipMemcpy2DAsync(cache, 2 * d * sizeof(float), e->qkv.as<float>() + (size_t)i * Tq * 3 * d + d,
+                                    3 * d * sizeof(float), 2 * d * sizeof(float), Tq, hipMemcpyDeviceToDevice, s));
+        }
+        launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, s);
+        gemm(e, s, e->att.as<float>(), d, w.wo, w.bo, x, d, M, d, d, ACT_NONE, 1.f, x, d);
+        for (int i = 0; i < n; ++i)     // history rows <- cnn cache (zeros on the first chunk)
+            HIPCHK(hipMemcpyAsync(e->lnpad.as<float>() + (size_t)i * (Tq + pad) * d,
+                                  st[i]->cnn.as<float>() + (size_t)l * pad * d, (size_t)pad * d * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+        CHK(conv_module(e, s, w, ctx));
+        for (int i = 0; i < n; ++i)     // new cache = last (kernel-1) rows of [cache | ln_out] (convolution.py:108)
+            HIPCHK(hipMemcpyAsync(st[i]->cnn.as<float>() + (size_t)l * pad * d,
+                                  e->lnpad.as<float>() + ((size_t)i * (Tq + pad) + Tq) * d,
+                                  (size_t)pad * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
+        launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
+    }
+    CHK(e->enc.ensure((size_t)M * d * sizeof(float)));
+    launch_layernorm(x, e->after_w, e->after_b, e->enc.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
+    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+    CHK(ctc_head(e, e->enc.as<float>(), M, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
+    for (int i = 0; i < n; ++i) st[i]->offset += Tq;
+    return 0;
+}
+
+int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, float* cnn_dev, void* stream) {
+    Stream* st;
+    CHK(stream_of(e, stream_id, &st));
+    hipStream_t s = (hipStream_t)stream;
+    const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1, H = e->cfg.heads;
+    if (att_dev && st->offset > 0)
+        launch_export_att(st->att.as<float>(), att_dev, L, H, st->cap, st->offset, d / H, s);
+    if (cnn_dev) launch_export_cnn(st->cnn.as<float>(), cnn_dev, L, pad, d, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- single ops -------------------------------------------------------------------------------------------
+
+int masr_op_layernorm(masr_engine* e, const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,
+                      int32_t M, float eps, void* stream) {
+    if (!e) return fail("null engine");
+    launch_layernorm(x_dev, w_dev, b_dev, y_dev, M, eps, 0, 0, nullptr, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
+                 float* c_dev, int32_t M, int32_t N, int32_t K, int32_t act, float alpha, void* stream) {
+    if (!e) return fail("null engine");
+    if (K % 32) return fail("K must be a multiple of 32");
+    gemm(e, (hipStream_t)stream, a_dev, K, w_dev, bias_dev, c_dev, N, M, N, K, act, alpha, res_dev, N);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int masr_profile_select(masr_engine* e, int32_t kind) {
+    if (!e) return fail("null engine");
+    e->prof_kind = kind;
+    return 0;
+}
+
+int masr_profile_read(masr_engine* e, double* total_ms, int64_t* launches, double* flops, int32_t reset) {
+    if (!e) return fail("null engine");
+    double tot = 0.0;
+    for (size_t i = 0; i < e->prof_used; ++i) {
+        HIPCHK(hipEventSynchronize(e->prof_events[i].second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->prof_events[i].first, e->prof_events[i].second));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)e->prof_used;
+    if (flops) *flops = e->prof_flops;
+    if (reset) {
+        e->prof_used = 0;
+        e->prof_flops = 0.0;
+    }
+    return 0;
+}
+
+}  // extern "C"

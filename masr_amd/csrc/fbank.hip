@@ -1,0 +1,303 @@
+// Batched feature front-end: int16 PCM -> (RMS-dB normalise -> int16 truncation) -> Kaldi fbank.
+//
+// Follows AudioFeaturizer.featurize (reference masr/data_utils/featurizer/audio_featurizer.py:37-69):
+//   AudioSegment float32 = pcm / 32768                         (data_utils/audio.py:532-546)
+//   normalize(target_db): gain = target - 10*log10(mean(x^2)); x *= 10^(gain/20)   (audio.py:287-304,256-264,519-529)
+//   to('int16'): x*32768, clip, C truncation                   (audio.py:549-574)
+//   torchaudio.compliance.kaldi.fbank(num_mel_bins=80, frame_length=25, frame_shift=10, dither=0)
+//       frames of 400 @ hop 160 (snip_edges) -> remove DC -> pre-emphasis 0.97 -> povey window ->
+//       zero-pad to 512 -> |rFFT|^2 -> 80 mel bins -> log(max(., eps))    (audio_featurizer.py:120-138)
+//
+// MI355X mapping: one wave64 per frame, 4 frames per workgroup.  The 400 samples of a frame are read
+// coalesced (int16), windowed in registers, and the 512-point real FFT is done as a 256-point complex
+// radix-2 FFT in LDS (2 butterflies per lane per stage) plus the real-split post-pass.  The mel
+// filterbank is applied from the LDS-resident power spectrum with per-bin [lo,hi) ranges.
+// Frames past an utterance's length are written as zeros (collate_fn zero padding, collate_fn.py:8-42).
+#include "common.h"
+
+namespace masr {
+
+// ---- per-utterance gain: s = float32(10 ** ((target - 10*log10(mean(x^2))) / 20)) -----------------
+// sample formats: int16 PCM (AudioSegment scales it by 1/32768, audio.py:532-546) or float32 samples
+__device__ __forceinline__ float to_unit(int16_t v) { return (float)v * (1.0f / 32768.0f); }
+__device__ __forceinline__ float to_unit(float v) { return v; }
+
+// mean(samples ** 2) exactly as numpy computes it for a contiguous float32 array (audio.py:519-529,
+// np.mean -> np.add.reduce): the reduction runs over buffered chunks of 8192 elements, accumulated
+// sequentially in float32, and every chunk is summed by numpy's pairwise routine
+// (numpy/core/src/umath/loops_utils.h.src: leaves of <= 128 elements with 8 strided accumulators
+// combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), split point n/2 rounded down to a multiple of 8).
+// Reproducing that order makes the gain -- and with it the int16 normalisation -- bit-identical
+// to the reference (pinned by oracle/fbank.py against numpy itself, tests/test_oracle_golden.py).
+template <class ST>
+__device__ __forceinline__ float sq_unit(const ST* x, int i) {
+    const float f = to_unit(x[i]);
+    return __fmul_rn(f, f);               // samples ** 2: rounded to float32 before any add
+}
+
+template <class ST>
+__device__ float pw_leaf(const ST* x, int off, int len) {
+    if (len < 8) {
+        float r = 0.f;
+        for (int i = 0; i < len; ++i) r = __fadd_rn(r, sq_unit(x, off + i));
+        return r;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = sq_unit(x, off + j);
+    int i = 8;
+    const int m = len - (len % 8);
+    for (; i < m; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], sq_unit(x, off + i + j));
+    }
+    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+    for (; i < len; ++i) res = __fadd_rn(res, sq_unit(x, off + i));
+    return res;
+}
+
+static constexpr int NP_BUF = 8192;       // numpy's default ufunc buffer size (elements)
+static constexpr int MAX_CHUNKS = 2048;   // 16.7 M samples (17 min @ 16 kHz) per utterance
+
+template <class ST>
+__global__ __launch_bounds__(256) void rms_gain_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp,
+                                                       int n_max, float target_db, float* __restrict__ gain) {
+    __shared__ float chunk_sum[MAX_CHUNKS];
+    __shared__ int leaf_off[64], leaf_len[64], prog[128];
+    __shared__ float leaf_val[64];
+    __shared__ int n_leaf, n_prog;
+    const int b = blockIdx.x;
+    const int n = min(nsamp[b], NP_BUF * MAX_CHUNKS);
+    const ST* x = pcm + (size_t)b * n_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc = n / NP_BUF, tail = n - nc * NP_BUF;
+    // full chunks: 64 leaves of 128 elements, balanced tree == xor-butterfly (fp add is commutative)
+    for (int c = wave; c < nc; c += 4) {
+        float v = pw_leaf(x, c * NP_BUF + lane * 128, 128);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) v = __fadd_rn(v, __shfl_xor(v, o, 64));
+        if (lane == 0) chunk_sum[c] = v;
+    }
+    // tail chunk (< 8192 elements): general pairwise recursion; thread 0 lists the leaves in DFS
+    // order together with a postfix program (leaf index = push, -1 = add the two top values)
+    if (threadIdx.x == 0) {
+        int nl = 0, np = 0;
+        if (tail > 0) {
+            int s_off[16], s_len[16], s_stage[16], sp = 0;
+            s_off[0] = nc * NP_BUF; s_len[0] = tail; s_stage[0] = 0; sp = 1;
+            while (sp > 0) {
+                const int t = sp - 1;
+                if (s_len[t] <= 128) {
+                    leaf_off[nl] = s_off[t]; leaf_len[nl] = s_len[t];
+                    prog[np++] = nl++;
+                    --sp;
+                } else if (s_stage[t] == 0) {
+                    int n2 = s_len[t] / 2; n2 -= n2 % 8;
+                    s_stage[t] = 1;
+                    s_off[sp] = s_off[t]; s_len[sp] = n2; s_stage[sp] = 0; ++sp;
+                } else if (s_stage[t] == 1) {
+                    int n2 = s_len[t] / 2; n2 -= n2 % 8;
+                    s_stage[t] = 2;
+                    s_off[sp] = s_off[t] + n2; s_len[sp] = s_len[t] - n2; s_stage[sp] = 0; ++sp;
+                } else {
+                    prog[np++] = -1;
+                    --sp;
+                }
+            }
+        }
+        n_leaf = nl; n_prog = np;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_leaf) leaf_val[threadIdx.x] = pw_leaf(x, leaf_off[threadIdx.x], leaf_len[threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int c = 0; c < nc; ++c) tot = __fadd_rn(tot, chunk_sum[c]);
+        if (n_prog > 0) {
+            float st[16]; int sp = 0;
+            for (int i = 0; i < n_prog; ++i) {
+                if (prog[i] >= 0) st[sp++] = leaf_val[prog[i]];
+                else { st[sp - 2] = __fadd_rn(st[sp - 2], st[sp - 1]); --sp; }
+            }
+            tot = __fadd_rn(tot, st[0]);
+        }
+        float ms = n > 0 ? __fdiv_rn(tot, (float)n) : 0.f;
+        if (ms == 0.f || !(ms == ms)) ms = 1.f;
+        // float32 scalar arithmetic of rms_db / normalize / gain_db (numpy >= 2 promotion): each
+        // step is evaluated in double and rounded once to float32
+        const float lg = (float)log10((double)ms);
+        const float rms_db = (float)(10.0 * (double)lg);
+        const float g = target_db - rms_db;
+        const float g20 = g / 20.0f;
+        gain[b] = (float)pow(10.0, (double)g20);
+    }
+}
+
+template <class ST>
+__device__ __forceinline__ float norm_sample(ST v, float s, int use_db) {
+    float f = to_unit(v);
+    if (use_db) f = __fmul_rn(f, s);
+    f = f * 32768.0f;
+    f = fminf(fmaxf(f, -32768.0f), 32767.0f);
+    return truncf(f);
+}
+
+template <class ST>
+__global__ __launch_bounds__(256) void norm_int16_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp,
+                                                         int n_max, const float* __restrict__ gain, int use_db,
+                                                         int16_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_max) return;
+    const float s = use_db ? gain[b] : 1.f;
+    out[(size_t)b * n_max + i] = i < nsamp[b] ? (int16_t)norm_sample(pcm[(size_t)b * n_max + i], s, use_db) : 0;
+}
+
+// ---- fbank ------------------------------------------------------------------------------------------
+static constexpr int WIN = 400, HOP = 160, NFFT = 512, NBIN = 257, NMEL = 80;
+
+template <class ST>
+__global__ __launch_bounds__(256) void fbank_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp,
+                                                    int n_max, int use_db, const float* __restrict__ gain,
+                                                    const float* __restrict__ window, const float* __restrict__ melw,
+                                                    const int* __restrict__ mel_lo, const int* __restrict__ mel_hi,
+                                                    const float* __restrict__ tw256, const float* __restrict__ tw512,
+                                                    float* __restrict__ feats, int T_max) {
+    __shared__ float re[4][256 + 4];
+    __shared__ float im[4][256 + 4];
+    __shared__ float pw[4][NBIN + 3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 4 + wv;
+    const int n = nsamp[b];
+    const int T = n >= WIN ? 1 + (n - WIN) / HOP : 0;
+    const bool live = t < T;               // wave-uniform
+    float* R = re[wv];
+    float* I = im[wv];
+    float* P = pw[wv];
+    const float s = use_db ? gain[b] : 1.f;
+
+    // ---- load 400 samples (lane handles j = lane + 64*i), DC removal, pre-emphasis, window -----------
+    float x[7];
+    float part = 0.f;
+    const ST* src = pcm + (size_t)b * n_max + (size_t)t * HOP;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int j = lane + 64 * i;
+        x[i] = (live && j < WIN) ? norm_sample(src[j], s, use_db) : 0.f;
+        part += x[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    const float mean = part / (float)WIN;
+    // stash DC-removed samples in LDS to fetch the left neighbour for pre-emphasis
+    __shared__ float tmp[4][WIN + 8];
+    float* Tm = tmp[wv];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int j = lane + 64 * i;
+        if (j < WIN) Tm[j] = x[i] - mean;
+    }
+    __syncthreads();
+    // z[n] = y[2n] + i*y[2n+1], written at bit-reversed n for the in-place DIT FFT
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;               // 0..511
+        float y = 0.f;
+        if (j < WIN) {
+            const float cur = Tm[j];
+            const float prev = Tm[j > 0 ? j - 1 : 0];
+            y = (cur - 0.97f * prev) * window[j];
+        }
+        const int nn = j >> 1;
+        const int br = __brev((unsigned)nn) >> 24;  // 8-bit reversal
+        if (j & 1) I[br] = y; else R[br] = y;
+    }
+    __syncthreads();
+
+    // ---- 256-point complex FFT, radix-2 DIT, 8 stages, 2 butterflies per lane per stage ---------------
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const int half = 1 << st;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int bf = lane + 64 * q;            // 0..127
+            const int grp = bf >> st;
+            const int pos = bf & (half - 1);
+            const int i0 = (grp << (st + 1)) + pos;
+            const int i1 = i0 + half;
+            const int tw = pos << (7 - st);          // pos * 256 / len, len = 2*half
+            const float wr = tw256[2 * tw], wi = tw256[2 * tw + 1];
+            const float ar = R[i0], ai = I[i0], br_ = R[i1], bi = I[i1];
+            const float tr = wr * br_ - wi * bi;
+            const float ti = wr * bi + wi * br_;
+            R[i0] = ar + tr; I[i0] = ai + ti;
+            R[i1] = ar - tr; I[i1] = ai - ti;
+        }
+        __syncthreads();
+    }
+
+    // ---- real-split post-pass: X[k] = (Z[k] + conj(Z[N-k]))/2 - i/2 * W^k * (Z[k] - conj(Z[N-k])), N = 256 ---
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int k = lane + 64 * i;                 // 0..256
+        if (k <= 256) {
+            const int ka = k & 255, kb = (256 - k) & 255;
+            const float zr = R[ka], zi = I[ka], yr = R[kb], yi = -I[kb];   // y = conj(Z[N-k])
+            const float er = 0.5f * (zr + yr), ei = 0.5f * (zi + yi);     // even part
+            const float dr = 0.5f * (zr - yr), di = 0.5f * (zi - yi);     // (Z - conj)/2
+            // odd part = -i * W512^k * d
+            const float wr = tw512[2 * k], wi = tw512[2 * k + 1];
+            const float pr = wr * dr - wi * di, pi = wr * di + wi * dr;   // W * d
+            const float xr = er + pi, xi = ei - pr;                        // e + (-i)*(pr + i pi) = e + pi - i pr
+            P[k] = xr * xr + xi * xi;
+        }
+    }
+    __syncthreads();
+
+    // ---- mel filterbank + log --------------------------------------------------------------------------
+    float* dst = feats + ((size_t)b * T_max + t) * NMEL;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = lane + 64 * i;
+        if (m < NMEL && t < T_max) {
+            float acc = 0.f;
+            if (live) {
+                const int lo = mel_lo[m], hi = mel_hi[m];
+                for (int k = lo; k < hi; ++k) acc = fmaf(melw[m * NBIN + k], P[k], acc);
+                acc = logf(fmaxf(acc, 1.1920928955078125e-07f));
+            }
+            dst[m] = acc;
+        }
+    }
+}
+
+template <class ST>
+static void launch_fbank_t(const ST* pcm, const int* nsamp, int B, int n_max, int use_db, float target_db,
+                           const float* window, const float* melw, const int* mel_lo, const int* mel_hi,
+                           const float* tw256, const float* tw512, float* feats, int T_max, float* gain_scratch,
+                           int16_t* norm_out, hipStream_t s) {
+    if (use_db)
+        hipLaunchKernelGGL(rms_gain_kernel<ST>, dim3(B), dim3(256), 0, s, pcm, nsamp, n_max, target_db, gain_scratch);
+    if (norm_out)
+        hipLaunchKernelGGL(norm_int16_kernel<ST>, dim3((n_max + 255) / 256, B), dim3(256), 0, s, pcm, nsamp, n_max,
+                           gain_scratch, use_db, norm_out);
+    if (T_max > 0)
+        hipLaunchKernelGGL(fbank_kernel<ST>, dim3((T_max + 3) / 4, B), dim3(256), 0, s, pcm, nsamp, n_max, use_db,
+                           gain_scratch, window, melw, mel_lo, mel_hi, tw256, tw512, feats, T_max);
+}
+
+void launch_fbank(const void* pcm, int sample_format, const int* nsamp, int B, int n_max, int use_db, float target_db,
+                  const float* window, const float* melw, const int* mel_lo, const int* mel_hi, const float* tw256,
+                  const float* tw512, float* feats, int T_max, float* gain_scratch, int16_t* norm_out, hipStream_t s) {
+    if (B <= 0) return;
+    if (sample_format == 0)
+        launch_fbank_t((const int16_t*)pcm, nsamp, B, n_max, use_db, target_db, window, melw, mel_lo, mel_hi, tw256,
+                       tw512, feats, T_max, gain_scratch, norm_out, s);
+    else
+        launch_fbank_t((const float*)pcm, nsamp, B, n_max, use_db, target_db, window, melw, mel_lo, mel_hi, tw256,
+                       tw512, feats, T_max, gain_scratch, norm_out, s);
+}
+
+}  // namespace masr

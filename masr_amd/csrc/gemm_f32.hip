@@ -1,0 +1,232 @@
+// fp32 GEMM on the CDNA4 matrix cores: C[M,N] = epilogue(A[M,K] * W[N,K]^T).
+//
+// * v_mfma_f32_32x32x2_f32 (exact fp32, == an fmaf chain): the reference computes this path in
+//   fp32 (torch Linear / Conv on CPU), north_star asks for 1e-3 fp32 logit parity.
+// * 256 threads = 4 wave64 per workgroup, WM x WN wave grid, each wave owns TM x TN tiles of 32x32.
+// * K is consumed in BK=32 slabs, register-staged global->LDS with one barrier per slab
+//   (double-buffered LDS).  LDS rows are padded to 36 floats so the ds_read_b128 fragment reads
+//   (row = lane&31, 16-byte column = lane>>5) are bank-conflict free (row stride 144 B = 9 slots).
+// * Fragment trick: MFMA sums over k in any order, so lane half h=(lane>>5) takes the 4 consecutive
+//   k values {8g+4h .. 8g+4h+3} of each 8-wide k group with ONE 16-byte LDS read for A and for W.
+// * A operand modes: plain row-major, or implicit-GEMM gather for the 3x3/stride-2 subsampling
+//   conv over channels-last activations (reference conformer/subsampling.py:86-110).
+// * Epilogues: bias, ReLU/SiLU, alpha, residual, row masking; or GLU (conformer/convolution.py:118).
+#include "common.h"
+
+namespace masr {
+
+static constexpr int BK = 32;
+static constexpr int LDP = 36;   // padded LDS row (floats)
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int AL = BM / 32;   // float4 loads per thread for the A slab
+    constexpr int WL = BN / 32;
+    extern __shared__ __align__(16) float smem[];
+    float* As = smem;                       // [2][BM][LDP]
+    float* Ws = smem + 2 * BM * LDP;        // [2][BN][LDP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: consecutive block ids land on different XCDs (id % 8); give every XCD a
+    // contiguous range of M-tiles so that the W panel and neighbouring A rows stay in that XCD's L2.
+    const int nbm = (p.M + BM - 1) / BM;
+    const int nbn = (p.N + BN - 1) / BN;
+    const int nblk = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = (bid / nbn) * BM;
+    const int bn = (bid % nbn) * BN;
+
+    // ---- per-thread global source pointers ------------------------------------------------
+    const int lrow = tid >> 3;          // 0..31
+    const int lc4 = (tid & 7) * 4;      // float offset inside the 32-wide slab
+    const float* aptr[AL];
+    bool aok[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int m = bm + lrow + 32 * i;
+        aok[i] = m < p.M;
+        const int mm = aok[i] ? m : 0;
+        if (AMODE == A_PLAIN) {
+            aptr[i] = p.A + (size_t)mm * p.lda + lc4;
+        } else {
+            const int f2 = mm % p.F2;
+            const int bt = mm / p.F2;
+            const int t2 = bt % p.T2;
+            const int b = bt / p.T2;
+            aptr[i] = p.A + (((size_t)b * p.T1 + 2 * t2) * p.F1 + 2 * f2) * p.Cc + lc4;
+        }
+    }
+    const float* wptr[WL];
+    bool wok[WL];
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+        const int n = bn + lrow + 32 * i;
+        wok[i] = n < p.N;
+        wptr[i] = p.W + (size_t)(wok[i] ? n : 0) * p.K + lc4;
+    }
+
+    f32x4 areg[AL], wreg[WL];
+    auto load_slab = [&](int kt) {
+        size_t aoff;
+        if (AMODE == A_PLAIN) {
+            aoff = (size_t)kt * BK;
+        } else {
+            const int kseg = 3 * p.Cc;            // one kh row of the 3x3 window: (kw, c) contiguous
+            const int k0 = kt * BK;
+            const int kh = k0 / kseg;
+            aoff = (size_t)kh * p.F1 * p.Cc + (k0 - kh * kseg);
+        }
+#pragma unroll
+        for (int i = 0; i < AL; ++i)
+            areg[i] = aok[i] ? *reinterpret_cast<const f32x4*>(aptr[i] + aoff) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < WL; ++i)
+            wreg[i] = wok[i] ? *reinterpret_cast<const f32x4*>(wptr[i] + (size_t)kt * BK) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AL; ++i)
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDP + lc4]) = areg[i];
+#pragma unroll
+        for (int i = 0; i < WL; ++i)
+            *reinterpret_cast<f32x4*>(&Ws[(buf * BN + lrow + 32 * i) * LDP + lc4]) = wreg[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int KT = p.K / BK;
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+
+    const int frow = lane & 31;
+    const int fcol = (lane >> 5) * 4;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_slab(kt + 1);
+        const float* Ab = &As[(buf * BM + wm * (BM / WM) + frow) * LDP + fcol];
+        const float* Wb = &Ws[(buf * BN + wn * (BN / WN) + frow) * LDP + fcol];
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            f32x4 af[TM], wf[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) af[m] = *reinterpret_cast<const f32x4*>(Ab + m * 32 * LDP + g * 8);
+#pragma unroll
+            for (int n = 0; n < TN; ++n) wf[n] = *reinterpret_cast<const f32x4*>(Wb + n * 32 * LDP + g * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][s], wf[n][s], acc[m][n], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    const int ccol = lane & 31;
+    const int rbase = 4 * (lane >> 5);
+    if (EPI == EPI_STD) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = bn + wn * (BN / WN) + n * 32 + ccol;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = bm + wm * (BM / WM) + m * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (row >= p.M) continue;
+                    float v = acc[m][n][r] + bv;
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ACT_SILU) v = silu_f(v);
+                    if (p.mask_tp > 0) {
+                        const int b = row / p.mask_tp, t = row - b * p.mask_tp;
+                        if (4 * t >= p.lens[b]) v = 0.f;
+                    }
+                    v *= p.alpha;
+                    if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                    p.C[(size_t)row * p.ldc + col] = v;
+                }
+            }
+        }
+    } else {
+        // GLU: W rows were permuted at load time so that tile n=0 holds the value channels and
+        // n=1 the matching gate channels of this wave (see engine.cpp: permute_glu).
+        static_assert(EPI != EPI_GLU || (TN == 2 && BN == 128 && WN == 2), "GLU tiling");
+        const int pc = bn + wn * 64 + ccol;              // permuted column of the value half
+        const int ch = (bn / 128) * 64 + wn * 32 + ccol; // output channel
+        if (pc + 32 < p.N) {
+            const float bva = p.bias ? p.bias[pc] : 0.f;
+            const float bvg = p.bias ? p.bias[pc + 32] : 0.f;
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = bm + wm * (BM / WM) + m * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (row >= p.M) continue;
+                    const float a = acc[m][0][r] + bva;
+                    const float g = acc[m][TN - 1][r] + bvg;
+                    p.C[(size_t)row * p.ldc + ch] = a * sigmoid_f(g);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+static void launch_t(const GemmArgs& a, hipStream_t s) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
+    auto k = gemm_f32_kernel<BM, BN, WM, WN, AMODE, EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(nbm * nbn), dim3(256), lds, s, a);
+}
+
+void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return;
+    if (epi == EPI_GLU) {
+        launch_t<128, 128, 2, 2, A_PLAIN, EPI_GLU>(a, s);
+        return;
+    }
+    if (amode == A_CONV2) {
+        launch_t<128, 128, 2, 2, A_CONV2, EPI_STD>(a, s);
+        return;
+    }
+    // Tile choice: fill >= 256 CUs.  128x128 when that already yields enough workgroups,
+    // otherwise 64x128 / 64x64 (N = 256 projections at M = B*T' ~ 8k rows).
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+    if (t128 >= 384) launch_t<128, 128, 2, 2, A_PLAIN, EPI_STD>(a, s);
+    else if (t64 >= 200) launch_t<64, 128, 2, 2, A_PLAIN, EPI_STD>(a, s);
+    else launch_t<64, 64, 2, 2, A_PLAIN, EPI_STD>(a, s);
+}
+
+}  // namespace masr

@@ -1,0 +1,64 @@
+"""AudioFeaturizer with the reference's constructor / ``featurize`` contract
+(masr/data_utils/featurizer/audio_featurizer.py:21-69), computed by the batched HIP front-end
+(masr_fbank_batch): dB normalisation, int16 truncation and Kaldi fbank all run on the GPU.
+"""
+import numpy as np
+import torch
+
+from masr_amd import runtime
+
+
+class AudioFeaturizer(object):
+    def __init__(self, feature_method='fbank', n_mels=80, n_mfcc=40, sample_rate=16000, use_dB_normalization=True,
+                 target_dB=-20, train=False):
+        if feature_method != 'fbank':
+            raise Exception('没有{}预处理方法'.format(feature_method) + ' (the MI355X path implements fbank only)')
+        if n_mels != 80 or sample_rate != 16000:
+            raise Exception('the MI355X fbank kernel is built for 80 mel bins @ 16 kHz')
+        self._feature_method = feature_method
+        self._target_sample_rate = sample_rate
+        self._n_mels = n_mels
+        self._n_mfcc = n_mfcc
+        self._use_dB_normalization = use_dB_normalization
+        self._target_dB = target_dB
+        self._train = train
+        self._engine = None
+
+    def bind(self, engine):
+        """Use a model engine's stream / device instead of the shared weight-less one."""
+        self._engine = engine
+
+    def _eng(self):
+        return self._engine if self._engine is not None else runtime.aux_engine()
+
+    def featurize(self, audio_segment):
+        """AudioSegment -> np.float32 [T, 80].  Like the reference, this mutates the segment
+        (resample, dB gain applied in place)."""
+        if audio_segment.sample_rate != self._target_sample_rate:
+            audio_segment.resample(self._target_sample_rate)
+        eng = self._eng()
+        x = audio_segment._samples
+        n = x.shape[0]
+        if n < 400:
+            if self._use_dB_normalization and n > 0:
+                self._normalize_only(eng, audio_segment)
+            return np.zeros((0, self._n_mels), np.float32)
+        xs = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None].to(eng.device)
+        ns = torch.tensor([n], dtype=torch.int32, device=eng.device)
+        feats, frames, gain = eng.fbank_batch(xs, ns, self._use_dB_normalization, self._target_dB, return_gain=True)
+        if self._use_dB_normalization:
+            g = float(gain[0])
+            if not np.isfinite(g) or 20.0 * np.log10(max(g, 1e-300)) > 300.0:
+                raise ValueError(f"无法将段规范化到{self._target_dB}dB，音频增益已经超过max_gain_db (300dB)")
+            audio_segment.gain_linear(g)          # the reference normalises in place (audio.py:304)
+        return feats[0].cpu().numpy()
+
+    def _normalize_only(self, eng, seg):
+        xs = torch.from_numpy(np.ascontiguousarray(seg._samples, dtype=np.float32))[None].to(eng.device)
+        ns = torch.tensor([xs.shape[1]], dtype=torch.int32, device=eng.device)
+        _, _, gain = eng.fbank_batch(xs, ns, True, self._target_dB, return_gain=True)
+        seg.gain_linear(float(gain[0]))
+
+    @property
+    def feature_dim(self):
+        return self._n_mels

@@ -1,0 +1,224 @@
+"""Python handle on the HIP engine (libmasr_hip.so).  torch is used only for device memory,
+streams and host<->device copies; all arithmetic of the hot path runs in the HIP kernels."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MasrConfig, check
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def positional_table(max_len, d):
+    """Same torch ops as the reference (conformer/embedding.py:31-37) -> bit-identical table."""
+    pe = torch.zeros(max_len, d)
+    pos = torch.arange(0, max_len, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def subsampled_len(t):
+    return ((t - 1) // 2 - 1) // 2
+
+
+class HipEngine:
+    """One engine per GPU rank.  ``state_dict`` uses the reference key names
+    (``encoder.*`` / ``ctc.*``; extra keys are ignored); ``state_dict=None`` gives a weight-less
+    engine that can run the model-independent kernels (fbank, argmax, CTC collapse)."""
+
+    def __init__(self, state_dict, encoder_conf=None, vocab_size=None, streaming=True, n_mels=80, device=0,
+                 max_pos=5000):
+        if not torch.cuda.is_available():
+            raise _lib.MasrError('no HIP device visible to torch: the MI355X engine has no CPU fallback')
+        self.lib = _lib.lib()
+        enc = dict(encoder_conf or {})
+        if vocab_size is None:
+            vocab_size = int(state_dict['ctc.ctc_lo.weight'].shape[0]) if state_dict is not None else 1
+        self.device = torch.device('cuda', device)
+        torch.cuda.set_device(self.device)
+        cfg = MasrConfig(model_kind=0, d_model=int(enc.get('output_size', 256)),
+                         heads=int(enc.get('attention_heads', 4)), d_ff=int(enc.get('linear_units', 2048)),
+                         num_blocks=int(enc.get('num_blocks', 12)), cnn_kernel=int(enc.get('cnn_module_kernel', 15)),
+                         n_mels=n_mels, vocab_size=int(vocab_size), causal=1 if streaming else 0, max_pos=max_pos,
+                         device_id=device)
+        self.cfg = cfg
+        self.d_model, self.vocab_size, self.n_mels = cfg.d_model, cfg.vocab_size, n_mels
+        self.num_blocks, self.heads, self.cnn_kernel = cfg.num_blocks, cfg.heads, cfg.cnn_kernel
+        h = C.c_void_p()
+        check(self.lib.masr_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.has_weights = state_dict is not None
+        if state_dict is None:      # weight-less engine: fbank / argmax / collapse kernels only
+            return
+        for name, t in state_dict.items():
+            if not (name.startswith('encoder.') or name.startswith('ctc.')):
+                continue
+            self._load(name, t)
+        self._load('__pos_table__', positional_table(max_pos, cfg.d_model))
+        check(self.lib.masr_finalize(self.h, _stream()))
+
+    def _load(self, name, t):
+        a = np.ascontiguousarray(t.detach().cpu().float().numpy())
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        check(self.lib.masr_load_tensor(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+
+    def close(self):
+        if getattr(self, 'h', None):
+            torch.cuda.synchronize()
+            self.lib.masr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- features -------------------------------------------------------------------------------
+    def fbank_batch(self, samples, n_samples, use_db_normalization=True, target_db=-20.0, return_norm=False,
+                    return_gain=False):
+        """samples int16 PCM or float32 [B, n_max] (device), n_samples int32 [B] (device)
+        -> feats [B,T,80], frames [B] (+ normalised int16 samples, + linear gains)."""
+        B, n_max = samples.shape
+        fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
+        T = 1 + (n_max - 400) // 160 if n_max >= 400 else 0
+        feats = torch.empty(B, T, self.n_mels, dtype=torch.float32, device=self.device)
+        frames = torch.empty(B, dtype=torch.int32, device=self.device)
+        norm = torch.empty(B, n_max, dtype=torch.int16, device=self.device) if return_norm else None
+        gain = torch.ones(B, dtype=torch.float32, device=self.device) if return_gain else None
+        check(self.lib.masr_fbank_batch(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max,
+                                        1 if use_db_normalization else 0, float(target_db), _ptr(feats), _ptr(frames),
+                                        _ptr(norm), _ptr(gain), _stream()))
+        res = [feats, frames]
+        if return_norm:
+            res.append(norm)
+        if return_gain:
+            res.append(gain)
+        return tuple(res)
+
+    # ---- encoder ----------------------------------------------------------------------------------
+    def encode_full(self, feats, lens, decoding_chunk_size=-1):
+        """feats f32 [B,T,80] (device, zero padded), lens int32 [B] (device) -> enc [B,T',d]."""
+        B, T, _ = feats.shape
+        Tp = subsampled_len(T)
+        enc = torch.empty(B, Tp, self.d_model, dtype=torch.float32, device=self.device)
+        check(self.lib.masr_encode_full(self.h, _ptr(feats), _ptr(lens), B, T, int(decoding_chunk_size), _ptr(enc),
+                                        _stream()))
+        return enc
+
+    def ctc_probs(self, enc, want_argmax=False):
+        M = enc.numel() // self.d_model
+        probs = torch.empty(*enc.shape[:-1], self.vocab_size, dtype=torch.float32, device=self.device)
+        idx = torch.empty(M, dtype=torch.int32, device=self.device) if want_argmax else None
+        mp = torch.empty(M, dtype=torch.float32, device=self.device) if want_argmax else None
+        check(self.lib.masr_ctc_probs(self.h, _ptr(enc), M, _ptr(probs), _ptr(idx), _ptr(mp), _stream()))
+        return (probs, idx, mp) if want_argmax else probs
+
+    def ctc_greedy_frames(self, enc):
+        M = enc.numel() // self.d_model
+        idx = torch.empty(enc.shape[:-1], dtype=torch.int32, device=self.device)
+        mp = torch.empty(enc.shape[:-1], dtype=torch.float32, device=self.device)
+        check(self.lib.masr_ctc_greedy_frames(self.h, _ptr(enc), M, _ptr(idx), _ptr(mp), _stream()))
+        return idx, mp
+
+    def ctc_collapse(self, idx, maxp, n_frames=None, blank=0):
+        B, Tp = idx.shape
+        tokens = torch.empty(B, Tp, dtype=torch.int32, device=self.device)
+        ntok = torch.empty(B, dtype=torch.int32, device=self.device)
+        score = torch.empty(B, dtype=torch.float32, device=self.device)
+        check(self.lib.masr_ctc_collapse(self.h, _ptr(idx), _ptr(maxp), _ptr(n_frames), B, Tp, blank, _ptr(tokens),
+                                         _ptr(ntok), _ptr(score), _stream()))
+        return tokens, ntok, score
+
+    def argmax_rows(self, probs):
+        M, V = probs.shape
+        idx = torch.empty(M, dtype=torch.int32, device=self.device)
+        mp = torch.empty(M, dtype=torch.float32, device=self.device)
+        check(self.lib.masr_argmax_rows(self.h, _ptr(probs), M, V, _ptr(idx), _ptr(mp), _stream()))
+        return idx, mp
+
+    def transcribe_batch(self, pcm, n_samples, use_db_normalization=True, target_db=-20.0, decode_all_frames=False,
+                         out=None):
+        """Whole offline hot path in one call, no host sync: PCM -> token ids."""
+        B, n_max = pcm.shape
+        Tp = subsampled_len(1 + (n_max - 400) // 160)
+        if out is None:
+            out = (torch.empty(B, Tp, dtype=torch.int32, device=self.device),
+                   torch.empty(B, dtype=torch.int32, device=self.device),
+                   torch.empty(B, dtype=torch.float32, device=self.device))
+        tokens, ntok, score = out
+        check(self.lib.masr_transcribe_batch(self.h, _ptr(pcm), _ptr(n_samples), B, n_max,
+                                             1 if use_db_normalization else 0, float(target_db),
+                                             1 if decode_all_frames else 0, _ptr(tokens), _ptr(ntok), _ptr(score),
+                                             _stream()))
+        return tokens, ntok, score
+
+    # ---- streaming ----------------------------------------------------------------------------------
+    def stream_open(self, max_frames_out=0):
+        sid = C.c_int32()
+        check(self.lib.masr_stream_open(self.h, int(max_frames_out), C.byref(sid)))
+        return sid.value
+
+    def stream_reset(self, sid):
+        check(self.lib.masr_stream_reset(self.h, sid))
+
+    def stream_close(self, sid):
+        check(self.lib.masr_stream_close(self.h, sid))
+
+    def stream_offset(self, sid):
+        off = C.c_int32()
+        check(self.lib.masr_stream_offset(self.h, sid, C.byref(off)))
+        return off.value
+
+    def encode_chunk(self, stream_ids, feats, want_probs=True, want_argmax=False):
+        """feats f32 [n, Tc, 80] (device) -> probs [n, Tc', V] (+ argmax/maxprob [n, Tc'])."""
+        n, Tc, _ = feats.shape
+        Tq = subsampled_len(Tc)
+        ids = (C.c_int32 * n)(*stream_ids)
+        probs = torch.empty(n, Tq, self.vocab_size, dtype=torch.float32, device=self.device) if want_probs else None
+        idx = torch.empty(n, Tq, dtype=torch.int32, device=self.device) if want_argmax else None
+        mp = torch.empty(n, Tq, dtype=torch.float32, device=self.device) if want_argmax else None
+        check(self.lib.masr_encode_chunk(self.h, ids, n, _ptr(feats), Tc, _ptr(probs), _ptr(idx), _ptr(mp), _stream()))
+        return probs, idx, mp
+
+    def stream_export_cache(self, sid):
+        t = self.stream_offset(sid)
+        dk = self.d_model // self.heads
+        att = torch.zeros(self.num_blocks, self.heads, t, 2 * dk, dtype=torch.float32, device=self.device)
+        cnn = torch.zeros(self.num_blocks, 1, self.d_model, self.cnn_kernel - 1, dtype=torch.float32, device=self.device)
+        check(self.lib.masr_stream_export_cache(self.h, sid, _ptr(att), _ptr(cnn), _stream()))
+        return att, cnn
+
+    # ---- single ops / profiling -----------------------------------------------------------------------
+    def op_layernorm(self, x, w, b, eps=1e-5):
+        y = torch.empty_like(x)
+        check(self.lib.masr_op_layernorm(self.h, _ptr(x), _ptr(w), _ptr(b), _ptr(y), x.numel() // x.shape[-1],
+                                         float(eps), _stream()))
+        return y
+
+    def op_gemm(self, a, w, bias=None, res=None, act=0, alpha=1.0):
+        M, K = a.shape
+        N = w.shape[0]
+        c = torch.empty(M, N, dtype=torch.float32, device=self.device)
+        check(self.lib.masr_op_gemm(self.h, _ptr(a), _ptr(w), _ptr(bias), _ptr(res), _ptr(c), M, N, K, int(act),
+                                    float(alpha), _stream()))
+        return c
+
+    def profile_select(self, kind):
+        check(self.lib.masr_profile_select(self.h, int(kind)))
+
+    def profile_read(self, reset=True):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        check(self.lib.masr_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(fl), 1 if reset else 0))
+        return ms.value, n.value, fl.value

@@ -1,0 +1,80 @@
+"""InferencePredictor -- drop-in for masr/infer_utils/inference_predictor.py on the HIP engine.
+
+Same constructor, same four methods, same numpy-in / numpy-out contract and error behaviour
+(:10-15, :52-102).  Instead of ``torch.jit.load(...).to(device)`` the exported artefact is only
+read for its weights: ``inference.pt`` (TorchScript of the whole model, trainer.py:684-689) or
+``model.pt`` (state_dict, trainer.py:308) -> ``state_dict`` -> libmasr_hip.so.
+"""
+import os
+
+import numpy as np
+import torch
+
+from masr_amd.engine import HipEngine
+
+
+def load_state_dict(model_path):
+    """inference.pt (TorchScript) or model.pt (plain state_dict) -> {name: tensor}."""
+    try:
+        m = torch.jit.load(model_path, map_location='cpu')
+        return {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    except RuntimeError:
+        sd = torch.load(model_path, map_location='cpu', weights_only=True)
+        if not isinstance(sd, dict):
+            raise
+        return sd
+
+
+class InferencePredictor:
+    def __init__(self, configs, use_model, streaming=True, model_path='models/conformer_streaming_fbank/inference.pt',
+                 use_gpu=True, state_dict=None):
+        self.configs = configs
+        self.use_gpu = use_gpu
+        self.use_model = use_model
+        self.streaming = streaming
+        if state_dict is None:
+            if not os.path.exists(model_path):
+                raise Exception(f"模型文件不存在，请检查{model_path}是否存在！")
+            state_dict = load_state_dict(model_path)
+        if not use_gpu:
+            raise Exception('masr_amd is the MI355X path: use_gpu=False is not available (no CPU fallback)')
+        assert (torch.cuda.is_available()), 'GPU不可用'
+        if use_model != 'conformer':
+            raise Exception(f'masr_amd implements the conformer encoder; got use_model={use_model}')
+        self.device = torch.device('cuda')
+        enc_conf = dict(configs.get('encoder_conf', {})) if configs is not None else {}
+        n_mels = int(configs.get('preprocess_conf', {}).get('n_mels', 80)) if configs is not None else 80
+        self.engine = HipEngine(state_dict, encoder_conf=enc_conf, streaming=streaming, n_mels=n_mels)
+        self._sid = None
+
+    # offline (inference_predictor.py:52-64): probs = softmax(ctc_lo(encoder(speech)))
+    def predict(self, speech, speech_lengths):
+        audio_data = torch.as_tensor(np.asarray(speech), dtype=torch.float32).to(self.device).contiguous()
+        audio_len = torch.as_tensor(np.asarray(speech_lengths)).to(torch.int32).to(self.device).contiguous()
+        enc = self.engine.encode_full(audio_data, audio_len, -1)
+        return self.engine.ctc_probs(enc).cpu().numpy()
+
+    def predict_chunk_deepspeech(self, x_chunk):
+        if not (self.use_model == 'deepspeech2' and self.streaming):
+            raise Exception(f'当前模型不支持该方法，当前模型为：{self.use_model}，参数streaming为：{self.streaming}')
+        raise NotImplementedError
+
+    # streaming (inference_predictor.py:80-94): att_cache / cnn_cache / offset live in the engine
+    def predict_chunk_conformer(self, x_chunk, required_cache_size):
+        if not ('former' in self.use_model and self.streaming):
+            raise Exception(f'当前模型不支持该方法，当前模型为：{self.use_model}，参数streaming为：{self.streaming}')
+        if required_cache_size >= 0:
+            raise Exception('only required_cache_size < 0 (keep all history, predict.py:312-313) is implemented')
+        if self._sid is None:
+            self._sid = self.engine.stream_open(0)
+        x = torch.as_tensor(np.asarray(x_chunk), dtype=torch.float32).to(self.device).contiguous()
+        probs, _, _ = self.engine.encode_chunk([self._sid], x)
+        return probs.cpu().numpy()
+
+    @property
+    def offset(self):
+        return 0 if self._sid is None else self.engine.stream_offset(self._sid)
+
+    def reset_stream(self):
+        if self._sid is not None:
+            self.engine.stream_reset(self._sid)

@@ -1,0 +1,182 @@
+"""MASRPredictor -- the reference facade (masr/predict.py) on the MI355X engine.
+
+Same constructor and ``predict`` / ``predict_stream`` / ``reset_stream`` contract
+(predict.py:20-26,167-171,237-244,346); the three hot components are the HIP-backed mirrors:
+AudioFeaturizer (fbank), InferencePredictor (Conformer encoder + CTC head) and the greedy
+decoders.  ``predict_batch`` is an addition: the whole PCM -> text path for a padded batch in one
+device call (no host round trip of probabilities).
+"""
+import os
+from io import BufferedReader
+
+import numpy as np
+import torch
+import yaml
+
+from masr_amd import SUPPORT_MODEL
+from masr_amd.data_utils.audio import AudioSegment
+from masr_amd.data_utils.featurizer.audio_featurizer import AudioFeaturizer
+from masr_amd.data_utils.featurizer.text_featurizer import TextFeaturizer
+from masr_amd.decoders.ctc_greedy_decoder import greedy_decoder, greedy_decoder_chunk
+from masr_amd.infer_utils.inference_predictor import InferencePredictor
+from masr_amd.utils.utils import dict_to_object
+
+
+class MASRPredictor:
+    def __init__(self, configs=None, model_tag='conformer_streaming_fbank_aishell',
+                 model_path='models/conformer_streaming_fbank/inference.pt', use_pun=False,
+                 pun_model_dir='models/pun_models/', use_gpu=True, state_dict=None):
+        if not configs:
+            raise Exception('no network here: pass `configs` (YAML path or dict) and `model_path` explicitly')
+        if isinstance(configs, str):
+            with open(configs, 'r', encoding='utf-8') as f:
+                configs = yaml.load(f.read(), Loader=yaml.FullLoader)
+        self.configs = dict_to_object(configs)
+        assert self.configs.use_model in SUPPORT_MODEL, f'没有该模型：{self.configs.use_model}'
+        if use_pun:
+            raise Exception('punctuation (PaddleNLP) is outside the hot path and not provided')
+        self.running = False
+        self.use_gpu = use_gpu
+        self._text_featurizer = TextFeaturizer(vocab_filepath=self.configs.dataset_conf.dataset_vocab)
+        self._audio_featurizer = AudioFeaturizer(**self.configs.preprocess_conf)
+        # streaming decode state (predict.py:69-73)
+        self.remained_wav = None
+        self.cached_feat = None
+        self.greedy_last_max_prob_list = None
+        self.greedy_last_max_index_list = None
+        if self.configs.decoder == 'ctc_beam_search':
+            # same degradation as the reference when paddlespeech_ctcdecoders is missing (predict.py:103-109)
+            import logging
+            logging.getLogger(__name__).warning('ctc_beam_search is not available on this path yet; using ctc_greedy')
+            self.configs.decoder = 'ctc_greedy'
+        if state_dict is None and not os.path.exists(model_path):
+            raise Exception("模型文件不存在，请检查{}是否存在！".format(model_path))
+        self.predictor = InferencePredictor(configs=self.configs, use_model=self.configs.use_model,
+                                            streaming=self.configs.streaming, model_path=model_path,
+                                            use_gpu=self.use_gpu, state_dict=state_dict)
+        self._audio_featurizer.bind(self.predictor.engine)
+        # warm-up like the reference (predict.py:89-92)
+        warmup_audio = np.random.uniform(low=-2.0, high=2.0, size=(134240,))
+        self.predict(audio_data=warmup_audio, is_itn=False)
+        self.reset_stream()
+
+    def decode(self, output_data, use_pun, is_itn):
+        """predict.py:118-144 (greedy branch)."""
+        score, text = greedy_decoder(probs_seq=output_data, vocabulary=self._text_featurizer.vocab_list)
+        if is_itn:
+            raise Exception('inverse text normalisation (WeTextProcessing) is outside the hot path')
+        return score, text
+
+    @staticmethod
+    def _load_audio(audio_data, sample_rate=16000):
+        """predict.py:146-164."""
+        if isinstance(audio_data, str):
+            return AudioSegment.from_file(audio_data)
+        elif isinstance(audio_data, BufferedReader):
+            return AudioSegment.from_file(audio_data)
+        elif isinstance(audio_data, np.ndarray):
+            return AudioSegment.from_ndarray(audio_data, sample_rate)
+        elif isinstance(audio_data, bytes):
+            return AudioSegment.from_bytes(audio_data)
+        raise Exception(f'不支持该数据类型，当前数据类型为：{type(audio_data)}')
+
+    def predict(self, audio_data, use_pun=False, is_itn=False, sample_rate=16000):
+        """predict.py:167-192: one utterance -> {'text', 'score'}."""
+        audio_segment = self._load_audio(audio_data=audio_data, sample_rate=sample_rate)
+        audio_feature = self._audio_featurizer.featurize(audio_segment)
+        input_data = np.array(audio_feature).astype(np.float32)[np.newaxis, :]
+        audio_len = np.array([input_data.shape[1]]).astype(np.int64)
+        output_data = self.predictor.predict(input_data, audio_len)[0]
+        score, text = self.decode(output_data=output_data, use_pun=use_pun, is_itn=is_itn)
+        return {'text': text, 'score': score}
+
+    def predict_batch(self, audio_list, sample_rate=16000, decode_all_frames=False):
+        """Batched offline path on the device: padded int16/float PCM -> fbank -> encoder -> greedy
+        in ONE library call.  Returns [{'text','score'}].  ``decode_all_frames=True`` reproduces
+        the reference's batch evaluation quirk of decoding padded frames (trainer.py:340)."""
+        eng = self.predictor.engine
+        segs = [self._load_audio(a, sample_rate) for a in audio_list]
+        for s in segs:
+            if s.sample_rate != 16000:
+                s.resample(16000)
+        n = np.array([s.num_samples for s in segs], np.int32)
+        buf = np.zeros((len(segs), int(n.max())), np.float32)
+        for i, s in enumerate(segs):
+            buf[i, :n[i]] = s._samples
+        xs = torch.from_numpy(buf).to(eng.device)
+        ns = torch.from_numpy(n).to(eng.device)
+        pc = self.configs.preprocess_conf
+        feats, frames = eng.fbank_batch(xs, ns, pc.use_dB_normalization, pc.target_dB)
+        enc = eng.encode_full(feats, frames, -1)
+        idx, mp = eng.ctc_greedy_frames(enc)
+        nenc = None if decode_all_frames else (((frames - 1) // 2 - 1) // 2).clamp(min=0).to(torch.int32)
+        tok, ntok, score = eng.ctc_collapse(idx, mp, nenc)
+        tok, ntok, score = tok.cpu().numpy(), ntok.cpu().numpy(), score.cpu().numpy()
+        vocab = self._text_featurizer.vocab_list
+        out = []
+        for i in range(len(segs)):
+            text = ''.join(vocab[j] for j in tok[i, :ntok[i]]).replace('<space>', ' ')
+            out.append({'text': text, 'score': float(score[i]) * 100.0 if ntok[i] > 0 or score[i] > 0 else 0})
+        return out
+
+    def predict_stream(self, audio_data, is_end=False, use_pun=False, is_itn=False, channels=1, samp_width=2,
+                       sample_rate=16000):
+        """predict.py:237-343: feed raw PCM bytes / ndarray chunks, get the transcript so far."""
+        if not self.configs.streaming:
+            raise Exception(f"不支持改该模型流式识别，当前模型：{self.configs.use_model}，参数streaming为：{self.configs.streaming}")
+        if isinstance(audio_data, np.ndarray):
+            audio_data = AudioSegment.from_ndarray(audio_data, sample_rate)
+        elif isinstance(audio_data, bytes):
+            audio_data = AudioSegment.from_pcm_bytes(audio_data, channels=channels, samp_width=samp_width,
+                                                     sample_rate=sample_rate)
+        else:
+            raise Exception(f'不支持该数据类型，当前数据类型为：{type(audio_data)}')
+        if self.remained_wav is None:
+            self.remained_wav = audio_data
+        else:
+            self.remained_wav = AudioSegment(np.concatenate([self.remained_wav.samples, audio_data.samples]),
+                                             audio_data.sample_rate)
+        # featurize everything not yet turned into frames; NB this re-normalises the carried-over
+        # samples in place on every call, exactly like the reference (predict.py:274, audio.py:304)
+        x_chunk = self._audio_featurizer.featurize(self.remained_wav)
+        x_chunk = np.array(x_chunk).astype(np.float32)[np.newaxis, :]
+        if self.cached_feat is None:
+            self.cached_feat = x_chunk
+        else:
+            self.cached_feat = np.concatenate([self.cached_feat, x_chunk], axis=1)
+        self.remained_wav._samples = self.remained_wav.samples[160 * x_chunk.shape[1]:]
+
+        decoding_chunk_size, context, subsampling = 16, 7, 4
+        cached_feature_num = context - subsampling                           # 3 frames of overlap
+        decoding_window = (decoding_chunk_size - 1) * subsampling + context  # 67
+        stride = subsampling * decoding_chunk_size                           # 64
+        num_frames = self.cached_feat.shape[1]
+        if num_frames < decoding_window and not is_end:
+            return None
+        if num_frames < context:
+            return None
+        left_frames = context if is_end else decoding_window
+        score, text, end = None, None, None
+        for cur in range(0, num_frames - left_frames + 1, stride):
+            end = min(cur + decoding_window, num_frames)
+            x_chunk = self.cached_feat[:, cur:end, :]
+            num_decoding_left_chunks = -1
+            required_cache_size = decoding_chunk_size * num_decoding_left_chunks
+            output_chunk_probs = self.predictor.predict_chunk_conformer(x_chunk=x_chunk,
+                                                                        required_cache_size=required_cache_size)
+            score, text, self.greedy_last_max_prob_list, self.greedy_last_max_index_list = \
+                greedy_decoder_chunk(probs_seq=output_chunk_probs[0], vocabulary=self._text_featurizer.vocab_list,
+                                     last_max_index_list=self.greedy_last_max_index_list,
+                                     last_max_prob_list=self.greedy_last_max_prob_list)
+        self.cached_feat = self.cached_feat[:, end - cached_feature_num:, :]
+        if is_itn:
+            raise Exception('inverse text normalisation (WeTextProcessing) is outside the hot path')
+        return {'text': text, 'score': score}
+
+    def reset_stream(self):
+        """predict.py:346-353."""
+        self.predictor.reset_stream()
+        self.remained_wav = None
+        self.cached_feat = None
+        self.greedy_last_max_prob_list = None
+        self.greedy_last_max_index_list = None

@@ -1,89 +1,7 @@
-"""TEST INFRASTRUCTURE ONLY -- deterministic synthetic checkpoints.
+"""TEST INFRASTRUCTURE ONLY -- synthetic checkpoints for the oracle side.
 
-The reference ships no weights (checkpoints are a separate download), so parity
-is pinned on synthetic ``state_dict``s whose key names / shapes are exactly the
-reference's (``ConformerModel.state_dict()``, layout listed in SURVEY.md 3.5;
-builder ``masr/trainer.py:167-203``).  Generation depends only on numpy so the
-same tensors can be rebuilt on the GPU box without ``/root/reference``.
+The generator itself is plain numpy (no hot-path arithmetic) and lives in
+``masr_amd/utils/synthetic.py`` so that ``bench.py`` can build random-init weights without
+importing the oracle; it is re-exported here for the tests and ``make_golden.py``.
 """
-import math
-import zlib
-
-import numpy as np
-import torch
-
-
-def _rng(seed, name):
-    return np.random.default_rng([seed, zlib.crc32(name.encode())])
-
-
-def _uniform(seed, name, shape, bound):
-    return torch.from_numpy(_rng(seed, name).uniform(-bound, bound, shape).astype(np.float32))
-
-
-def conformer_state_dict(seed=0, vocab_size=4233, d=256, heads=4, d_ff=2048, num_blocks=12,
-                         kernel=15, n_mels=80, ctc_gain=6.0):
-    """Keys/shapes == reference ``encoder.*`` + ``ctc.*`` entries (attention-decoder
-    ``decoder.*`` entries are never used by get_encoder_out*, model.py:152-190)."""
-    sd = {}
-    f2 = ((n_mels - 1) // 2 - 1) // 2
-
-    def lin(name, out_f, in_f, bias=True, gain=1.0):
-        b = gain / math.sqrt(in_f)
-        sd[name + '.weight'] = _uniform(seed, name + '.weight', (out_f, in_f), b * math.sqrt(3.0))
-        if bias:
-            sd[name + '.bias'] = _uniform(seed, name + '.bias', (out_f,), 0.1)
-
-    def ln(name, n=d):
-        sd[name + '.weight'] = 1.0 + _uniform(seed, name + '.weight', (n,), 0.2)
-        sd[name + '.bias'] = _uniform(seed, name + '.bias', (n,), 0.1)
-
-    sd['encoder.global_cmvn.mean'] = 13.5 + _uniform(seed, 'cmvn.mean', (n_mels,), 1.0)
-    sd['encoder.global_cmvn.istd'] = 0.3 + _uniform(seed, 'cmvn.istd', (n_mels,), 0.05)
-    sd['encoder.embed.conv.0.weight'] = _uniform(seed, 'conv0.w', (d, 1, 3, 3), math.sqrt(3.0 / 9))
-    sd['encoder.embed.conv.0.bias'] = _uniform(seed, 'conv0.b', (d,), 0.1)
-    sd['encoder.embed.conv.2.weight'] = _uniform(seed, 'conv2.w', (d, d, 3, 3), math.sqrt(3.0 / (9 * d)))
-    sd['encoder.embed.conv.2.bias'] = _uniform(seed, 'conv2.b', (d,), 0.1)
-    lin('encoder.embed.out.0', d, d * f2)
-    for i in range(num_blocks):
-        p = f'encoder.encoders.{i}.'
-        for q in ('linear_q', 'linear_k', 'linear_v', 'linear_out'):
-            lin(p + 'self_attn.' + q, d, d)
-        lin(p + 'self_attn.linear_pos', d, d, bias=False)
-        sd[p + 'self_attn.pos_bias_u'] = _uniform(seed, p + 'u', (heads, d // heads), 0.3)
-        sd[p + 'self_attn.pos_bias_v'] = _uniform(seed, p + 'v', (heads, d // heads), 0.3)
-        for ff in ('feed_forward', 'feed_forward_macaron'):
-            lin(p + ff + '.w_1', d_ff, d)
-            lin(p + ff + '.w_2', d, d_ff)
-        sd[p + 'conv_module.pointwise_conv1.weight'] = _uniform(seed, p + 'pw1.w', (2 * d, d, 1), math.sqrt(3.0 / d))
-        sd[p + 'conv_module.pointwise_conv1.bias'] = _uniform(seed, p + 'pw1.b', (2 * d,), 0.1)
-        sd[p + 'conv_module.depthwise_conv.weight'] = _uniform(seed, p + 'dw.w', (d, 1, kernel), math.sqrt(3.0 / kernel))
-        sd[p + 'conv_module.depthwise_conv.bias'] = _uniform(seed, p + 'dw.b', (d,), 0.1)
-        ln(p + 'conv_module.norm')
-        sd[p + 'conv_module.pointwise_conv2.weight'] = _uniform(seed, p + 'pw2.w', (d, d, 1), math.sqrt(3.0 / d))
-        sd[p + 'conv_module.pointwise_conv2.bias'] = _uniform(seed, p + 'pw2.b', (d,), 0.1)
-        for n in ('norm_ff', 'norm_mha', 'norm_ff_macaron', 'norm_conv', 'norm_final'):
-            ln(p + n)
-    ln('encoder.after_norm')
-    # sharpened CTC head: with gain 1 the softmax over V is nearly flat and the
-    # greedy argmax is decided by 1e-6 gaps
-    lin('ctc.ctc_lo', vocab_size, d, gain=ctc_gain)
-    return sd
-
-
-def synthetic_vocab(vocab_size=4233):
-    """vocabulary.txt convention of trainer.py:480-488: <blank>, <unk>, tokens..., <eos>."""
-    toks = ['<blank>', '<unk>', '<space>']
-    cp = 0x4E00
-    while len(toks) < vocab_size - 1:
-        toks.append(chr(cp))
-        cp += 1
-    toks.append('<eos>')
-    return toks
-
-
-def synthetic_pcm(batch, n_samples, seed=1234):
-    """BASELINE.md config-2 generator: N(0, 3000) -> rint -> clip -> int16."""
-    rng = np.random.default_rng(seed)
-    x = rng.normal(0, 3000, (batch, n_samples))
-    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+from masr_amd.utils.synthetic import conformer_state_dict, synthetic_pcm, synthetic_vocab  # noqa: F401

@@ -1,0 +1,336 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the committed golden
+fixtures generated from the real reference, and size-independent properties at BASELINE sizes.
+
+Tolerances (north_star): fbank <= 1e-3 in the log domain, encoder / probabilities <= 1e-3 fp32,
+greedy transcript identical, integer outputs bit-exact (up to the documented +-1 LSB gain effect).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def g(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope='module')
+def oracle_mods():
+    from oracle import conformer as oc, decoders as od, fbank as ofb, weights
+    from oracle.make_golden import golden_inputs
+    return oc, od, ofb, weights, golden_inputs
+
+
+@pytest.fixture(scope='module')
+def eng512(oracle_mods):
+    from masr_amd.engine import HipEngine
+    oc, od, ofb, weights, _ = oracle_mods
+    sd = weights.conformer_state_dict(0, 512)
+    e = HipEngine(sd, vocab_size=512)
+    yield e, sd
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def eng4233(oracle_mods):
+    from masr_amd.engine import HipEngine
+    oc, od, ofb, weights, _ = oracle_mods
+    sd = weights.conformer_state_dict(0, 4233)
+    e = HipEngine(sd, vocab_size=4233)
+    yield e, sd
+    e.close()
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+# single kernels
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K,act', [(300, 256, 256, 0), (257, 768, 256, 0), (1000, 2048, 256, 2), (500, 256, 2048, 0),
+                                       (130, 4233, 256, 0), (64, 256, 4864, 1), (7, 512, 64, 0), (8000, 256, 256, 2)])
+def test_gemm_against_fp64(eng512, M, N, K, act):
+    e, _ = eng512
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / np.sqrt(K)
+    b = torch.randn(N, generator=gen)
+    r = torch.randn(M, N, generator=gen)
+    ref = a.double() @ w.double().T + b.double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = ref * torch.sigmoid(ref)
+    ref = r.double() + 0.5 * ref
+    out = e.op_gemm(dev(a), dev(w), dev(b), dev(r), act=act, alpha=0.5).cpu().double()
+    err = (out - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, np.sqrt(K) / 16), f'gemm {M}x{N}x{K} act={act}: max err {err}'
+
+
+def test_layernorm(eng512):
+    e, _ = eng512
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1003, 256, generator=gen) * 3 + 1
+    w = torch.randn(256, generator=gen)
+    b = torch.randn(256, generator=gen)
+    ref = torch.nn.functional.layer_norm(x.double(), (256,), w.double(), b.double(), 1e-5)
+    out = e.op_layernorm(dev(x), dev(w), dev(b)).cpu().double()
+    assert (out - ref).abs().max() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# features
+# ---------------------------------------------------------------------------------------------------
+def test_fbank_testwav_against_reference_fixture(eng512, oracle_mods):
+    e, _ = eng512
+    oc, od, ofb, weights, _ = oracle_mods
+    z = g('testwav.npz')
+    pcm = dev(z['pcm'][None, :])
+    n = dev(np.array([z['pcm'].shape[0]], np.int32))
+    feats, frames, norm = e.fbank_batch(pcm, n, True, -20.0, return_norm=True)
+    assert int(frames[0]) == 837 and feats.shape == (1, 837, 80)
+    mine_i16 = norm[0].cpu().numpy()
+    diff = (mine_i16.astype(np.int32) - z['norm_i16'].astype(np.int32))
+    # integer work: bit-exact against the reference's AudioSegment.normalize + to('int16')
+    assert np.array_equal(mine_i16, z['norm_i16']), f'int16 normalisation: max {np.abs(diff).max()} frac {(diff != 0).mean()}'
+    out = feats[0].cpu().numpy()
+    # the FFT / mel numerics in isolation: oracle fbank (float64) of the SAME int16 samples
+    f64 = ofb.kaldi_fbank(mine_i16, 80, np.float64)
+    assert np.abs(out - f64).max() < 1e-3, np.abs(out - f64).max()
+    assert np.abs(out - z['fbank']).max() < 1e-3, np.abs(out - z['fbank']).max()
+
+
+def test_fbank_ragged_batch(eng512, oracle_mods):
+    e, _ = eng512
+    oc, od, ofb, weights, _ = oracle_mods
+    lens = [16000, 400, 399, 5000, 23456]
+    n_max = max(lens)
+    pcm = weights.synthetic_pcm(len(lens), n_max, seed=11)
+    for i, l in enumerate(lens):
+        pcm[i, l:] = 0
+    feats, frames = e.fbank_batch(dev(pcm), dev(np.array(lens, np.int32)), True, -20.0)
+    feats = feats.cpu().numpy()
+    for i, l in enumerate(lens):
+        T = ofb.num_frames(l)
+        assert int(frames[i]) == T
+        if T:
+            ref, _ = ofb.featurize_pcm16(pcm[i, :l], dtype=np.float64)
+            assert np.abs(feats[i, :T] - ref).max() < 1e-3, (i, np.abs(feats[i, :T] - ref).max())
+        assert np.all(feats[i, T:] == 0.0)          # collate_fn zero padding
+    # without dB normalisation
+    feats2, _ = e.fbank_batch(dev(pcm[:1]), dev(np.array(lens[:1], np.int32)), False, -20.0)
+    ref = ofb.kaldi_fbank(pcm[0, :lens[0]], 80, np.float64)
+    assert np.abs(feats2[0].cpu().numpy()[:ref.shape[0]] - ref).max() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# encoder: golden fixtures of the real reference (B=3, ragged) + oracle
+# ---------------------------------------------------------------------------------------------------
+def test_encoder_full_against_reference_fixture(eng512, oracle_mods):
+    e, sd = eng512
+    oc, od, ofb, weights, golden_inputs = oracle_mods
+    z = g('conformer_v512.npz')
+    feats, lens = golden_inputs()
+    enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1)
+    err = np.abs(enc.cpu().numpy() - z['enc']).max()
+    assert err < 1e-3, f'encoder_out max err {err}'
+    probs = e.ctc_probs(enc).cpu().numpy()
+    perr = np.abs(probs - z['probs']).max()
+    assert perr < 1e-3, f'probs max err {perr}'
+    assert np.abs(probs.sum(-1) - 1).max() < 1e-4
+    # pre-softmax logits (north_star: "logits within 1e-3")
+    with torch.no_grad():
+        ref_logits = oc.ctc_logits(sd, torch.from_numpy(z['enc']))
+        my_logits = oc.ctc_logits(sd, enc.cpu())
+    assert (ref_logits - my_logits).abs().max() < 1e-3
+
+
+def test_encoder_chunk_mask_against_reference_fixture(eng512, oracle_mods):
+    e, sd = eng512
+    _, _, _, _, golden_inputs = oracle_mods
+    z = g('conformer_v512.npz')
+    feats, lens = golden_inputs()
+    enc = e.encode_full(dev(feats), dev(lens, torch.int32), 16)
+    err = np.abs(enc.cpu().numpy() - z['enc16']).max()
+    assert err < 1e-3, f'chunk-16 encoder_out max err {err}'
+
+
+def test_v4233_top4_against_reference_fixture(eng4233, oracle_mods):
+    e, sd = eng4233
+    _, _, _, _, golden_inputs = oracle_mods
+    z = g('conformer_v4233.npz')
+    feats, lens = golden_inputs()
+    enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1)
+    probs, idx, mp = e.ctc_probs(enc, want_argmax=True)
+    top = torch.topk(probs, 4, dim=-1)
+    assert np.abs(top.values.cpu().numpy() - z['top_p']).max() < 1e-3
+    margin = z['top_p'][..., 0] - z['top_p'][..., 1]
+    safe = margin > 2e-3
+    assert (idx.cpu().numpy().reshape(3, -1)[safe] == z['top_i'][..., 0][safe]).all()
+    assert np.abs(mp.cpu().numpy().reshape(3, -1) - z['top_p'][..., 0]).max() < 1e-3
+    idx2, mp2 = e.ctc_greedy_frames(enc)
+    assert torch.equal(idx2.reshape(-1), idx) and torch.allclose(mp2.reshape(-1), mp, atol=1e-6)
+
+
+def test_streaming_chunks_against_reference_fixture(eng512, oracle_mods):
+    e, sd = eng512
+    _, _, _, _, golden_inputs = oracle_mods
+    z = g('conformer_v512.npz')
+    feats, lens = golden_inputs()
+    x = dev(feats[:1])
+    sid = e.stream_open(400)
+    for k, cur in enumerate(range(0, 331 - 67 + 1, 64)):
+        probs, _, _ = e.encode_chunk([sid], x[:, cur:cur + 67].contiguous())
+        err = np.abs(probs[0].cpu().numpy() - z['chunk_probs'][k]).max()
+        assert err < 1e-3, f'chunk {k}: max err {err}'
+    assert e.stream_offset(sid) == int(z['att_shape'][2])
+    att, cnn = e.stream_export_cache(sid)
+    assert list(att.shape) == list(z['att_shape'])
+    assert np.abs(att[:, :, -16:].cpu().numpy() - z['att_tail']).max() < 1e-3
+    assert np.abs(cnn.cpu().numpy() - z['cnn']).max() < 1e-3
+    # reset -> identical first chunk again (reset_stream, inference_predictor.py:97-102)
+    e.stream_reset(sid)
+    probs, _, _ = e.encode_chunk([sid], x[:, 0:67].contiguous())
+    assert np.abs(probs[0].cpu().numpy() - z['chunk_probs'][0]).max() < 1e-3
+    e.stream_close(sid)
+
+
+def test_streaming_multi_stream_lockstep(eng512, oracle_mods):
+    """n streams batched per chunk step == each stream alone (streams are independent)."""
+    e, sd = eng512
+    gen = torch.Generator().manual_seed(9)
+    feats = torch.randn(3, 195, 80, generator=gen) * 3 + 13
+    x = dev(feats)
+    sids = [e.stream_open(200) for _ in range(3)]
+    solo = e.stream_open(200)
+    outs = []
+    for cur in range(0, 195 - 67 + 1, 64):
+        p, _, _ = e.encode_chunk(sids, x[:, cur:cur + 67].contiguous())
+        outs.append(p)
+    for cur_i, cur in enumerate(range(0, 195 - 67 + 1, 64)):
+        p, _, _ = e.encode_chunk([solo], x[1:2, cur:cur + 67].contiguous())
+        assert (p[0] - outs[cur_i][1]).abs().max() < 1e-5
+    for s in sids + [solo]:
+        e.stream_close(s)
+
+
+def test_short_last_chunk(eng512, oracle_mods):
+    """is_end chunks are shorter than 67 frames (predict.py:296-305)."""
+    e, sd = eng512
+    oc, _, _, _, _ = oracle_mods
+    gen = torch.Generator().manual_seed(4)
+    feats = torch.randn(1, 67 + 64 + 23, 80, generator=gen) * 3 + 13
+    sid = e.stream_open(100)
+    att = torch.zeros(0, 0, 0, 0)
+    cnn = torch.zeros(0, 0, 0, 0)
+    off = 0
+    for cur, end in ((0, 67), (64, 131), (128, 154)):
+        ch = feats[:, cur:end]
+        with torch.no_grad():
+            ref, att, cnn = oc.get_encoder_out_chunk(sd, ch, off, -16, att, cnn)
+        off += ref.shape[1]
+        p, _, _ = e.encode_chunk([sid], dev(ch))
+        assert p.shape == ref.shape
+        assert (p.cpu() - ref).abs().max() < 1e-3
+    e.stream_close(sid)
+
+
+# ---------------------------------------------------------------------------------------------------
+# decode
+# ---------------------------------------------------------------------------------------------------
+def test_ctc_collapse_against_oracle(eng512, oracle_mods):
+    e, _ = eng512
+    _, od, _, _, _ = oracle_mods
+    rng = np.random.default_rng(5)
+    B, T, V = 7, 93, 12
+    probs = rng.dirichlet(np.ones(V) * 0.2, size=(B, T)).astype(np.float32)
+    probs[0, :, 0] = 1.0                      # an all-blank utterance -> score 0, empty text
+    vocab = ['<blank>'] + [chr(97 + i) for i in range(V - 1)]
+    idx, mp = e.argmax_rows(dev(probs.reshape(B * T, V)))
+    assert np.array_equal(idx.cpu().numpy().reshape(B, T), probs.argmax(-1))
+    assert np.array_equal(mp.cpu().numpy().reshape(B, T), probs.max(-1))
+    nfr = np.array([T, T, 50, 1, 0, T, 77], np.int32)
+    tok, ntok, score = e.ctc_collapse(idx.reshape(B, T), mp.reshape(B, T), dev(nfr))
+    tok, ntok, score = tok.cpu().numpy(), ntok.cpu().numpy(), score.cpu().numpy()
+    for b in range(B):
+        s_ref, t_ref = od.greedy_decoder(probs[b, :nfr[b]], vocab) if nfr[b] else (0, '')
+        text = ''.join(vocab[i] for i in tok[b, :ntok[b]])
+        assert text == t_ref
+        assert float(score[b]) * 100.0 == s_ref      # bit-identical sequential fp32 mean
+        assert (tok[b, ntok[b]:] == -1).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# end to end + properties at BASELINE size
+# ---------------------------------------------------------------------------------------------------
+def test_transcribe_batch_against_oracle(eng4233, oracle_mods):
+    """Ragged padded batch.  The oracle runs the SAME padded batch (collate_fn zero padding +
+    get_encoder_out, trainer.py:632): the reference's pad mask keeps key j while 4*j < len, i.e.
+    one more key than an utterance has when decoded alone, so batch != single by construction."""
+    e, sd = eng4233
+    oc, od, ofb, weights, _ = oracle_mods
+    lens = [48000, 31000, 16000, 40123]
+    n_max = max(lens)
+    pcm = weights.synthetic_pcm(len(lens), n_max, seed=21)
+    for i, l in enumerate(lens):
+        pcm[i, l:] = 0
+    tok, ntok, score = e.transcribe_batch(dev(pcm), dev(np.array(lens, np.int32)))
+    tok, ntok, score = tok.cpu().numpy(), ntok.cpu().numpy(), score.cpu().numpy()
+    vocab = weights.synthetic_vocab(4233)
+    T = ofb.num_frames(n_max)
+    feats = np.zeros((len(lens), T, 80), np.float32)
+    frames = []
+    for i, l in enumerate(lens):
+        f, _ = ofb.featurize_pcm16(pcm[i, :l])
+        feats[i, :f.shape[0]] = f
+        frames.append(f.shape[0])
+    with torch.no_grad():
+        probs = oc.get_encoder_out(sd, torch.from_numpy(feats), torch.tensor(frames)).numpy()
+    for i in range(len(lens)):
+        n_enc = oc.subsampled_len(frames[i])
+        s_ref, t_ref = od.greedy_decoder(probs[i, :n_enc], vocab)
+        text = ''.join(vocab[j] for j in tok[i, :ntok[i]]).replace('<space>', ' ')
+        top2 = np.sort(probs[i, :n_enc], axis=-1)[:, -2:]
+        if (top2[:, 1] - top2[:, 0]).min() > 2e-3:       # argmax is numerically decided
+            assert text == t_ref, (i, text, t_ref)
+        assert od.cer(t_ref, text) <= 0.05, (i, text, t_ref)
+        assert abs(float(score[i]) * 100.0 - s_ref) < 0.1
+    # decode_all_frames reproduces the reference batch quirk (trainer.py:340: padded frames decoded too)
+    tok2, ntok2, _ = e.transcribe_batch(dev(pcm), dev(np.array(lens, np.int32)), decode_all_frames=True)
+    for i in range(len(lens)):
+        _, t_ref = od.greedy_decoder(probs[i], vocab)
+        text = ''.join(vocab[j] for j in tok2[i, :int(ntok2[i])].cpu().numpy()).replace('<space>', ' ')
+        assert od.cer(t_ref, text) <= 0.05, (i, text, t_ref)
+
+
+def test_baseline_size_properties(eng4233, oracle_mods):
+    """B=32 x 10 s (BASELINE config 2): finite, deterministic, batch-invariant."""
+    e, sd = eng4233
+    oc, od, ofb, weights, _ = oracle_mods
+    pcm = dev(weights.synthetic_pcm(32, 160000, seed=1234))
+    n = dev(np.full(32, 160000, np.int32))
+    t1, n1, s1 = e.transcribe_batch(pcm, n)
+    t2, n2, s2 = e.transcribe_batch(pcm, n)
+    assert torch.equal(t1, t2) and torch.equal(n1, n2) and torch.equal(s1, s2)       # idempotent / deterministic
+    assert torch.isfinite(s1).all() and (n1 >= 0).all() and (n1 <= 248).all()
+    # an utterance decoded alone == the same utterance inside the batch (no cross-utterance math)
+    ta, na, sa = e.transcribe_batch(pcm[5:6].contiguous(), n[5:6].contiguous())
+    assert int(na[0]) == int(n1[5]) and torch.equal(ta[0, :int(na[0])], t1[5, :int(na[0])])
+    assert abs(float(sa[0]) - float(s1[5])) < 1e-5
+    # oracle on one utterance of the batch
+    feat, _ = ofb.featurize_pcm16(pcm[5].cpu().numpy())
+    with torch.no_grad():
+        probs = oc.get_encoder_out(sd, torch.from_numpy(feat)[None], torch.tensor([feat.shape[0]]))[0].numpy()
+    s_ref, t_ref = od.greedy_decoder(probs, weights.synthetic_vocab(4233))
+    vocab = weights.synthetic_vocab(4233)
+    text = ''.join(vocab[j] for j in t1[5, :int(n1[5])].cpu().numpy()).replace('<space>', ' ')
+    assert od.cer(t_ref, text) <= 0.05 and abs(float(s1[5]) * 100 - s_ref) < 0.1

@@ -1,0 +1,125 @@
+"""CPU: the oracle restatement against the committed fixtures produced by the REAL reference
+(oracle/make_golden.py) and, when /root/reference is present, against the reference live."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import conformer as oc
+from oracle import decoders as od
+from oracle import fbank as ofb
+from oracle import shims, weights
+from oracle.make_golden import golden_inputs
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def g(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def test_greedy_toy_known_answer():
+    # derived by running the reference greedy_decoder
+    vocab = ['<blank>', '<unk>', 'a', 'b', '<space>', '<eos>']
+    p = np.array([[.1, 0, .8, .1, 0, 0], [.1, 0, .7, .2, 0, 0], [.9, 0, .05, .05, 0, 0], [.1, 0, .6, .3, 0, 0],
+                  [0, 0, .1, .2, .7, 0], [.2, 0, .1, .7, 0, 0]], np.float32)
+    assert od.greedy_decoder(p, vocab) == (69.9999988079071, 'aa b')
+    s, t, a, b = od.greedy_decoder_chunk(p[:3], vocab)
+    assert (s, t) == (75.0, 'a')
+    s, t, a, b = od.greedy_decoder_chunk(p[3:], vocab, a, b)
+    assert (s, t) == (69.9999988079071, 'aa b')
+
+
+def test_greedy_against_reference_fixture():
+    z = g('greedy.npz')
+    v6 = ['<blank>', '<unk>', 'a', 'b', '<space>', '<eos>']
+    s, t = od.greedy_decoder(z['probs'], v6)
+    assert s == float(z['score']) and t == str(z['text'])
+    a = b = None
+    for k, (rs, rt) in enumerate(zip(z['chunk_scores'], z['chunk_texts'])):
+        sc, tx, a, b = od.greedy_decoder_chunk(z['probs'][8 * k:8 * k + 8], v6, a, b)
+        assert sc == float(rs) and tx == str(rt)
+
+
+def test_audio_segment_and_fbank_fixture():
+    z = g('testwav.npz')
+    feat, i16 = ofb.featurize_pcm16(z['pcm'])
+    assert np.array_equal(i16, z['norm_i16'])          # reference AudioSegment.normalize + to('int16')
+    assert feat.shape == (837, 80)
+    np.testing.assert_allclose(feat, z['fbank'], atol=1e-5)
+    f64, _ = ofb.featurize_pcm16(z['pcm'], dtype=np.float64)
+    assert np.abs(f64 - feat).max() < 1e-3
+
+
+def test_fbank_cross_check_transformers():
+    """torchaudio is absent (parity unpinned at the reference level): cross-check the restatement
+    against the independent numpy Kaldi mimic shipped with `transformers`."""
+    au = pytest.importorskip('transformers.audio_utils')
+    z = g('testwav.npz')
+    mf = au.mel_filter_bank(257, 80, 20, 8000, 16000, norm=None, mel_scale='kaldi', triangularize_in_mel_space=True)
+    ref = au.spectrogram(z['norm_i16'].astype(np.float64), au.window_function(400, 'povey', periodic=False),
+                         frame_length=400, hop_length=160, fft_length=512, power=2.0, center=False, preemphasis=0.97,
+                         mel_filters=mf, log_mel='log', mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+    mine = ofb.kaldi_fbank(z['norm_i16'], 80, np.float64)
+    assert ref.shape == mine.shape
+    assert np.abs(ref - mine).max() < 1e-3
+
+
+def test_conformer_full_and_chunk_fixture():
+    z = g('conformer_v512.npz')
+    feats, lens = golden_inputs()
+    sd = weights.conformer_state_dict(0, 512)
+    with torch.no_grad():
+        enc = oc.encoder_full(sd, feats, lens, -1)
+        np.testing.assert_allclose(enc.numpy(), z['enc'], atol=2e-5)
+        np.testing.assert_allclose(oc.ctc_probs(sd, enc).numpy(), z['probs'], atol=2e-6)
+        np.testing.assert_allclose(oc.encoder_full(sd, feats, lens, 16).numpy(), z['enc16'], atol=2e-5)
+        att = torch.zeros(0, 0, 0, 0)
+        cnn = torch.zeros(0, 0, 0, 0)
+        off = 0
+        for k, cur in enumerate(range(0, 331 - 67 + 1, 64)):
+            p, att, cnn = oc.get_encoder_out_chunk(sd, feats[:1, cur:cur + 67], off, -16, att, cnn)
+            off += p.shape[1]
+            np.testing.assert_allclose(p[0].numpy(), z['chunk_probs'][k], atol=2e-6)
+        assert list(att.shape) == list(z['att_shape'])
+        np.testing.assert_allclose(att[:, :, -16:].numpy(), z['att_tail'], atol=2e-5)
+        np.testing.assert_allclose(cnn.numpy(), z['cnn'], atol=2e-5)
+
+
+def test_conformer_v4233_top4_fixture():
+    z = g('conformer_v4233.npz')
+    feats, lens = golden_inputs()
+    sd = weights.conformer_state_dict(0, 4233)
+    with torch.no_grad():
+        probs = oc.get_encoder_out(sd, feats, lens)
+    top = torch.topk(probs, 4, dim=-1)
+    np.testing.assert_allclose(top.values.numpy(), z['top_p'], atol=2e-6)
+    assert (top.indices.numpy()[..., 0] == z['top_i'][..., 0]).mean() > 0.999
+
+
+def test_flop_model_matches_survey():
+    # 23.18 GFLOP per 10 s utterance (+ the once-per-batch pos projection)
+    per_utt = oc.conformer_flops(998) - 12 * 2 * 256 * 256 * 248
+    assert abs(per_utt / 1e9 - 23.18) < 0.02
+
+
+@pytest.mark.skipif(not shims.reference_available(), reason='/root/reference not present')
+def test_oracle_against_live_reference():
+    import json
+    import tempfile
+    import yaml
+    shims.install()
+    from masr.model_utils.conformer.model import ConformerModel
+    cfg = yaml.safe_load(open(os.path.join(shims.REFERENCE_ROOT, 'configs', 'conformer.yml'), encoding='utf-8'))
+    sd = weights.conformer_state_dict(3, 300)
+    p = os.path.join(tempfile.mkdtemp(), 'm.json')
+    json.dump({'mean': [0.0] * 80, 'istd': [1.0] * 80}, open(p, 'w'))
+    m = ConformerModel(input_dim=80, vocab_size=300, mean_istd_path=p, streaming=True,
+                       encoder_conf=cfg['encoder_conf'], decoder_conf=cfg['decoder_conf'], **cfg['model_conf']).eval()
+    m.load_state_dict(sd, strict=False)
+    torch.manual_seed(5)
+    x = torch.randn(2, 150, 80) * 3 + 13
+    lens = torch.tensor([150, 99])
+    with torch.no_grad():
+        assert (m.get_encoder_out(x, lens) - oc.get_encoder_out(sd, x, lens)).abs().max() < 1e-6
