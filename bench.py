@@ -75,7 +75,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--profile-kind', type=int, default=2, help='kernel class timed with HIP events (2 = FFN W1 GEMM)')
+    ap.add_argument('--profile-kind', type=int, default=2, help='kernel class timed with HIP events (2 = fused FFN)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -133,7 +133,7 @@ def main():
         roofline = None
         if prof_n > 0 and prof_ms > 0:
             achieved = prof_flops / (prof_ms * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<128,128> (FFN w_1: [B*T\',256]x[256,2048], SiLU epilogue)',
+            roofline = {'bound': 'mfma', 'kernel': 'ffn_fused_kernel (LN + [B*T\',256]x[256,2048] + SiLU + x[2048,256] + residual)',
                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
                         'launches': int(prof_n), 'avg_us': round(prof_ms * 1e3 / prof_n, 2),

@@ -130,6 +130,9 @@ int masr_op_layernorm(masr_engine* e, const float* x_dev, const float* w_dev, co
 int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
                  float* c_dev, int32_t M, int32_t N, int32_t K, int32_t act, float alpha, void* stream);
 
+/* Diagnostics (kernel ablation switches for profiling; key 1 = fused-FFN variant, 0 = production). */
+int masr_debug_set(masr_engine* e, int32_t key, int32_t value);
+
 /* Profiling: time every launch of one kernel class with HIP events on the launch stream.
  * kind: 0 none, 1 gemm (all), 2 ffn-w1 gemm, 3 conv2 gemm, 4 attention, 5 fbank.
  * masr_profile_read synchronises the events and returns total ms / launch count / flops since reset. */

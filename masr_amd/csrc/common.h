@@ -53,6 +53,12 @@ void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, hipStream
 void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s);
 void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hipStream_t s);
 
+// Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_fused.hip)
+void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                      const float* b2, int M, int dff, float eps, float scale, hipStream_t s);
+
+void set_ffn_variant(int v);   // diagnostic ablations of the fused FFN kernel (0 = production)
+
 // ---- attention ---------------------------------------------------------------------------
 struct AttSeq {            // one per sequence, device memory
     const float* q;        // first query row of this sequence (row stride q_stride)

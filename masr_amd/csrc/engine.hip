@@ -434,10 +434,8 @@ struct EncodeCtx {
 int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb, const float* w1, const float* b1,
         const float* w2, const float* b2) {
     const int d = e->cfg.d_model, dff = e->cfg.d_ff;
-    float* x = e->x.as<float>();
-    launch_layernorm(x, lnw, lnb, e->ln.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
-    gemm(e, s, e->ln.as<float>(), d, w1, b1, e->hid.as<float>(), dff, M, dff, d, ACT_SILU, 1.f, nullptr, 0, PROF_FFN1);
-    gemm(e, s, e->hid.as<float>(), dff, w2, b2, x, d, M, d, dff, ACT_NONE, 0.5f, x, d);
+    ProfScope ps(e, s, PROF_FFN1, 4.0 * M * (double)dff * d);
+    launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, 0.5f, s);
     return 0;
 }
 
@@ -466,10 +464,9 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
 }
 
 int ensure_layer_ws(masr_engine* e, int nseq, int Tq) {
-    const int d = e->cfg.d_model, dff = e->cfg.d_ff, pad = e->cfg.cnn_kernel - 1;
+    const int d = e->cfg.d_model, pad = e->cfg.cnn_kernel - 1;
     const size_t M = (size_t)nseq * Tq;
     CHK(e->ln.ensure(M * d * sizeof(float)));
-    CHK(e->hid.ensure(M * dff * sizeof(float)));
     CHK(e->qkv.ensure(M * 3 * d * sizeof(float)));
     CHK(e->att.ensure(M * d * sizeof(float)));
     CHK(e->lnpad.ensure((size_t)nseq * (Tq + pad) * d * sizeof(float)));
@@ -788,6 +785,13 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
     if (K % 32) return fail("K must be a multiple of 32");
     gemm(e, (hipStream_t)stream, a_dev, K, w_dev, bias_dev, c_dev, N, M, N, K, act, alpha, res_dev, N);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
+    if (!e) return fail("null engine");
+    if (key == 1) set_ffn_variant(value);
+    else return fail("unknown debug key");
     return 0;
 }
 

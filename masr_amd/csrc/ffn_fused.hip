@@ -1,0 +1,267 @@
+// Fused position-wise feed-forward block of the Conformer layer, in place on x:
+//     x <- x + scale * ( W2 . silu( W1 . LayerNorm(x) + b1 ) + b2 )        (scale = 0.5, macaron style)
+// Reference: ConformerEncoderLayer.forward (conformer/encoder.py:113-121,150-158) +
+// PositionwiseFeedForward.forward (conformer/positionwise.py:30-37) + Swish (utils/common.py).
+//
+// This is 54 % of the model's FLOPs.  Unfused it is LN + GEMM(K=256) + GEMM(N=256): two short GEMMs
+// whose prologue/epilogue and the 65 MB hidden-activation round trip cost as much as the MFMAs.
+// Fused: one workgroup owns 32 rows (M = B*T' = 7936 -> 248 workgroups ~ one per CU of the 256),
+// keeps LayerNorm(x) [32,256] and the running output accumulator [32,256] on chip, and streams
+// W1 / W2 through LDS (d_ff is consumed in chunks of 128 hidden units):
+//     per chunk:  h[32,128] = silu(xn . W1c^T + b1c)   -> LDS
+//                 acc2[32,256] += h . W2c^T
+// All MFMA is v_mfma_f32_32x32x2_f32 (exact fp32).  Structure and pipeline: see the kernel comment.
+// LDS rows are padded (+4 floats) so every 16-byte fragment read is bank-conflict free.
+#include "common.h"
+
+namespace masr {
+
+static constexpr int FF_BM = 32;
+static constexpr int FF_D = 256;
+static constexpr int FF_CH = 128;          // hidden units per chunk
+static constexpr int XN_LD = FF_D + 4;     // 260
+static constexpr int HS_LD = FF_CH + 4;    // 132
+static constexpr int W_LD = 32 + 4;        // wave-private weight slab: [32 rows][32 k], padded
+static constexpr int WSLAB = 32 * W_LD;    // 1152 floats = 4.5 KB
+static constexpr int NSET = 4;             // prefetch register sets (must divide 8)
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// 512 threads = 8 waves = 2 waves per SIMD, and NO workgroup barrier on the weight stream:
+//   GEMM1 (h = xn . W1c^T): 4 output tiles of 32x32; wave w computes tile (w & 3) over the k-half (w >> 2);
+//          the two partial accumulators are exchanged through LDS (8 registers each way) and each wave
+//          finishes bias + SiLU for half of the tile's rows.
+//   GEMM2 (acc2 += h . W2c^T): 8 output tiles of 32x32, one per wave.
+// In both GEMMs the B operand of a wave (32 weight rows x 32 k per slab) is needed by that wave only, so
+// every wave stages its own 4 KB weight slabs through a wave-private, double-buffered LDS region
+// (coalesced 128-byte global reads -> padded rows -> 16-byte fragment reads).  LDS operations of one wave
+// execute in order, so no barrier is needed; waves drift freely and the partner wave on the same SIMD
+// fills the matrix pipe whenever one of them waits.  Only the shared activations synchronise the
+// workgroup: twice per 128-wide hidden chunk (partial-sum exchange, hidden tile ready).
+// (Measured with per-slab barriers: 54-57 % MFMA-busy, ~450 cycles of barrier skew + ~800 cycles of
+//  exposed L2 latency per 2048-cycle slab.)
+// VAR (diagnostic ablations, production = 0): 1 = no global weight loads, 2 = no MFMA, 3 = no LDS stores of weights
+template <int VAR>
+__global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* __restrict__ lnw,
+                                                        const float* __restrict__ lnb, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, int M, int dff, float eps,
+                                                        float scale) {
+    extern __shared__ __align__(16) float sm[];
+    float* xn = sm;                              // [32][260]   LayerNorm(x) tile (A operand of GEMM1)
+    float* hs = xn + FF_BM * XN_LD;              // [2][32][132] hidden tile (A operand of GEMM2), double-buffered
+    float* wpv = hs + 2 * FF_BM * HS_LD;         // [8 waves][2][32][36] wave-private weight slabs
+    float* xch = wpv + 8 * 2 * WSLAB;            // [8 waves][8 regs][64 lanes]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): uniform branches below
+    const int row0 = blockIdx.x * FF_BM;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int t1 = wave & 3, kh = wave >> 2;     // GEMM1 tile / k-half
+    float* wmine = wpv + wave * 2 * WSLAB;
+
+    // ---- LayerNorm prologue: wave w normalises rows 4w..4w+3 ----------------------------------------
+    {
+        const f32x4 gw = *reinterpret_cast<const f32x4*>(lnw + lane * 4);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = wave * 4 + rr, row = row0 + lr;
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < M) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * FF_D + lane * 4);
+                const float mean = wsum64(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                const float var = wsum64(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + eps);
+                o[0] = d0 * rstd * gw[0] + gb[0];
+                o[1] = d1 * rstd * gw[1] + gb[1];
+                o[2] = d2 * rstd * gw[2] + gb[2];
+                o[3] = d3 * rstd * gw[3] + gb[3];
+            }
+            *reinterpret_cast<f32x4*>(&xn[lr * XN_LD + lane * 4]) = o;
+        }
+    }
+
+    // ---- this wave's weight slab stream ----------------------------------------------------------------
+    // slab s = chunk*8 + j, 32 rows x 32 k each (piece i covers rows 8i + (lane>>3), 16 bytes at k = 4*(lane&7)):
+    //   j <  4 : W1[chunk*128 + 32*t1 + r][64j + 32kh .. +31]
+    //   j >= 4 : W2[32*wave + r][chunk*128 + 32(j-4) .. +31]
+    // NSET register sets in rotation: in iteration s set (s+1)%NSET (slab s+1) is written to LDS buffer (s+1)&1
+    // and then refilled with slab s+1+NSET; the other sets hold slabs s+2 .. s+NSET in flight.
+    const int nslab = (dff / FF_CH) * 8;
+    const int lr8 = lane >> 3, lc4 = (lane & 7) * 4;
+    f32x4 pre[NSET][4];   // register sets in rotation: slab s+1 (-> LDS), s+2 .. s+NSET in flight
+    auto src_of = [&](int chunk, int j, int i) -> const float* {   // j is a compile-time constant at every call
+        if (j < 4) return w1 + ((size_t)chunk * FF_CH + t1 * 32 + lr8 + 8 * i) * FF_D + j * 64 + kh * 32 + lc4;
+        return w2 + (size_t)(wave * 32 + lr8 + 8 * i) * dff + chunk * FF_CH + (j - 4) * 32 + lc4;
+    };
+    auto dst_of = [&](int s, int i) -> float* { return wmine + (s & 1) * WSLAB + (lr8 + 8 * i) * W_LD + lc4; };
+    // one side operation per MFMA issue slot (16 slots per slab); unconditional memory ops: past the end the
+    // last chunk is re-fetched / re-stored into a buffer nobody reads any more (chunk index clamped)
+    const int nlast = dff / FF_CH - 1;
+    auto side_work = [&](int s, int jj, int pset, int slot) {   // jj = s & 7 (compile-time)
+        const int p = pset;                      // == (s + 1) % 3, compile-time after unrolling
+        // slots 0,2,4,6: LDS-store piece of slab s+1 from set p; slots 8,10,12,14: refill set p with slab
+        // s+1+NSET.  The L2-hit latency under this load is several thousand cycles (a 2-slab distance ran
+        // 20 % slower than 3 slabs), hence the deep rotation.
+        if (slot < 8) {
+            if ((slot & 1) == 0 && VAR != 3 && VAR != 4) *reinterpret_cast<f32x4*>(dst_of(s + 1, slot >> 1)) = pre[p][slot >> 1];
+        } else if ((slot & 1) == 0 && VAR != 1 && VAR != 4) {
+            pre[p][(slot - 8) >> 1] = *reinterpret_cast<const f32x4*>(
+                src_of(min((s >> 3) + (jj + 1 + NSET) / 8, nlast), (jj + 1 + NSET) & 7, (slot - 8) >> 1));
+        }
+    };
+
+    // Two interleaved accumulators per output tile (even / odd k-steps) keep consecutive MFMAs independent.
+    f32x16 acc2[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
+    const float bv2 = b2[wave * 32 + frow];
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(0, 0, i));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+#pragma unroll
+    for (int k = 1; k <= NSET; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[k % NSET][i] = *reinterpret_cast<const f32x4*>(src_of(0, k, i));
+    __syncthreads();                                 // xn tile complete
+
+    const float* xa = xn + frow * XN_LD + 4 * fh + 32 * kh;     // this wave's k-half of every 64-wide slab
+    const float* wfrag = wmine + frow * W_LD + 4 * fh;
+    const int nchunk = dff / FF_CH;
+    // 8 slabs per chunk, NSET = 4 sets: the set index (s + 1) % 4 == (j + 1) % 4 is a compile-time constant
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        f32x16 acc1[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[0][r] = 0.f; acc1[1][r] = 0.f; }
+        // bias of this chunk's hidden column: issued now, consumed after GEMM1 (a dependent global load
+        // after the exchange barrier would expose ~2000 cycles of L2 latency in every chunk)
+        const float bv1 = b1[chunk * FF_CH + t1 * 32 + frow];
+        float* hcur = hs + (chunk & 1) * FF_BM * HS_LD;
+        const float* ha = hcur + frow * HS_LD + 4 * fh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = chunk * 8 + j;
+            const float* wp = wfrag + (j & 1) * WSLAB;       // (s & 1) == (j & 1)
+            if (j < 4) {
+                f32x4 a[2], b[2];
+                a[0] = *reinterpret_cast<const f32x4*>(xa + j * 64);
+                b[0] = *reinterpret_cast<const f32x4*>(wp);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g + 1 < 4 && VAR != 4) {
+                        a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(xa + j * 64 + 8 * (g + 1));
+                        b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                    } else if (g + 1 < 4) { a[(g + 1) & 1] = a[g & 1]; b[(g + 1) & 1] = b[g & 1]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (VAR == 2) acc1[q & 1][q] = fmaf(a[g & 1][q], b[g & 1][q], acc1[q & 1][q]);
+                        else acc1[q & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc1[q & 1], 0, 0, 0);
+                        side_work(s, j, (j + 1) % NSET, g * 4 + q);
+                    }
+                }
+                if (j == 3) {
+                    // Exchange with the partner wave (same tile, other k-half): k-half 0 finishes C registers
+                    // 0..7, k-half 1 registers 8..15.  kh is wave-uniform, so the two paths are scalar branches
+                    // with compile-time register indices (a runtime register index costs a 16-way select chain).
+                    // C layout: col = lane&31, row = (r&3) + 8(r>>2) + 4*fh.
+                    float* xo = xch + (wave * 8) * 64 + lane;
+                    const float* xi = xch + ((wave ^ 4) * 8) * 64 + lane;
+                    const int hc = t1 * 32 + frow;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[0][r] += acc1[1][r];
+                    if (kh == 0) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) xo[r * 64] = acc1[0][8 + r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) xo[r * 64] = acc1[0][r];
+                    }
+                    __syncthreads();
+                    if (kh == 0) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float v = (acc1[0][r] + xi[r * 64]) + bv1;
+                            hcur[((r & 3) + 8 * (r >> 2) + 4 * fh) * HS_LD + hc] = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float v = (xi[r * 64] + acc1[0][8 + r]) + bv1;
+                            hcur[(((8 + r) & 3) + 8 * ((8 + r) >> 2) + 4 * fh) * HS_LD + hc] = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                        }
+                    }
+                    __syncthreads();
+                }
+            } else {
+                f32x4 a[2], b[2];
+                a[0] = *reinterpret_cast<const f32x4*>(ha + (j - 4) * 32);
+                b[0] = *reinterpret_cast<const f32x4*>(wp);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g + 1 < 4 && VAR != 4) {
+                        a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(ha + (j - 4) * 32 + 8 * (g + 1));
+                        b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                    } else if (g + 1 < 4) { a[(g + 1) & 1] = a[g & 1]; b[(g + 1) & 1] = b[g & 1]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (VAR == 2) acc2[q & 1][q] = fmaf(a[g & 1][q], b[g & 1][q], acc2[q & 1][q]);
+                        else acc2[q & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc2[q & 1], 0, 0, 0);
+                        side_work(s, j, (j + 1) % NSET, g * 4 + q);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: x <- x + scale * (acc2 + b2) ---------------------------------------------------------
+    {
+        const int col = wave * 32 + frow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (row < M) {
+                float* p = x + (size_t)row * FF_D + col;
+                *p = *p + scale * ((acc2[0][r] + acc2[1][r]) + bv2);
+            }
+        }
+    }
+}
+
+static int g_ffn_variant = 0;
+void set_ffn_variant(int v) { g_ffn_variant = v; }
+
+template <int VAR>
+static void launch_ffn_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                         const float* b2, int M, int dff, float eps, float scale, hipStream_t s) {
+    const size_t lds = (size_t)(FF_BM * XN_LD + 2 * FF_BM * HS_LD + 8 * 2 * WSLAB + 8 * 8 * 64) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fused_kernel<VAR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(ffn_fused_kernel<VAR>, dim3((M + FF_BM - 1) / FF_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
+                       b2, M, dff, eps, scale);
+}
+
+void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                      const float* b2, int M, int dff, float eps, float scale, hipStream_t s) {
+    if (M <= 0) return;
+    switch (g_ffn_variant) {
+        case 1: launch_ffn_t<1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+        case 2: launch_ffn_t<2>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+        case 3: launch_ffn_t<3>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+        case 4: launch_ffn_t<4>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+        default: launch_ffn_t<0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+    }
+}
+
+}  // namespace masr
