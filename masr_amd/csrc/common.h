@@ -53,6 +53,28 @@ void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, hipStream
 void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s);
 void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hipStream_t s);
 
+// ---- row-block GEMM for the K = 256 projections (rowgemm.hip) -------------------------------------
+enum RowGemmPro { RG_PRO_PLAIN = 0, RG_PRO_LN = 1, RG_PRO_LN_PAD = 2 };
+enum RowGemmEpi { RG_EPI_STORE = 0, RG_EPI_RESID = 1, RG_EPI_GLU = 2, RG_EPI_CTC = 3 };
+struct RowGemmArgs {
+    const float* A;       // [rows, lda] source rows (K = 256)
+    const float* lnw;     // LayerNorm weight / bias (PRO_LN*)
+    const float* lnb;
+    const float* W;       // [N, 256]
+    const float* bias;    // [N]
+    float* C;             // output [M, ldc]
+    const float* R;       // residual [M, ldr] (EPI_RESID; may alias C)
+    const int* lens;      // per-sequence feature lengths (pad masks), or nullptr
+    int* out_idx;         // EPI_CTC: per-row argmax
+    float* out_maxp;      // EPI_CTC: per-row softmax probability of the argmax
+    int M, N;             // output rows / weight rows
+    int lda, ldc, ldr;
+    float eps, alpha;
+    int seq_t, pad;       // PRO_LN_PAD: output rows index [nseq][pad + seq_t], source rows [nseq][seq_t]
+    int mask_tp;          // EPI_RESID: >0 -> row r = (b, t) with t = r % mask_tp masked when 4*t >= lens[b]
+};
+void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);
+
 // Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_fused.hip)
 void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                       const float* b2, int M, int dff, float eps, float scale, hipStream_t s);
@@ -77,6 +99,7 @@ void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q
 void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, hipStream_t s);
 
 // ---- features ------------------------------------------------------------------------------
+size_t fbank_gain_scratch_floats(int B);   // size of gain_scratch ([B] gains + partial sums)
 void launch_fbank(const void* pcm, int sample_format /*0 int16, 1 float32*/, const int* nsamp, int B, int n_max,
                   int use_db, float target_db, const float* window, const float* melw, const int* mel_lo,
                   const int* mel_hi, const float* tw256, const float* tw512, float* feats, int T_max,

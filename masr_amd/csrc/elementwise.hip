@@ -244,33 +244,50 @@ void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs
 // the SEQUENTIAL fp32 sum (python sum over np.float32) of the max-probs of all non-blank frames,
 // divided by their count.  T' <= ~1250, one lane per utterance is plenty.
 // ------------------------------------------------------------------------------------------
-__global__ void ctc_collapse_kernel(const int* __restrict__ idx, const float* __restrict__ maxp,
-                                    const int* __restrict__ nframes, int B, int Tp, int blank, int* tokens, int* ntok,
-                                    float* score) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// One wave per utterance: 64 frames per step; a frame emits a token when it is non-blank and differs from
+// its predecessor (ballot + prefix popcount gives the output slot); the score stays a strictly sequential
+// fp32 accumulation (lane 0 walks the non-blank max-probs staged in LDS, in frame order).
+__global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* __restrict__ idx, const float* __restrict__ maxp,
+                                                          const int* __restrict__ nframes, int Tp, int blank,
+                                                          int* tokens, int* ntok, float* score) {
+    extern __shared__ float nbp[];          // [Tp] max-probs of the non-blank frames, compacted in frame order
+    const int b = blockIdx.x, lane = threadIdx.x;
     const int n = nframes ? min(nframes[b], Tp) : Tp;
-    int prev = -1, cnt = 0, nb = 0;
-    float acc = 0.f;
-    for (int t = 0; t < n; ++t) {
-        const int id = idx[(size_t)b * Tp + t];
-        if (id != blank) {
-            acc = acc + maxp[(size_t)b * Tp + t];
-            ++nb;
-            if (id != prev) tokens[(size_t)b * Tp + cnt++] = id;
-        }
-        prev = id;
+    const int* ib = idx + (size_t)b * Tp;
+    const float* pb = maxp + (size_t)b * Tp;
+    int* tb = tokens + (size_t)b * Tp;
+    int cnt = 0, nb = 0, carry = -1;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        const bool in = t < n;
+        const int id = in ? ib[t] : blank;
+        int prev = __shfl_up(id, 1, 64);
+        if (lane == 0) prev = carry;
+        const bool nonblank = in && id != blank;
+        const bool emit = nonblank && id != prev;
+        const unsigned long long me = __ballot(emit), mn = __ballot(nonblank);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (emit) tb[cnt + __popcll(me & below)] = id;
+        if (nonblank) nbp[nb + __popcll(mn & below)] = pb[t];
+        cnt += __popcll(me);
+        nb += __popcll(mn);
+        carry = __shfl(id, 63, 64);
     }
-    for (int t = cnt; t < Tp; ++t) tokens[(size_t)b * Tp + t] = -1;
-    ntok[b] = cnt;
-    score[b] = nb > 0 ? acc / (float)nb : 0.f;
+    for (int t = cnt + lane; t < Tp; t += 64) tb[t] = -1;
+    __syncthreads();
+    if (lane == 0) {
+        float acc = 0.f;
+        for (int i = 0; i < nb; ++i) acc = acc + nbp[i];
+        ntok[b] = cnt;
+        score[b] = nb > 0 ? acc / (float)nb : 0.f;
+    }
 }
 
 void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank, int* tokens,
                          int* ntok, float* score, hipStream_t s) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, s, idx, maxp, nframes, B, Tp, blank,
-                       tokens, ntok, score);
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(64), (size_t)Tp * sizeof(float), s, idx, maxp, nframes, Tp,
+                       blank, tokens, ntok, score);
 }
 
 // argmax / max over rows of an existing probability matrix (np.argmax semantics: first maximum)

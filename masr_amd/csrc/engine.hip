@@ -170,6 +170,18 @@ void gemm(masr_engine* e, hipStream_t s, const float* A, int lda, const float* W
     launch_gemm(a, A_PLAIN, EPI_STD, s);
 }
 
+void rowgemm(masr_engine* e, hipStream_t s, int pro, int epi, const float* A, int lda, const float* lnw,
+             const float* lnb, const float* W, const float* bias, float* C, int ldc, int M, int N, const float* R,
+             int ldr, float alpha, const int* lens, int mask_tp, int seq_t, int pad, int* out_idx, float* out_maxp,
+             int kind = PROF_GEMM) {
+    RowGemmArgs a{};
+    a.A = A; a.lda = lda; a.lnw = lnw; a.lnb = lnb; a.W = W; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N;
+    a.R = R; a.ldr = ldr; a.alpha = alpha; a.lens = lens; a.mask_tp = mask_tp; a.seq_t = seq_t; a.pad = pad;
+    a.out_idx = out_idx; a.out_maxp = out_maxp; a.eps = 1e-5f;
+    ProfScope ps(e, s, kind, 2.0 * M * (double)N * 256);
+    launch_rowgemm(a, pro, epi, s);
+}
+
 }  // namespace
 
 namespace {
@@ -373,22 +385,8 @@ int masr_finalize(masr_engine* e, void* stream) {
         CHK(up(e, p + "self_attn.linear_pos.weight", {d, d}, &w.wpos));
         CHK(up(e, p + "self_attn.pos_bias_u", {H, dk}, &w.pos_u));
         CHK(up(e, p + "self_attn.pos_bias_v", {H, dk}, &w.pos_v));
-        {   // pointwise_conv1 [2d, d, 1]: permute rows so that every wave's two 32-column MFMA tiles hold
-            // (value, gate) of the same 32 channels (GLU epilogue, gemm_f32.hip)
-            CHK(get(e, p + "conv_module.pointwise_conv1.weight", {2 * d, d, 1}, &t));
-            const HostTensor* tb;
-            CHK(get(e, p + "conv_module.pointwise_conv1.bias", {2 * d}, &tb));
-            std::vector<float> wp((size_t)2 * d * d), bp(2 * d);
-            for (int pr = 0; pr < 2 * d; ++pr) {
-                const int j = pr / 128, q = pr % 128, wv = q / 64, n = (q % 64) / 32, ii = q % 32;
-                const int ch = j * 64 + wv * 32 + ii;
-                const int src = ch + n * d;
-                memcpy(&wp[(size_t)pr * d], &t->v[(size_t)src * d], sizeof(float) * d);
-                bp[pr] = tb->v[src];
-            }
-            CHK(upload(e, wp, &w.pw1_w));
-            CHK(upload(e, bp, &w.pw1_b));
-        }
+        CHK(up(e, p + "conv_module.pointwise_conv1.weight", {2 * d, d, 1}, &w.pw1_w));   // rows: value c, gate d + c
+        CHK(up(e, p + "conv_module.pointwise_conv1.bias", {2 * d}, &w.pw1_b));
         {   // depthwise [d,1,K] -> [K][d]
             CHK(get(e, p + "conv_module.depthwise_conv.weight", {d, 1, K}, &t));
             std::vector<float> wd((size_t)K * d);
@@ -475,25 +473,41 @@ int ensure_layer_ws(masr_engine* e, int nseq, int Tq) {
     return 0;
 }
 
-// conv module on x (in place residual); lnpad rows [0,pad) of every sequence must already hold the
-// history (zeros or cnn cache)
-int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c) {
+// conv module on x (in place residual).
+//  offline  (hist == false): LayerNorm + zero history rows + pad masking are fused into the pointwise_conv1
+//                            GEMM's A-tile prologue (rowgemm PRO_LN_PAD); lnpad is not used.
+//  streaming (hist == true): lnpad rows [0,pad) of every sequence already hold the cnn cache; LayerNorm writes
+//                            the new rows behind them (needed for the next cache) and the GEMM reads lnpad.
+int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, bool hist) {
     const int d = e->cfg.d_model, K = e->cfg.cnn_kernel, pad = K - 1;
     const int M = c.nseq * c.Tq, Mp = c.nseq * (c.Tq + pad);
     float* x = e->x.as<float>();
-    launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, c.Tq, pad, c.lens, s);
-    {
-        GemmArgs a{};
-        a.A = e->lnpad.as<float>(); a.lda = d; a.W = w.pw1_w; a.bias = w.pw1_b; a.C = e->glu.as<float>(); a.ldc = d;
-        a.M = Mp; a.N = 2 * d; a.K = d; a.alpha = 1.f;
-        ProfScope ps(e, s, PROF_GEMM, 2.0 * a.M * (double)a.N * a.K);
-        launch_gemm(a, A_PLAIN, EPI_GLU, s);
+    if (hist) {
+        launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, c.Tq, pad, c.lens, s);
+        rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
+                e->glu.as<float>(), d, Mp, 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+    } else {
+        rowgemm(e, s, RG_PRO_LN_PAD, RG_EPI_GLU, x, d, w.ln_conv_w, w.ln_conv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d,
+                Mp, 2 * d, nullptr, 0, 1.f, c.lens, 0, c.Tq, pad, nullptr, nullptr);
     }
     launch_dwconv_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), c.nseq, c.Tq, K,
                           1e-5f, s);
-    gemm(e, s, e->dwo.as<float>(), d, w.pw2_w, w.pw2_b, x, d, M, d, d, ACT_NONE, 1.f, x, d, PROF_GEMM, c.lens,
-         c.lens ? c.Tq : 0);
+    rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x, d,
+            1.f, c.lens, c.lens ? c.Tq : 0, 0, 0, nullptr, nullptr);
     return 0;
+}
+
+// multi-head self-attention block on x (in place residual); seqs describe where K/V live
+void mhsa(masr_engine* e, hipStream_t s, const LayerW& w, int M) {
+    const int d = e->cfg.d_model;
+    rowgemm(e, s, RG_PRO_LN, RG_EPI_STORE, e->x.as<float>(), d, w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(),
+            3 * d, M, 3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+}
+void mhsa_out(masr_engine* e, hipStream_t s, const LayerW& w, int M) {
+    const int d = e->cfg.d_model;
+    float* x = e->x.as<float>();
+    rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->att.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d, 1.f,
+            nullptr, 0, 0, 0, nullptr, nullptr);
 }
 
 }  // namespace
@@ -512,21 +526,19 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     const int M = B * Tq;
     CHK(ensure_layer_ws(e, B, Tq));
     CHK(e->attseq.ensure(sizeof(AttSeq) * B));
-    HIPCHK(hipMemsetAsync(e->lnpad.p, 0, (size_t)B * (Tq + pad) * d * sizeof(float), s));
     float* x = e->x.as<float>();
     EncodeCtx ctx{B, Tq, feat_lens_dev};
     launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), feat_lens_dev, B, Tq, s);
     for (const LayerW& w : e->layers) {
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
-        launch_layernorm(x, w.ln_mha_w, w.ln_mha_b, e->ln.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
-        gemm(e, s, e->ln.as<float>(), d, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M, 3 * d, d, ACT_NONE, 1.f, nullptr, 0);
+        mhsa(e, s, w, M);
         {
             ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
             launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v,
                              decoding_chunk_size > 0 ? decoding_chunk_size : 0, s);
         }
-        gemm(e, s, e->att.as<float>(), d, w.wo, w.bo, x, d, M, d, d, ACT_NONE, 1.f, x, d);
-        CHK(conv_module(e, s, w, ctx));
+        mhsa_out(e, s, w, M);
+        CHK(conv_module(e, s, w, ctx, false));
         CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
         launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
     }
@@ -560,8 +572,11 @@ int masr_ctc_probs(masr_engine* e, const float* enc_dev, int32_t M, float* probs
 int masr_ctc_greedy_frames(masr_engine* e, const float* enc_dev, int32_t M, int32_t* argmax_dev, float* maxprob_dev,
                            void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
-    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
-    return ctc_head(e, enc_dev, M, nullptr, 0, argmax_dev, maxprob_dev, (hipStream_t)stream);
+    // fused: logits GEMM + online softmax statistics + argmax, nothing but (idx, prob) leaves the chip
+    rowgemm(e, (hipStream_t)stream, RG_PRO_PLAIN, RG_EPI_CTC, enc_dev, e->cfg.d_model, nullptr, nullptr, e->ctc_w,
+            e->ctc_b, nullptr, 0, M, e->cfg.vocab_size, nullptr, 0, 1.f, nullptr, 0, 0, 0, argmax_dev, maxprob_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 int masr_ctc_collapse(masr_engine* e, const int32_t* argmax_dev, const float* maxprob_dev, const int32_t* n_frames_dev,
@@ -590,16 +605,15 @@ int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_for
     if (sample_format != 0 && sample_format != 1) return fail("sample_format must be 0 (int16) or 1 (float32)");
     hipStream_t s = (hipStream_t)stream;
     const int T_max = n_max >= 400 ? 1 + (n_max - 400) / 160 : 0;
-    float* gain = gain_dev;
-    if (!gain) {
-        CHK(e->gain.ensure(sizeof(float) * B));
-        gain = e->gain.as<float>();
-    }
+    CHK(e->gain.ensure(sizeof(float) * fbank_gain_scratch_floats(B)));
+    float* gain = e->gain.as<float>();
     {
         ProfScope ps(e, s, PROF_FBANK, 0.0);
         launch_fbank(samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, target_db, e->window,
                      e->melw, e->mel_lo, e->mel_hi, e->tw256, e->tw512, feats_dev, T_max, gain, norm_pcm_dev, s);
     }
+    if (gain_dev && use_db_normalization)
+        HIPCHK(hipMemcpyAsync(gain_dev, gain, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     if (n_frames_dev) launch_frame_counts(n_samples_dev, B, n_frames_dev, nullptr, s);
     HIPCHK(hipGetLastError());
     return 0;
@@ -728,20 +742,19 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
     for (int l = 0; l < L; ++l) {
         const LayerW& w = e->layers[l];
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
-        launch_layernorm(x, w.ln_mha_w, w.ln_mha_b, e->ln.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
-        gemm(e, s, e->ln.as<float>(), d, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M, 3 * d, d, ACT_NONE, 1.f, nullptr, 0);
+        mhsa(e, s, w, M);
         for (int i = 0; i < n; ++i) {   // append this chunk's k|v rows to the stream's cache
             float* cache = st[i]->att.as<float>() + ((size_t)l * st[i]->cap + st[i]->offset) * 2 * d;
             HIPCHK(hipMemcpy2DAsync(cache, 2 * d * sizeof(float), e->qkv.as<float>() + (size_t)i * Tq * 3 * d + d,
                                     3 * d * sizeof(float), 2 * d * sizeof(float), Tq, hipMemcpyDeviceToDevice, s));
         }
         launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, s);
-        gemm(e, s, e->att.as<float>(), d, w.wo, w.bo, x, d, M, d, d, ACT_NONE, 1.f, x, d);
+        mhsa_out(e, s, w, M);
         for (int i = 0; i < n; ++i)     // history rows <- cnn cache (zeros on the first chunk)
             HIPCHK(hipMemcpyAsync(e->lnpad.as<float>() + (size_t)i * (Tq + pad) * d,
                                   st[i]->cnn.as<float>() + (size_t)l * pad * d, (size_t)pad * d * sizeof(float),
                                   hipMemcpyDeviceToDevice, s));
-        CHK(conv_module(e, s, w, ctx));
+        CHK(conv_module(e, s, w, ctx, true));
         for (int i = 0; i < n; ++i)     // new cache = last (kernel-1) rows of [cache | ln_out] (convolution.py:108)
             HIPCHK(hipMemcpyAsync(st[i]->cnn.as<float>() + (size_t)l * pad * d,
                                   e->lnpad.as<float>() + ((size_t)i * (Tq + pad) + Tq) * d,

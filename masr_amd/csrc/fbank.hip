@@ -13,6 +13,8 @@
 // radix-2 FFT in LDS (2 butterflies per lane per stage) plus the real-split post-pass.  The mel
 // filterbank is applied from the LDS-resident power spectrum with per-bin [lo,hi) ranges.
 // Frames past an utterance's length are written as zeros (collate_fn zero padding, collate_fn.py:8-42).
+#include <algorithm>
+
 #include "common.h"
 
 namespace masr {
@@ -60,27 +62,31 @@ __device__ float pw_leaf(const ST* x, int off, int len) {
 static constexpr int NP_BUF = 8192;       // numpy's default ufunc buffer size (elements)
 static constexpr int MAX_CHUNKS = 2048;   // 16.7 M samples (17 min @ 16 kHz) per utterance
 
+// pass 1: one wave per 8192-sample chunk (grid.x blocks of 4 waves, grid.y = utterance); the block with
+// blockIdx.x == gridDim.x - 1 additionally sums the tail chunk (< 8192 samples) with the general recursion
 template <class ST>
-__global__ __launch_bounds__(256) void rms_gain_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp,
-                                                       int n_max, float target_db, float* __restrict__ gain) {
-    __shared__ float chunk_sum[MAX_CHUNKS];
+__global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp,
+                                                          int n_max, float* __restrict__ chunk_sum /*[B][MAX_CHUNKS+1]*/) {
     __shared__ int leaf_off[64], leaf_len[64], prog[128];
     __shared__ float leaf_val[64];
     __shared__ int n_leaf, n_prog;
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const int n = min(nsamp[b], NP_BUF * MAX_CHUNKS);
     const ST* x = pcm + (size_t)b * n_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = n / NP_BUF, tail = n - nc * NP_BUF;
-    // full chunks: 64 leaves of 128 elements, balanced tree == xor-butterfly (fp add is commutative)
-    for (int c = wave; c < nc; c += 4) {
+    float* out = chunk_sum + (size_t)b * (MAX_CHUNKS + 1);
+    // full chunk: 64 leaves of 128 elements, balanced tree == xor-butterfly (fp add is commutative)
+    const int c = blockIdx.x * 4 + wave;
+    if (c < nc) {
         float v = pw_leaf(x, c * NP_BUF + lane * 128, 128);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) v = __fadd_rn(v, __shfl_xor(v, o, 64));
-        if (lane == 0) chunk_sum[c] = v;
+        if (lane == 0) out[c] = v;
     }
-    // tail chunk (< 8192 elements): general pairwise recursion; thread 0 lists the leaves in DFS
-    // order together with a postfix program (leaf index = push, -1 = add the two top values)
+    if (blockIdx.x != gridDim.x - 1) return;
+    // tail chunk: thread 0 lists the leaves in DFS order together with a postfix program
+    // (leaf index = push, -1 = add the two top values)
     if (threadIdx.x == 0) {
         int nl = 0, np = 0;
         if (tail > 0) {
@@ -112,26 +118,39 @@ __global__ __launch_bounds__(256) void rms_gain_kernel(const ST* __restrict__ pc
     if ((int)threadIdx.x < n_leaf) leaf_val[threadIdx.x] = pw_leaf(x, leaf_off[threadIdx.x], leaf_len[threadIdx.x]);
     __syncthreads();
     if (threadIdx.x == 0) {
-        float tot = 0.f;
-        for (int c = 0; c < nc; ++c) tot = __fadd_rn(tot, chunk_sum[c]);
+        float tv = 0.f;
         if (n_prog > 0) {
             float st[16]; int sp = 0;
             for (int i = 0; i < n_prog; ++i) {
                 if (prog[i] >= 0) st[sp++] = leaf_val[prog[i]];
                 else { st[sp - 2] = __fadd_rn(st[sp - 2], st[sp - 1]); --sp; }
             }
-            tot = __fadd_rn(tot, st[0]);
+            tv = st[0];
         }
-        float ms = n > 0 ? __fdiv_rn(tot, (float)n) : 0.f;
-        if (ms == 0.f || !(ms == ms)) ms = 1.f;
-        // float32 scalar arithmetic of rms_db / normalize / gain_db (numpy >= 2 promotion): each
-        // step is evaluated in double and rounded once to float32
-        const float lg = (float)log10((double)ms);
-        const float rms_db = (float)(10.0 * (double)lg);
-        const float g = target_db - rms_db;
-        const float g20 = g / 20.0f;
-        gain[b] = (float)pow(10.0, (double)g20);
+        out[MAX_CHUNKS] = tv;
     }
+}
+
+// pass 2: sequential float32 accumulation of the chunk sums (numpy's buffered reduction) + the gain
+__global__ void rms_final_kernel(const int* __restrict__ nsamp, int B, float target_db,
+                                 const float* __restrict__ chunk_sum, float* __restrict__ gain) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = min(nsamp[b], NP_BUF * MAX_CHUNKS);
+    const int nc = n / NP_BUF, tail = n - nc * NP_BUF;
+    const float* cs = chunk_sum + (size_t)b * (MAX_CHUNKS + 1);
+    float tot = 0.f;
+    for (int c = 0; c < nc; ++c) tot = __fadd_rn(tot, cs[c]);
+    if (tail > 0) tot = __fadd_rn(tot, cs[MAX_CHUNKS]);
+    float ms = n > 0 ? __fdiv_rn(tot, (float)n) : 0.f;
+    if (ms == 0.f || !(ms == ms)) ms = 1.f;
+    // float32 scalar arithmetic of rms_db / normalize / gain_db (numpy >= 2 promotion): each
+    // step is evaluated in double and rounded once to float32
+    const float lg = (float)log10((double)ms);
+    const float rms_db = (float)(10.0 * (double)lg);
+    const float g = target_db - rms_db;
+    const float g20 = g / 20.0f;
+    gain[b] = (float)pow(10.0, (double)g20);
 }
 
 template <class ST>
@@ -278,8 +297,14 @@ static void launch_fbank_t(const ST* pcm, const int* nsamp, int B, int n_max, in
                            const float* window, const float* melw, const int* mel_lo, const int* mel_hi,
                            const float* tw256, const float* tw512, float* feats, int T_max, float* gain_scratch,
                            int16_t* norm_out, hipStream_t s) {
-    if (use_db)
-        hipLaunchKernelGGL(rms_gain_kernel<ST>, dim3(B), dim3(256), 0, s, pcm, nsamp, n_max, target_db, gain_scratch);
+    if (use_db) {
+        // gain_scratch: [B] gains followed by [B][MAX_CHUNKS + 1] chunk sums
+        float* chunk_sum = gain_scratch + B;
+        const int nblk = (std::min(n_max / NP_BUF, MAX_CHUNKS) + 3) / 4 + 1;
+        hipLaunchKernelGGL(rms_partial_kernel<ST>, dim3(nblk, B), dim3(256), 0, s, pcm, nsamp, n_max, chunk_sum);
+        hipLaunchKernelGGL(rms_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, nsamp, B, target_db, chunk_sum,
+                           gain_scratch);
+    }
     if (norm_out)
         hipLaunchKernelGGL(norm_int16_kernel<ST>, dim3((n_max + 255) / 256, B), dim3(256), 0, s, pcm, nsamp, n_max,
                            gain_scratch, use_db, norm_out);
@@ -300,4 +325,8 @@ void launch_fbank(const void* pcm, int sample_format, const int* nsamp, int B, i
                        tw512, feats, T_max, gain_scratch, norm_out, s);
 }
 
+}  // namespace masr
+
+namespace masr {
+size_t fbank_gain_scratch_floats(int B) { return (size_t)B * (MAX_CHUNKS + 2); }
 }  // namespace masr

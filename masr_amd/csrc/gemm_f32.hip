@@ -10,7 +10,9 @@
 //   k values {8g+4h .. 8g+4h+3} of each 8-wide k group with ONE 16-byte LDS read for A and for W.
 // * A operand modes: plain row-major, or implicit-GEMM gather for the 3x3/stride-2 subsampling
 //   conv over channels-last activations (reference conformer/subsampling.py:86-110).
-// * Epilogues: bias, ReLU/SiLU, alpha, residual, row masking; or GLU (conformer/convolution.py:118).
+// * Epilogue: bias, ReLU/SiLU, alpha, residual, row masking.  (The K = 256 projections of the layers use
+//   rowgemm.hip, the FFN ffn_fused.hip; this kernel serves conv2, the embed projection, the positional-key
+//   precompute and the full-probability CTC head.)
 #include "common.h"
 
 namespace masr {
@@ -173,27 +175,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                 }
             }
         }
-    } else {
-        // GLU: W rows were permuted at load time so that tile n=0 holds the value channels and
-        // n=1 the matching gate channels of this wave (see engine.cpp: permute_glu).
-        static_assert(EPI != EPI_GLU || (TN == 2 && BN == 128 && WN == 2), "GLU tiling");
-        const int pc = bn + wn * 64 + ccol;              // permuted column of the value half
-        const int ch = (bn / 128) * 64 + wn * 32 + ccol; // output channel
-        if (pc + 32 < p.N) {
-            const float bva = p.bias ? p.bias[pc] : 0.f;
-            const float bvg = p.bias ? p.bias[pc + 32] : 0.f;
-#pragma unroll
-            for (int m = 0; m < TM; ++m) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = bm + wm * (BM / WM) + m * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    if (row >= p.M) continue;
-                    const float a = acc[m][0][r] + bva;
-                    const float g = acc[m][TN - 1][r] + bvg;
-                    p.C[(size_t)row * p.ldc + ch] = a * sigmoid_f(g);
-                }
-            }
-        }
     }
 }
 
@@ -212,10 +193,6 @@ static void launch_t(const GemmArgs& a, hipStream_t s) {
 
 void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
-    if (epi == EPI_GLU) {
-        launch_t<128, 128, 2, 2, A_PLAIN, EPI_GLU>(a, s);
-        return;
-    }
     if (amode == A_CONV2) {
         launch_t<128, 128, 2, 2, A_CONV2, EPI_STD>(a, s);
         return;

@@ -1,0 +1,275 @@
+// Row-block GEMM for the K = 256 projections of the Conformer layer:
+//     out[32 rows, N] = epilogue( prologue(A)[32, 256] . W[N, 256]^T + bias )
+// One workgroup (8 waves, 2 per SIMD) owns 32 rows and ALL N columns: the (optionally LayerNorm-ed) A
+// tile is built once in LDS and stays resident while the workgroup walks over the column groups of 256;
+// wave w owns columns [32w, 32w+32) of every group, so its B operand (32 weight rows) is private to
+// it and streamed through a wave-private, double-buffered LDS region with a 4-deep register prefetch
+// (same machinery as ffn_fused.hip, no workgroup barrier in the main loop).  M = B*T' = 7936 rows give
+// 248 workgroups ~ one per CU.  v_mfma_f32_32x32x2_f32 (exact fp32) throughout.
+//
+// Prologues: plain rows | LayerNorm(256) | LayerNorm into the conv module's padded time layout
+//            (14 zero history rows per sequence, padded frames zeroed; conformer/convolution.py:98-108).
+// Epilogues: store (fused QKV)            -- conformer/attention.py:53-79
+//            residual + alpha*(.) [+ pad mask]   (attention out-proj, pointwise_conv2) -- encoder.py:123-145
+//            GLU (pointwise_conv1: value rows c, gate rows 256+c) -- convolution.py:117-118
+//            CTC greedy: online (max, argmax, sum exp) over all V columns, never writing logits --
+//            loss/ctc.py:62-70 + ctc_greedy_decoder.py:20-21
+#include "common.h"
+
+namespace masr {
+
+static constexpr int RG_BM = 32;
+static constexpr int RG_K = 256;
+static constexpr int RG_ALD = RG_K + 4;
+static constexpr int RG_WLD = 32 + 4;
+static constexpr int RG_WSLAB = 32 * RG_WLD;
+static constexpr int RG_NSET = 4;
+
+__device__ __forceinline__ float rg_wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
+    extern __shared__ __align__(16) float sm[];
+    float* at = sm;                               // [32][260] A tile
+    float* wpv = at + RG_BM * RG_ALD;             // [8][2][32][36] wave-private weight slabs
+    float* red = wpv + 8 * 2 * RG_WSLAB;          // CTC: [8 waves][32 rows][3]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    const int row0 = blockIdx.x * RG_BM;          // first OUTPUT row of this workgroup
+    float* wmine = wpv + wave * 2 * RG_WSLAB;
+
+    // ---- A tile prologue: wave w prepares rows 4w..4w+3 -----------------------------------------------
+    {
+        f32x4 gw = f32x4{1.f, 1.f, 1.f, 1.f}, gb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (PRO != RG_PRO_PLAIN) {
+            gw = *reinterpret_cast<const f32x4*>(p.lnw + lane * 4);
+            gb = *reinterpret_cast<const f32x4*>(p.lnb + lane * 4);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = wave * 4 + rr, row = row0 + lr;
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            bool live = row < p.M;
+            size_t src_row = row;
+            if (PRO == RG_PRO_LN_PAD && live) {
+                // output row index lives in the padded layout [nseq][pad + Tq]; history rows and padded frames are zero
+                const int per = p.seq_t + p.pad;
+                const int b = row / per, tp = row - b * per;
+                live = tp >= p.pad;
+                const int t = tp - p.pad;
+                if (live && p.lens && 4 * t >= p.lens[b]) live = false;
+                src_row = (size_t)b * p.seq_t + t;
+            }
+            if (live) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.A + src_row * p.lda + lane * 4);
+                if (PRO == RG_PRO_PLAIN) {
+                    o = v;
+                } else {
+                    const float mean = rg_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                    const float var = rg_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                    const float rstd = 1.0f / sqrtf(var + p.eps);
+                    o[0] = d0 * rstd * gw[0] + gb[0];
+                    o[1] = d1 * rstd * gw[1] + gb[1];
+                    o[2] = d2 * rstd * gw[2] + gb[2];
+                    o[3] = d3 * rstd * gw[3] + gb[3];
+                }
+            }
+            *reinterpret_cast<f32x4*>(&at[lr * RG_ALD + lane * 4]) = o;
+        }
+    }
+
+    // ---- weight tile stream: tile t = 32 weight rows starting at wrow(t), 8 slabs of 32 k -------------
+    // EPI_GLU: tiles come in (value, gate) pairs -> tile 2g = rows 32w.., tile 2g+1 = rows 256 + 32w..
+    const int ngroups = (EPI == RG_EPI_GLU) ? 1 : (p.N + 255) / 256;
+    const int ntiles = (EPI == RG_EPI_GLU) ? 2 : ngroups;
+    auto wrow_of = [&](int t) -> int {
+        if (EPI == RG_EPI_GLU) return (t & 1) * 256 + wave * 32;
+        return t * 256 + wave * 32;
+    };
+    const int lr8 = lane >> 3, lc4 = (lane & 7) * 4;
+    f32x4 pre[RG_NSET][4];
+    auto src_of = [&](int t, int j, int i) -> const float* {
+        const int tt = min(t, ntiles - 1);
+        const int r = min(wrow_of(tt) + lr8 + 8 * i, p.N - 1);         // clamp: rows >= N are masked in the epilogue
+        return p.W + (size_t)r * RG_K + j * 32 + lc4;
+    };
+    auto dst_of = [&](int buf, int i) -> float* { return wmine + buf * RG_WSLAB + (lr8 + 8 * i) * RG_WLD + lc4; };
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(0, 0, i));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+#pragma unroll
+    for (int k = 1; k <= RG_NSET; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[k % RG_NSET][i] = *reinterpret_cast<const f32x4*>(src_of(k / 8, k & 7, i));
+    __syncthreads();                                  // A tile complete
+
+    const float* aa = at + frow * RG_ALD + 4 * fh;
+    const float* wfrag = wmine + frow * RG_WLD + 4 * fh;
+
+    // CTC running state of this lane's row (row = lane & 31; the two half-waves hold different columns)
+    float cm = -INFINITY, cs = 0.f;
+    int ci = 0x7fffffff;
+
+    f32x16 accv;      // value tile of the GLU pair
+    for (int t = 0; t < ntiles; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* wp = wfrag + (j & 1) * RG_WSLAB;          // slab index t*8 + j -> buffer j & 1
+            f32x4 a[2], b[2];
+            a[0] = *reinterpret_cast<const f32x4*>(aa + j * 32);
+            b[0] = *reinterpret_cast<const f32x4*>(wp);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) {
+                    a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(aa + j * 32 + 8 * (g + 1));
+                    b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // EPI_CTC accumulates the TRANSPOSED tile (A operand = weight rows, B operand = activation
+                    // rows): each lane then owns ONE output row and 16 of the tile's 32 columns, so the row-wise
+                    // softmax statistics need no cross-lane butterfly (only one lane^32 exchange per tile).
+                    if (EPI == RG_EPI_CTC) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[g & 1][q], a[g & 1][q], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc, 0, 0, 0);
+                    const int slot = g * 4 + q;
+                    // slots 0,2,4,6: store piece of slab s+1 (set (j+1)%NSET) into buffer (j+1)&1;
+                    // slots 8..14: refill that set with slab s+1+NSET
+                    if (slot < 8) {
+                        if ((slot & 1) == 0)
+                            *reinterpret_cast<f32x4*>(dst_of((j + 1) & 1, slot >> 1)) = pre[(j + 1) % RG_NSET][slot >> 1];
+                    } else if ((slot & 1) == 0) {
+                        pre[(j + 1) % RG_NSET][(slot - 8) >> 1] = *reinterpret_cast<const f32x4*>(
+                            src_of(t + (j + 1 + RG_NSET) / 8, (j + 1 + RG_NSET) & 7, (slot - 8) >> 1));
+                    }
+                }
+            }
+        }
+
+        // ---- per-tile epilogue (C layout: col = lane&31, row = (r&3) + 8(r>>2) + 4*fh) ---------------------
+        const int col = wrow_of(t) + frow;
+        if (EPI == RG_EPI_STORE || EPI == RG_EPI_RESID) {
+            if (col < p.N) {
+                const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (row >= p.M) continue;
+                    float v = acc[r] + bv;
+                    if (EPI == RG_EPI_RESID) {
+                        if (p.mask_tp > 0) {
+                            const int b = row / p.mask_tp, tt = row - b * p.mask_tp;
+                            if (4 * tt >= p.lens[b]) v = 0.f;
+                        }
+                        v = p.R[(size_t)row * p.ldr + col] + p.alpha * v;
+                    }
+                    p.C[(size_t)row * p.ldc + col] = v;
+                }
+            }
+        } else if (EPI == RG_EPI_GLU) {
+            if (t == 0) {
+                accv = acc;
+            } else {
+                const int ch = wave * 32 + frow;
+                const float bva = p.bias[ch], bvg = p.bias[256 + ch];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (row >= p.M) continue;
+                    const float g = acc[r] + bvg;
+                    p.C[(size_t)row * p.ldc + ch] = (accv[r] + bva) * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+                }
+            }
+        } else {   // RG_EPI_CTC: fold this 32-column tile into the running (max, argmax, sum exp) of my row
+            // transposed C layout: lane&31 = output row, column-in-tile = (r&3) + 8(r>>2) + 4*fh
+            float v[16];
+            float m = -INFINITY;
+            int mi = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = wrow_of(t) + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                v[r] = c < p.N ? acc[r] + p.bias[min(c, p.N - 1)] : -INFINITY;
+                if (v[r] > m) { m = v[r]; mi = c; }              // ascending c: first maximum wins
+            }
+            {
+                const float om = __shfl_xor(m, 32, 64);
+                const int oi = __shfl_xor(mi, 32, 64);
+                if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+            }
+            const float mnew = fmaxf(cm, m);
+            const float mref = (mnew == -INFINITY) ? 0.f : mnew;   // stripe without a valid column yet
+            float e = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e += __expf(v[r] - mref);  // -inf -> 0
+            e += __shfl_xor(e, 32, 64);
+            cs = cs * __expf(cm - mref) + e;
+            if (m > cm || (m == cm && mi < ci)) ci = mi;
+            cm = mnew;
+        }
+    }
+
+    if (EPI == RG_EPI_CTC) {
+        // combine the 8 waves (column stripes) per row
+        if (fh == 0) {
+            float* d = red + (wave * RG_BM + frow) * 3;
+            d[0] = cm;
+            d[1] = cs;
+            d[2] = __int_as_float(ci);
+        }
+        __syncthreads();
+        if (tid < RG_BM && row0 + tid < p.M) {
+            float M = -INFINITY;
+            int I = 0x7fffffff;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float* d = red + (w * RG_BM + tid) * 3;
+                const int wi = __float_as_int(d[2]);
+                if (d[0] > M || (d[0] == M && wi < I)) { M = d[0]; I = wi; }
+            }
+            float S = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float* d = red + (w * RG_BM + tid) * 3;
+                S += d[1] * __expf(d[0] - M);
+            }
+            p.out_idx[row0 + tid] = I;
+            p.out_maxp[row0 + tid] = 1.0f / S;       // softmax probability of the argmax = exp(0) / sum
+        }
+    }
+}
+
+template <int PRO, int EPI>
+static void launch_rg(const RowGemmArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(RG_BM * RG_ALD + 8 * 2 * RG_WSLAB + 8 * RG_BM * 3) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_kernel<PRO, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI>), dim3((a.M + RG_BM - 1) / RG_BM), dim3(512), lds, s, a);
+}
+
+void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return;
+    if (pro == RG_PRO_LN && epi == RG_EPI_STORE) launch_rg<RG_PRO_LN, RG_EPI_STORE>(a, s);
+    else if (pro == RG_PRO_PLAIN && epi == RG_EPI_STORE) launch_rg<RG_PRO_PLAIN, RG_EPI_STORE>(a, s);
+    else if (pro == RG_PRO_PLAIN && epi == RG_EPI_RESID) launch_rg<RG_PRO_PLAIN, RG_EPI_RESID>(a, s);
+    else if (pro == RG_PRO_LN_PAD && epi == RG_EPI_GLU) launch_rg<RG_PRO_LN_PAD, RG_EPI_GLU>(a, s);
+    else if (pro == RG_PRO_PLAIN && epi == RG_EPI_GLU) launch_rg<RG_PRO_PLAIN, RG_EPI_GLU>(a, s);
+    else if (pro == RG_PRO_PLAIN && epi == RG_EPI_CTC) launch_rg<RG_PRO_PLAIN, RG_EPI_CTC>(a, s);
+    else if (pro == RG_PRO_LN && epi == RG_EPI_CTC) launch_rg<RG_PRO_LN, RG_EPI_CTC>(a, s);
+}
+
+}  // namespace masr
