@@ -71,24 +71,32 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttSeq* __restrict
     // staging assignment: 512 float4 per 32x64 tile, 2 per thread
     const int srow = tid >> 4;            // 0..15 (+16)
     const int sc4 = (tid & 15) * 4;       // float offset 0..60
+    // register-prefetched staging: tile kt+1 is fetched from global memory while tile kt is multiplied
+    f32x4 pk[2], pp[2], pv[2];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = kt * 32 + srow + 16 * i;
+            const int jc = min(j, sq.nk - 1);                      // clamped address, masked below
+            pk[i] = *reinterpret_cast<const f32x4*>(sq.k + (size_t)jc * kv_stride + head * DK + sc4);
+            pv[i] = *reinterpret_cast<const f32x4*>(sq.v + (size_t)jc * kv_stride + head * DK + sc4);
+            pp[i] = *reinterpret_cast<const f32x4*>(ptab + (size_t)(sq.pos0 + jc) * 256 + head * DK + sc4);
+            if (j >= sq.nk) { pk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[i] = pk[i]; pp[i] = pk[i]; }
+        }
+    };
+    fetch(0);
     for (int kt = 0; kt < ntile; ++kt) {
         const int j0 = kt * 32;
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = srow + 16 * i;
-            const int j = j0 + r;
-            f32x4 kk = f32x4{0.f, 0.f, 0.f, 0.f}, pp = kk, vv = kk;
-            if (j < sq.nk) {
-                kk = *reinterpret_cast<const f32x4*>(sq.k + (size_t)j * kv_stride + head * DK + sc4);
-                vv = *reinterpret_cast<const f32x4*>(sq.v + (size_t)j * kv_stride + head * DK + sc4);
-                pp = *reinterpret_cast<const f32x4*>(ptab + (size_t)(sq.pos0 + j) * 256 + head * DK + sc4);
-            }
-            *reinterpret_cast<f32x4*>(&Ks[r * KP_LD + sc4]) = kk;
-            *reinterpret_cast<f32x4*>(&Ps[r * KP_LD + sc4]) = pp;
-            *reinterpret_cast<f32x4*>(&Vs[r * V_LD + sc4]) = vv;
+            *reinterpret_cast<f32x4*>(&Ks[r * KP_LD + sc4]) = pk[i];
+            *reinterpret_cast<f32x4*>(&Ps[r * KP_LD + sc4]) = pp[i];
+            *reinterpret_cast<f32x4*>(&Vs[r * V_LD + sc4]) = pv[i];
         }
         __syncthreads();
+        if (kt + 1 < ntile) fetch(kt + 1);
 
         // ---- S^T tile: rows = 32 keys, cols = this wave's 32 queries -------------------------
         f32x16 st;

@@ -158,20 +158,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
             const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
             for (int m = 0; m < TM; ++m) {
+                float res[16];   // residual loads before the stores (R may alias C)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(bm + wm * (BM / WM) + m * 32 + (r & 3) + 8 * (r >> 2) + rbase, p.M - 1);
+                    res[r] = p.R ? p.R[(size_t)row * p.ldr + col] : 0.f;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = bm + wm * (BM / WM) + m * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    if (row >= p.M) continue;
                     float v = acc[m][n][r] + bv;
                     if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.act == ACT_SILU) v = silu_f(v);
                     if (p.mask_tp > 0) {
-                        const int b = row / p.mask_tp, t = row - b * p.mask_tp;
+                        const int rc = min(row, p.M - 1);
+                        const int b = rc / p.mask_tp, t = rc - b * p.mask_tp;
                         if (4 * t >= p.lens[b]) v = 0.f;
                     }
-                    v *= p.alpha;
-                    if (p.R) v += p.R[(size_t)row * p.ldr + col];
-                    p.C[(size_t)row * p.ldc + col] = v;
+                    v = res[r] + v * p.alpha;
+                    if (row < p.M) p.C[(size_t)row * p.ldc + col] = v;
                 }
             }
         }

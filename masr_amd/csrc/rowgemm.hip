@@ -51,36 +51,45 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
             gw = *reinterpret_cast<const f32x4*>(p.lnw + lane * 4);
             gb = *reinterpret_cast<const f32x4*>(p.lnb + lane * 4);
         }
+        // issue all four row loads first (clamped addresses, no branches around memory ops), then normalise:
+        // a load -> wait -> reduce chain per row would expose the global latency four times
+        f32x4 v4[4];
+        bool live4[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int lr = wave * 4 + rr, row = row0 + lr;
-            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int row = row0 + wave * 4 + rr;
             bool live = row < p.M;
-            size_t src_row = row;
-            if (PRO == RG_PRO_LN_PAD && live) {
+            size_t src_row = live ? row : 0;
+            if (PRO == RG_PRO_LN_PAD) {
                 // output row index lives in the padded layout [nseq][pad + Tq]; history rows and padded frames are zero
                 const int per = p.seq_t + p.pad;
-                const int b = row / per, tp = row - b * per;
-                live = tp >= p.pad;
-                const int t = tp - p.pad;
-                if (live && p.lens && 4 * t >= p.lens[b]) live = false;
+                const int rc = live ? row : 0;
+                const int b = rc / per, tp = rc - b * per;
+                const int t = max(tp - p.pad, 0);
+                live = live && tp >= p.pad && !(p.lens && 4 * t >= p.lens[b]);
                 src_row = (size_t)b * p.seq_t + t;
             }
-            if (live) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(p.A + src_row * p.lda + lane * 4);
-                if (PRO == RG_PRO_PLAIN) {
-                    o = v;
-                } else {
-                    const float mean = rg_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
-                    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-                    const float var = rg_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
-                    const float rstd = 1.0f / sqrtf(var + p.eps);
-                    o[0] = d0 * rstd * gw[0] + gb[0];
-                    o[1] = d1 * rstd * gw[1] + gb[1];
-                    o[2] = d2 * rstd * gw[2] + gb[2];
-                    o[3] = d3 * rstd * gw[3] + gb[3];
-                }
+            live4[rr] = live;
+            v4[rr] = *reinterpret_cast<const f32x4*>(p.A + src_row * p.lda + lane * 4);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = wave * 4 + rr;
+            const f32x4 v = v4[rr];
+            f32x4 o;
+            if (PRO == RG_PRO_PLAIN) {
+                o = v;
+            } else {
+                const float mean = rg_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                const float var = rg_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + p.eps);
+                o[0] = d0 * rstd * gw[0] + gb[0];
+                o[1] = d1 * rstd * gw[1] + gb[1];
+                o[2] = d2 * rstd * gw[2] + gb[2];
+                o[3] = d3 * rstd * gw[3] + gb[3];
             }
+            if (!live4[rr]) o = f32x4{0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(&at[lr * RG_ALD + lane * 4]) = o;
         }
     }
@@ -162,19 +171,29 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
         if (EPI == RG_EPI_STORE || EPI == RG_EPI_RESID) {
             if (col < p.N) {
                 const float bv = p.bias ? p.bias[col] : 0.f;
+                // all residual loads are issued before the first store (R may alias C, so the compiler cannot
+                // hoist them itself: 16 load -> wait -> store round trips otherwise)
+                float res[16];
+                if (EPI == RG_EPI_RESID) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, p.M - 1);
+                        res[r] = p.R[(size_t)row * p.ldr + col];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    if (row >= p.M) continue;
                     float v = acc[r] + bv;
                     if (EPI == RG_EPI_RESID) {
                         if (p.mask_tp > 0) {
-                            const int b = row / p.mask_tp, tt = row - b * p.mask_tp;
+                            const int rc = min(row, p.M - 1);
+                            const int b = rc / p.mask_tp, tt = rc - b * p.mask_tp;
                             if (4 * tt >= p.lens[b]) v = 0.f;
                         }
-                        v = p.R[(size_t)row * p.ldr + col] + p.alpha * v;
+                        v = res[r] + p.alpha * v;
                     }
-                    p.C[(size_t)row * p.ldc + col] = v;
+                    if (row < p.M) p.C[(size_t)row * p.ldc + col] = v;
                 }
             }
         } else if (EPI == RG_EPI_GLU) {
