@@ -26,7 +26,8 @@ static constexpr int V_LD = 68;
 __global__ __launch_bounds__(256) void attention_kernel(const AttSeq* __restrict__ seqs, int q_stride, int kv_stride,
                                                         const float* __restrict__ ptab,
                                                         const float* __restrict__ bias_u,
-                                                        const float* __restrict__ bias_v, int chunk_size) {
+                                                        const float* __restrict__ bias_v, int chunk_size,
+                                                        int pos_stride) {
     __shared__ __align__(16) float Ks[32 * KP_LD];
     __shared__ __align__(16) float Ps[32 * KP_LD];
     __shared__ __align__(16) float Vs[32 * V_LD];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttSeq* __restrict
             const int jc = min(j, sq.nk - 1);                      // clamped address, masked below
             pk[i] = *reinterpret_cast<const f32x4*>(sq.k + (size_t)jc * kv_stride + head * DK + sc4);
             pv[i] = *reinterpret_cast<const f32x4*>(sq.v + (size_t)jc * kv_stride + head * DK + sc4);
-            pp[i] = *reinterpret_cast<const f32x4*>(ptab + (size_t)(sq.pos0 + jc) * 256 + head * DK + sc4);
+            pp[i] = *reinterpret_cast<const f32x4*>(ptab + (size_t)(sq.pos0 + jc * pos_stride) * 256 + head * DK + sc4);
             if (j >= sq.nk) { pk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[i] = pk[i]; pp[i] = pk[i]; }
         }
     };
@@ -170,16 +171,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttSeq* __restrict
 }
 
 void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q_stride, int kv_stride,
-                      const float* ptab, const float* bias_u, const float* bias_v, int chunk_size, hipStream_t s) {
+                      const float* ptab, const float* bias_u, const float* bias_v, int chunk_size, int pos_stride,
+                      hipStream_t s) {
     if (nseq <= 0 || max_nq <= 0) return;
     hipLaunchKernelGGL(attention_kernel, dim3((max_nq + 127) / 128, heads, nseq), dim3(256), 0, s, seqs, q_stride,
-                       kv_stride, ptab, bias_u, bias_v, chunk_size);
+                       kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride);
 }
 
 // Sequence descriptors for the full-context batch path: q/k/v interleaved in one [B*Tp, 768] buffer
-// (fused QKV projection), keys j valid iff 4*j < len_b (subsampled pad mask, subsampling.py:112).
+// (fused QKV projection), keys j valid iff mstride*j < len_b (subsampled pad mask, subsampling.py:112;
+// mstride = 8 between the Squeezeformer time reduction and recovery).
 __global__ void attseq_full_kernel(AttSeq* seqs, const float* qkv, float* out, const int* __restrict__ lens, int B,
-                                   int Tp) {
+                                   int Tp, int mstride) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     AttSeq s;
@@ -189,15 +192,16 @@ __global__ void attseq_full_kernel(AttSeq* seqs, const float* qkv, float* out, c
     s.out = out + (size_t)b * Tp * 256;
     s.nq = Tp;
     s.nk = Tp;
-    s.klen = min(Tp, (lens[b] + 3) / 4);
+    s.klen = min(Tp, (lens[b] + mstride - 1) / mstride);
     s.pos0 = 0;
     s.q_abs0 = 0;
     s.pad_ = 0;
     seqs[b] = s;
 }
 
-void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, hipStream_t s) {
-    hipLaunchKernelGGL(attseq_full_kernel, dim3((B + 63) / 64), dim3(64), 0, s, seqs, qkv, out, lens, B, Tp);
+void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, int mstride,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(attseq_full_kernel, dim3((B + 63) / 64), dim3(64), 0, s, seqs, qkv, out, lens, B, Tp, mstride);
 }
 
 }  // namespace masr

@@ -26,6 +26,7 @@ struct GemmArgs {
     int act;             // GemmAct (EPI_STD only)
     float alpha;         // out = R + alpha * act(acc + bias)
     int mask_tp;         // >0: row r -> (b = r / mask_tp, t = r % mask_tp); rows with 4*t >= lens[b] give act(..)=0
+    int bias_after_alpha; // 1: out = R + alpha*act(acc) + bias  (Squeezeformer input_proj: scaling precedes the Linear)
     // A_CONV2 geometry: row m -> (b, t2, f2) with m = (b*T2 + t2)*F2 + f2 ; k -> (kh, kw*C + c)
     int T1, F1, T2, F2, Cc;
 };
@@ -43,6 +44,14 @@ void launch_conv1(const float* feats, const float* mean, const float* istd, cons
 // depthwise causal conv (k taps) + LayerNorm(C=256) + SiLU on padded layout [nseq, pad+Tq, 256] -> [nseq*Tq, 256]
 void launch_dwconv_ln_silu(const float* g, const float* wkc, const float* bias, const float* lnw, const float* lnb,
                            float* out, int nseq, int Tq, int ktaps, float eps, hipStream_t s);
+// same with an eval-mode BatchNorm folded into a per-channel scale/shift instead of the LayerNorm
+void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, const float* scale, const float* shift,
+                           float* out, int nseq, int Tq, int ktaps, hipStream_t s);
+// Squeezeformer TimeReductionLayer1D depthwise part: k=5, stride 2, padding 3, pad-masked input -> [B, ceil(T/2), 256]
+void launch_time_reduce_dw(const float* x, const float* w5c, const float* bias, const int* lens, float* out, int B, int T,
+                           int mstride, hipStream_t s);
+// Squeezeformer recover: x[b,t,:] = saved[b,t,:] + y[b, t/2, :]
+void launch_recover_add(const float* saved, const float* y, float* x, int B, int T, int L, hipStream_t s);
 // softmax over V per row (in place) + argmax / max prob
 void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs, int* idx, float* maxp, hipStream_t s);
 // CTC collapse per utterance
@@ -54,7 +63,7 @@ void launch_export_att(const float* cache, float* out, int L, int H, int cap, in
 void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hipStream_t s);
 
 // ---- row-block GEMM for the K = 256 projections (rowgemm.hip) -------------------------------------
-enum RowGemmPro { RG_PRO_PLAIN = 0, RG_PRO_LN = 1, RG_PRO_LN_PAD = 2 };
+enum RowGemmPro { RG_PRO_PLAIN = 0, RG_PRO_LN = 1, RG_PRO_LN_PAD = 2, RG_PRO_AFFINE = 3 };
 enum RowGemmEpi { RG_EPI_STORE = 0, RG_EPI_RESID = 1, RG_EPI_GLU = 2, RG_EPI_CTC = 3 };
 struct RowGemmArgs {
     const float* A;       // [rows, lda] source rows (K = 256)
@@ -71,13 +80,16 @@ struct RowGemmArgs {
     int lda, ldc, ldr;
     float eps, alpha;
     int seq_t, pad;       // PRO_LN_PAD: output rows index [nseq][pad + seq_t], source rows [nseq][seq_t]
-    int mask_tp;          // EPI_RESID: >0 -> row r = (b, t) with t = r % mask_tp masked when 4*t >= lens[b]
+    int mask_tp;          // EPI_RESID: >0 -> row r = (b, t) with t = r % mask_tp masked when mstride*t >= lens[b]
+    int mstride;          // feature frames per encoder frame for the pad masks (4; 8 after Squeezeformer time reduction)
+    int out_seq_t;        // >0: output row (b, t) is stored at b*(out_seq_t + out_pad_tot) + out_pad_l + t
+    int out_pad_l, out_pad_tot;
 };
 void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);
 
 // Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_fused.hip)
 void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                      const float* b2, int M, int dff, float eps, float scale, hipStream_t s);
+                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, hipStream_t s);
 
 void set_ffn_variant(int v);   // diagnostic ablations of the fused FFN kernel (0 = production)
 
@@ -95,8 +107,9 @@ struct AttSeq {            // one per sequence, device memory
 };
 void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q_stride, int kv_stride,
                       const float* ptab /*[max_pos,256]*/, const float* bias_u, const float* bias_v,
-                      int chunk_size, hipStream_t s);
-void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, hipStream_t s);
+                      int chunk_size, int pos_stride, hipStream_t s);
+void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, int mstride,
+                        hipStream_t s);
 
 // ---- features ------------------------------------------------------------------------------
 size_t fbank_gain_scratch_floats(int B);   // size of gain_scratch ([B] gains + partial sums)

@@ -111,7 +111,10 @@ void launch_conv1(const float* feats, const float* mean, const float* istd, cons
 // then the tile is transposed through LDS so that each wave normalises whole rows.
 // ------------------------------------------------------------------------------------------
 static constexpr int DW_TT = 16;
-template <int KT>
+// NORM = 0: LayerNorm(C) (Conformer);  NORM = 1: eval-mode BatchNorm1d folded into scale/shift passed in
+// lnw / lnb (Squeezeformer, convolution.py:62-67,137-141).  The padded layout is the same in both cases:
+// KT - 1 extra rows per sequence (all in front for the causal conv, (KT-1)/2 on each side for the symmetric one).
+template <int KT, int NORM>
 __global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const float* __restrict__ g, const float* __restrict__ wkc,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ lnw,
@@ -148,15 +151,20 @@ __global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const float* __rest
     const f32x4 bb = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
     for (int r = wave; r < nrows; r += 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[r][lane * 4]);
-        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
-        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-        const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
-        const float rstd = 1.0f / sqrtf(var + eps);
         f32x4 o;
-        o[0] = d0 * rstd * ww[0] + bb[0];
-        o[1] = d1 * rstd * ww[1] + bb[1];
-        o[2] = d2 * rstd * ww[2] + bb[2];
-        o[3] = d3 * rstd * ww[3] + bb[3];
+        if (NORM == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = v[i] * ww[i] + bb[i];
+        } else {
+            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+            const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+            const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+            const float rstd = 1.0f / sqrtf(var + eps);
+            o[0] = d0 * rstd * ww[0] + bb[0];
+            o[1] = d1 * rstd * ww[1] + bb[1];
+            o[2] = d2 * rstd * ww[2] + bb[2];
+            o[3] = d3 * rstd * ww[3] + bb[3];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = o[i] / (1.0f + expf(-o[i]));
         *reinterpret_cast<f32x4*>(out + ((size_t)seq * Tq + t0 + r) * 256 + lane * 4) = o;
@@ -168,9 +176,58 @@ void launch_dwconv_ln_silu(const float* g, const float* wkc, const float* bias, 
     if (nseq * Tq <= 0) return;
     const int tiles = (Tq + DW_TT - 1) / DW_TT;
     const dim3 grid(nseq * tiles), blk(256);
-    if (ktaps == 15) hipLaunchKernelGGL(dwconv_ln_silu_kernel<15>, grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
-    else if (ktaps == 7) hipLaunchKernelGGL(dwconv_ln_silu_kernel<7>, grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
-    else if (ktaps == 31) hipLaunchKernelGGL(dwconv_ln_silu_kernel<31>, grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
+    if (ktaps == 15) hipLaunchKernelGGL((dwconv_ln_silu_kernel<15, 0>), grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
+    else if (ktaps == 7) hipLaunchKernelGGL((dwconv_ln_silu_kernel<7, 0>), grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
+    else if (ktaps == 31) hipLaunchKernelGGL((dwconv_ln_silu_kernel<31, 0>), grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
+}
+
+void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, const float* scale, const float* shift,
+                           float* out, int nseq, int Tq, int ktaps, hipStream_t s) {
+    if (nseq * Tq <= 0) return;
+    const int tiles = (Tq + DW_TT - 1) / DW_TT;
+    const dim3 grid(nseq * tiles), blk(256);
+    if (ktaps == 31) hipLaunchKernelGGL((dwconv_ln_silu_kernel<31, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f);
+    else if (ktaps == 15) hipLaunchKernelGGL((dwconv_ln_silu_kernel<15, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------
+// Squeezeformer TimeReductionLayer1D, depthwise part (time_reduction.py:53-66): pad-masked input,
+// Conv1d(k=5, stride=2, padding=3, groups=C); only the first L = ceil(T/2) outputs are kept (:68-74).
+// out[b][j][c] = bias[c] + sum_k w[k][c] * xm[b][2j + k - 3][c]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_reduce_dw_kernel(const float* __restrict__ x, const float* __restrict__ w5c,
+                                                             const float* __restrict__ bias,
+                                                             const int* __restrict__ lens, float* __restrict__ out,
+                                                             int T, int L, int mstride) {
+    const int b = blockIdx.y, j = blockIdx.x, c = threadIdx.x;
+    const int len = lens ? lens[b] : 0x7fffffff;
+    float acc = bias[c];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int t = 2 * j + k - 3;
+        if (t >= 0 && t < T && (long)mstride * t < len) acc = fmaf(w5c[k * 256 + c], x[((size_t)b * T + t) * 256 + c], acc);
+    }
+    out[((size_t)b * L + j) * 256 + c] = acc;
+}
+
+void launch_time_reduce_dw(const float* x, const float* w5c, const float* bias, const int* lens, float* out, int B, int T,
+                           int mstride, hipStream_t s) {
+    const int L = (T + 1) / 2;
+    if (B * L <= 0) return;
+    hipLaunchKernelGGL(time_reduce_dw_kernel, dim3(L, B), dim3(256), 0, s, x, w5c, bias, lens, out, T, L, mstride);
+}
+
+// Squeezeformer recovery (encoder.py:199-205): x = recover_tensor + Linear(repeat_interleave(x, 2))[:, :T]
+// (Linear commutes with the repeat: y = Linear(x_reduced) is computed once per reduced frame)
+__global__ __launch_bounds__(256) void recover_add_kernel(const float* __restrict__ saved, const float* __restrict__ y,
+                                                          float* __restrict__ x, int T, int L) {
+    const int b = blockIdx.y, t = blockIdx.x, c = threadIdx.x;
+    x[((size_t)b * T + t) * 256 + c] = saved[((size_t)b * T + t) * 256 + c] + y[((size_t)b * L + (t >> 1)) * 256 + c];
+}
+
+void launch_recover_add(const float* saved, const float* y, float* x, int B, int T, int L, hipStream_t s) {
+    if (B * T <= 0) return;
+    hipLaunchKernelGGL(recover_add_kernel, dim3(T, B), dim3(256), 0, s, saved, y, x, T, L);
 }
 
 // ------------------------------------------------------------------------------------------

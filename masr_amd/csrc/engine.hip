@@ -64,6 +64,13 @@ struct LayerW {
     float *ln_fin_w, *ln_fin_b;
 };
 
+struct SqLayerW {   // Squeezeformer block (post-LN, adaptive scale/bias, BatchNorm conv module)
+    float *att_s, *att_b, *wqkv, *bqkv, *wo, *bo, *pos_u, *pos_v, *wpos, *ptab, *ln1_w, *ln1_b;
+    float *f1_s, *f1_b, *f1_w1, *f1_b1, *f1_w2, *f1_b2, *ln2_w, *ln2_b;
+    float *cv_s, *cv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *bn_scale, *bn_shift, *pw2_w, *pw2_b, *ln3_w, *ln3_b;
+    float *f2_s, *f2_b, *f2_w1, *f2_b1, *f2_w2, *f2_b2, *ln4_w, *ln4_b;
+};
+
 struct HostTensor {
     std::vector<float> v;
     std::vector<int64_t> shape;
@@ -91,11 +98,16 @@ struct masr_engine {
           *conv2_b = nullptr, *embed_w = nullptr, *embed_b = nullptr, *after_w = nullptr, *after_b = nullptr,
           *ctc_w = nullptr, *ctc_b = nullptr, *pe = nullptr;
     std::vector<LayerW> layers;
+    std::vector<SqLayerW> sq_layers;
+    float *preln_w = nullptr, *preln_b = nullptr, *tr_dw_w = nullptr, *tr_dw_b = nullptr, *tr_pw_w = nullptr,
+          *tr_pw_b = nullptr, *rec_w = nullptr, *rec_b = nullptr;
+    int reduce_idx = -1, recover_idx = -1;
     // fbank tables
     float *window = nullptr, *melw = nullptr, *tw256 = nullptr, *tw512 = nullptr;
     int *mel_lo = nullptr, *mel_hi = nullptr;
     // workspace
-    DevBuf x1, x2, x, ln, hid, qkv, att, lnpad, glu, dwo, logits, feats, enc, idx, maxp, attseq, gain, nframes, lens;
+    DevBuf x1, x2, x, ln, hid, qkv, att, lnpad, glu, dwo, logits, feats, enc, idx, maxp, attseq, gain, nframes, lens, xsave,
+        xred;
     // streams
     std::vector<Stream> streams;
     // profiling
@@ -173,11 +185,12 @@ void gemm(masr_engine* e, hipStream_t s, const float* A, int lda, const float* W
 void rowgemm(masr_engine* e, hipStream_t s, int pro, int epi, const float* A, int lda, const float* lnw,
              const float* lnb, const float* W, const float* bias, float* C, int ldc, int M, int N, const float* R,
              int ldr, float alpha, const int* lens, int mask_tp, int seq_t, int pad, int* out_idx, float* out_maxp,
-             int kind = PROF_GEMM) {
+             int kind = PROF_GEMM, int mstride = 4, int out_seq_t = 0, int out_pad_l = 0, int out_pad_tot = 0) {
     RowGemmArgs a{};
     a.A = A; a.lda = lda; a.lnw = lnw; a.lnb = lnb; a.W = W; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N;
     a.R = R; a.ldr = ldr; a.alpha = alpha; a.lens = lens; a.mask_tp = mask_tp; a.seq_t = seq_t; a.pad = pad;
-    a.out_idx = out_idx; a.out_maxp = out_maxp; a.eps = 1e-5f;
+    a.out_idx = out_idx; a.out_maxp = out_maxp; a.eps = 1e-5f; a.mstride = mstride;
+    a.out_seq_t = out_seq_t; a.out_pad_l = out_pad_l; a.out_pad_tot = out_pad_tot;
     ProfScope ps(e, s, kind, 2.0 * M * (double)N * 256);
     launch_rowgemm(a, pro, epi, s);
 }
@@ -241,11 +254,18 @@ int masr_version(void) { return 1; }
 
 int masr_create(const masr_config* cfg, masr_engine** out) {
     if (!cfg || !out) return fail("null argument");
-    if (cfg->model_kind != 0) return fail("only model_kind 0 (conformer) is implemented");
+    if (cfg->model_kind != 0 && cfg->model_kind != 1)
+        return fail("model_kind must be 0 (conformer) or 1 (squeezeformer, non-streaming)");
     if (cfg->d_model != 256 || cfg->heads != 4) return fail("kernels are specialised for d_model=256, heads=4");
     if (cfg->n_mels != 80) return fail("n_mels must be 80");
-    if (cfg->d_ff % 128 || cfg->cnn_kernel != 15) return fail("unsupported d_ff / cnn_module_kernel");
-    if (!cfg->causal) return fail("only the streaming-trained (causal conv) conformer is implemented");
+    if (cfg->d_ff % 128) return fail("unsupported d_ff");
+    if (cfg->model_kind == 0) {
+        if (cfg->cnn_kernel != 15) return fail("conformer: cnn_module_kernel must be 15");
+        if (!cfg->causal) return fail("only the streaming-trained (causal conv) conformer is implemented");
+    } else {
+        if (cfg->cnn_kernel != 31) return fail("squeezeformer: cnn_module_kernel must be 31");
+        if (cfg->causal) return fail("only the non-streaming squeezeformer (symmetric conv + BatchNorm) is implemented");
+    }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail("no HIP device");
@@ -253,6 +273,8 @@ int masr_create(const masr_config* cfg, masr_engine** out) {
     masr_engine* e = new masr_engine();
     e->cfg = *cfg;
     if (e->cfg.max_pos <= 0) e->cfg.max_pos = 5000;
+    e->reduce_idx = cfg->model_kind == 1 ? cfg->reserved[0] : -1;
+    e->recover_idx = cfg->model_kind == 1 ? cfg->reserved[1] : -1;
     if (build_fbank_tables(e)) {
         masr_destroy(e);
         return 1;
@@ -265,7 +287,8 @@ void masr_destroy(masr_engine* e) {
     if (!e) return;
     for (void* p : e->owned) (void)hipFree(p);
     DevBuf* bufs[] = {&e->x1, &e->x2, &e->x, &e->ln, &e->hid, &e->qkv, &e->att, &e->lnpad, &e->glu, &e->dwo,
-                      &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens};
+                      &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens, &e->xsave,
+                      &e->xred};
     for (DevBuf* b : bufs) b->release();
     for (auto& s : e->streams) {
         s.att.release();
@@ -294,8 +317,11 @@ int masr_load_tensor(masr_engine* e, const char* name, const float* host, const 
     return 0;
 }
 
+static int finalize_squeezeformer(masr_engine* e, hipStream_t s);
+
 int masr_finalize(masr_engine* e, void* stream) {
     if (!e) return fail("null engine");
+    if (e->cfg.model_kind == 1) return finalize_squeezeformer(e, (hipStream_t)stream);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(e->cfg.device_id));
     const int d = e->cfg.d_model, dff = e->cfg.d_ff, L = e->cfg.num_blocks, V = e->cfg.vocab_size, F = e->cfg.n_mels;
@@ -430,10 +456,10 @@ struct EncodeCtx {
 };
 
 int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb, const float* w1, const float* b1,
-        const float* w2, const float* b2) {
+        const float* w2, const float* b2, float scale = 0.5f, int affine = 0) {
     const int d = e->cfg.d_model, dff = e->cfg.d_ff;
     ProfScope ps(e, s, PROF_FFN1, 4.0 * M * (double)dff * d);
-    launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, 0.5f, s);
+    launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine, s);
     return 0;
 }
 
@@ -455,8 +481,14 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
         ProfScope ps(e, s, PROF_CONV2, 2.0 * a.M * (double)a.N * a.K);
         launch_gemm(a, A_CONV2, EPI_STD, s);
     }
-    gemm(e, s, e->x2.as<float>(), F2 * d, e->embed_w, e->embed_b, e->x.as<float>(), d, M, d, F2 * d, ACT_NONE,
-         sqrtf((float)d), nullptr, 0);
+    {   // Conformer: (W.x + b) * sqrt(d)  (embedding.py:97);  Squeezeformer: W.(x * sqrt(d)) + b  (subsampling.py:72-75)
+        GemmArgs a{};
+        a.A = e->x2.as<float>(); a.lda = F2 * d; a.W = e->embed_w; a.bias = e->embed_b; a.C = e->x.as<float>(); a.ldc = d;
+        a.M = M; a.N = d; a.K = F2 * d; a.act = ACT_NONE; a.alpha = sqrtf((float)d);
+        a.bias_after_alpha = e->cfg.model_kind == 1 ? 1 : 0;
+        ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)d * F2 * d);
+        launch_gemm(a, A_PLAIN, EPI_STD, s);
+    }
     *Tq_out = Tq;
     return 0;
 }
@@ -512,6 +544,230 @@ void mhsa_out(masr_engine* e, hipStream_t s, const LayerW& w, int M) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Squeezeformer (non-streaming build): weights + full-context forward
+// reference: masr/model_utils/squeezeformer/{encoder,attention,convolution,positionwise,subsampling,time_reduction}.py
+// ------------------------------------------------------------------------------------------------
+static int upload_conv_frontend(masr_engine* e, const std::string& c1, const std::string& c2, const std::string& proj) {
+    const int d = e->cfg.d_model, F = e->cfg.n_mels, F1 = (F - 1) / 2, F2 = (F1 - 1) / 2;
+    const HostTensor* t;
+    CHK(up(e, "encoder.global_cmvn.mean", {F}, &e->cmvn_mean));
+    CHK(up(e, "encoder.global_cmvn.istd", {F}, &e->cmvn_istd));
+    CHK(get(e, c1 + ".weight", {d, 1, 3, 3}, &t));
+    {
+        std::vector<float> w(9 * d);
+        for (int c = 0; c < d; ++c)
+            for (int k = 0; k < 9; ++k) w[k * d + c] = t->v[c * 9 + k];
+        CHK(upload(e, w, &e->conv1_w));
+    }
+    CHK(up(e, c1 + ".bias", {d}, &e->conv1_b));
+    CHK(get(e, c2 + ".weight", {d, d, 3, 3}, &t));
+    {
+        std::vector<float> w((size_t)d * 9 * d);
+        for (int co = 0; co < d; ++co)
+            for (int ci = 0; ci < d; ++ci)
+                for (int k = 0; k < 9; ++k) w[(size_t)co * 9 * d + k * d + ci] = t->v[((size_t)co * d + ci) * 9 + k];
+        CHK(upload(e, w, &e->conv2_w));
+    }
+    CHK(up(e, c2 + ".bias", {d}, &e->conv2_b));
+    CHK(get(e, proj + ".weight", {d, (int64_t)d * F2}, &t));
+    {
+        std::vector<float> w((size_t)d * d * F2);
+        for (int o = 0; o < d; ++o)
+            for (int c = 0; c < d; ++c)
+                for (int f = 0; f < F2; ++f) w[(size_t)o * d * F2 + f * d + c] = t->v[(size_t)o * d * F2 + c * F2 + f];
+        CHK(upload(e, w, &e->embed_w));
+    }
+    CHK(up(e, proj + ".bias", {d}, &e->embed_b));
+    return 0;
+}
+
+static int upload_pos_table(masr_engine* e) {
+    const int d = e->cfg.d_model;
+    auto it = e->host.find("__pos_table__");
+    if (it != e->host.end()) {
+        if ((int64_t)it->second.v.size() != (int64_t)e->cfg.max_pos * d) return fail("__pos_table__ has wrong size");
+        return upload(e, it->second.v, &e->pe);
+    }
+    std::vector<float> pe((size_t)e->cfg.max_pos * d);
+    for (int i = 0; i < d; i += 2) {
+        const float div = expf((float)i * (float)(-(log(10000.0) / d)));
+        for (int p = 0; p < e->cfg.max_pos; ++p) {
+            pe[(size_t)p * d + i] = sinf((float)p * div);
+            pe[(size_t)p * d + i + 1] = cosf((float)p * div);
+        }
+    }
+    return upload(e, pe, &e->pe);
+}
+
+static int finalize_squeezeformer(masr_engine* e, hipStream_t s) {
+    HIPCHK(hipSetDevice(e->cfg.device_id));
+    const int d = e->cfg.d_model, dff = e->cfg.d_ff, L = e->cfg.num_blocks, V = e->cfg.vocab_size, K = e->cfg.cnn_kernel,
+              H = e->cfg.heads, dk = d / H;
+    const HostTensor* t;
+    CHK(upload_conv_frontend(e, "encoder.embed.pw_conv", "encoder.embed.dw_conv", "encoder.embed.input_proj.0"));
+    CHK(upload_pos_table(e));
+    CHK(up(e, "encoder.preln.weight", {d}, &e->preln_w));
+    CHK(up(e, "encoder.preln.bias", {d}, &e->preln_b));
+    e->sq_layers.assign(L, SqLayerW{});
+    for (int i = 0; i < L; ++i) {
+        SqLayerW& w = e->sq_layers[i];
+        const std::string p = "encoder.encoders." + std::to_string(i) + ".";
+        auto vec = [&](const std::string& n, float** out) -> int { return up(e, p + n, {d}, out); };
+        CHK(vec("self_attn.ada_scale", &w.att_s));
+        CHK(vec("self_attn.ada_bias", &w.att_b));
+        {
+            std::vector<float> wq((size_t)3 * d * d), bq(3 * d);
+            const char* nm[3] = {"linear_q", "linear_k", "linear_v"};
+            for (int j = 0; j < 3; ++j) {
+                CHK(get(e, p + "self_attn." + nm[j] + ".weight", {d, d}, &t));
+                memcpy(&wq[(size_t)j * d * d], t->v.data(), sizeof(float) * d * d);
+                CHK(get(e, p + "self_attn." + nm[j] + ".bias", {d}, &t));
+                memcpy(&bq[j * d], t->v.data(), sizeof(float) * d);
+            }
+            CHK(upload(e, wq, &w.wqkv));
+            CHK(upload(e, bq, &w.bqkv));
+        }
+        CHK(up(e, p + "self_attn.linear_out.weight", {d, d}, &w.wo));
+        CHK(up(e, p + "self_attn.linear_out.bias", {d}, &w.bo));
+        CHK(up(e, p + "self_attn.linear_pos.weight", {d, d}, &w.wpos));
+        CHK(up(e, p + "self_attn.pos_bias_u", {H, dk}, &w.pos_u));
+        CHK(up(e, p + "self_attn.pos_bias_v", {H, dk}, &w.pos_v));
+        {
+            void* pt = nullptr;
+            HIPCHK(hipMalloc(&pt, (size_t)e->cfg.max_pos * d * sizeof(float)));
+            e->owned.push_back(pt);
+            w.ptab = (float*)pt;
+            gemm(e, s, e->pe, d, w.wpos, nullptr, w.ptab, d, e->cfg.max_pos, d, d, ACT_NONE, 1.f, nullptr, 0, PROF_NONE);
+        }
+        CHK(vec("layer_norm1.weight", &w.ln1_w)); CHK(vec("layer_norm1.bias", &w.ln1_b));
+        CHK(vec("layer_norm2.weight", &w.ln2_w)); CHK(vec("layer_norm2.bias", &w.ln2_b));
+        CHK(vec("layer_norm3.weight", &w.ln3_w)); CHK(vec("layer_norm3.bias", &w.ln3_b));
+        CHK(vec("layer_norm4.weight", &w.ln4_w)); CHK(vec("layer_norm4.bias", &w.ln4_b));
+        CHK(vec("ffn1.ada_scale", &w.f1_s)); CHK(vec("ffn1.ada_bias", &w.f1_b));
+        CHK(up(e, p + "ffn1.w_1.weight", {dff, d}, &w.f1_w1)); CHK(up(e, p + "ffn1.w_1.bias", {dff}, &w.f1_b1));
+        CHK(up(e, p + "ffn1.w_2.weight", {d, dff}, &w.f1_w2)); CHK(up(e, p + "ffn1.w_2.bias", {d}, &w.f1_b2));
+        CHK(vec("ffn2.ada_scale", &w.f2_s)); CHK(vec("ffn2.ada_bias", &w.f2_b));
+        CHK(up(e, p + "ffn2.w_1.weight", {dff, d}, &w.f2_w1)); CHK(up(e, p + "ffn2.w_1.bias", {dff}, &w.f2_b1));
+        CHK(up(e, p + "ffn2.w_2.weight", {d, dff}, &w.f2_w2)); CHK(up(e, p + "ffn2.w_2.bias", {d}, &w.f2_b2));
+        CHK(vec("conv_module.ada_scale", &w.cv_s)); CHK(vec("conv_module.ada_bias", &w.cv_b));
+        CHK(up(e, p + "conv_module.pointwise_conv1.weight", {2 * d, d, 1}, &w.pw1_w));
+        CHK(up(e, p + "conv_module.pointwise_conv1.bias", {2 * d}, &w.pw1_b));
+        {
+            CHK(get(e, p + "conv_module.depthwise_conv.weight", {d, 1, K}, &t));
+            std::vector<float> wd((size_t)K * d);
+            for (int c = 0; c < d; ++c)
+                for (int j = 0; j < K; ++j) wd[(size_t)j * d + c] = t->v[(size_t)c * K + j];
+            CHK(upload(e, wd, &w.dw_w));
+            CHK(up(e, p + "conv_module.depthwise_conv.bias", {d}, &w.dw_b));
+        }
+        {   // eval-mode BatchNorm1d folded: y = x * scale + shift, scale = w / sqrt(var + eps), shift = b - mean * scale
+            const HostTensor *tw, *tb, *tm, *tv;
+            CHK(get(e, p + "conv_module.norm.weight", {d}, &tw));
+            CHK(get(e, p + "conv_module.norm.bias", {d}, &tb));
+            CHK(get(e, p + "conv_module.norm.running_mean", {d}, &tm));
+            CHK(get(e, p + "conv_module.norm.running_var", {d}, &tv));
+            std::vector<float> sc(d), sh(d);
+            for (int c = 0; c < d; ++c) {
+                sc[c] = tw->v[c] / sqrtf(tv->v[c] + 1e-5f);
+                sh[c] = tb->v[c] - tm->v[c] * sc[c];
+            }
+            CHK(upload(e, sc, &w.bn_scale));
+            CHK(upload(e, sh, &w.bn_shift));
+        }
+        CHK(up(e, p + "conv_module.pointwise_conv2.weight", {d, d, 1}, &w.pw2_w));
+        CHK(up(e, p + "conv_module.pointwise_conv2.bias", {d}, &w.pw2_b));
+    }
+    {
+        CHK(get(e, "encoder.time_reduction_layer.dw_conv.weight", {d, 1, 5}, &t));
+        std::vector<float> wd((size_t)5 * d);
+        for (int c = 0; c < d; ++c)
+            for (int j = 0; j < 5; ++j) wd[(size_t)j * d + c] = t->v[(size_t)c * 5 + j];
+        CHK(upload(e, wd, &e->tr_dw_w));
+        CHK(up(e, "encoder.time_reduction_layer.dw_conv.bias", {d}, &e->tr_dw_b));
+        CHK(up(e, "encoder.time_reduction_layer.pw_conv.weight", {d, d, 1}, &e->tr_pw_w));
+        CHK(up(e, "encoder.time_reduction_layer.pw_conv.bias", {d}, &e->tr_pw_b));
+        CHK(up(e, "encoder.time_recover_layer.weight", {d, d}, &e->rec_w));
+        CHK(up(e, "encoder.time_recover_layer.bias", {d}, &e->rec_b));
+    }
+    CHK(up(e, "ctc.ctc_lo.weight", {V, d}, &e->ctc_w));
+    CHK(up(e, "ctc.ctc_lo.bias", {V}, &e->ctc_b));
+    HIPCHK(hipStreamSynchronize(s));
+    e->host.clear();
+    e->finalized = true;
+    return 0;
+}
+
+// SqueezeformerEncoder.forward, streaming = False (squeezeformer/encoder.py:168-216)
+static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float* feats, const int* lens, int B, int T,
+                                     float* enc_out) {
+    const int d = e->cfg.d_model, H = e->cfg.heads, K = e->cfg.cnn_kernel, half = (K - 1) / 2;
+    int T0 = 0;
+    CHK(embed(e, s, feats, B, T, &T0));
+    if (T0 >= e->cfg.max_pos) return fail("sequence longer than max_pos");
+    CHK(ensure_layer_ws(e, B, T0));
+    CHK(e->attseq.ensure(sizeof(AttSeq) * B));
+    CHK(e->xsave.ensure((size_t)B * T0 * d * sizeof(float)));
+    CHK(e->xred.ensure((size_t)B * ((T0 + 1) / 2) * d * sizeof(float)));
+    float* x = e->x.as<float>();
+    launch_layernorm(x, e->preln_w, e->preln_b, x, B * T0, 1e-5f, 0, 0, nullptr, s);
+    int Tq = T0, mstride = 4, pstride = 1;
+    auto new_resolution = [&]() -> int {     // zero the symmetric pad rows of the GLU buffer, rebuild the descriptors
+        HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + 2 * half) * d * sizeof(float), s));
+        launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), lens, B, Tq, mstride, s);
+        return 0;
+    };
+    CHK(new_resolution());
+    const int L = e->cfg.num_blocks;
+    for (int i = 0; i < L; ++i) {
+        const SqLayerW& w = e->sq_layers[i];
+        if (i == e->reduce_idx) {
+            // TimeReductionLayer1D (time_reduction.py:53-76): keep x for the recovery, halve the frame rate
+            HIPCHK(hipMemcpyAsync(e->xsave.p, x, (size_t)B * Tq * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+            launch_time_reduce_dw(x, e->tr_dw_w, e->tr_dw_b, lens, e->xred.as<float>(), B, Tq, mstride, s);
+            const int Lr = (Tq + 1) / 2;
+            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_STORE, e->xred.as<float>(), d, nullptr, nullptr, e->tr_pw_w, e->tr_pw_b, x, d,
+                    B * Lr, d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+            Tq = Lr; mstride = 8; pstride = 2;
+            CHK(new_resolution());
+        }
+        if (i == e->recover_idx && e->reduce_idx >= 0) {
+            // x = saved + Linear(repeat_interleave(x, 2))[:, :T0]   (encoder.py:199-205)
+            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_STORE, x, d, nullptr, nullptr, e->rec_w, e->rec_b, e->xred.as<float>(), d,
+                    B * Tq, d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+            launch_recover_add(e->xsave.as<float>(), e->xred.as<float>(), x, B, T0, Tq, s);
+            Tq = T0; mstride = 4; pstride = 1;
+            CHK(new_resolution());
+        }
+        const int M = B * Tq;
+        // x = LN1(x + MHSA(ada(x)))
+        rowgemm(e, s, RG_PRO_AFFINE, RG_EPI_STORE, x, d, w.att_s, w.att_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M,
+                3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+        {
+            ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
+            launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v, 0, pstride, s);
+        }
+        rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->att.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d, 1.f,
+                nullptr, 0, 0, 0, nullptr, nullptr);
+        launch_layernorm(x, w.ln1_w, w.ln1_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        // x = LN2(x + FFN1(ada(x)))
+        CHK(ffn(e, s, M, w.f1_s, w.f1_b, w.f1_w1, w.f1_b1, w.f1_w2, w.f1_b2, 1.0f, 1));
+        launch_layernorm(x, w.ln2_w, w.ln2_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        // x = LN3(x + Conv(ada(x)))   symmetric depthwise conv: (K-1)/2 zero rows on both sides of the GLU output
+        rowgemm(e, s, RG_PRO_AFFINE, RG_EPI_GLU, x, d, w.cv_s, w.cv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d, M, 2 * d,
+                nullptr, 0, 1.f, lens, 0, Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, Tq, half, 2 * half);
+        launch_dwconv_bn_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.bn_scale, w.bn_shift, e->dwo.as<float>(), B, Tq, K, s);
+        rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x,
+                d, 1.f, lens, Tq, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
+        launch_layernorm(x, w.ln3_w, w.ln3_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        // x = LN4(x + FFN2(ada(x)))
+        CHK(ffn(e, s, M, w.f2_s, w.f2_b, w.f2_w1, w.f2_b1, w.f2_w2, w.f2_b2, 1.0f, 1));
+        launch_layernorm(x, w.ln4_w, w.ln4_b, i == L - 1 ? enc_out : x, M, 1e-5f, 0, 0, nullptr, s);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat_lens_dev, int32_t B, int32_t T,
@@ -519,6 +775,10 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     if (!e || !e->finalized) return fail("engine not finalized");
     if (B <= 0) return fail("empty batch");
     hipStream_t s = (hipStream_t)stream;
+    if (e->cfg.model_kind == 1) {
+        if (decoding_chunk_size > 0) return fail("squeezeformer (non-streaming): chunk masks are not available");
+        return encode_full_squeezeformer(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev);
+    }
     const int d = e->cfg.d_model, H = e->cfg.heads, pad = e->cfg.cnn_kernel - 1;
     int Tq = 0;
     CHK(embed(e, s, feats_dev, B, T, &Tq));
@@ -528,14 +788,14 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     CHK(e->attseq.ensure(sizeof(AttSeq) * B));
     float* x = e->x.as<float>();
     EncodeCtx ctx{B, Tq, feat_lens_dev};
-    launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), feat_lens_dev, B, Tq, s);
+    launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), feat_lens_dev, B, Tq, 4, s);
     for (const LayerW& w : e->layers) {
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
         mhsa(e, s, w, M);
         {
             ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
             launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v,
-                             decoding_chunk_size > 0 ? decoding_chunk_size : 0, s);
+                             decoding_chunk_size > 0 ? decoding_chunk_size : 0, 1, s);
         }
         mhsa_out(e, s, w, M);
         CHK(conv_module(e, s, w, ctx, false));
@@ -649,6 +909,7 @@ int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t*
 
 int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id) {
     if (!e || !e->finalized) return fail("engine not finalized");
+    if (e->cfg.model_kind != 0) return fail("streaming is implemented for the conformer only");
     if (max_frames_out <= 0 || max_frames_out > e->cfg.max_pos) max_frames_out = e->cfg.max_pos;
     int id = -1;
     for (size_t i = 0; i < e->streams.size(); ++i)
@@ -748,7 +1009,7 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
             HIPCHK(hipMemcpy2DAsync(cache, 2 * d * sizeof(float), e->qkv.as<float>() + (size_t)i * Tq * 3 * d + d,
                                     3 * d * sizeof(float), 2 * d * sizeof(float), Tq, hipMemcpyDeviceToDevice, s));
         }
-        launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, s);
+        launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, 1, s);
         mhsa_out(e, s, w, M);
         for (int i = 0; i < n; ++i)     // history rows <- cnn cache (zeros on the first chunk)
             HIPCHK(hipMemcpyAsync(e->lnpad.as<float>() + (size_t)i * (Tq + pad) * d,

@@ -45,7 +45,7 @@ __device__ __forceinline__ float wsum64(float v) {
 // (Measured with per-slab barriers: 54-57 % MFMA-busy, ~450 cycles of barrier skew + ~800 cycles of
 //  exposed L2 latency per 2048-cycle slab.)
 // VAR (diagnostic ablations, production = 0): 1 = no global weight loads, 2 = no MFMA, 3 = no LDS stores of weights
-template <int VAR>
+template <int VAR, int AFFINE>
 __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* __restrict__ lnw,
                                                         const float* __restrict__ lnb, const float* __restrict__ w1,
                                                         const float* __restrict__ b1, const float* __restrict__ w2,
@@ -74,14 +74,21 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row < M) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * FF_D + lane * 4);
-                const float mean = wsum64(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
-                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-                const float var = wsum64(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
-                const float rstd = 1.0f / sqrtf(var + eps);
-                o[0] = d0 * rstd * gw[0] + gb[0];
-                o[1] = d1 * rstd * gw[1] + gb[1];
-                o[2] = d2 * rstd * gw[2] + gb[2];
-                o[3] = d3 * rstd * gw[3] + gb[3];
+                if (AFFINE) {      // Squeezeformer: ada_scale * x + ada_bias (positionwise.py:57-58), no LayerNorm
+                    o[0] = gw[0] * v[0] + gb[0];
+                    o[1] = gw[1] * v[1] + gb[1];
+                    o[2] = gw[2] * v[2] + gb[2];
+                    o[3] = gw[3] * v[3] + gb[3];
+                } else {
+                    const float mean = wsum64(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                    const float var = wsum64(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                    const float rstd = 1.0f / sqrtf(var + eps);
+                    o[0] = d0 * rstd * gw[0] + gb[0];
+                    o[1] = d1 * rstd * gw[1] + gb[1];
+                    o[2] = d2 * rstd * gw[2] + gb[2];
+                    o[3] = d3 * rstd * gw[3] + gb[3];
+                }
             }
             *reinterpret_cast<f32x4*>(&xn[lr * XN_LD + lane * 4]) = o;
         }
@@ -238,29 +245,32 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
 static int g_ffn_variant = 0;
 void set_ffn_variant(int v) { g_ffn_variant = v; }
 
-template <int VAR>
+template <int VAR, int AFFINE>
 static void launch_ffn_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                          const float* b2, int M, int dff, float eps, float scale, hipStream_t s) {
     const size_t lds = (size_t)(FF_BM * XN_LD + 2 * FF_BM * HS_LD + 8 * 2 * WSLAB + 8 * 8 * 64) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fused_kernel<VAR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fused_kernel<VAR, AFFINE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(ffn_fused_kernel<VAR>, dim3((M + FF_BM - 1) / FF_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
-                       b2, M, dff, eps, scale);
+    hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE>), dim3((M + FF_BM - 1) / FF_BM), dim3(512), lds, s, x, lnw, lnb, w1,
+                       b1, w2, b2, M, dff, eps, scale);
 }
 
 void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                      const float* b2, int M, int dff, float eps, float scale, hipStream_t s) {
+                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, hipStream_t s) {
     if (M <= 0) return;
+    if (affine_prologue) {
+        launch_ffn_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s);
+        return;
+    }
     switch (g_ffn_variant) {
-        case 1: launch_ffn_t<1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
-        case 2: launch_ffn_t<2>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
-        case 3: launch_ffn_t<3>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
-        case 4: launch_ffn_t<4>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
-        default: launch_ffn_t<0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+        case 1: launch_ffn_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+        case 2: launch_ffn_t<2, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+        case 4: launch_ffn_t<4, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+        default: launch_ffn_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
     }
 }
 

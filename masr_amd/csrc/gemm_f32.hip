@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = bm + wm * (BM / WM) + m * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    float v = acc[m][n][r] + bv;
+                    float v = acc[m][n][r] + (p.bias_after_alpha ? 0.f : bv);
                     if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.act == ACT_SILU) v = silu_f(v);
                     if (p.mask_tp > 0) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                         const int b = rc / p.mask_tp, t = rc - b * p.mask_tp;
                         if (4 * t >= p.lens[b]) v = 0.f;
                     }
-                    v = res[r] + v * p.alpha;
+                    v = res[r] + v * p.alpha + (p.bias_after_alpha ? bv : 0.f);
                     if (row < p.M) p.C[(size_t)row * p.ldc + col] = v;
                 }
             }

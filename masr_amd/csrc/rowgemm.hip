@@ -7,7 +7,8 @@
 // (same machinery as ffn_fused.hip, no workgroup barrier in the main loop).  M = B*T' = 7936 rows give
 // 248 workgroups ~ one per CU.  v_mfma_f32_32x32x2_f32 (exact fp32) throughout.
 //
-// Prologues: plain rows | LayerNorm(256) | LayerNorm into the conv module's padded time layout
+// Prologues: plain rows | per-channel affine (Squeezeformer adaptive scale/bias, optional pad masking) |
+//            LayerNorm(256) | LayerNorm into the conv module's padded time layout
 //            (14 zero history rows per sequence, padded frames zeroed; conformer/convolution.py:98-108).
 // Epilogues: store (fused QKV)            -- conformer/attention.py:53-79
 //            residual + alpha*(.) [+ pad mask]   (attention out-proj, pointwise_conv2) -- encoder.py:123-145
@@ -60,13 +61,19 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
             const int row = row0 + wave * 4 + rr;
             bool live = row < p.M;
             size_t src_row = live ? row : 0;
+            if (PRO == RG_PRO_AFFINE && p.lens && p.seq_t > 0) {
+                // Squeezeformer conv module: padded frames are zeroed AFTER the adaptive scale/bias (convolution.py:109-115)
+                const int rc = live ? row : 0;
+                const int b = rc / p.seq_t, t = rc - b * p.seq_t;
+                live = live && p.mstride * t < p.lens[b];
+            }
             if (PRO == RG_PRO_LN_PAD) {
                 // output row index lives in the padded layout [nseq][pad + Tq]; history rows and padded frames are zero
                 const int per = p.seq_t + p.pad;
                 const int rc = live ? row : 0;
                 const int b = rc / per, tp = rc - b * per;
                 const int t = max(tp - p.pad, 0);
-                live = live && tp >= p.pad && !(p.lens && 4 * t >= p.lens[b]);
+                live = live && tp >= p.pad && !(p.lens && p.mstride * t >= p.lens[b]);
                 src_row = (size_t)b * p.seq_t + t;
             }
             live4[rr] = live;
@@ -79,6 +86,11 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
             f32x4 o;
             if (PRO == RG_PRO_PLAIN) {
                 o = v;
+            } else if (PRO == RG_PRO_AFFINE) {          // adaptive scale / bias (squeezeformer ada_scale, ada_bias)
+                o[0] = gw[0] * v[0] + gb[0];
+                o[1] = gw[1] * v[1] + gb[1];
+                o[2] = gw[2] * v[2] + gb[2];
+                o[3] = gw[3] * v[3] + gb[3];
             } else {
                 const float mean = rg_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
                 const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
                         if (p.mask_tp > 0) {
                             const int rc = min(row, p.M - 1);
                             const int b = rc / p.mask_tp, tt = rc - b * p.mask_tp;
-                            if (4 * tt >= p.lens[b]) v = 0.f;
+                            if (p.mstride * tt >= p.lens[b]) v = 0.f;
                         }
                         v = res[r] + p.alpha * v;
                     }
@@ -206,8 +218,13 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                     if (row >= p.M) continue;
+                    size_t crow = row;
+                    if (p.out_seq_t > 0) {               // symmetric-padded layout for the non-causal depthwise conv
+                        const int b = row / p.out_seq_t, t = row - b * p.out_seq_t;
+                        crow = (size_t)b * (p.out_seq_t + p.out_pad_tot) + p.out_pad_l + t;
+                    }
                     const float g = acc[r] + bvg;
-                    p.C[(size_t)row * p.ldc + ch] = (accv[r] + bva) * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+                    p.C[crow * p.ldc + ch] = (accv[r] + bva) * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
                 }
             }
         } else {   // RG_EPI_CTC: fold this 32-column tile into the running (max, argmax, sum exp) of my row
@@ -287,6 +304,8 @@ void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_RESID) launch_rg<RG_PRO_PLAIN, RG_EPI_RESID>(a, s);
     else if (pro == RG_PRO_LN_PAD && epi == RG_EPI_GLU) launch_rg<RG_PRO_LN_PAD, RG_EPI_GLU>(a, s);
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_GLU) launch_rg<RG_PRO_PLAIN, RG_EPI_GLU>(a, s);
+    else if (pro == RG_PRO_AFFINE && epi == RG_EPI_STORE) launch_rg<RG_PRO_AFFINE, RG_EPI_STORE>(a, s);
+    else if (pro == RG_PRO_AFFINE && epi == RG_EPI_GLU) launch_rg<RG_PRO_AFFINE, RG_EPI_GLU>(a, s);
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_CTC) launch_rg<RG_PRO_PLAIN, RG_EPI_CTC>(a, s);
     else if (pro == RG_PRO_LN && epi == RG_EPI_CTC) launch_rg<RG_PRO_LN, RG_EPI_CTC>(a, s);
 }

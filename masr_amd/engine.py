@@ -38,7 +38,7 @@ class HipEngine:
     engine that can run the model-independent kernels (fbank, argmax, CTC collapse)."""
 
     def __init__(self, state_dict, encoder_conf=None, vocab_size=None, streaming=True, n_mels=80, device=0,
-                 max_pos=5000):
+                 max_pos=5000, use_model='conformer'):
         if not torch.cuda.is_available():
             raise _lib.MasrError('no HIP device visible to torch: the MI355X engine has no CPU fallback')
         self.lib = _lib.lib()
@@ -47,11 +47,28 @@ class HipEngine:
             vocab_size = int(state_dict['ctc.ctc_lo.weight'].shape[0]) if state_dict is not None else 1
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
-        cfg = MasrConfig(model_kind=0, d_model=int(enc.get('output_size', 256)),
-                         heads=int(enc.get('attention_heads', 4)), d_ff=int(enc.get('linear_units', 2048)),
-                         num_blocks=int(enc.get('num_blocks', 12)), cnn_kernel=int(enc.get('cnn_module_kernel', 15)),
-                         n_mels=n_mels, vocab_size=int(vocab_size), causal=1 if streaming else 0, max_pos=max_pos,
-                         device_id=device)
+        if use_model == 'conformer':
+            cfg = MasrConfig(model_kind=0, d_model=int(enc.get('output_size', 256)),
+                             heads=int(enc.get('attention_heads', 4)), d_ff=int(enc.get('linear_units', 2048)),
+                             num_blocks=int(enc.get('num_blocks', 12)),
+                             cnn_kernel=int(enc.get('cnn_module_kernel', 15)), n_mels=n_mels,
+                             vocab_size=int(vocab_size), causal=1 if streaming else 0, max_pos=max_pos,
+                             device_id=device)
+        elif use_model == 'squeezeformer':
+            # configs/squeezeformer.yml: encoder_dim, feed_forward_expansion_factor, reduce_idx / recover_idx
+            dim = int(enc.get('encoder_dim', 256))
+            cfg = MasrConfig(model_kind=1, d_model=dim, heads=int(enc.get('attention_heads', 4)),
+                             d_ff=dim * int(enc.get('feed_forward_expansion_factor', 8)),
+                             num_blocks=int(enc.get('num_blocks', 12)),
+                             cnn_kernel=int(enc.get('cnn_module_kernel', 31)), n_mels=n_mels,
+                             vocab_size=int(vocab_size), causal=1 if streaming else 0, max_pos=max_pos,
+                             device_id=device)
+            red, rec = enc.get('reduce_idx', 5), enc.get('recover_idx', 11)
+            cfg.reserved[0] = -1 if red is None else int(red)
+            cfg.reserved[1] = -1 if rec is None else int(rec)
+        else:
+            raise _lib.MasrError(f'use_model={use_model}: only conformer and squeezeformer are implemented')
+        self.use_model = use_model
         self.cfg = cfg
         self.d_model, self.vocab_size, self.n_mels = cfg.d_model, cfg.vocab_size, n_mels
         self.num_blocks, self.heads, self.cnn_kernel = cfg.num_blocks, cfg.heads, cfg.cnn_kernel

@@ -87,3 +87,68 @@ def synthetic_pcm(batch, n_samples, seed=1234):
     rng = np.random.default_rng(seed)
     x = rng.normal(0, 3000, (batch, n_samples))
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def squeezeformer_state_dict(seed=0, vocab_size=4233, d=256, heads=4, ff_factor=8, num_blocks=12, kernel=31,
+                             n_mels=80, ctc_gain=6.0):
+    """Keys/shapes == reference SqueezeformerModel ``encoder.*`` + ``ctc.*`` (non-streaming build:
+    TimeReductionLayer1D, BatchNorm conv module; masr/model_utils/squeezeformer/)."""
+    sd = {}
+    f2 = ((n_mels - 1) // 2 - 1) // 2
+    d_ff = d * ff_factor
+
+    def lin(name, out_f, in_f, bias=True, gain=1.0):
+        b = gain / math.sqrt(in_f)
+        sd[name + '.weight'] = _uniform(seed, name + '.weight', (out_f, in_f), b * math.sqrt(3.0))
+        if bias:
+            sd[name + '.bias'] = _uniform(seed, name + '.bias', (out_f,), 0.1)
+
+    def ln(name, n=d):
+        sd[name + '.weight'] = 1.0 + _uniform(seed, name + '.weight', (n,), 0.2)
+        sd[name + '.bias'] = _uniform(seed, name + '.bias', (n,), 0.1)
+
+    def ada(p):
+        sd[p + '.ada_scale'] = (1.0 + _uniform(seed, p + '.ada_scale', (1, 1, d), 0.2))
+        sd[p + '.ada_bias'] = _uniform(seed, p + '.ada_bias', (1, 1, d), 0.1)
+
+    sd['encoder.global_cmvn.mean'] = 13.5 + _uniform(seed, 'cmvn.mean', (n_mels,), 1.0)
+    sd['encoder.global_cmvn.istd'] = 0.3 + _uniform(seed, 'cmvn.istd', (n_mels,), 0.05)
+    sd['encoder.embed.pw_conv.weight'] = _uniform(seed, 'sq.conv0.w', (d, 1, 3, 3), math.sqrt(3.0 / 9))
+    sd['encoder.embed.pw_conv.bias'] = _uniform(seed, 'sq.conv0.b', (d,), 0.1)
+    sd['encoder.embed.dw_conv.weight'] = _uniform(seed, 'sq.conv2.w', (d, d, 3, 3), math.sqrt(3.0 / (9 * d)))
+    sd['encoder.embed.dw_conv.bias'] = _uniform(seed, 'sq.conv2.b', (d,), 0.1)
+    # input_proj sees x * sqrt(d) (pos_enc scaling happens BEFORE the projection, subsampling.py:72-75)
+    lin('encoder.embed.input_proj.0', d, d * f2, gain=1.0 / math.sqrt(d))
+    ln('encoder.preln')
+    for i in range(num_blocks):
+        p = f'encoder.encoders.{i}.'
+        for q in ('linear_q', 'linear_k', 'linear_v', 'linear_out'):
+            lin(p + 'self_attn.' + q, d, d)
+        lin(p + 'self_attn.linear_pos', d, d, bias=False)
+        sd[p + 'self_attn.pos_bias_u'] = _uniform(seed, p + 'u', (heads, d // heads), 0.3)
+        sd[p + 'self_attn.pos_bias_v'] = _uniform(seed, p + 'v', (heads, d // heads), 0.3)
+        ada(p + 'self_attn')
+        for ff in ('ffn1', 'ffn2'):
+            lin(p + ff + '.w_1', d_ff, d)
+            lin(p + ff + '.w_2', d, d_ff)
+            ada(p + ff)
+        ada(p + 'conv_module')
+        sd[p + 'conv_module.pointwise_conv1.weight'] = _uniform(seed, p + 'pw1.w', (2 * d, d, 1), math.sqrt(3.0 / d))
+        sd[p + 'conv_module.pointwise_conv1.bias'] = _uniform(seed, p + 'pw1.b', (2 * d,), 0.1)
+        sd[p + 'conv_module.depthwise_conv.weight'] = _uniform(seed, p + 'dw.w', (d, 1, kernel), math.sqrt(3.0 / kernel))
+        sd[p + 'conv_module.depthwise_conv.bias'] = _uniform(seed, p + 'dw.b', (d,), 0.1)
+        ln(p + 'conv_module.norm')
+        sd[p + 'conv_module.norm.running_mean'] = _uniform(seed, p + 'bn.mean', (d,), 0.2)
+        sd[p + 'conv_module.norm.running_var'] = 0.25 + _uniform(seed, p + 'bn.var', (d,), 0.1)
+        sd[p + 'conv_module.norm.num_batches_tracked'] = torch.tensor(100, dtype=torch.long)
+        sd[p + 'conv_module.pointwise_conv2.weight'] = _uniform(seed, p + 'pw2.w', (d, d, 1), math.sqrt(3.0 / d))
+        sd[p + 'conv_module.pointwise_conv2.bias'] = _uniform(seed, p + 'pw2.b', (d,), 0.1)
+        for n in ('layer_norm1', 'layer_norm2', 'layer_norm3', 'layer_norm4'):
+            ln(p + n)
+    sd['encoder.time_reduction_layer.dw_conv.weight'] = _uniform(seed, 'tr.dw.w', (d, 1, 5), math.sqrt(3.0 / 5))
+    sd['encoder.time_reduction_layer.dw_conv.bias'] = _uniform(seed, 'tr.dw.b', (d,), 0.1)
+    sd['encoder.time_reduction_layer.pw_conv.weight'] = _uniform(seed, 'tr.pw.w', (d, d, 1), math.sqrt(3.0 / d))
+    sd['encoder.time_reduction_layer.pw_conv.bias'] = _uniform(seed, 'tr.pw.b', (d,), 0.1)
+    lin('encoder.time_recover_layer', d, d)
+    lin('ctc.ctc_lo', vocab_size, d, gain=ctc_gain)
+    return sd

@@ -95,6 +95,20 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'conformer_v4233.npz'), top_p=top.values.numpy(),
                         top_i=top.indices.numpy().astype(np.int32))
 
+    # ---- squeezeformer (configs/squeezeformer.yml, streaming: False) V=512 -------------------------
+    from masr.model_utils.squeezeformer.model import SqueezeformerModel
+    sq_cfg = yaml.safe_load(open(os.path.join(REF, 'configs', 'squeezeformer.yml'), encoding='utf-8'))
+    sq_sd = weights.squeezeformer_state_dict(0, 512)
+    sq = SqueezeformerModel(input_dim=80, vocab_size=512, mean_istd_path=mean_istd, streaming=False,
+                            encoder_conf=sq_cfg['encoder_conf'], decoder_conf=sq_cfg['decoder_conf'],
+                            **sq_cfg['model_conf'])
+    missing, unexpected = sq.load_state_dict(sq_sd, strict=False)
+    assert not unexpected and all(k.startswith('decoder.') for k in missing)
+    sq.eval()
+    sq_enc, _ = sq.encoder(feats, lens, -1, -1)
+    sq_probs = sq.get_encoder_out(feats, lens)
+    np.savez_compressed(os.path.join(OUT, 'squeezeformer_v512.npz'), enc=sq_enc.numpy(), probs=sq_probs.numpy())
+
     # ---- MASRPredictor facade on the TorchScript export ---------------------------
     from masr.predict import MASRPredictor
     vocab = weights.synthetic_vocab(4233)

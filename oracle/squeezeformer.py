@@ -1,0 +1,134 @@
+"""TEST INFRASTRUCTURE ONLY -- torch-CPU fp32 restatement of the reference Squeezeformer inference
+forward, non-streaming build (``streaming: False`` -> symmetric depthwise conv + BatchNorm,
+TimeReductionLayer1D, pad masks only; ``configs/squeezeformer.yml``).  Driven by a ``state_dict``
+with the reference key names; paths below are relative to ``masr/model_utils``.  Pinned against the
+real reference modules by tests/test_oracle_golden.py (live + committed fixture)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle.conformer import positional_table
+
+
+def _ln(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + '.weight'], sd[p + '.bias'], 1e-5)
+
+
+def _ada(sd, p, x):
+    """adaptive scale / bias (squeezeformer/attention.py:112-115, positionwise.py:57-58, convolution.py:109-110)."""
+    return sd[p + '.ada_scale'] * x + sd[p + '.ada_bias']
+
+
+def embed(sd, feats):
+    """GlobalCMVN + DepthwiseConv2DSubsampling4.forward (squeezeformer/subsampling.py:60-76; dw_stride=False
+    => the second conv is a full 256->256 conv).  NB the sqrt(d) scaling is applied BEFORE input_proj."""
+    x = (feats - sd['encoder.global_cmvn.mean']) * sd['encoder.global_cmvn.istd']
+    x = x.unsqueeze(1)
+    x = F.relu(F.conv2d(x, sd['encoder.embed.pw_conv.weight'], sd['encoder.embed.pw_conv.bias'], stride=2))
+    x = F.relu(F.conv2d(x, sd['encoder.embed.dw_conv.weight'], sd['encoder.embed.dw_conv.bias'], stride=2))
+    b, c, t, f = x.shape
+    x = x.permute(0, 2, 1, 3).contiguous().view(b, t, c * f)
+    x = x * math.sqrt(c)
+    return F.linear(x, sd['encoder.embed.input_proj.0.weight'], sd['encoder.embed.input_proj.0.bias'])
+
+
+def _attention(sd, p, x, pos_emb, key_mask, heads):
+    """squeezeformer/attention.py:88-167 (rel_shift removed, ada scale on q/k/v inputs)."""
+    B, T, d = x.shape
+    dk = d // heads
+    xs = _ada(sd, p, x)
+    q = F.linear(xs, sd[p + '.linear_q.weight'], sd[p + '.linear_q.bias']).view(B, T, heads, dk)
+    k = F.linear(xs, sd[p + '.linear_k.weight'], sd[p + '.linear_k.bias']).view(B, T, heads, dk).transpose(1, 2)
+    v = F.linear(xs, sd[p + '.linear_v.weight'], sd[p + '.linear_v.bias']).view(B, T, heads, dk).transpose(1, 2)
+    pp = F.linear(pos_emb, sd[p + '.linear_pos.weight']).view(1, -1, heads, dk).transpose(1, 2)
+    qu = (q + sd[p + '.pos_bias_u']).transpose(1, 2)
+    qv = (q + sd[p + '.pos_bias_v']).transpose(1, 2)
+    scores = (qu @ k.transpose(-2, -1) + qv @ pp.transpose(-2, -1)) / math.sqrt(dk)
+    m = ~key_mask.unsqueeze(1)                         # (B,1,1,T)
+    scores = scores.masked_fill(m, -float('inf'))
+    attn = torch.softmax(scores, dim=-1).masked_fill(m, 0.0)
+    o = (attn @ v).transpose(1, 2).reshape(B, T, d)
+    return F.linear(o, sd[p + '.linear_out.weight'], sd[p + '.linear_out.bias'])
+
+
+def _ffn(sd, p, x):
+    """squeezeformer/positionwise.py:49-59."""
+    h = F.silu(F.linear(_ada(sd, p, x), sd[p + '.w_1.weight'], sd[p + '.w_1.bias']))
+    return F.linear(h, sd[p + '.w_2.weight'], sd[p + '.w_2.bias'])
+
+
+def _conv_module(sd, p, x, pad_mask, kernel):
+    """squeezeformer/convolution.py:92-148, non-causal + BatchNorm1d in eval mode."""
+    x = _ada(sd, p, x).transpose(1, 2)
+    x = x.masked_fill(~pad_mask.unsqueeze(1), 0.0)
+    x = F.conv1d(x, sd[p + '.pointwise_conv1.weight'], sd[p + '.pointwise_conv1.bias'])
+    x = F.glu(x, dim=1)
+    x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], padding=(kernel - 1) // 2,
+                 groups=x.shape[1])
+    x = F.batch_norm(x, sd[p + '.norm.running_mean'], sd[p + '.norm.running_var'], sd[p + '.norm.weight'],
+                     sd[p + '.norm.bias'], False, 0.1, 1e-5)
+    x = F.silu(x)
+    x = F.conv1d(x, sd[p + '.pointwise_conv2.weight'], sd[p + '.pointwise_conv2.bias'])
+    x = x.masked_fill(~pad_mask.unsqueeze(1), 0.0)
+    return x.transpose(1, 2)
+
+
+def _layer(sd, i, x, pos_emb, pad_mask, heads, kernel):
+    """SqueezeformerEncoderLayer.forward, normalize_before=False (squeezeformer/encoder.py:412-463)."""
+    p = f'encoder.encoders.{i}'
+    x = _ln(sd, p + '.layer_norm1', x + _attention(sd, p + '.self_attn', x, pos_emb, pad_mask.unsqueeze(1), heads))
+    x = _ln(sd, p + '.layer_norm2', x + _ffn(sd, p + '.ffn1', x))
+    x = _ln(sd, p + '.layer_norm3', x + _conv_module(sd, p + '.conv_module', x, pad_mask, kernel))
+    x = _ln(sd, p + '.layer_norm4', x + _ffn(sd, p + '.ffn2', x))
+    return x
+
+
+def _time_reduce(sd, x, pad_mask):
+    """TimeReductionLayer1D.forward (squeezeformer/time_reduction.py:53-76): dw k=5 s=2 pad=3 + pw."""
+    p = 'encoder.time_reduction_layer'
+    y = x.transpose(1, 2).masked_fill(~pad_mask.unsqueeze(1), 0.0)
+    y = F.conv1d(y, sd[p + '.dw_conv.weight'], sd[p + '.dw_conv.bias'], stride=2, padding=3, groups=y.shape[1])
+    y = F.conv1d(y, sd[p + '.pw_conv.weight'], sd[p + '.pw_conv.bias']).transpose(1, 2)
+    pm = pad_mask[:, ::2]
+    L, T = pm.shape[1], y.shape[1]
+    if L - T < 0:
+        y = y[:, :L - T, :].contiguous()
+    else:
+        y = torch.cat([y, torch.zeros(y.shape[0], L - T, y.shape[2])], dim=1)
+    return y, pm
+
+
+def num_blocks_of(sd):
+    return 1 + max(int(k.split('.')[2]) for k in sd if k.startswith('encoder.encoders.'))
+
+
+def encoder_full(sd, feats, lens, heads=4, kernel=31, reduce_idx=5, recover_idx=11):
+    """SqueezeformerEncoder.forward, streaming=False (squeezeformer/encoder.py:168-216)."""
+    B, T, _ = feats.shape
+    pad = torch.arange(T)[None, :] < lens[:, None]
+    x = embed(sd, feats)
+    Tp = x.shape[1]
+    pad_s = pad[:, :-2:2][:, :-2:2]
+    pos_emb = positional_table(5000, x.shape[-1])[:Tp].unsqueeze(0)
+    x = _ln(sd, 'encoder.preln', x)
+    saved = None
+    for i in range(num_blocks_of(sd)):
+        if i == reduce_idx:
+            saved = (x, pad_s, pos_emb)
+            x, pad_s = _time_reduce(sd, x, pad_s)
+            pos_emb = pos_emb[:, ::2, :]
+        if i == recover_idx:
+            rx, rpad, rpos = saved
+            y = torch.repeat_interleave(x, repeats=2, dim=1)
+            y = F.linear(y, sd['encoder.time_recover_layer.weight'], sd['encoder.time_recover_layer.bias'])
+            x = rx + y[:, :rx.shape[1], :]
+            pad_s, pos_emb = rpad, rpos
+        x = _layer(sd, i, x, pos_emb, pad_s, heads, kernel)
+    return x
+
+
+def get_encoder_out(sd, feats, lens, **kw):
+    """SqueezeformerModel.get_encoder_out (squeezeformer/model.py) -> CTC softmax probabilities."""
+    enc = encoder_full(sd, feats, lens, **kw)
+    return torch.softmax(F.linear(enc, sd['ctc.ctc_lo.weight'], sd['ctc.ctc_lo.bias']), dim=2)

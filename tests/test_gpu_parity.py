@@ -348,3 +348,48 @@ def test_baseline_size_properties(eng4233, oracle_mods):
     vocab = weights.synthetic_vocab(4233)
     text = ''.join(vocab[j] for j in t1[5, :int(n1[5])].cpu().numpy()).replace('<space>', ' ')
     assert od.cer(t_ref, text) <= 0.05 and abs(float(s1[5]) * 100 - s_ref) < 0.1
+
+
+# ---------------------------------------------------------------------------------------------------
+# Squeezeformer (configs/squeezeformer.yml, streaming: False)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def sq512(oracle_mods):
+    from masr_amd.engine import HipEngine
+    _, _, _, weights, _ = oracle_mods
+    sd = weights.squeezeformer_state_dict(0, 512)
+    e = HipEngine(sd, vocab_size=512, streaming=False, use_model='squeezeformer',
+                  encoder_conf={'encoder_dim': 256, 'attention_heads': 4, 'num_blocks': 12, 'reduce_idx': 5,
+                                'recover_idx': 11, 'feed_forward_expansion_factor': 8, 'cnn_module_kernel': 31})
+    yield e, sd
+    e.close()
+
+
+def test_squeezeformer_against_reference_fixture(sq512, oracle_mods):
+    e, sd = sq512
+    _, _, _, _, golden_inputs = oracle_mods
+    z = g('squeezeformer_v512.npz')
+    feats, lens = golden_inputs()
+    enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1)
+    err = np.abs(enc.cpu().numpy() - z['enc']).max()
+    assert err < 1e-3, f'squeezeformer encoder_out max err {err}'
+    probs = e.ctc_probs(enc).cpu().numpy()
+    assert np.abs(probs - z['probs']).max() < 1e-3
+    idx, mp = e.ctc_greedy_frames(enc)
+    margin = np.sort(z['probs'], axis=-1)
+    safe = (margin[..., -1] - margin[..., -2]) > 2e-3
+    assert (idx.cpu().numpy()[safe] == z['probs'].argmax(-1)[safe]).all()
+
+
+def test_squeezeformer_odd_lengths_against_oracle(sq512, oracle_mods):
+    """odd T' (time reduction trims, recovery slices) and a ragged batch."""
+    from oracle import squeezeformer as osq
+    e, sd = sq512
+    gen = torch.Generator().manual_seed(12)
+    feats = torch.randn(2, 203, 80, generator=gen) * 3 + 13        # T' = 49 (odd)
+    lens = torch.tensor([203, 120])
+    feats = feats * (torch.arange(203)[None, :, None] < lens[:, None, None])
+    with torch.no_grad():
+        ref = osq.encoder_full(sd, feats, lens)
+    enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
+    assert ref.shape == enc.shape and (ref - enc).abs().max() < 1e-3

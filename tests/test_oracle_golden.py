@@ -98,6 +98,17 @@ def test_conformer_v4233_top4_fixture():
     assert (top.indices.numpy()[..., 0] == z['top_i'][..., 0]).mean() > 0.999
 
 
+def test_squeezeformer_fixture():
+    from oracle import squeezeformer as osq
+    z = g('squeezeformer_v512.npz')
+    feats, lens = golden_inputs()
+    sd = weights.squeezeformer_state_dict(0, 512)
+    with torch.no_grad():
+        enc = osq.encoder_full(sd, feats, lens)
+        np.testing.assert_allclose(enc.numpy(), z['enc'], atol=2e-5)
+        np.testing.assert_allclose(osq.get_encoder_out(sd, feats, lens).numpy(), z['probs'], atol=2e-6)
+
+
 def test_flop_model_matches_survey():
     # 23.18 GFLOP per 10 s utterance (+ the once-per-batch pos projection)
     per_utt = oc.conformer_flops(998) - 12 * 2 * 256 * 256 * 248
