@@ -102,6 +102,29 @@ int masr_ctc_collapse(masr_engine* e, const int32_t* argmax_dev, const float* ma
 int masr_argmax_rows(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t* argmax_dev,
                      float* maxprob_dev, void* stream);
 
+/* CTC prefix beam search.  Replaces BeamSearchDecoder.* -> paddlespeech_ctcdecoders
+ * (masr/decoders/beam_search_decoder.py:45-96, swig_wrapper.py:35-121; third-party, un-vendored: parity
+ * unpinned, external LM scorer not implemented = the alpha 0 path).
+ * masr_ctc_topk (GPU): per-frame vocabulary pruning (cutoff_prob / cutoff_top_n, conformer.yml:74-88):
+ *   idx_dev/logp_dev [M, top_n] candidates in descending probability (log(p + FLT_MIN)), count_dev [M].
+ * masr_beam_* (host, like the reference's C++ thread pool): prefix search over those candidates.
+ *   offline batch: masr_beam_search_batch over [B, T_stride, K] candidate arrays, frames_host [B] valid frames,
+ *   tokens_host [B, max_len] out, len_host [B], score_host [B] = log probability of the best prefix;
+ *   streaming: masr_beam_create / advance / result / reset / destroy (decode_chunk, reset_decoder). */
+typedef struct masr_beam masr_beam;
+int masr_ctc_topk(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t top_n, float cutoff_prob,
+                  int32_t* idx_dev, float* logp_dev, int32_t* count_dev, void* stream);
+int masr_beam_create(int32_t beam_size, int32_t blank, masr_beam** out);
+void masr_beam_destroy(masr_beam* h);
+int masr_beam_reset(masr_beam* h);
+int masr_beam_advance(masr_beam* h, const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
+                      int32_t T, int32_t K);
+int masr_beam_result(masr_beam* h, int32_t* tokens_host, int32_t max_len, int32_t* len, float* score);
+int masr_beam_search_batch(const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
+                           const int32_t* frames_host, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
+                           int32_t blank, int32_t num_threads, int32_t* tokens_host, int32_t max_len, int32_t* len_host,
+                           float* score_host);
+
 /* One call for the whole offline hot path (MASRPredictor.predict semantics, masr/predict.py:167-192,
  * batched like MASRTrainer.evaluate, trainer.py:632): PCM -> fbank -> encoder -> CTC greedy.
  * decode_all_frames != 0 reproduces the reference batch quirk of decoding padded frames. */

@@ -40,6 +40,13 @@ SIGNATURES = {
     'masr_ctc_greedy_frames': [_P, _P, _I, _P, _P, _P],
     'masr_ctc_collapse': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     'masr_argmax_rows': [_P, _P, _I, _I, _P, _P, _P],
+    'masr_ctc_topk': [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
+    'masr_beam_create': [_I, _I, C.POINTER(_P)],
+    'masr_beam_destroy': [_P],
+    'masr_beam_reset': [_P],
+    'masr_beam_advance': [_P, _P, _P, _P, _I, _I],
+    'masr_beam_result': [_P, _P, _I, C.POINTER(_I), C.POINTER(_F)],
+    'masr_beam_search_batch': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     'masr_transcribe_batch': [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     'masr_stream_open': [_P, _I, C.POINTER(_I)],
     'masr_stream_reset': [_P, _I],
@@ -53,7 +60,7 @@ SIGNATURES = {
     'masr_profile_select': [_P, _I],
     'masr_profile_read': [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _I],
 }
-_RESTYPE = {'masr_last_error': C.c_char_p, 'masr_destroy': None}
+_RESTYPE = {'masr_last_error': C.c_char_p, 'masr_destroy': None, 'masr_beam_destroy': None}
 
 
 def lib():

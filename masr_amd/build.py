@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, 'csrc')
 LIB_DIR = os.path.join(ROOT, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmasr_hip.so')
-SOURCES = ['gemm_f32.hip', 'ffn_fused.hip', 'rowgemm.hip', 'elementwise.hip', 'attention.hip', 'fbank.hip', 'engine.hip']
+SOURCES = ['gemm_f32.hip', 'ffn_fused.hip', 'rowgemm.hip', 'elementwise.hip', 'attention.hip', 'fbank.hip', 'engine.hip', 'beam_search.cpp']
 
 
 def _hipcc():
@@ -32,14 +32,14 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace('.hip', '.o'))
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + '.o')
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-c',
                os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', LIB_PATH] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

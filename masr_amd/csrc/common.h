@@ -57,6 +57,8 @@ void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs
 // CTC collapse per utterance
 void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank,
                          int* tokens, int* ntok, float* score, hipStream_t s);
+void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff_prob, int* out_idx, float* out_logp,
+                       int* out_cnt, hipStream_t s);
 void launch_argmax_rows(const float* probs, int M, int V, int* idx, float* maxp, hipStream_t s);
 void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, hipStream_t s);
 void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s);

@@ -419,4 +419,68 @@ void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hi
     hipLaunchKernelGGL(export_cnn_kernel, dim3(L), dim3(256), 0, s, cache, out, pad, d);
 }
 
+// ------------------------------------------------------------------------------------------
+// Vocabulary pruning for the CTC prefix beam search (get_pruned_log_probs of the third-party
+// ctc_beam_search_decoder: sort descending, keep the shortest prefix whose cumulative probability reaches
+// cutoff_prob, at most top_n entries; log(p + FLT_MIN)).  One workgroup per frame, top_n rounds of a
+// block-wide arg-max over the register-resident row (ties -> smaller index).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_prune_kernel(const float* __restrict__ probs, int V, int top_n,
+                                                         float cutoff_prob, int* __restrict__ out_idx,
+                                                         float* __restrict__ out_logp, int* __restrict__ out_cnt) {
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    const float* x = probs + (size_t)blockIdx.x * V;
+    float v[SM_MAXPT];
+#pragma unroll
+    for (int i = 0; i < SM_MAXPT; ++i) {
+        const int j = threadIdx.x + i * 256;
+        v[i] = j < V ? x[j] : -1.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double cum = 0.0;
+    int cnt = 0;
+    for (int k = 0; k < top_n; ++k) {
+        float m = -1.f;
+        int mi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < SM_MAXPT; ++i) {
+            const int j = threadIdx.x + i * 256;
+            if (v[i] > m) { m = v[i]; mi = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(m, o, 64);
+            const int oi = __shfl_xor(mi, o, 64);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { red_v[wave] = m; red_i[wave] = mi; }
+        __syncthreads();
+        m = red_v[0]; mi = red_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (red_v[w] > m || (red_v[w] == m && red_i[w] < mi)) { m = red_v[w]; mi = red_i[w]; }
+        if (m < 0.f) break;                              // vocabulary exhausted (V < top_n)
+        if (threadIdx.x == 0) {
+            out_idx[(size_t)blockIdx.x * top_n + k] = mi;
+            out_logp[(size_t)blockIdx.x * top_n + k] = logf(m + 1.17549435e-38f);
+        }
+        // remove the winner from its owner's registers
+#pragma unroll
+        for (int i = 0; i < SM_MAXPT; ++i)
+            if (threadIdx.x + i * 256 == mi) v[i] = -1.f;
+        cum += (double)m;
+        ++cnt;
+        if (cutoff_prob < 1.0f && cum >= (double)cutoff_prob) break;
+    }
+    if (threadIdx.x == 0) out_cnt[blockIdx.x] = cnt;
+}
+
+void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff_prob, int* out_idx, float* out_logp,
+                       int* out_cnt, hipStream_t s) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(topk_prune_kernel, dim3(M), dim3(256), 0, s, probs, V, top_n, cutoff_prob, out_idx, out_logp, out_cnt);
+}
+
 }  // namespace masr

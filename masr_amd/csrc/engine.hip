@@ -858,6 +858,16 @@ int masr_argmax_rows(masr_engine* e, const float* probs_dev, int32_t M, int32_t 
     return 0;
 }
 
+int masr_ctc_topk(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t top_n, float cutoff_prob,
+                  int32_t* idx_dev, float* logp_dev, int32_t* count_dev, void* stream) {
+    if (!e) return fail("null engine");
+    if (V > 8192) return fail("V > 8192 not supported");
+    if (top_n <= 0) return fail("top_n must be positive");
+    launch_topk_prune(probs_dev, M, V, top_n, cutoff_prob, idx_dev, logp_dev, count_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev,
                      int32_t B, int32_t n_max, int32_t use_db_normalization, float target_db, float* feats_dev,
                      int32_t* n_frames_dev, int16_t* norm_pcm_dev, float* gain_dev, void* stream) {

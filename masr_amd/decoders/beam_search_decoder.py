@@ -1,0 +1,117 @@
+"""BeamSearchDecoder with the reference's constructor / method contract
+(masr/decoders/beam_search_decoder.py:9-96).  The reference hands the search to the third-party SWIG
+module ``paddlespeech_ctcdecoders`` (+ a KenLM language model); here the per-frame vocabulary pruning runs
+on the GPU (masr_ctc_topk) and the LM-free CTC prefix beam search runs on host threads inside
+libmasr_hip.so (masr_beam_*).  The external LM scorer (alpha / beta) is NOT implemented: a missing
+language model file is not an error, scores are the log probability of the best prefix (alpha = 0 path)."""
+import ctypes as C
+import logging
+
+import numpy as np
+import torch
+
+from masr_amd import _lib, runtime
+from masr_amd._lib import check
+
+logger = logging.getLogger(__name__)
+
+
+class BeamSearchDecoder:
+    def __init__(self, alpha, beta, beam_size, cutoff_prob, cutoff_top_n, vocab_list, num_processes=10, blank_id=0,
+                 language_model_path='lm/zh_giga.no_cna_cmn.prune01244.klm'):
+        self.alpha, self.beta = alpha, beta
+        self.beam_size = int(beam_size)
+        self.cutoff_prob = float(cutoff_prob)
+        self.cutoff_top_n = int(cutoff_top_n)
+        self.vocab_list = vocab_list
+        self.num_processes = int(num_processes)
+        self.blank_id = int(blank_id)
+        if alpha or beta:
+            logger.warning('masr_amd BeamSearchDecoder: the external language-model scorer is not implemented; '
+                           'decoding with the acoustic CTC scores only (alpha = beta = 0)')
+        self._lib = _lib.lib()
+        h = C.c_void_p()
+        if self._lib.masr_beam_create(self.beam_size, self.blank_id, C.byref(h)) != 0:
+            raise _lib.MasrError('masr_beam_create failed')
+        self._stream = h
+
+    def __del__(self):
+        try:
+            if getattr(self, '_stream', None):
+                self._lib.masr_beam_destroy(self._stream)
+                self._stream = None
+        except Exception:
+            pass
+
+    # ---- GPU: per-frame candidate pruning ----------------------------------------------------------
+    def _candidates(self, probs):
+        """probs np/torch [M, V] -> host arrays idx [M,K] int32, logp [M,K] f32, count [M] int32."""
+        eng = runtime.aux_engine()
+        p = torch.as_tensor(np.asarray(probs) if not torch.is_tensor(probs) else probs, dtype=torch.float32)
+        p = p.to(eng.device).contiguous()
+        M, V = p.shape
+        K = min(self.cutoff_top_n, V)
+        idx = torch.zeros(M, K, dtype=torch.int32, device=eng.device)
+        logp = torch.zeros(M, K, dtype=torch.float32, device=eng.device)
+        cnt = torch.zeros(M, dtype=torch.int32, device=eng.device)
+        if M:
+            check(self._lib.masr_ctc_topk(eng.h, C.c_void_p(p.data_ptr()), M, V, K, C.c_float(self.cutoff_prob),
+                                          C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                          C.c_void_p(cnt.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return idx.cpu().numpy(), logp.cpu().numpy(), cnt.cpu().numpy(), K
+
+    def _text(self, toks):
+        return ''.join(self.vocab_list[t] for t in toks).replace('<space>', ' ')
+
+    # ---- reference API -----------------------------------------------------------------------------
+    def decode_beam_search_offline(self, probs_split):
+        """one utterance: probs [T, V] -> (score, text)  (beam_search_decoder.py:45-56)."""
+        score, text = self._batch([np.asarray(probs_split)])[0]
+        return score, text
+
+    def decode_batch_beam_search_offline(self, probs_split):
+        """list of [T_i, V] -> list of texts (beam_search_decoder.py:59-73), num_processes host threads."""
+        return [t for _, t in self._batch([np.asarray(p) for p in probs_split])]
+
+    def _batch(self, probs_list):
+        B = len(probs_list)
+        frames = np.array([p.shape[0] for p in probs_list], np.int32)
+        Ts = int(frames.max()) if B else 0
+        V = probs_list[0].shape[1]
+        if torch.is_tensor(probs_list[0]):          # device-resident probabilities: no host round trip
+            stacked = torch.zeros(B, Ts, V, dtype=torch.float32, device=probs_list[0].device)
+        else:
+            stacked = np.zeros((B, Ts, V), np.float32)
+        for i, p in enumerate(probs_list):
+            stacked[i, :p.shape[0]] = p
+        idx, logp, cnt, K = self._candidates(stacked.reshape(B * Ts, V))
+        max_len = max(Ts, 1)
+        toks = np.zeros((B, max_len), np.int32)
+        lens = np.zeros(B, np.int32)
+        scores = np.zeros(B, np.float32)
+        rc = self._lib.masr_beam_search_batch(idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
+                                              cnt.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.c_void_p), B, Ts, K,
+                                              self.beam_size, self.blank_id, self.num_processes,
+                                              toks.ctypes.data_as(C.c_void_p), max_len, lens.ctypes.data_as(C.c_void_p),
+                                              scores.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise _lib.MasrError('masr_beam_search_batch failed')
+        return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(B)]
+
+    def decode_chunk(self, probs, logits_lens):
+        """streaming: feed a chunk probs [1, T, V]; returns (score, text) of the best prefix so far
+        (beam_search_decoder.py:75-91)."""
+        p = np.asarray(probs)[0][:int(np.asarray(logits_lens).reshape(-1)[0])]
+        idx, logp, cnt, K = self._candidates(p)
+        if p.shape[0]:
+            self._lib.masr_beam_advance(self._stream, idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
+                                        cnt.ctypes.data_as(C.c_void_p), p.shape[0], K)
+        toks = np.zeros(4096, np.int32)
+        n, sc = C.c_int32(), C.c_float()
+        self._lib.masr_beam_result(self._stream, toks.ctypes.data_as(C.c_void_p), 4096, C.byref(n), C.byref(sc))
+        return float(sc.value), self._text(toks[:n.value])
+
+    def reset_decoder(self):
+        """beam_search_decoder.py:93-96."""
+        self._lib.masr_beam_reset(self._stream)

@@ -39,12 +39,15 @@ class InferencePredictor:
         if not use_gpu:
             raise Exception('masr_amd is the MI355X path: use_gpu=False is not available (no CPU fallback)')
         assert (torch.cuda.is_available()), 'GPU不可用'
-        if use_model != 'conformer':
-            raise Exception(f'masr_amd implements the conformer encoder; got use_model={use_model}')
+        if use_model not in ('conformer', 'squeezeformer'):
+            raise Exception(f'masr_amd implements the conformer and squeezeformer encoders; got use_model={use_model}')
+        if use_model == 'squeezeformer' and streaming:
+            raise Exception('masr_amd implements the non-streaming squeezeformer (streaming: False) only')
         self.device = torch.device('cuda')
         enc_conf = dict(configs.get('encoder_conf', {})) if configs is not None else {}
         n_mels = int(configs.get('preprocess_conf', {}).get('n_mels', 80)) if configs is not None else 80
-        self.engine = HipEngine(state_dict, encoder_conf=enc_conf, streaming=streaming, n_mels=n_mels)
+        self.engine = HipEngine(state_dict, encoder_conf=enc_conf, streaming=streaming, n_mels=n_mels,
+                                use_model=use_model)
         self._sid = None
 
     # offline (inference_predictor.py:52-64): probs = softmax(ctc_lo(encoder(speech)))

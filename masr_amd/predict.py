@@ -44,11 +44,12 @@ class MASRPredictor:
         self.cached_feat = None
         self.greedy_last_max_prob_list = None
         self.greedy_last_max_index_list = None
+        self.beam_search_decoder = None
         if self.configs.decoder == 'ctc_beam_search':
-            # same degradation as the reference when paddlespeech_ctcdecoders is missing (predict.py:103-109)
-            import logging
-            logging.getLogger(__name__).warning('ctc_beam_search is not available on this path yet; using ctc_greedy')
-            self.configs.decoder = 'ctc_greedy'
+            # predict.py:96-109; here the search is masr_amd's own (GPU pruning + host prefix search, LM-free)
+            from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+            self.beam_search_decoder = BeamSearchDecoder(vocab_list=self._text_featurizer.vocab_list,
+                                                         **self.configs.ctc_beam_search_decoder_conf)
         if state_dict is None and not os.path.exists(model_path):
             raise Exception("模型文件不存在，请检查{}是否存在！".format(model_path))
         self.predictor = InferencePredictor(configs=self.configs, use_model=self.configs.use_model,
@@ -61,8 +62,11 @@ class MASRPredictor:
         self.reset_stream()
 
     def decode(self, output_data, use_pun, is_itn):
-        """predict.py:118-144 (greedy branch)."""
-        score, text = greedy_decoder(probs_seq=output_data, vocabulary=self._text_featurizer.vocab_list)
+        """predict.py:118-144."""
+        if self.configs.decoder == 'ctc_beam_search':
+            score, text = self.beam_search_decoder.decode_beam_search_offline(probs_split=output_data)
+        else:
+            score, text = greedy_decoder(probs_seq=output_data, vocabulary=self._text_featurizer.vocab_list)
         if is_itn:
             raise Exception('inverse text normalisation (WeTextProcessing) is outside the hot path')
         return score, text
@@ -108,8 +112,14 @@ class MASRPredictor:
         pc = self.configs.preprocess_conf
         feats, frames = eng.fbank_batch(xs, ns, pc.use_dB_normalization, pc.target_dB)
         enc = eng.encode_full(feats, frames, -1)
-        idx, mp = eng.ctc_greedy_frames(enc)
         nenc = None if decode_all_frames else (((frames - 1) // 2 - 1) // 2).clamp(min=0).to(torch.int32)
+        if self.configs.decoder == 'ctc_beam_search':
+            # probabilities stay on the GPU for the vocabulary pruning; the prefix search runs on host threads
+            probs = eng.ctc_probs(enc)
+            n_host = [probs.shape[1]] * len(segs) if nenc is None else nenc.cpu().tolist()
+            res = self.beam_search_decoder._batch([probs[i, :n_host[i]] for i in range(len(segs))])
+            return [{'text': t, 'score': sc} for sc, t in res]
+        idx, mp = eng.ctc_greedy_frames(enc)
         tok, ntok, score = eng.ctc_collapse(idx, mp, nenc)
         tok, ntok, score = tok.cpu().numpy(), ntok.cpu().numpy(), score.cpu().numpy()
         vocab = self._text_featurizer.vocab_list
@@ -164,10 +174,14 @@ class MASRPredictor:
             required_cache_size = decoding_chunk_size * num_decoding_left_chunks
             output_chunk_probs = self.predictor.predict_chunk_conformer(x_chunk=x_chunk,
                                                                         required_cache_size=required_cache_size)
-            score, text, self.greedy_last_max_prob_list, self.greedy_last_max_index_list = \
-                greedy_decoder_chunk(probs_seq=output_chunk_probs[0], vocabulary=self._text_featurizer.vocab_list,
-                                     last_max_index_list=self.greedy_last_max_index_list,
-                                     last_max_prob_list=self.greedy_last_max_prob_list)
+            output_lens = np.array([output_chunk_probs.shape[1]])
+            if self.configs.decoder == 'ctc_beam_search':
+                score, text = self.beam_search_decoder.decode_chunk(probs=output_chunk_probs, logits_lens=output_lens)
+            else:
+                score, text, self.greedy_last_max_prob_list, self.greedy_last_max_index_list = \
+                    greedy_decoder_chunk(probs_seq=output_chunk_probs[0], vocabulary=self._text_featurizer.vocab_list,
+                                         last_max_index_list=self.greedy_last_max_index_list,
+                                         last_max_prob_list=self.greedy_last_max_prob_list)
         self.cached_feat = self.cached_feat[:, end - cached_feature_num:, :]
         if is_itn:
             raise Exception('inverse text normalisation (WeTextProcessing) is outside the hot path')
@@ -180,3 +194,5 @@ class MASRPredictor:
         self.cached_feat = None
         self.greedy_last_max_prob_list = None
         self.greedy_last_max_index_list = None
+        if self.configs.decoder == 'ctc_beam_search' and getattr(self, 'beam_search_decoder', None) is not None:
+            self.beam_search_decoder.reset_decoder()

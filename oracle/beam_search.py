@@ -1,0 +1,123 @@
+"""TEST INFRASTRUCTURE ONLY -- pure-Python restatement of the LM-free CTC prefix beam search of the
+third-party decoder the reference wraps (``paddlespeech_ctcdecoders``: ctc_beam_search_decoder.cpp /
+path_trie.cpp of DeepSpeech2 / PaddleSpeech; call sites ``masr/decoders/swig_wrapper.py:35-64``,
+``beam_search_decoder.py:45-56``).  That module is not vendored, not version-pinned and absent here:
+**parity unpinned**; this file states the published algorithm (no external scorer, i.e. alpha = 0) and
+is what the HIP/host implementation is checked against.  Small inputs only (pure Python)."""
+import math
+
+import numpy as np
+
+NEG_INF = -float('inf')
+FLT_MIN = 1.17549435e-38
+
+
+def _lse(x, y):
+    if x == NEG_INF:
+        return y
+    if y == NEG_INF:
+        return x
+    m = max(x, y)
+    return np.float32(m + np.float32(math.log(math.exp(x - m) + math.exp(y - m))))
+
+
+def pruned_log_probs(prob_step, cutoff_prob=1.0, cutoff_top_n=40):
+    """get_pruned_log_probs: descending sort, cumulative cutoff, top-n cap; returns [(index, log p)]."""
+    prob_step = np.asarray(prob_step)
+    order = sorted(range(len(prob_step)), key=lambda i: (-float(prob_step[i]), i))
+    cutoff_len = len(order)
+    if cutoff_prob < 1.0 or cutoff_top_n < cutoff_len:
+        if cutoff_prob < 1.0:
+            cum, cutoff_len = 0.0, 0
+            for i in order:
+                cum += float(prob_step[i])
+                cutoff_len += 1
+                if cum >= cutoff_prob or cutoff_len >= cutoff_top_n:
+                    break
+        else:
+            cutoff_len = min(cutoff_len, cutoff_top_n)
+        order = order[:cutoff_len]
+    return [(i, np.float32(math.log(float(prob_step[i]) + FLT_MIN))) for i in order]
+
+
+class _Node:
+    __slots__ = ('b_prev', 'nb_prev', 'b_cur', 'nb_cur', 'score', 'ch', 'parent', 'exists', 'kids')
+
+    def __init__(self, ch=-1, parent=None):
+        self.b_prev = self.nb_prev = self.b_cur = self.nb_cur = self.score = NEG_INF
+        self.ch, self.parent, self.exists, self.kids = ch, parent, True, []
+
+
+def prefix_beam_search(cands_per_frame, beam_size=300, blank=0):
+    """cands_per_frame: list over frames of [(index, log prob)] in descending probability.
+    Returns (log prob of the best prefix, token id list)."""
+    root = _Node()
+    root.score = root.b_prev = np.float32(0.0)
+    prefixes = [root]
+
+    def child(n, c):
+        for k in n.kids:
+            if k.ch == c:
+                if not k.exists:
+                    k.exists = True
+                    k.b_prev = k.nb_prev = k.b_cur = k.nb_cur = k.score = NEG_INF
+                return k
+        k = _Node(c, n)
+        n.kids.append(k)
+        return k
+
+    def collect(n, out):
+        if n.exists:
+            n.b_prev, n.nb_prev = n.b_cur, n.nb_cur
+            n.b_cur = n.nb_cur = NEG_INF
+            n.score = _lse(n.b_prev, n.nb_prev)
+            out.append(n)
+        for k in list(n.kids):
+            collect(k, out)
+
+    def remove(n):
+        n.exists = False
+        while n.parent is not None and not n.exists and not n.kids:
+            n.parent.kids.remove(n)
+            n = n.parent
+
+    def key(n):
+        return (-n.score, n.ch)
+
+    for cands in cands_per_frame:
+        live = prefixes[:beam_size]
+        for c, lp in cands:
+            for p in live:
+                if c == blank:
+                    p.b_cur = _lse(p.b_cur, np.float32(lp + p.score))
+                    continue
+                if c == p.ch:
+                    p.nb_cur = _lse(p.nb_cur, np.float32(lp + p.nb_prev))
+                q = child(p, c)
+                add = NEG_INF
+                if c == p.ch and p.b_prev > NEG_INF:
+                    add = np.float32(lp + p.b_prev)
+                elif c != p.ch:
+                    add = np.float32(lp + p.score)
+                q.nb_cur = _lse(q.nb_cur, add)
+        prefixes = []
+        collect(root, prefixes)
+        if len(prefixes) >= beam_size:
+            prefixes.sort(key=key)
+            for n in prefixes[beam_size:]:
+                remove(n)
+            prefixes = prefixes[:beam_size]
+    prefixes.sort(key=key)
+    n = prefixes[0]
+    score = float(n.score)
+    toks = []
+    while n.parent is not None:
+        toks.append(n.ch)
+        n = n.parent
+    return score, toks[::-1]
+
+
+def decode(probs, vocabulary, beam_size=300, cutoff_prob=1.0, cutoff_top_n=40, blank=0):
+    cands = [pruned_log_probs(p, cutoff_prob, cutoff_top_n) for p in np.asarray(probs)]
+    score, toks = prefix_beam_search(cands, beam_size, blank)
+    return score, ''.join(vocabulary[t] for t in toks).replace('<space>', ' ')

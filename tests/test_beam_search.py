@@ -1,0 +1,115 @@
+"""CTC prefix beam search: host search (CPU, no GPU needed) against the pure-Python oracle restatement;
+GPU candidate pruning + the drop-in BeamSearchDecoder (gpu-marked)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import beam_search as obs
+from oracle import decoders as od
+
+
+def _host_search(cands, beam, blank=0):
+    from masr_amd import _lib
+    lib = _lib.lib()
+    T = len(cands)
+    K = max(len(c) for c in cands)
+    idx = np.zeros((T, K), np.int32)
+    logp = np.zeros((T, K), np.float32)
+    cnt = np.zeros(T, np.int32)
+    for t, c in enumerate(cands):
+        cnt[t] = len(c)
+        for k, (i, lp) in enumerate(c):
+            idx[t, k], logp[t, k] = i, lp
+    frames = np.array([T], np.int32)
+    toks = np.zeros((1, T + 1), np.int32)
+    lens = np.zeros(1, np.int32)
+    score = np.zeros(1, np.float32)
+    rc = lib.masr_beam_search_batch(idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
+                                    cnt.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.c_void_p), 1, T, K, beam, blank,
+                                    2, toks.ctypes.data_as(C.c_void_p), T + 1, lens.ctypes.data_as(C.c_void_p),
+                                    score.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return float(score[0]), list(toks[0, :lens[0]])
+
+
+@pytest.mark.parametrize('seed,V,T,beam,cut,topn', [(0, 6, 12, 4, 1.0, 40), (1, 12, 30, 8, 0.99, 5), (2, 30, 25, 20, 0.95, 10),
+                                                    (3, 5, 40, 300, 1.0, 40), (4, 50, 18, 3, 0.9, 40)])
+def test_host_prefix_search_matches_oracle(built_lib, seed, V, T, beam, cut, topn):
+    rng = np.random.default_rng(seed)
+    probs = rng.dirichlet(np.ones(V) * 0.4, size=T).astype(np.float32)
+    cands = [obs.pruned_log_probs(p, cut, topn) for p in probs]
+    s_ref, t_ref = obs.prefix_beam_search(cands, beam, 0)
+    s, t = _host_search(cands, beam)
+    assert t == t_ref
+    assert abs(s - s_ref) < 1e-4
+
+
+def test_streaming_equals_offline(built_lib):
+    from masr_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(9)
+    probs = rng.dirichlet(np.ones(8) * 0.3, size=40).astype(np.float32)
+    cands = [obs.pruned_log_probs(p, 1.0, 40) for p in probs]
+    s_ref, t_ref = _host_search(cands, 16)
+    h = C.c_void_p()
+    assert lib.masr_beam_create(16, 0, C.byref(h)) == 0
+    for lo in range(0, 40, 7):
+        part = cands[lo:lo + 7]
+        idx = np.array([[i for i, _ in c] for c in part], np.int32)
+        lp = np.array([[l for _, l in c] for c in part], np.float32)
+        cnt = np.full(len(part), 8, np.int32)
+        assert lib.masr_beam_advance(h, idx.ctypes.data_as(C.c_void_p), lp.ctypes.data_as(C.c_void_p),
+                                     cnt.ctypes.data_as(C.c_void_p), len(part), 8) == 0
+    toks = np.zeros(64, np.int32)
+    n, sc = C.c_int32(), C.c_float()
+    lib.masr_beam_result(h, toks.ctypes.data_as(C.c_void_p), 64, C.byref(n), C.byref(sc))
+    assert list(toks[:n.value]) == t_ref and abs(sc.value - s_ref) < 1e-5
+    lib.masr_beam_reset(h)
+    lib.masr_beam_result(h, toks.ctypes.data_as(C.c_void_p), 64, C.byref(n), C.byref(sc))
+    assert n.value == 0
+    lib.masr_beam_destroy(h)
+
+
+def test_peaked_distribution_equals_greedy(built_lib):
+    """with (almost) one-hot frames the best prefix is the greedy best path"""
+    rng = np.random.default_rng(3)
+    V, T = 10, 50
+    ids = rng.integers(0, V, T)
+    probs = np.full((T, V), 1e-4, np.float32)
+    probs[np.arange(T), ids] = 1.0 - 1e-4 * (V - 1)
+    vocab = ['<blank>'] + [chr(97 + i) for i in range(V - 1)]
+    _, t_greedy = od.greedy_decoder(probs, vocab)
+    s, toks = _host_search([obs.pruned_log_probs(p, 1.0, 40) for p in probs], 10)
+    assert ''.join(vocab[t] for t in toks) == t_greedy
+
+
+@pytest.mark.gpu
+def test_gpu_pruning_and_decoder_api():
+    from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    rng = np.random.default_rng(11)
+    V = 300
+    vocab = ['<blank>', '<unk>', '<space>'] + [chr(0x4e00 + i) for i in range(V - 4)] + ['<eos>']
+    dec = BeamSearchDecoder(alpha=2.2, beta=4.3, beam_size=20, cutoff_prob=0.99, cutoff_top_n=40, vocab_list=vocab,
+                            num_processes=4)
+    probs = [rng.dirichlet(np.ones(V) * 0.02, size=T).astype(np.float32) for T in (37, 12, 25)]
+    # pruning kernel == oracle pruning
+    idx, logp, cnt, K = dec._candidates(probs[0])
+    for t in range(37):
+        ref = obs.pruned_log_probs(probs[0][t], 0.99, 40)
+        assert cnt[t] == len(ref)
+        assert [int(i) for i in idx[t, :cnt[t]]] == [i for i, _ in ref]
+        assert np.allclose(logp[t, :cnt[t]], [l for _, l in ref], atol=1e-6)
+    texts = dec.decode_batch_beam_search_offline(probs)
+    for p, text in zip(probs, texts):
+        s_ref, t_ref = obs.decode(p, vocab, 20, 0.99, 40)
+        assert text == t_ref
+    s, t = dec.decode_beam_search_offline(probs[1])
+    assert t == texts[1]
+    # streaming chunks give the offline result
+    dec.reset_decoder()
+    out = None
+    for lo in range(0, 37, 16):
+        out = dec.decode_chunk(probs[0][None, lo:lo + 16], np.array([min(16, 37 - lo)]))
+    assert out[1] == texts[0]
+    dec.reset_decoder()

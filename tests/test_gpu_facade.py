@@ -121,3 +121,40 @@ def test_featurizer_api(predictor):
     # the segment was normalised in place, like the reference (audio.py:304)
     ms = float(np.mean(seg.samples.astype(np.float64) ** 2))
     assert abs(10 * np.log10(ms) + 20.0) < 1e-3 and not np.allclose(before, seg.samples)
+
+
+def test_squeezeformer_beam_search_facade(tmp_path):
+    """BASELINE config 3 shape: squeezeformer.yml (streaming: False) + ctc_beam_search through the facade,
+    checked against the oracle pipeline (fbank -> Squeezeformer -> LM-free prefix beam search)."""
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.utils import synthetic
+    from oracle import beam_search as obs, fbank as ofb, squeezeformer as osq
+    V = 300
+    vocab = synthetic.synthetic_vocab(V)
+    vpath = os.path.join(tmp_path, 'vocabulary.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in vocab:
+            f.write(f'{t}\t1\n')
+    cfg = {'encoder_conf': {'encoder_dim': 256, 'output_size': 256, 'attention_heads': 4, 'num_blocks': 12, 'reduce_idx': 5,
+                            'recover_idx': 11, 'feed_forward_expansion_factor': 8, 'cnn_module_kernel': 31},
+           'preprocess_conf': {'feature_method': 'fbank', 'n_mels': 80, 'n_mfcc': 40, 'sample_rate': 16000,
+                               'use_dB_normalization': True, 'target_dB': -20},
+           'ctc_beam_search_decoder_conf': {'alpha': 2.2, 'beta': 4.3, 'beam_size': 10, 'num_processes': 4,
+                                            'cutoff_prob': 0.99, 'cutoff_top_n': 40,
+                                            'language_model_path': 'lm/absent.klm'},
+           'dataset_conf': {'dataset_vocab': vpath}, 'use_model': 'squeezeformer', 'streaming': False,
+           'decoder': 'ctc_beam_search', 'metrics_type': 'cer'}
+    sd = synthetic.squeezeformer_state_dict(0, V)
+    pred = MASRPredictor(configs=cfg, use_gpu=True, state_dict=sd)
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm'][:48000]
+    res = pred.predict(audio_data=pcm.copy())
+    feat, _ = ofb.featurize_pcm16(pcm)
+    with torch.no_grad():
+        probs = osq.get_encoder_out(sd, torch.from_numpy(feat)[None], torch.tensor([feat.shape[0]]))[0].numpy()
+    s_ref, t_ref = obs.decode(probs, vocab, 10, 0.99, 40)
+    assert _close(t_ref, res['text']) <= 0.1, (res['text'], t_ref)
+    assert abs(res['score'] - s_ref) < 0.05 * max(1.0, abs(s_ref))
+    batch = pred.predict_batch([pcm.copy(), pcm.copy()])
+    assert batch[0]['text'] == batch[1]['text'] and _close(res['text'], batch[0]['text']) <= 0.05
+    with pytest.raises(Exception):
+        pred.predict_stream(audio_data=pcm[:8000].tobytes())       # streaming: False (predict.py:253-255)
