@@ -204,4 +204,179 @@ void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* l
     hipLaunchKernelGGL(attseq_full_kernel, dim3((B + 63) / 64), dim3(64), 0, s, seqs, qkv, out, lens, B, Tp, mstride);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Grouped relative-position attention of the Efficient Conformer (efficient_conformer/attention.py:35-69,
+// 120-182, group_size g = 3): q, k, v, p [T, H*dk] are zero-padded in time to a multiple of g and FLAT-reshaped
+// to [T/g, H, g*dk]; attention then runs over T/g positions with d_k' = g*dk = 192 and scale 1/sqrt(192).
+// Same transposed-score scheme as attention_kernel, with the head dimension templated: the query fragment
+// (q only, 96 registers) stays in registers, u / v are added on the fly from LDS, O^T uses DKG/32 accumulators.
+// Inputs are PLANAR buffers [B][Tpad][256] (flat == [B][T/g][H][g*dk]); P comes from the per-layer positional
+// table, rows past the true length T read as zero (the reference pads P with zeros, not with PE).
+// ------------------------------------------------------------------------------------------------
+template <int DKG, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_grouped_kernel(const AttSeq* __restrict__ seqs, int row_stride,
+                                                                      const float* __restrict__ ptab, int t_true,
+                                                                      const float* __restrict__ bias_u,
+                                                                      const float* __restrict__ bias_v, float scale) {
+    constexpr int LD = DKG + 4;
+    constexpr int NG = DKG / 8;       // 8-wide k groups per operand half
+    constexpr int NT = DKG / 32;      // 32-row output tiles of O^T
+    extern __shared__ __align__(16) float smg[];
+    float* Ks = smg;                  // [32][LD]
+    float* Ps = Ks + 32 * LD;
+    float* Vs = Ps + 32 * LD;
+    float* Us = Vs + 32 * LD;         // [DKG] u, [DKG] v of this head
+    const AttSeq sq = seqs[blockIdx.z];
+    const int head = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.x * 32 * NW;
+    if (q0 >= sq.nq) return;
+    const int qi = q0 + wave * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const bool q_ok = qi < sq.nq;
+    for (int i = tid; i < 2 * DKG; i += 64 * NW) Us[i] = i < DKG ? bias_u[head * DKG + i] : bias_v[head * DKG + i - DKG];
+
+    f32x4 qf[NG];
+    {
+        const float* qrow = sq.q + (size_t)(q_ok ? qi : sq.nq - 1) * row_stride + head * DKG;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qrow + 8 * g + 4 * h);
+    }
+    f32x16 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int jlim = sq.klen;
+    const int ntile = (sq.nk + 31) / 32;
+    constexpr int F4_PER_ROW = DKG / 4;
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int j0 = kt * 32;
+        __syncthreads();
+        for (int i = tid; i < 32 * F4_PER_ROW; i += 64 * NW) {
+            const int r = i / F4_PER_ROW, c4 = (i % F4_PER_ROW) * 4;
+            const int j = j0 + r;
+            f32x4 kk = f32x4{0.f, 0.f, 0.f, 0.f}, pp = kk, vv = kk;
+            if (j < sq.nk) {
+                kk = *reinterpret_cast<const f32x4*>(sq.k + (size_t)j * row_stride + head * DKG + c4);
+                vv = *reinterpret_cast<const f32x4*>(sq.v + (size_t)j * row_stride + head * DKG + c4);
+                // flat element index of P'[j][head][c4] in the [T,256] positional-key matrix
+                const size_t e = (size_t)j * row_stride + head * DKG + c4;
+                if ((int)(e / 256) < t_true) pp = *reinterpret_cast<const f32x4*>(ptab + (size_t)sq.pos0 * 256 + e);
+            }
+            *reinterpret_cast<f32x4*>(&Ks[r * LD + c4]) = kk;
+            *reinterpret_cast<f32x4*>(&Ps[r * LD + c4]) = pp;
+            *reinterpret_cast<f32x4*>(&Vs[r * LD + c4]) = vv;
+        }
+        __syncthreads();
+
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        const float* kb = &Ks[(lane & 31) * LD + 4 * h];
+        const float* pb = &Ps[(lane & 31) * LD + 4 * h];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(kb + 8 * g);
+            const f32x4 pf = *reinterpret_cast<const f32x4*>(pb + 8 * g);
+            const f32x4 uu = *reinterpret_cast<const f32x4*>(&Us[8 * g + 4 * h]);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(&Us[DKG + 8 * g + 4 * h]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s] + uu[s], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[s], qf[g][s] + vv[s], st, 0, 0, 0);
+            }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            st[r] = j < jlim ? st[r] * scale : -INFINITY;
+            tmax = fmaxf(tmax, st[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float corr = expf(m_run - m_safe);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = expf(st[r] - m_safe);
+            psum += st[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * corr + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= corr;
+        const float* vb = &Vs[(4 * h) * LD + (lane & 31)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[krow * LD + 32 * t], st[r], o[t], 0, 0, 0);
+        }
+    }
+    if (q_ok) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        float* orow = sq.out + (size_t)qi * row_stride + head * DKG;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                f32x4 a;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[s] = o[t][rr * 4 + s] * inv;
+                *reinterpret_cast<f32x4*>(orow + 32 * t + 8 * rr + 4 * h) = a;
+            }
+    }
+}
+
+void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int heads, int group, const float* ptab,
+                              int t_true, const float* bias_u, const float* bias_v, hipStream_t s) {
+    if (nseq <= 0 || max_nq <= 0 || group != 3) return;
+    constexpr int DKG = 192, NW = 2;
+    const size_t lds = (size_t)(3 * 32 * (DKG + 4) + 2 * DKG) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_grouped_kernel<DKG, NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((attention_grouped_kernel<DKG, NW>), dim3((max_nq + 32 * NW - 1) / (32 * NW), heads, nseq),
+                       dim3(64 * NW), lds, s, seqs, heads * DKG, ptab, t_true, bias_u, bias_v, 1.0f / sqrtf((float)DKG));
+}
+
+// descriptors for the grouped layout: planar q / k / v / out buffers [B][Tpad][256] == [B][Tg][H][g*dk];
+// grouped key j is valid iff the pad mask keeps frame g*j, i.e. mstride * g * j < len
+__global__ void attseq_grouped_kernel(AttSeq* seqs, const float* q, const float* k, const float* v, float* out,
+                                      const int* __restrict__ lens, int B, int Tg, int group, int mstride) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t per = (size_t)Tg * group * 256;
+    AttSeq s;
+    s.q = q + b * per;
+    s.k = k + b * per;
+    s.v = v + b * per;
+    s.out = out + b * per;
+    s.nq = Tg;
+    s.nk = Tg;
+    const int ms = mstride * group;
+    s.klen = min(Tg, (lens[b] + ms - 1) / ms);
+    s.pos0 = 0;
+    s.q_abs0 = 0;
+    s.pad_ = 0;
+    seqs[b] = s;
+}
+
+void launch_attseq_grouped(AttSeq* seqs, const float* q, const float* k, const float* v, float* out, const int* lens,
+                           int B, int Tg, int group, int mstride, hipStream_t s) {
+    hipLaunchKernelGGL(attseq_grouped_kernel, dim3((B + 63) / 64), dim3(64), 0, s, seqs, q, k, v, out, lens, B, Tg, group,
+                       mstride);
+}
+
 }  // namespace masr

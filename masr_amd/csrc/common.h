@@ -47,6 +47,11 @@ void launch_dwconv_ln_silu(const float* g, const float* wkc, const float* bias, 
 // same with an eval-mode BatchNorm folded into a per-channel scale/shift instead of the LayerNorm
 void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, const float* scale, const float* shift,
                            float* out, int nseq, int Tq, int ktaps, hipStream_t s);
+// Efficient-Conformer stride layer: depthwise causal conv with stride 2 (+ LayerNorm + SiLU) on the padded layout
+// [nseq][ktaps-1 + Tin][256] -> [nseq * ceil(Tin/2), 256]; and the AvgPool1d(2, ceil_mode) residual path
+void launch_dwconv_stride2_ln_silu(const float* g, const float* wkc, const float* bias, const float* lnw,
+                                   const float* lnb, float* out, int nseq, int Tin, int ktaps, float eps, hipStream_t s);
+void launch_avgpool2(const float* x, float* out, int B, int T, hipStream_t s);
 // Squeezeformer TimeReductionLayer1D depthwise part: k=5, stride 2, padding 3, pad-masked input -> [B, ceil(T/2), 256]
 void launch_time_reduce_dw(const float* x, const float* w5c, const float* bias, const int* lens, float* out, int B, int T,
                            int mstride, hipStream_t s);
@@ -60,7 +65,7 @@ void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, 
 void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff_prob, int* out_idx, float* out_logp,
                        int* out_cnt, hipStream_t s);
 void launch_argmax_rows(const float* probs, int M, int V, int* idx, float* maxp, hipStream_t s);
-void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, hipStream_t s);
+void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, int halve, hipStream_t s);
 void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s);
 void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hipStream_t s);
 
@@ -86,6 +91,9 @@ struct RowGemmArgs {
     int mstride;          // feature frames per encoder frame for the pad masks (4; 8 after Squeezeformer time reduction)
     int out_seq_t;        // >0: output row (b, t) is stored at b*(out_seq_t + out_pad_tot) + out_pad_l + t
     int out_pad_l, out_pad_tot;
+    int plane_cols;       // EPI_STORE: >0 -> column c goes to plane c / plane_cols (planar q | k | v buffers)
+    long plane_stride;    //            floats between planes
+    int a_seq_t, a_seq_stride;   // PRO_PLAIN: >0 -> source row of (b, t) = b * a_seq_stride + t, with (b, t) = divmod(row, a_seq_t)
 };
 void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);
 
@@ -110,6 +118,10 @@ struct AttSeq {            // one per sequence, device memory
 void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q_stride, int kv_stride,
                       const float* ptab /*[max_pos,256]*/, const float* bias_u, const float* bias_v,
                       int chunk_size, int pos_stride, hipStream_t s);
+void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int heads, int group, const float* ptab,
+                              int t_true, const float* bias_u, const float* bias_v, hipStream_t s);
+void launch_attseq_grouped(AttSeq* seqs, const float* q, const float* k, const float* v, float* out, const int* lens,
+                           int B, int Tg, int group, int mstride, hipStream_t s);
 void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, int mstride,
                         hipStream_t s);
 

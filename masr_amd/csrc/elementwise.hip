@@ -191,6 +191,83 @@ void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Efficient-Conformer StrideConformerEncoderLayer pieces (efficient_conformer/encoder.py:454-545,
+// convolution.py:43-49): causal depthwise conv with stride 2 + LayerNorm + SiLU, and the residual path
+// AvgPool1d(kernel 2, stride 2, ceil_mode=True, count_include_pad=False).
+//   out[j] = b + sum_k w[k] * gpad[2j + k],  j < ceil(Tin / 2)   (gpad = KT-1 history rows + Tin rows)
+// ------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void dwconv_stride2_ln_silu_kernel(const float* __restrict__ g,
+                                                                     const float* __restrict__ wkc,
+                                                                     const float* __restrict__ bias,
+                                                                     const float* __restrict__ lnw,
+                                                                     const float* __restrict__ lnb,
+                                                                     float* __restrict__ out, int Tin, int Tout,
+                                                                     float eps) {
+    __shared__ __align__(16) float tile[DW_TT][256 + 4];
+    const int tiles = (Tout + DW_TT - 1) / DW_TT;
+    const int seq = blockIdx.x / tiles;
+    const int t0 = (blockIdx.x % tiles) * DW_TT;
+    const int c = threadIdx.x;
+    const float* gin = g + ((size_t)seq * (KT - 1 + Tin)) * 256 + c;
+    float w[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) w[j] = wkc[j * 256 + c];
+    const float bv = bias[c];
+    const int nrows = min(DW_TT, Tout - t0);
+    for (int r = 0; r < nrows; ++r) {
+        float acc = bv;
+        const float* gp = gin + (size_t)(2 * (t0 + r)) * 256;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc = fmaf(w[j], gp[(size_t)j * 256], acc);
+        tile[r][c] = acc;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(lnw + lane * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
+    for (int r = wave; r < nrows; r += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&tile[r][lane * 4]);
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+        const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        f32x4 o;
+        o[0] = d0 * rstd * ww[0] + bb[0];
+        o[1] = d1 * rstd * ww[1] + bb[1];
+        o[2] = d2 * rstd * ww[2] + bb[2];
+        o[3] = d3 * rstd * ww[3] + bb[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = o[i] / (1.0f + expf(-o[i]));
+        *reinterpret_cast<f32x4*>(out + ((size_t)seq * Tout + t0 + r) * 256 + lane * 4) = o;
+    }
+}
+
+void launch_dwconv_stride2_ln_silu(const float* g, const float* wkc, const float* bias, const float* lnw,
+                                   const float* lnb, float* out, int nseq, int Tin, int ktaps, float eps, hipStream_t s) {
+    const int Tout = (Tin + 1) / 2;
+    if (nseq * Tout <= 0 || ktaps != 15) return;
+    const int tiles = (Tout + DW_TT - 1) / DW_TT;
+    hipLaunchKernelGGL(dwconv_stride2_ln_silu_kernel<15>, dim3(nseq * tiles), dim3(256), 0, s, g, wkc, bias, lnw, lnb, out,
+                       Tin, Tout, eps);
+}
+
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ x, float* __restrict__ out, int T,
+                                                       int Tout) {
+    const int b = blockIdx.y, j = blockIdx.x, c = threadIdx.x;
+    const float a = x[((size_t)b * T + 2 * j) * 256 + c];
+    float v = a;
+    if (2 * j + 1 < T) v = (a + x[((size_t)b * T + 2 * j + 1) * 256 + c]) / 2.0f;
+    out[((size_t)b * Tout + j) * 256 + c] = v;
+}
+
+void launch_avgpool2(const float* x, float* out, int B, int T, hipStream_t s) {
+    const int Tout = (T + 1) / 2;
+    if (B * Tout <= 0) return;
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(Tout, B), dim3(256), 0, s, x, out, T, Tout);
+}
+
+// ------------------------------------------------------------------------------------------
 // Squeezeformer TimeReductionLayer1D, depthwise part (time_reduction.py:53-66): pad-masked input,
 // Conv1d(k=5, stride=2, padding=3, groups=C); only the first L = ceil(T/2) outputs are kept (:68-74).
 // out[b][j][c] = bias[c] + sum_k w[k][c] * xm[b][2j + k - 3][c]
@@ -382,18 +459,21 @@ void launch_argmax_rows(const float* probs, int M, int V, int* idx, float* maxp,
 }
 
 // samples -> fbank frames (snip_edges) -> encoder frames (two 3x3/stride-2 convs)
-__global__ void frame_counts_kernel(const int* __restrict__ nsamp, int B, int* nfr, int* nenc) {
+__global__ void frame_counts_kernel(const int* __restrict__ nsamp, int B, int* nfr, int* nenc, int halve) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int n = nsamp[b];
     const int T = n >= 400 ? 1 + (n - 400) / 160 : 0;
     if (nfr) nfr[b] = T;
-    if (nenc) nenc[b] = T >= 7 ? ((T - 1) / 2 - 1) / 2 : 0;
+    if (nenc) {
+        const int n4 = T >= 7 ? ((T - 1) / 2 - 1) / 2 : 0;
+        nenc[b] = halve ? (n4 + 1) / 2 : n4;
+    }
 }
 
-void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, hipStream_t s) {
+void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, int halve, hipStream_t s) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(frame_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, nsamp, B, nfr, nenc);
+    hipLaunchKernelGGL(frame_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, nsamp, B, nfr, nenc, halve);
 }
 
 // stream caches -> reference layouts (encoder.py:404-419): att [L,H,t,2dk], cnn [L,1,d,pad]

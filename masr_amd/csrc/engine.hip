@@ -102,6 +102,8 @@ struct masr_engine {
     float *preln_w = nullptr, *preln_b = nullptr, *tr_dw_w = nullptr, *tr_dw_b = nullptr, *tr_pw_w = nullptr,
           *tr_pw_b = nullptr, *rec_w = nullptr, *rec_b = nullptr;
     int reduce_idx = -1, recover_idx = -1;
+    int stride_idx = -1, n_group_layers = 0, group_size = 3;   // Efficient-Conformer (model_kind 2)
+    DevBuf qplanes, attp;                                      // planar q|k|v and attention output, [B][Tpad][256]
     // fbank tables
     float *window = nullptr, *melw = nullptr, *tw256 = nullptr, *tw512 = nullptr;
     int *mel_lo = nullptr, *mel_hi = nullptr;
@@ -185,12 +187,14 @@ void gemm(masr_engine* e, hipStream_t s, const float* A, int lda, const float* W
 void rowgemm(masr_engine* e, hipStream_t s, int pro, int epi, const float* A, int lda, const float* lnw,
              const float* lnb, const float* W, const float* bias, float* C, int ldc, int M, int N, const float* R,
              int ldr, float alpha, const int* lens, int mask_tp, int seq_t, int pad, int* out_idx, float* out_maxp,
-             int kind = PROF_GEMM, int mstride = 4, int out_seq_t = 0, int out_pad_l = 0, int out_pad_tot = 0) {
+             int kind = PROF_GEMM, int mstride = 4, int out_seq_t = 0, int out_pad_l = 0, int out_pad_tot = 0,
+             int plane_cols = 0, long plane_stride = 0, int a_seq_t = 0, int a_seq_stride = 0) {
     RowGemmArgs a{};
     a.A = A; a.lda = lda; a.lnw = lnw; a.lnb = lnb; a.W = W; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N;
     a.R = R; a.ldr = ldr; a.alpha = alpha; a.lens = lens; a.mask_tp = mask_tp; a.seq_t = seq_t; a.pad = pad;
     a.out_idx = out_idx; a.out_maxp = out_maxp; a.eps = 1e-5f; a.mstride = mstride;
     a.out_seq_t = out_seq_t; a.out_pad_l = out_pad_l; a.out_pad_tot = out_pad_tot;
+    a.plane_cols = plane_cols; a.plane_stride = plane_stride; a.a_seq_t = a_seq_t; a.a_seq_stride = a_seq_stride;
     ProfScope ps(e, s, kind, 2.0 * M * (double)N * 256);
     launch_rowgemm(a, pro, epi, s);
 }
@@ -254,12 +258,12 @@ int masr_version(void) { return 1; }
 
 int masr_create(const masr_config* cfg, masr_engine** out) {
     if (!cfg || !out) return fail("null argument");
-    if (cfg->model_kind != 0 && cfg->model_kind != 1)
-        return fail("model_kind must be 0 (conformer) or 1 (squeezeformer, non-streaming)");
+    if (cfg->model_kind < 0 || cfg->model_kind > 2)
+        return fail("model_kind must be 0 (conformer), 1 (squeezeformer, non-streaming) or 2 (efficient_conformer)");
     if (cfg->d_model != 256 || cfg->heads != 4) return fail("kernels are specialised for d_model=256, heads=4");
     if (cfg->n_mels != 80) return fail("n_mels must be 80");
     if (cfg->d_ff % 128) return fail("unsupported d_ff");
-    if (cfg->model_kind == 0) {
+    if (cfg->model_kind == 0 || cfg->model_kind == 2) {
         if (cfg->cnn_kernel != 15) return fail("conformer: cnn_module_kernel must be 15");
         if (!cfg->causal) return fail("only the streaming-trained (causal conv) conformer is implemented");
     } else {
@@ -275,6 +279,12 @@ int masr_create(const masr_config* cfg, masr_engine** out) {
     if (e->cfg.max_pos <= 0) e->cfg.max_pos = 5000;
     e->reduce_idx = cfg->model_kind == 1 ? cfg->reserved[0] : -1;
     e->recover_idx = cfg->model_kind == 1 ? cfg->reserved[1] : -1;
+    if (cfg->model_kind == 2) {
+        e->stride_idx = cfg->reserved[0];
+        e->n_group_layers = cfg->reserved[1];
+        e->group_size = cfg->reserved[2];
+        if (e->group_size != 3) { delete e; return fail("efficient_conformer: group_size must be 3"); }
+    }
     if (build_fbank_tables(e)) {
         masr_destroy(e);
         return 1;
@@ -288,7 +298,7 @@ void masr_destroy(masr_engine* e) {
     for (void* p : e->owned) (void)hipFree(p);
     DevBuf* bufs[] = {&e->x1, &e->x2, &e->x, &e->ln, &e->hid, &e->qkv, &e->att, &e->lnpad, &e->glu, &e->dwo,
                       &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens, &e->xsave,
-                      &e->xred};
+                      &e->xred, &e->qplanes, &e->attp};
     for (DevBuf* b : bufs) b->release();
     for (auto& s : e->streams) {
         s.att.release();
@@ -318,6 +328,10 @@ int masr_load_tensor(masr_engine* e, const char* name, const float* host, const 
 }
 
 static int finalize_squeezeformer(masr_engine* e, hipStream_t s);
+static int layer_kernel(const masr_engine* e, int i) {          // efficient conformer: kernel // stride after the stride layer
+    return (e->cfg.model_kind == 2 && e->stride_idx >= 0 && i > e->stride_idx) ? e->cfg.cnn_kernel / 2 : e->cfg.cnn_kernel;
+}
+static bool layer_grouped(const masr_engine* e, int i) { return e->cfg.model_kind == 2 && i < e->n_group_layers; }
 
 int masr_finalize(masr_engine* e, void* stream) {
     if (!e) return fail("null engine");
@@ -409,11 +423,13 @@ int masr_finalize(masr_engine* e, void* stream) {
         CHK(up(e, p + "self_attn.linear_out.weight", {d, d}, &w.wo));
         CHK(up(e, p + "self_attn.linear_out.bias", {d}, &w.bo));
         CHK(up(e, p + "self_attn.linear_pos.weight", {d, d}, &w.wpos));
-        CHK(up(e, p + "self_attn.pos_bias_u", {H, dk}, &w.pos_u));
-        CHK(up(e, p + "self_attn.pos_bias_v", {H, dk}, &w.pos_v));
+        const int gk = layer_grouped(e, i) ? dk * e->group_size : dk;
+        CHK(up(e, p + "self_attn.pos_bias_u", {H, gk}, &w.pos_u));
+        CHK(up(e, p + "self_attn.pos_bias_v", {H, gk}, &w.pos_v));
         CHK(up(e, p + "conv_module.pointwise_conv1.weight", {2 * d, d, 1}, &w.pw1_w));   // rows: value c, gate d + c
         CHK(up(e, p + "conv_module.pointwise_conv1.bias", {2 * d}, &w.pw1_b));
-        {   // depthwise [d,1,K] -> [K][d]
+        {   // depthwise [d,1,K_i] -> [K_i][d]
+            const int K = layer_kernel(e, i);
             CHK(get(e, p + "conv_module.depthwise_conv.weight", {d, 1, K}, &t));
             std::vector<float> wd((size_t)K * d);
             for (int c = 0; c < d; ++c)
@@ -510,8 +526,9 @@ int ensure_layer_ws(masr_engine* e, int nseq, int Tq) {
 //                            GEMM's A-tile prologue (rowgemm PRO_LN_PAD); lnpad is not used.
 //  streaming (hist == true): lnpad rows [0,pad) of every sequence already hold the cnn cache; LayerNorm writes
 //                            the new rows behind them (needed for the next cache) and the GEMM reads lnpad.
-int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, bool hist) {
-    const int d = e->cfg.d_model, K = e->cfg.cnn_kernel, pad = K - 1;
+int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, bool hist, int K = 0, int mstride = 4) {
+    if (K <= 0) K = e->cfg.cnn_kernel;
+    const int d = e->cfg.d_model, pad = K - 1;
     const int M = c.nseq * c.Tq, Mp = c.nseq * (c.Tq + pad);
     float* x = e->x.as<float>();
     if (hist) {
@@ -520,12 +537,12 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
                 e->glu.as<float>(), d, Mp, 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
     } else {
         rowgemm(e, s, RG_PRO_LN_PAD, RG_EPI_GLU, x, d, w.ln_conv_w, w.ln_conv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d,
-                Mp, 2 * d, nullptr, 0, 1.f, c.lens, 0, c.Tq, pad, nullptr, nullptr);
+                Mp, 2 * d, nullptr, 0, 1.f, c.lens, 0, c.Tq, pad, nullptr, nullptr, PROF_GEMM, mstride);
     }
     launch_dwconv_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), c.nseq, c.Tq, K,
                           1e-5f, s);
     rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x, d,
-            1.f, c.lens, c.lens ? c.Tq : 0, 0, 0, nullptr, nullptr);
+            1.f, c.lens, c.lens ? c.Tq : 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
     return 0;
 }
 
@@ -768,6 +785,80 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Efficient Conformer, full-context forward (efficient_conformer/encoder.py:213-265): Conformer layers with
+// grouped attention in the first n_group_layers blocks, a stride-2 conv block at stride_idx (AvgPool residual),
+// half frame rate + kernel 7 afterwards.  Weights share the Conformer key names (masr_finalize).
+// ------------------------------------------------------------------------------------------------
+static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* feats, const int* lens, int B, int T,
+                                 float* enc_out) {
+    const int d = e->cfg.d_model, H = e->cfg.heads, G = e->group_size;
+    int T0 = 0;
+    CHK(embed(e, s, feats, B, T, &T0));
+    if (T0 >= e->cfg.max_pos) return fail("sequence longer than max_pos");
+    CHK(ensure_layer_ws(e, B, T0));
+    const int Tg = (T0 + G - 1) / G, Tpad = Tg * G;
+    const size_t plane = (size_t)B * Tpad * d;
+    CHK(e->attseq.ensure(sizeof(AttSeq) * 2 * B));
+    CHK(e->qplanes.ensure(3 * plane * sizeof(float)));
+    CHK(e->attp.ensure(plane * sizeof(float)));
+    CHK(e->xsave.ensure((size_t)B * ((T0 + 1) / 2) * d * sizeof(float)));
+    float* x = e->x.as<float>();
+    float* qp = e->qplanes.as<float>();
+    AttSeq* seq_g = e->attseq.as<AttSeq>();
+    AttSeq* seq_r = seq_g + B;
+    HIPCHK(hipMemsetAsync(qp, 0, 3 * plane * sizeof(float), s));     // time padding rows of q/k/v stay zero (pad4group)
+    int Tq = T0, mstride = 4, pstride = 1;
+    launch_attseq_grouped(seq_g, qp, qp + plane, qp + 2 * plane, e->attp.as<float>(), lens, B, Tg, G, mstride, s);
+    launch_attseq_full(seq_r, e->qkv.as<float>(), e->att.as<float>(), lens, B, Tq, mstride, s);
+    const int L = e->cfg.num_blocks;
+    for (int i = 0; i < L; ++i) {
+        const LayerW& w = e->layers[i];
+        int M = B * Tq;
+        CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
+        if (layer_grouped(e, i)) {
+            if (Tq != T0) return fail("grouped attention after the stride layer is not supported");
+            // q | k | v -> planar, time-padded buffers; attention over T/3 positions with d_k' = 192
+            rowgemm(e, s, RG_PRO_LN, RG_EPI_STORE, x, d, w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, qp, d, M, 3 * d, nullptr,
+                    0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride, Tq, 0, Tpad - Tq, d, (long)plane);
+            {
+                ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B / G);
+                launch_attention_grouped(seq_g, B, Tg, H, G, w.ptab, Tq, w.pos_u, w.pos_v, s);
+            }
+            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->attp.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d,
+                    1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride, 0, 0, 0, 0, 0, Tq, Tpad);
+        } else {
+            mhsa(e, s, w, M);
+            {
+                ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
+                launch_attention(seq_r, B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v, 0, pstride, s);
+            }
+            mhsa_out(e, s, w, M);
+        }
+        EncodeCtx ctx{B, Tq, lens};
+        if (i == e->stride_idx) {
+            // StrideConformerEncoderLayer (encoder.py:454-545): x = AvgPool(x) + conv_module_stride2(LN(x))
+            const int K = layer_kernel(e, i), pad = K - 1, T2 = (Tq + 1) / 2;
+            rowgemm(e, s, RG_PRO_LN_PAD, RG_EPI_GLU, x, d, w.ln_conv_w, w.ln_conv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d,
+                    B * (Tq + pad), 2 * d, nullptr, 0, 1.f, lens, 0, Tq, pad, nullptr, nullptr, PROF_GEMM, mstride);
+            launch_dwconv_stride2_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), B, Tq, K,
+                                          1e-5f, s);
+            launch_avgpool2(x, e->xsave.as<float>(), B, Tq, s);
+            Tq = T2; mstride *= 2; pstride *= 2; M = B * Tq;
+            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d,
+                    e->xsave.as<float>(), d, 1.f, lens, Tq, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
+            launch_attseq_full(seq_r, e->qkv.as<float>(), e->att.as<float>(), lens, B, Tq, mstride, s);
+        } else {
+            CHK(conv_module(e, s, w, ctx, false, layer_kernel(e, i), mstride));
+        }
+        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
+        launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
+    }
+    launch_layernorm(x, e->after_w, e->after_b, enc_out, B * Tq, 1e-5f, 0, 0, nullptr, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat_lens_dev, int32_t B, int32_t T,
@@ -778,6 +869,10 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     if (e->cfg.model_kind == 1) {
         if (decoding_chunk_size > 0) return fail("squeezeformer (non-streaming): chunk masks are not available");
         return encode_full_squeezeformer(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev);
+    }
+    if (e->cfg.model_kind == 2) {
+        if (decoding_chunk_size > 0) return fail("efficient_conformer: only full-context decoding is implemented");
+        return encode_full_efficient(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev);
     }
     const int d = e->cfg.d_model, H = e->cfg.heads, pad = e->cfg.cnn_kernel - 1;
     int Tq = 0;
@@ -884,7 +979,7 @@ int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_for
     }
     if (gain_dev && use_db_normalization)
         HIPCHK(hipMemcpyAsync(gain_dev, gain, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
-    if (n_frames_dev) launch_frame_counts(n_samples_dev, B, n_frames_dev, nullptr, s);
+    if (n_frames_dev) launch_frame_counts(n_samples_dev, B, n_frames_dev, nullptr, 0, s);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -896,8 +991,10 @@ int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t*
     if (n_max < 400) return fail("n_max < 400 samples: no frame");
     hipStream_t s = (hipStream_t)stream;
     const int d = e->cfg.d_model, F = e->cfg.n_mels;
-    const int T = 1 + (n_max - 400) / 160, T1 = (T - 1) / 2, Tq = (T1 - 1) / 2;
-    if (Tq <= 0) return fail("utterances too short");
+    const int T = 1 + (n_max - 400) / 160, T1 = (T - 1) / 2, Tsub = (T1 - 1) / 2;
+    const bool halved = e->cfg.model_kind == 2 && e->stride_idx >= 0;      // efficient conformer: one more stride-2 stage
+    const int Tq = halved ? (Tsub + 1) / 2 : Tsub;
+    if (Tsub <= 0) return fail("utterances too short");
     CHK(e->feats.ensure((size_t)B * T * F * sizeof(float)));
     CHK(e->nframes.ensure(sizeof(int) * 2 * B));
     CHK(e->enc.ensure((size_t)B * Tq * d * sizeof(float)));
@@ -907,7 +1004,7 @@ int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t*
     int* nenc = nfr + B;
     CHK(masr_fbank_batch(e, pcm_dev, 0, n_samples_dev, B, n_max, use_db_normalization, target_db,
                          e->feats.as<float>(), nullptr, nullptr, nullptr, stream));
-    launch_frame_counts(n_samples_dev, B, nfr, nenc, s);
+    launch_frame_counts(n_samples_dev, B, nfr, nenc, halved ? 1 : 0, s);
     CHK(masr_encode_full(e, e->feats.as<float>(), nfr, B, T, -1, e->enc.as<float>(), stream));
     CHK(masr_ctc_greedy_frames(e, e->enc.as<float>(), B * Tq, e->idx.as<int>(), e->maxp.as<float>(), stream));
     CHK(masr_ctc_collapse(e, e->idx.as<int>(), e->maxp.as<float>(), decode_all_frames ? nullptr : nenc, B, Tq, 0,

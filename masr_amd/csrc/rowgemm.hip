@@ -61,6 +61,11 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
             const int row = row0 + wave * 4 + rr;
             bool live = row < p.M;
             size_t src_row = live ? row : 0;
+            if (PRO == RG_PRO_PLAIN && p.a_seq_t > 0) {       // rows live in a per-sequence padded buffer
+                const int rc = live ? row : 0;
+                const int b = rc / p.a_seq_t;
+                src_row = (size_t)b * p.a_seq_stride + (rc - b * p.a_seq_t);
+            }
             if (PRO == RG_PRO_AFFINE && p.lens && p.seq_t > 0) {
                 // Squeezeformer conv module: padded frames are zeroed AFTER the adaptive scale/bias (convolution.py:109-115)
                 const int rc = live ? row : 0;
@@ -205,7 +210,22 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
                         }
                         v = res[r] + p.alpha * v;
                     }
-                    if (row < p.M) p.C[(size_t)row * p.ldc + col] = v;
+                    if (row < p.M) {
+                        size_t crow = row;
+                        int ccol = col;
+                        float* cb = p.C;
+                        if (EPI == RG_EPI_STORE) {
+                            if (p.out_seq_t > 0) {
+                                const int b = row / p.out_seq_t, t = row - b * p.out_seq_t;
+                                crow = (size_t)b * (p.out_seq_t + p.out_pad_tot) + p.out_pad_l + t;
+                            }
+                            if (p.plane_cols > 0) {
+                                cb += (size_t)(col / p.plane_cols) * p.plane_stride;
+                                ccol = col % p.plane_cols;
+                            }
+                        }
+                        cb[crow * p.ldc + ccol] = v;
+                    }
                 }
             }
         } else if (EPI == RG_EPI_GLU) {

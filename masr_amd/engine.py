@@ -66,8 +66,26 @@ class HipEngine:
             red, rec = enc.get('reduce_idx', 5), enc.get('recover_idx', 11)
             cfg.reserved[0] = -1 if red is None else int(red)
             cfg.reserved[1] = -1 if rec is None else int(rec)
+        elif use_model == 'efficient_conformer':
+            # configs/efficient_conformer.yml: the nested efficient_conf is swallowed by **kwargs in the reference
+            # (efficient_conformer/encoder.py:54); its constructor defaults equal the shipped YAML values
+            eff = dict(enc.get('efficient_conf', {}) or {})
+            stride_idx = eff.get('stride_layer_idx', [3])
+            stride_idx = stride_idx if isinstance(stride_idx, (list, tuple)) else [stride_idx]
+            groups = list(eff.get('group_layer_idx', [0, 1, 2, 3]))
+            if len(stride_idx) != 1 or list(eff.get('stride', [2])) not in ([2], 2) or groups != list(range(len(groups))):
+                raise _lib.MasrError('efficient_conformer: only one stride-2 layer and leading grouped layers are supported')
+            cfg = MasrConfig(model_kind=2, d_model=int(enc.get('output_size', 256)),
+                             heads=int(enc.get('attention_heads', 4)), d_ff=int(enc.get('linear_units', 2048)),
+                             num_blocks=int(enc.get('num_blocks', 12)),
+                             cnn_kernel=int(enc.get('cnn_module_kernel', 15)), n_mels=n_mels,
+                             vocab_size=int(vocab_size), causal=1 if streaming else 0, max_pos=max_pos,
+                             device_id=device)
+            cfg.reserved[0] = int(stride_idx[0])
+            cfg.reserved[1] = len(groups)
+            cfg.reserved[2] = int(eff.get('group_size', 3))
         else:
-            raise _lib.MasrError(f'use_model={use_model}: only conformer and squeezeformer are implemented')
+            raise _lib.MasrError(f'use_model={use_model}: conformer, squeezeformer, efficient_conformer are implemented')
         self.use_model = use_model
         self.cfg = cfg
         self.d_model, self.vocab_size, self.n_mels = cfg.d_model, cfg.vocab_size, n_mels
@@ -128,11 +146,16 @@ class HipEngine:
     def encode_full(self, feats, lens, decoding_chunk_size=-1):
         """feats f32 [B,T,80] (device, zero padded), lens int32 [B] (device) -> enc [B,T',d]."""
         B, T, _ = feats.shape
-        Tp = subsampled_len(T)
+        Tp = self.out_frames(T)
         enc = torch.empty(B, Tp, self.d_model, dtype=torch.float32, device=self.device)
         check(self.lib.masr_encode_full(self.h, _ptr(feats), _ptr(lens), B, T, int(decoding_chunk_size), _ptr(enc),
                                         _stream()))
         return enc
+
+    def out_frames(self, T):
+        """encoder output frames for T feature frames (the Efficient Conformer halves the rate once more)."""
+        Tp = subsampled_len(T)
+        return (Tp + 1) // 2 if getattr(self, 'use_model', 'conformer') == 'efficient_conformer' else Tp
 
     def ctc_probs(self, enc, want_argmax=False):
         M = enc.numel() // self.d_model
@@ -169,7 +192,7 @@ class HipEngine:
                          out=None):
         """Whole offline hot path in one call, no host sync: PCM -> token ids."""
         B, n_max = pcm.shape
-        Tp = subsampled_len(1 + (n_max - 400) // 160)
+        Tp = self.out_frames(1 + (n_max - 400) // 160)
         if out is None:
             out = (torch.empty(B, Tp, dtype=torch.int32, device=self.device),
                    torch.empty(B, dtype=torch.int32, device=self.device),

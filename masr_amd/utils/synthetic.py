@@ -152,3 +152,23 @@ def squeezeformer_state_dict(seed=0, vocab_size=4233, d=256, heads=4, ff_factor=
     lin('encoder.time_recover_layer', d, d)
     lin('ctc.ctc_lo', vocab_size, d, gain=ctc_gain)
     return sd
+
+
+def efficient_conformer_state_dict(seed=0, vocab_size=4233, d=256, heads=4, d_ff=2048, num_blocks=12, kernel=15,
+                                   n_mels=80, ctc_gain=6.0, stride_layer_idx=(3,), stride=(2,),
+                                   group_layer_idx=(0, 1, 2, 3), group_size=3):
+    """Keys/shapes == reference EfficientConformerModel ``encoder.*`` + ``ctc.*``
+    (configs/efficient_conformer.yml: streaming, layer_norm conv module, grouped attention in blocks 0-3,
+    strided depthwise conv in block 3, kernel 15 -> 7 afterwards; masr/model_utils/efficient_conformer/)."""
+    sd = conformer_state_dict(seed, vocab_size, d, heads, d_ff, num_blocks, kernel, n_mels, ctc_gain)
+    k = kernel
+    for i in range(num_blocks):
+        p = f'encoder.encoders.{i}.'
+        if i in group_layer_idx:
+            sd[p + 'self_attn.pos_bias_u'] = _uniform(seed, p + 'gu', (heads, (d // heads) * group_size), 0.3)
+            sd[p + 'self_attn.pos_bias_v'] = _uniform(seed, p + 'gv', (heads, (d // heads) * group_size), 0.3)
+        if k != kernel:
+            sd[p + 'conv_module.depthwise_conv.weight'] = _uniform(seed, p + 'dw.w', (d, 1, k), math.sqrt(3.0 / k))
+        if i in stride_layer_idx:
+            k = k // stride[list(stride_layer_idx).index(i)]
+    return sd

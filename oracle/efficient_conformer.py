@@ -1,0 +1,88 @@
+"""TEST INFRASTRUCTURE ONLY -- torch-CPU fp32 restatement of the reference Efficient-Conformer full-context
+forward (``configs/efficient_conformer.yml``: streaming-trained => causal convs; conv2d (x4) front-end;
+GroupedRelPositionMultiHeadedAttention (group 3) in blocks 0-3; block 3 = StrideConformerEncoderLayer with a
+stride-2 depthwise conv and an AvgPool1d residual; blocks >= 4 run at half the frame rate with kernel 7).
+Paths are relative to ``masr/model_utils``.  Pinned against the real reference modules by
+tests/test_oracle_golden.py (live + committed fixture)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import conformer as oc
+
+
+def _grouped_attention(sd, p, x, pos_emb, key_mask, heads, g=3):
+    """GroupedRelPositionMultiHeadedAttention.forward / pad4group (efficient_conformer/attention.py:35-69,120-182).
+    key_mask bool [B, T] (True = keep); mask[:, ::g, ::g] -> grouped key j keeps key_mask[:, g*j]."""
+    B, T, d = x.shape
+    dk = d // heads
+    q = F.linear(x, sd[p + '.linear_q.weight'], sd[p + '.linear_q.bias'])       # [B,T,d] (head-major features)
+    k = F.linear(x, sd[p + '.linear_k.weight'], sd[p + '.linear_k.bias'])
+    v = F.linear(x, sd[p + '.linear_v.weight'], sd[p + '.linear_v.bias'])
+    pp = F.linear(pos_emb, sd[p + '.linear_pos.weight'])                        # [1,T,d]
+    pad = (g - T % g) % g
+
+    def grp(t):   # zero-pad time to a multiple of g, then a flat reshape [T, H*dk] -> [T/g, H, g*dk]
+        t = F.pad(t, (0, 0, 0, pad))
+        return t.reshape(t.shape[0], -1, heads, dk * g).transpose(1, 2)
+
+    Q, K, V, P = grp(q), grp(k), grp(v), grp(pp)
+    qu = Q + sd[p + '.pos_bias_u'][None, :, None, :]
+    qv = Q + sd[p + '.pos_bias_v'][None, :, None, :]
+    scores = (qu @ K.transpose(-2, -1) + qv @ P.transpose(-2, -1)) / math.sqrt(dk * g)
+    m = ~key_mask[:, ::g][:, None, None, :]
+    scores = scores.masked_fill(m, -float('inf'))
+    attn = torch.softmax(scores, dim=-1).masked_fill(m, 0.0)
+    o = (attn @ V).transpose(1, 2).reshape(B, -1, d)[:, :T]
+    return F.linear(o, sd[p + '.linear_out.weight'], sd[p + '.linear_out.bias'])
+
+
+def _conv_module(sd, p, x, pad_mask, stride=1):
+    """efficient_conformer/convolution.py:71-134, causal + layer_norm, optional stride in the depthwise conv."""
+    kernel = sd[p + '.depthwise_conv.weight'].shape[-1]
+    x = x.transpose(1, 2).masked_fill(~pad_mask.unsqueeze(1), 0.0)
+    x = F.pad(x, (kernel - 1, 0))
+    x = F.conv1d(x, sd[p + '.pointwise_conv1.weight'], sd[p + '.pointwise_conv1.bias'])
+    x = F.glu(x, dim=1)
+    x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], stride=stride, groups=x.shape[1])
+    x = F.silu(oc._ln(sd, p + '.norm', x.transpose(1, 2))).transpose(1, 2)
+    x = F.conv1d(x, sd[p + '.pointwise_conv2.weight'], sd[p + '.pointwise_conv2.bias'])
+    pm = pad_mask if pad_mask.shape[1] == x.shape[2] else pad_mask[:, ::stride]
+    return x.masked_fill(~pm.unsqueeze(1), 0.0).transpose(1, 2)
+
+
+def encoder_full(sd, feats, lens, heads=4, stride_layer_idx=(3,), stride=(2,), group_layer_idx=(0, 1, 2, 3), group_size=3):
+    """EfficientConformerEncoder.forward with decoding_chunk_size = -1 (efficient_conformer/encoder.py:213-265);
+    layer bodies: ConformerEncoderLayer (conformer/encoder.py:82-163) / StrideConformerEncoderLayer (:454-545)."""
+    B, T, _ = feats.shape
+    pad = torch.arange(T)[None, :] < lens[:, None]
+    x = oc.embed(sd, feats)
+    Tp = x.shape[1]
+    pad_s = pad[:, :-2:2][:, :-2:2]
+    pos_emb = oc.positional_table(5000, x.shape[-1])[:Tp].unsqueeze(0)
+    for i in range(oc.num_blocks_of(sd)):
+        p = f'encoder.encoders.{i}'
+        x = x + 0.5 * oc._ffn(sd, p + '.feed_forward_macaron', oc._ln(sd, p + '.norm_ff_macaron', x))
+        xn = oc._ln(sd, p + '.norm_mha', x)
+        if i in group_layer_idx:
+            a = _grouped_attention(sd, p + '.self_attn', xn, pos_emb, pad_s, heads, group_size)
+        else:
+            a, _ = oc._attention(sd, p + '.self_attn', xn, pos_emb, pad_s[:, None, :], heads)
+        x = x + a
+        if i in stride_layer_idx:
+            st = stride[list(stride_layer_idx).index(i)]
+            c = _conv_module(sd, p + '.conv_module', oc._ln(sd, p + '.norm_conv', x), pad_s, st)
+            res = F.avg_pool1d(x.transpose(1, 2), st, st, 0, True, False).transpose(1, 2)
+            x = res + c
+            pad_s = pad_s[:, ::st]
+            pos_emb = pos_emb[:, ::st, :]
+        else:
+            x = x + _conv_module(sd, p + '.conv_module', oc._ln(sd, p + '.norm_conv', x), pad_s)
+        x = x + 0.5 * oc._ffn(sd, p + '.feed_forward', oc._ln(sd, p + '.norm_ff', x))
+        x = oc._ln(sd, p + '.norm_final', x)
+    return oc._ln(sd, 'encoder.after_norm', x)
+
+
+def get_encoder_out(sd, feats, lens, **kw):
+    return oc.ctc_probs(sd, encoder_full(sd, feats, lens, **kw))

@@ -109,6 +109,20 @@ def main():
     sq_probs = sq.get_encoder_out(feats, lens)
     np.savez_compressed(os.path.join(OUT, 'squeezeformer_v512.npz'), enc=sq_enc.numpy(), probs=sq_probs.numpy())
 
+    # ---- efficient conformer (configs/efficient_conformer.yml, streaming: True) V=512 ------------------
+    from masr.model_utils.efficient_conformer.model import EfficientConformerModel
+    ef_cfg = yaml.safe_load(open(os.path.join(REF, 'configs', 'efficient_conformer.yml'), encoding='utf-8'))
+    ef_sd = weights.efficient_conformer_state_dict(0, 512)
+    ef = EfficientConformerModel(input_dim=80, vocab_size=512, mean_istd_path=mean_istd, streaming=True,
+                                 encoder_conf=ef_cfg['encoder_conf'], decoder_conf=ef_cfg['decoder_conf'],
+                                 **ef_cfg['model_conf'])
+    missing, unexpected = ef.load_state_dict(ef_sd, strict=False)
+    assert not unexpected and all(k.startswith('decoder.') or 'concat_linear' in k for k in missing)
+    ef.eval()
+    ef_enc, _ = ef.encoder(feats, lens, -1, -1)
+    ef_probs = ef.get_encoder_out(feats, lens)
+    np.savez_compressed(os.path.join(OUT, 'efficient_conformer_v512.npz'), enc=ef_enc.numpy(), probs=ef_probs.numpy())
+
     # ---- MASRPredictor facade on the TorchScript export ---------------------------
     from masr.predict import MASRPredictor
     vocab = weights.synthetic_vocab(4233)

@@ -393,3 +393,48 @@ def test_squeezeformer_odd_lengths_against_oracle(sq512, oracle_mods):
         ref = osq.encoder_full(sd, feats, lens)
     enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
     assert ref.shape == enc.shape and (ref - enc).abs().max() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# Efficient Conformer (configs/efficient_conformer.yml), full-context get_encoder_out
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def eff512(oracle_mods):
+    from masr_amd.engine import HipEngine
+    _, _, _, weights, _ = oracle_mods
+    sd = weights.efficient_conformer_state_dict(0, 512)
+    e = HipEngine(sd, vocab_size=512, streaming=True, use_model='efficient_conformer',
+                  encoder_conf={'output_size': 256, 'attention_heads': 4, 'linear_units': 2048, 'num_blocks': 12,
+                                'cnn_module_kernel': 15,
+                                'efficient_conf': {'stride_layer_idx': [3], 'stride': [2], 'group_layer_idx': [0, 1, 2, 3],
+                                                   'group_size': 3, 'stride_kernel': True}})
+    yield e, sd
+    e.close()
+
+
+def test_efficient_conformer_against_reference_fixture(eff512, oracle_mods):
+    e, sd = eff512
+    _, _, _, _, golden_inputs = oracle_mods
+    z = g('efficient_conformer_v512.npz')
+    feats, lens = golden_inputs()
+    enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1)
+    assert tuple(enc.shape) == z['enc'].shape
+    err = np.abs(enc.cpu().numpy() - z['enc']).max()
+    assert err < 1e-3, f'efficient conformer encoder_out max err {err}'
+    probs = e.ctc_probs(enc).cpu().numpy()
+    assert np.abs(probs - z['probs']).max() < 1e-3
+
+
+@pytest.mark.parametrize('T', [203, 204, 205, 331])
+def test_efficient_conformer_lengths_against_oracle(eff512, oracle_mods, T):
+    """T' mod 3 = 0/1/2 (grouping pad) and odd / even T' (stride layer, AvgPool ceil mode), ragged batch."""
+    from oracle import efficient_conformer as oe
+    e, sd = eff512
+    gen = torch.Generator().manual_seed(T)
+    feats = torch.randn(2, T, 80, generator=gen) * 3 + 13
+    lens = torch.tensor([T, T // 2 + 9])
+    feats = feats * (torch.arange(T)[None, :, None] < lens[:, None, None])
+    with torch.no_grad():
+        ref = oe.encoder_full(sd, feats, lens)
+    enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
+    assert ref.shape == enc.shape and (ref - enc).abs().max() < 1e-3

@@ -109,6 +109,18 @@ def test_squeezeformer_fixture():
         np.testing.assert_allclose(osq.get_encoder_out(sd, feats, lens).numpy(), z['probs'], atol=2e-6)
 
 
+def test_efficient_conformer_fixture():
+    from oracle import efficient_conformer as oe
+    z = g('efficient_conformer_v512.npz')
+    feats, lens = golden_inputs()
+    sd = weights.efficient_conformer_state_dict(0, 512)
+    with torch.no_grad():
+        enc = oe.encoder_full(sd, feats, lens)
+        assert enc.shape[1] == 41                      # T' = 82 -> 41 after the stride layer
+        np.testing.assert_allclose(enc.numpy(), z['enc'], atol=2e-5)
+        np.testing.assert_allclose(oe.get_encoder_out(sd, feats, lens).numpy(), z['probs'], atol=2e-6)
+
+
 def test_flop_model_matches_survey():
     # 23.18 GFLOP per 10 s utterance (+ the once-per-batch pos projection)
     per_utt = oc.conformer_flops(998) - 12 * 2 * 256 * 256 * 248
