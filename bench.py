@@ -27,6 +27,16 @@ def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
+def committed_traffic():
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this build
+    (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if absent."""
+    try:
+        k = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
+        return k['masr::ffn_fused_kernel<0, 0>']['hbm_bytes']
+    except Exception:
+        return None
+
+
 def host_cores():
     """Threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -135,7 +145,9 @@ def main():
             achieved = prof_flops / (prof_ms * 1e-3) / 1e12
             roofline = {'bound': 'mfma', 'kernel': 'ffn_fused_kernel (LN + [B*T\',256]x[256,2048] + SiLU + x[2048,256] + residual)',
                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': committed_traffic(),
+                        'traffic_note': 'HBM bytes per launch from committed PMC passes (profiles/r01_hbm_traffic.json); '
+                                        'algorithmic bytes per launch = 20.4 MB (x in/out + W1 + W2)',
                         'launches': int(prof_n), 'avg_us': round(prof_ms * 1e3 / prof_n, 2),
                         'flops_per_launch': prof_flops / prof_n}
         res = {'metric': 'audio-seconds/sec (RTF^-1), conformer_streaming_fbank b32x10s, PCM->fbank->encoder->ctc_greedy',
