@@ -79,12 +79,94 @@ def cpu_baseline(sample_utts=4, reps=2):
                       f'median of {reps}, torch threads={cores}'}
 
 
+def other_workload(args, device):
+    """Secondary workloads (parity-test configurations of BASELINE.json timed for DESIGN.md; NOT the contract line)."""
+    import ctypes as C
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    torch.cuda.set_device(device)
+    rng = np.random.default_rng(1234)
+    if args.workload == 'efficient_b32':
+        eng = HipEngine(synthetic.efficient_conformer_state_dict(0, VOCAB), vocab_size=VOCAB, streaming=True,
+                        use_model='efficient_conformer', device=device)
+        pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234)).cuda()
+        n = torch.full((BATCH,), N_SAMPLES, dtype=torch.int32, device='cuda')
+        step = lambda: eng.transcribe_batch(pcm, n)
+        audio = BATCH * 10.0
+        desc = 'configs[3] shard: efficient_conformer.yml, 32 x 10 s per GPU, ctc_greedy'
+    elif args.workload == 'squeezeformer_b64_beam':
+        from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+        eng = HipEngine(synthetic.squeezeformer_state_dict(0, VOCAB), vocab_size=VOCAB, streaming=False,
+                        use_model='squeezeformer', device=device)
+        lens = rng.integers(32000, 320001, 64).astype(np.int32)
+        order = np.argsort(-lens)                       # longest first (one padded batch; sort limits nothing here)
+        lens = lens[order]
+        pcm_h = synthetic.synthetic_pcm(64, int(lens.max()), seed=1234)
+        for i, l in enumerate(lens):
+            pcm_h[i, l:] = 0
+        pcm = torch.from_numpy(pcm_h).cuda()
+        n = torch.from_numpy(lens).cuda()
+        dec = BeamSearchDecoder(alpha=0, beta=0, beam_size=300, cutoff_prob=0.99, cutoff_top_n=40,
+                                vocab_list=synthetic.synthetic_vocab(VOCAB), num_processes=min(host_cores(), 32))
+
+        def step():
+            feats, frames = eng.fbank_batch(pcm, n)
+            enc = eng.encode_full(feats, frames, -1)
+            probs = eng.ctc_probs(enc)
+            nenc = (((frames - 1) // 2 - 1) // 2).clamp(min=0).cpu().tolist()
+            return dec._batch([probs[i, :nenc[i]] for i in range(64)])
+        audio = float(lens.sum()) / 16000.0
+        desc = f'configs[2]: squeezeformer.yml non-streaming, 64 utterances 2-20 s padded ({audio:.1f} audio-s), ctc_beam_search ' \
+               f'(LM-free, beam 300, {dec.num_processes} host threads)'
+    elif args.workload == 'stream16':
+        eng = HipEngine(synthetic.conformer_state_dict(0, VOCAB), vocab_size=VOCAB, device=device)
+        ns = 16
+        pcm = torch.from_numpy(synthetic.synthetic_pcm(ns, N_SAMPLES, seed=1234)).cuda()
+        n = torch.full((ns,), N_SAMPLES, dtype=torch.int32, device='cuda')
+        feats, _ = eng.fbank_batch(pcm, n)                       # [16, 998, 80]
+        sids = [eng.stream_open(300) for _ in range(ns)]
+        lat = []
+
+        def step():
+            for sid in sids:
+                eng.stream_reset(sid)
+            for cur in range(0, feats.shape[1] - 67 + 1, 64):     # 15 chunk steps of 0.64 s each, 16 streams in lock-step
+                t0 = time.perf_counter()
+                _, idx, mp = eng.encode_chunk(sids, feats[:, cur:cur + 67].contiguous(), want_probs=False, want_argmax=True)
+                idx.cpu()
+                lat.append(time.perf_counter() - t0)
+        audio = ns * 15 * 0.64
+        desc = 'configs[4] shard: conformer.yml streaming, 16 concurrent streams per GPU in lock-step, 67-frame windows / 64 stride'
+    else:
+        raise SystemExit(f'unknown workload {args.workload}')
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if args.workload == 'stream16':
+        lat.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {'workload': desc, 'value': round(audio * args.steps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1,
+           'steps': args.steps, 'ms_per_step': round(dt * 1e3 / args.steps, 3), 'dtype': 'f32', 'data': 'synthetic'}
+    if args.workload == 'stream16':
+        res['chunk_call_latency_ms'] = {'p50': round(float(np.percentile(lat, 50)) * 1e3, 3),
+                                        'p95': round(float(np.percentile(lat, 95)) * 1e3, 3), 'calls': len(lat)}
+    eng.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='conformer_b32',
+                    help='conformer_b32 (BASELINE configs[1], the contract line) | squeezeformer_b64_beam (configs[2]) | '
+                         'efficient_b32 (configs[3] per-GPU shard) | stream16 (configs[4] per-GPU shard)')
     ap.add_argument('--profile-kind', type=int, default=2, help='kernel class timed with HIP events (2 = fused FFN)')
     args = ap.parse_args()
 
@@ -100,6 +182,10 @@ def main():
 
     from masr_amd.engine import HipEngine, subsampled_len
     from masr_amd.utils import synthetic
+    if args.workload != 'conformer_b32':
+        if rank == 0:
+            print(json.dumps(other_workload(args, local)), flush=True)
+        return
     sd = synthetic.conformer_state_dict(0, VOCAB)
     eng = HipEngine(sd, vocab_size=VOCAB, device=local)
     pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234 + rank)).cuda()

@@ -99,7 +99,8 @@ void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);
 
 // Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_fused.hip)
 void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, hipStream_t s);
+                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
+                      int nsplit, hipStream_t s);   // partial/nsplit: split-d_ff mode for small M (streaming)
 
 void set_ffn_variant(int v);   // diagnostic ablations of the fused FFN kernel (0 = production)
 
@@ -122,6 +123,8 @@ void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int head
                               int t_true, const float* bias_u, const float* bias_v, hipStream_t s);
 void launch_attseq_grouped(AttSeq* seqs, const float* q, const float* k, const float* v, float* out, const int* lens,
                            int B, int Tg, int group, int mstride, hipStream_t s);
+void launch_kv_append(const AttSeq* seqs, const float* qkv, int n, int Tq, hipStream_t s);
+void launch_cnn_cache_move(float* const* caches, float* lnpad, int n, int Tq, int pad, int dir, hipStream_t s);
 void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, int mstride,
                         hipStream_t s);
 

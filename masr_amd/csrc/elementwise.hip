@@ -563,4 +563,37 @@ void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff
     hipLaunchKernelGGL(topk_prune_kernel, dim3(M), dim3(256), 0, s, probs, V, top_n, cutoff_prob, out_idx, out_logp, out_cnt);
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming cache maintenance for n lock-step streams in ONE launch each (encoder.py:404-419 does
+// torch.concat / slicing per stream): append this chunk's k|v rows to every stream's KV cache, and
+// move the conv-module history rows between the per-stream cnn caches and the padded LN buffer.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void kv_append_kernel(const AttSeq* __restrict__ seqs, const float* __restrict__ qkv,
+                                                        int Tq) {
+    const int i = blockIdx.y, r = blockIdx.x;
+    const AttSeq sq = seqs[i];
+    // cache row = [k(256) | v(256)], the new rows go to positions nk - nq .. nk - 1
+    float* dst = const_cast<float*>(sq.k) + (size_t)(sq.nk - sq.nq + r) * 512;
+    const float* src = qkv + ((size_t)i * Tq + r) * 768 + 256;
+    reinterpret_cast<f32x4*>(dst)[threadIdx.x] = reinterpret_cast<const f32x4*>(src)[threadIdx.x];
+}
+void launch_kv_append(const AttSeq* seqs, const float* qkv, int n, int Tq, hipStream_t s) {
+    if (n * Tq <= 0) return;
+    hipLaunchKernelGGL(kv_append_kernel, dim3(Tq, n), dim3(128), 0, s, seqs, qkv, Tq);
+}
+
+// dir 0: lnpad[i][0..pad) <- cache_i ;  dir 1: cache_i <- lnpad[i][Tq .. Tq+pad)
+__global__ __launch_bounds__(64) void cnn_cache_move_kernel(float* const* __restrict__ caches, float* lnpad, int Tq,
+                                                            int pad, int dir) {
+    const int i = blockIdx.y, r = blockIdx.x;
+    float* c = caches[i] + (size_t)r * 256;
+    float* l = lnpad + ((size_t)i * (Tq + pad) + (dir ? Tq + r : r)) * 256;
+    if (dir) reinterpret_cast<f32x4*>(c)[threadIdx.x] = reinterpret_cast<const f32x4*>(l)[threadIdx.x];
+    else reinterpret_cast<f32x4*>(l)[threadIdx.x] = reinterpret_cast<const f32x4*>(c)[threadIdx.x];
+}
+void launch_cnn_cache_move(float* const* caches, float* lnpad, int n, int Tq, int pad, int dir, hipStream_t s) {
+    if (n * pad <= 0) return;
+    hipLaunchKernelGGL(cnn_cache_move_kernel, dim3(pad, n), dim3(64), 0, s, caches, lnpad, Tq, pad, dir);
+}
+
 }  // namespace masr

@@ -103,7 +103,7 @@ struct masr_engine {
           *tr_pw_b = nullptr, *rec_w = nullptr, *rec_b = nullptr;
     int reduce_idx = -1, recover_idx = -1;
     int stride_idx = -1, n_group_layers = 0, group_size = 3;   // Efficient-Conformer (model_kind 2)
-    DevBuf qplanes, attp;                                      // planar q|k|v and attention output, [B][Tpad][256]
+    DevBuf qplanes, attp, cnnptrs, ffpart;                                      // planar q|k|v and attention output, [B][Tpad][256]
     // fbank tables
     float *window = nullptr, *melw = nullptr, *tw256 = nullptr, *tw512 = nullptr;
     int *mel_lo = nullptr, *mel_hi = nullptr;
@@ -298,7 +298,7 @@ void masr_destroy(masr_engine* e) {
     for (void* p : e->owned) (void)hipFree(p);
     DevBuf* bufs[] = {&e->x1, &e->x2, &e->x, &e->ln, &e->hid, &e->qkv, &e->att, &e->lnpad, &e->glu, &e->dwo,
                       &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens, &e->xsave,
-                      &e->xred, &e->qplanes, &e->attp};
+                      &e->xred, &e->qplanes, &e->attp, &e->cnnptrs, &e->ffpart};
     for (DevBuf* b : bufs) b->release();
     for (auto& s : e->streams) {
         s.att.release();
@@ -474,8 +474,16 @@ struct EncodeCtx {
 int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb, const float* w1, const float* b1,
         const float* w2, const float* b2, float scale = 0.5f, int affine = 0) {
     const int d = e->cfg.d_model, dff = e->cfg.d_ff;
+    // few rows (streaming chunk steps): split d_ff across workgroups so that >= ~128 CUs work on the block
+    int nsplit = 1;
+    const int rowblocks = (M + 31) / 32;
+    if (rowblocks < 64) {
+        nsplit = std::min(dff / 128, std::max(1, 128 / rowblocks));
+        CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
+    }
     ProfScope ps(e, s, PROF_FFN1, 4.0 * M * (double)dff * d);
-    launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine, s);
+    launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine,
+                     nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s);
     return 0;
 }
 
@@ -1103,30 +1111,26 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
             a.q_abs0 = st[i]->offset;
             a.pad_ = 0;
         }
+    std::vector<float*> hp((size_t)n * L);        // cnn cache base of (layer, stream)
+    for (int l = 0; l < L; ++l)
+        for (int i = 0; i < n; ++i) hp[(size_t)l * n + i] = st[i]->cnn.as<float>() + (size_t)l * pad * d;
+    CHK(e->cnnptrs.ensure(sizeof(float*) * hp.size()));
     HIPCHK(hipMemcpyAsync(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // hs is a stack-lifetime host buffer
+    HIPCHK(hipMemcpyAsync(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // hs / hp are stack-lifetime host buffers
     float* x = e->x.as<float>();
     EncodeCtx ctx{n, Tq, nullptr};
     for (int l = 0; l < L; ++l) {
         const LayerW& w = e->layers[l];
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
         mhsa(e, s, w, M);
-        for (int i = 0; i < n; ++i) {   // append this chunk's k|v rows to the stream's cache
-            float* cache = st[i]->att.as<float>() + ((size_t)l * st[i]->cap + st[i]->offset) * 2 * d;
-            HIPCHK(hipMemcpy2DAsync(cache, 2 * d * sizeof(float), e->qkv.as<float>() + (size_t)i * Tq * 3 * d + d,
-                                    3 * d * sizeof(float), 2 * d * sizeof(float), Tq, hipMemcpyDeviceToDevice, s));
-        }
+        launch_kv_append(e->attseq.as<AttSeq>() + (size_t)l * n, e->qkv.as<float>(), n, Tq, s);   // k|v rows -> caches
         launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, 1, s);
         mhsa_out(e, s, w, M);
-        for (int i = 0; i < n; ++i)     // history rows <- cnn cache (zeros on the first chunk)
-            HIPCHK(hipMemcpyAsync(e->lnpad.as<float>() + (size_t)i * (Tq + pad) * d,
-                                  st[i]->cnn.as<float>() + (size_t)l * pad * d, (size_t)pad * d * sizeof(float),
-                                  hipMemcpyDeviceToDevice, s));
+        float* const* cptr = e->cnnptrs.as<float*>() + (size_t)l * n;
+        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 0, s);   // history rows <- cnn cache (zeros at first)
         CHK(conv_module(e, s, w, ctx, true));
-        for (int i = 0; i < n; ++i)     // new cache = last (kernel-1) rows of [cache | ln_out] (convolution.py:108)
-            HIPCHK(hipMemcpyAsync(st[i]->cnn.as<float>() + (size_t)l * pad * d,
-                                  e->lnpad.as<float>() + ((size_t)i * (Tq + pad) + Tq) * d,
-                                  (size_t)pad * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 1, s);   // new cache = last kernel-1 rows (convolution.py:108)
         CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
         launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
     }

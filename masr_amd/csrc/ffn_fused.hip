@@ -50,7 +50,10 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
                                                         const float* __restrict__ lnb, const float* __restrict__ w1,
                                                         const float* __restrict__ b1, const float* __restrict__ w2,
                                                         const float* __restrict__ b2, int M, int dff, float eps,
-                                                        float scale) {
+                                                        float scale, float* partial, int chunks_per_block) {
+    // Small-M (streaming) mode: partial != nullptr -> blockIdx.y owns `chunks_per_block` consecutive 128-wide hidden
+    // chunks and writes its [32,256] partial output to partial[blockIdx.y][row][col]; ffn_reduce_kernel then adds the
+    // partials in a fixed order.  M = n_streams * 16 rows would otherwise occupy only M/32 CUs for ~150 us.
     extern __shared__ __align__(16) float sm[];
     float* xn = sm;                              // [32][260]   LayerNorm(x) tile (A operand of GEMM1)
     float* hs = xn + FF_BM * XN_LD;              // [2][32][132] hidden tile (A operand of GEMM2), double-buffered
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
     //   j >= 4 : W2[32*wave + r][chunk*128 + 32(j-4) .. +31]
     // NSET register sets in rotation: in iteration s set (s+1)%NSET (slab s+1) is written to LDS buffer (s+1)&1
     // and then refilled with slab s+1+NSET; the other sets hold slabs s+2 .. s+NSET in flight.
-    const int nslab = (dff / FF_CH) * 8;
+    const int chunk_lo = partial ? blockIdx.y * chunks_per_block : 0;
+    const int chunk_hi = partial ? min(chunk_lo + chunks_per_block, dff / FF_CH) : dff / FF_CH;
     const int lr8 = lane >> 3, lc4 = (lane & 7) * 4;
     f32x4 pre[NSET][4];   // register sets in rotation: slab s+1 (-> LDS), s+2 .. s+NSET in flight
     auto src_of = [&](int chunk, int j, int i) -> const float* {   // j is a compile-time constant at every call
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
     auto dst_of = [&](int s, int i) -> float* { return wmine + (s & 1) * WSLAB + (lr8 + 8 * i) * W_LD + lc4; };
     // one side operation per MFMA issue slot (16 slots per slab); unconditional memory ops: past the end the
     // last chunk is re-fetched / re-stored into a buffer nobody reads any more (chunk index clamped)
-    const int nlast = dff / FF_CH - 1;
+    const int nlast = chunk_hi - 1;
     auto side_work = [&](int s, int jj, int pset, int slot) {   // jj = s & 7 (compile-time)
         const int p = pset;                      // == (s + 1) % 3, compile-time after unrolling
         // slots 0,2,4,6: LDS-store piece of slab s+1 from set p; slots 8,10,12,14: refill set p with slab
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
             if ((slot & 1) == 0 && VAR != 3 && VAR != 4) *reinterpret_cast<f32x4*>(dst_of(s + 1, slot >> 1)) = pre[p][slot >> 1];
         } else if ((slot & 1) == 0 && VAR != 1 && VAR != 4) {
             pre[p][(slot - 8) >> 1] = *reinterpret_cast<const f32x4*>(
-                src_of(min((s >> 3) + (jj + 1 + NSET) / 8, nlast), (jj + 1 + NSET) & 7, (slot - 8) >> 1));
+                src_of(min(chunk_lo + (s >> 3) + (jj + 1 + NSET) / 8, nlast), (jj + 1 + NSET) & 7, (slot - 8) >> 1));
         }
     };
 
@@ -131,20 +135,19 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
     const float bv2 = b2[wave * 32 + frow];
 
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(0, 0, i));
+    for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, 0, i));
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
 #pragma unroll
     for (int k = 1; k <= NSET; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pre[k % NSET][i] = *reinterpret_cast<const f32x4*>(src_of(0, k, i));
+        for (int i = 0; i < 4; ++i) pre[k % NSET][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, k, i));
     __syncthreads();                                 // xn tile complete
 
     const float* xa = xn + frow * XN_LD + 4 * fh + 32 * kh;     // this wave's k-half of every 64-wide slab
     const float* wfrag = wmine + frow * W_LD + 4 * fh;
-    const int nchunk = dff / FF_CH;
     // 8 slabs per chunk, NSET = 4 sets: the set index (s + 1) % 4 == (j + 1) % 4 is a compile-time constant
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
         f32x16 acc1[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc1[0][r] = 0.f; acc1[1][r] = 0.f; }
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
         const float* ha = hcur + frow * HS_LD + 4 * fh;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int s = chunk * 8 + j;
+            const int s = (chunk - chunk_lo) * 8 + j;     // slab index relative to this block's first chunk
             const float* wp = wfrag + (j & 1) * WSLAB;       // (s & 1) == (j & 1)
             if (j < 4) {
                 f32x4 a[2], b[2];
@@ -231,15 +234,42 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
     // ---- epilogue: x <- x + scale * (acc2 + b2) ---------------------------------------------------------
     {
         const int col = wave * 32 + frow;
+        if (partial) {
+            float* pp = partial + (size_t)blockIdx.y * M * FF_D;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (row < M) {
-                float* p = x + (size_t)row * FF_D + col;
-                *p = *p + scale * ((acc2[0][r] + acc2[1][r]) + bv2);
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row < M) pp[(size_t)row * FF_D + col] = acc2[0][r] + acc2[1][r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row < M) {
+                    float* p = x + (size_t)row * FF_D + col;
+                    *p = *p + scale * ((acc2[0][r] + acc2[1][r]) + bv2);
+                }
             }
         }
     }
+}
+
+// x <- x + scale * (sum_s partial[s] + b2), partials added in ascending s (deterministic)
+__global__ __launch_bounds__(256) void ffn_reduce_kernel(float* x, const float* __restrict__ partial,
+                                                         const float* __restrict__ b2, int M, int nsplit, float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;        // float4 index
+    if (i >= (size_t)M * FF_D / 4) return;
+    f32x4 acc = reinterpret_cast<const f32x4*>(partial)[i];
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const f32x4 p = reinterpret_cast<const f32x4*>(partial + (size_t)sp * M * FF_D)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += p[k];
+    }
+    const f32x4 bb = reinterpret_cast<const f32x4*>(b2)[i % (FF_D / 4)];
+    f32x4 xv = reinterpret_cast<f32x4*>(x)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[k] = xv[k] + scale * (acc[k] + bb[k]);
+    reinterpret_cast<f32x4*>(x)[i] = xv;
 }
 
 static int g_ffn_variant = 0;
@@ -247,7 +277,8 @@ void set_ffn_variant(int v) { g_ffn_variant = v; }
 
 template <int VAR, int AFFINE>
 static void launch_ffn_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                         const float* b2, int M, int dff, float eps, float scale, hipStream_t s) {
+                         const float* b2, int M, int dff, float eps, float scale, float* partial, int nsplit,
+                         hipStream_t s) {
     const size_t lds = (size_t)(FF_BM * XN_LD + 2 * FF_BM * HS_LD + 8 * 2 * WSLAB + 8 * 8 * 64) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -255,22 +286,33 @@ static void launch_ffn_t(float* x, const float* lnw, const float* lnb, const flo
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE>), dim3((M + FF_BM - 1) / FF_BM), dim3(512), lds, s, x, lnw, lnb, w1,
-                       b1, w2, b2, M, dff, eps, scale);
+    const int nchunk = dff / FF_CH;
+    if (partial && nsplit > 1) {
+        const int cpb = (nchunk + nsplit - 1) / nsplit;
+        const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
+        hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE>), dim3((M + FF_BM - 1) / FF_BM, ny), dim3(512), lds, s, x, lnw,
+                           lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, cpb);
+        hipLaunchKernelGGL(ffn_reduce_kernel, dim3((unsigned)(((size_t)M * FF_D / 4 + 255) / 256)), dim3(256), 0, s, x, partial,
+                           b2, M, ny, scale);
+    } else {
+        hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE>), dim3((M + FF_BM - 1) / FF_BM), dim3(512), lds, s, x, lnw, lnb, w1,
+                           b1, w2, b2, M, dff, eps, scale, (float*)nullptr, 0);
+    }
 }
 
 void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, hipStream_t s) {
+                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
+                      int nsplit, hipStream_t s) {
     if (M <= 0) return;
     if (affine_prologue) {
-        launch_ffn_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s);
+        launch_ffn_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);
         return;
     }
     switch (g_ffn_variant) {
-        case 1: launch_ffn_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
-        case 2: launch_ffn_t<2, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
-        case 4: launch_ffn_t<4, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
-        default: launch_ffn_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s); break;
+        case 1: launch_ffn_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s); break;
+        case 2: launch_ffn_t<2, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s); break;
+        case 4: launch_ffn_t<4, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s); break;
+        default: launch_ffn_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s); break;
     }
 }
 
