@@ -5,4 +5,4 @@ PCM -> Kaldi fbank -> Conformer encoder -> CTC greedy, as hand-written HIP kerne
 computes imports ``masr_amd._lib`` which raises if the library is missing.
 """
 __version__ = '0.1.0'
-SUPPORT_MODEL = ['squeezeformer', 'efficient_conformer', 'conformer']
+SUPPORT_MODEL = ['squeezeformer', 'efficient_conformer', 'conformer', 'deepspeech2']

@@ -104,6 +104,13 @@ void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float*
 
 void set_ffn_variant(int v);   // diagnostic ablations of the fused FFN kernel (0 = production)
 
+// ---- DeepSpeech2 (lstm.hip) --------------------------------------------------------------------
+void launch_lstm_step(const float* gx, const float* whh, const float* h_prev, float* h_next, float* c, float* out,
+                      const int* lens, int B, int T, int H, int step, int ndir, hipStream_t s);
+void launch_layernorm_generic(const float* x, const float* w, const float* b, float* y, int M, int N, float eps,
+                              hipStream_t s);
+void launch_ds2_lens(const int* lens, int B, int Tq, int* out, hipStream_t s);
+
 // ---- attention ---------------------------------------------------------------------------
 struct AttSeq {            // one per sequence, device memory
     const float* q;        // first query row of this sequence (row stride q_stride)

@@ -71,6 +71,11 @@ struct SqLayerW {   // Squeezeformer block (post-LN, adaptive scale/bias, BatchN
     float *f2_s, *f2_b, *f2_w1, *f2_b1, *f2_w2, *f2_b2, *ln4_w, *ln4_b;
 };
 
+struct Ds2LayerW {  // DeepSpeech2 RNN layer: input projection of both directions stacked, recurrent weights, LayerNorm
+    float *wih, *bih, *whh, *ln_w, *ln_b;
+    int kin;
+};
+
 struct HostTensor {
     std::vector<float> v;
     std::vector<int64_t> shape;
@@ -81,7 +86,7 @@ struct Stream {
     int offset = 0;
     int cap = 0;
     DevBuf att;  // [L][cap][2*d]  (k | v per row)
-    DevBuf cnn;  // [L][kernel-1][d]
+    DevBuf cnn;  // [L][kernel-1][d]   (DeepSpeech2: LSTM state [L][2 (h, c)][rnn_size])
 };
 
 enum ProfKind { PROF_NONE = 0, PROF_GEMM = 1, PROF_FFN1 = 2, PROF_CONV2 = 3, PROF_ATT = 4, PROF_FBANK = 5 };
@@ -99,6 +104,8 @@ struct masr_engine {
           *ctc_w = nullptr, *ctc_b = nullptr, *pe = nullptr;
     std::vector<LayerW> layers;
     std::vector<SqLayerW> sq_layers;
+    std::vector<Ds2LayerW> ds2_layers;
+    DevBuf gx, rnn_out, hstate, cstate, ds2_lens;                               // DeepSpeech2 workspaces
     float *preln_w = nullptr, *preln_b = nullptr, *tr_dw_w = nullptr, *tr_dw_b = nullptr, *tr_pw_w = nullptr,
           *tr_pw_b = nullptr, *rec_w = nullptr, *rec_b = nullptr;
     int reduce_idx = -1, recover_idx = -1;
@@ -258,12 +265,19 @@ int masr_version(void) { return 1; }
 
 int masr_create(const masr_config* cfg, masr_engine** out) {
     if (!cfg || !out) return fail("null argument");
-    if (cfg->model_kind < 0 || cfg->model_kind > 2)
-        return fail("model_kind must be 0 (conformer), 1 (squeezeformer, non-streaming) or 2 (efficient_conformer)");
-    if (cfg->d_model != 256 || cfg->heads != 4) return fail("kernels are specialised for d_model=256, heads=4");
+    if (cfg->model_kind < 0 || cfg->model_kind > 3)
+        return fail("model_kind must be 0 (conformer), 1 (squeezeformer, non-streaming), 2 (efficient_conformer) or 3 (deepspeech2)");
     if (cfg->n_mels != 80) return fail("n_mels must be 80");
-    if (cfg->d_ff % 128) return fail("unsupported d_ff");
-    if (cfg->model_kind == 0 || cfg->model_kind == 2) {
+    if (cfg->model_kind == 3) {
+        if (cfg->d_model != 1024) return fail("deepspeech2: the LSTM step kernel is specialised for rnn_size=1024");
+        if (cfg->num_blocks <= 0) return fail("deepspeech2: num_rnn_layers must be positive");
+    } else if (cfg->d_model != 256 || cfg->heads != 4) {
+        return fail("kernels are specialised for d_model=256, heads=4");
+    } else if (cfg->d_ff % 128) {
+        return fail("unsupported d_ff");
+    }
+    if (cfg->model_kind == 3) {
+    } else if (cfg->model_kind == 0 || cfg->model_kind == 2) {
         if (cfg->cnn_kernel != 15) return fail("conformer: cnn_module_kernel must be 15");
         if (!cfg->causal) return fail("only the streaming-trained (causal conv) conformer is implemented");
     } else {
@@ -298,7 +312,8 @@ void masr_destroy(masr_engine* e) {
     for (void* p : e->owned) (void)hipFree(p);
     DevBuf* bufs[] = {&e->x1, &e->x2, &e->x, &e->ln, &e->hid, &e->qkv, &e->att, &e->lnpad, &e->glu, &e->dwo,
                       &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens, &e->xsave,
-                      &e->xred, &e->qplanes, &e->attp, &e->cnnptrs, &e->ffpart};
+                      &e->xred, &e->qplanes, &e->attp, &e->cnnptrs, &e->ffpart, &e->gx, &e->rnn_out, &e->hstate, &e->cstate,
+                      &e->ds2_lens};
     for (DevBuf* b : bufs) b->release();
     for (auto& s : e->streams) {
         s.att.release();
@@ -314,7 +329,8 @@ void masr_destroy(masr_engine* e) {
 int masr_load_tensor(masr_engine* e, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
     if (!e || !name || !host) return fail("null argument");
     std::string n(name);
-    if (n.rfind("encoder.", 0) != 0 && n.rfind("ctc.", 0) != 0 && n != "__pos_table__") return 0;
+    if (n.rfind("encoder.", 0) != 0 && n.rfind("ctc.", 0) != 0 && n.rfind("decoder.ctc_lo.", 0) != 0 && n != "__pos_table__")
+        return 0;
     HostTensor t;
     int64_t cnt = 1;
     for (int i = 0; i < ndim; ++i) {
@@ -328,6 +344,10 @@ int masr_load_tensor(masr_engine* e, const char* name, const float* host, const 
 }
 
 static int finalize_squeezeformer(masr_engine* e, hipStream_t s);
+static int finalize_ds2(masr_engine* e);
+static int enc_dim(const masr_engine* e) {      // width of the encoder output rows
+    return e->cfg.model_kind == 3 ? e->cfg.d_model * (e->cfg.causal ? 1 : 2) : e->cfg.d_model;
+}
 static int layer_kernel(const masr_engine* e, int i) {          // efficient conformer: kernel // stride after the stride layer
     return (e->cfg.model_kind == 2 && e->stride_idx >= 0 && i > e->stride_idx) ? e->cfg.cnn_kernel / 2 : e->cfg.cnn_kernel;
 }
@@ -336,6 +356,7 @@ static bool layer_grouped(const masr_engine* e, int i) { return e->cfg.model_kin
 int masr_finalize(masr_engine* e, void* stream) {
     if (!e) return fail("null engine");
     if (e->cfg.model_kind == 1) return finalize_squeezeformer(e, (hipStream_t)stream);
+    if (e->cfg.model_kind == 3) return finalize_ds2(e);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(e->cfg.device_id));
     const int d = e->cfg.d_model, dff = e->cfg.d_ff, L = e->cfg.num_blocks, V = e->cfg.vocab_size, F = e->cfg.n_mels;
@@ -867,6 +888,142 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// DeepSpeech2 (model_kind 3): weights + forward (full utterances and stateful chunks)
+// reference: masr/model_utils/deepspeech2/{model.py:64-108, encoder.py:36-129, conv.py:5-22}
+// ------------------------------------------------------------------------------------------------
+static int finalize_ds2(masr_engine* e) {
+    HIPCHK(hipSetDevice(e->cfg.device_id));
+    const int H = e->cfg.d_model, L = e->cfg.num_blocks, ndir = e->cfg.causal ? 1 : 2, V = e->cfg.vocab_size;
+    const int F = e->cfg.n_mels, F1 = (F - 1) / 2, F2 = (F1 - 1) / 2, C = 32, D = H * ndir;
+    const HostTensor* t;
+    CHK(up(e, "encoder.global_cmvn.mean", {F}, &e->cmvn_mean));
+    CHK(up(e, "encoder.global_cmvn.istd", {F}, &e->cmvn_istd));
+    CHK(get(e, "encoder.conv.conv.0.weight", {C, 1, 3, 3}, &t));
+    {
+        std::vector<float> w(9 * C);
+        for (int c = 0; c < C; ++c)
+            for (int k = 0; k < 9; ++k) w[k * C + c] = t->v[c * 9 + k];
+        CHK(upload(e, w, &e->conv1_w));
+    }
+    CHK(up(e, "encoder.conv.conv.0.bias", {C}, &e->conv1_b));
+    CHK(get(e, "encoder.conv.conv.2.weight", {C, C, 3, 3}, &t));
+    {
+        std::vector<float> w((size_t)C * 9 * C);
+        for (int co = 0; co < C; ++co)
+            for (int ci = 0; ci < C; ++ci)
+                for (int k = 0; k < 9; ++k) w[(size_t)co * 9 * C + k * C + ci] = t->v[((size_t)co * C + ci) * 9 + k];
+        CHK(upload(e, w, &e->conv2_w));
+    }
+    CHK(up(e, "encoder.conv.conv.2.bias", {C}, &e->conv2_b));
+    e->ds2_layers.assign(L, Ds2LayerW{});
+    for (int i = 0; i < L; ++i) {
+        Ds2LayerW& w = e->ds2_layers[i];
+        const std::string p = "encoder.rnns." + std::to_string(i) + ".";
+        const int kin = i == 0 ? C * F2 : D;
+        w.kin = kin;
+        std::vector<float> wih((size_t)ndir * 4 * H * kin), bih((size_t)ndir * 4 * H), whh((size_t)ndir * 4 * H * H);
+        for (int dir = 0; dir < ndir; ++dir) {
+            const std::string suf = dir ? "_reverse" : "";
+            const HostTensor *a, *b, *c, *d;
+            CHK(get(e, p + "rnn.weight_ih_l0" + suf, {4 * H, kin}, &a));
+            CHK(get(e, p + "rnn.weight_hh_l0" + suf, {4 * H, H}, &b));
+            CHK(get(e, p + "rnn.bias_ih_l0" + suf, {4 * H}, &c));
+            CHK(get(e, p + "rnn.bias_hh_l0" + suf, {4 * H}, &d));
+            float* dst = wih.data() + (size_t)dir * 4 * H * kin;
+            if (i == 0) {   // conv output is channels-last here: column f*32 + c  <-  reference column c*F2 + f (conv.py:20)
+                for (int r = 0; r < 4 * H; ++r)
+                    for (int c2 = 0; c2 < C; ++c2)
+                        for (int f = 0; f < F2; ++f) dst[(size_t)r * kin + f * C + c2] = a->v[(size_t)r * kin + c2 * F2 + f];
+            } else {
+                std::copy(a->v.begin(), a->v.end(), dst);
+            }
+            std::copy(b->v.begin(), b->v.end(), whh.begin() + (size_t)dir * 4 * H * H);
+            for (int r = 0; r < 4 * H; ++r) bih[(size_t)dir * 4 * H + r] = c->v[r] + d->v[r];
+        }
+        CHK(upload(e, wih, &w.wih));
+        CHK(upload(e, bih, &w.bih));
+        CHK(upload(e, whh, &w.whh));
+        CHK(up(e, p + "layer_norm.weight", {D}, &w.ln_w));
+        CHK(up(e, p + "layer_norm.bias", {D}, &w.ln_b));
+    }
+    CHK(up(e, "decoder.ctc_lo.weight", {V, D}, &e->ctc_w));
+    CHK(up(e, "decoder.ctc_lo.bias", {V}, &e->ctc_b));
+    e->host.clear();
+    e->finalized = true;
+    return 0;
+}
+
+// feats [nseq, T, 80] -> enc_out [nseq*Tq, D].  lens: device feature lengths (full utterances) or nullptr (chunks:
+// every row is valid, inference_predictor.py:70).  st: per-sequence streams carrying (h, c) of every layer, or nullptr.
+static int ds2_forward(masr_engine* e, hipStream_t s, const float* feats, const int* lens, int nseq, int T, float* enc_out,
+                       Stream** st, int* Tq_out) {
+    const int H = e->cfg.d_model, L = e->cfg.num_blocks, ndir = e->cfg.causal ? 1 : 2, D = H * ndir, C = 32;
+    const int F = e->cfg.n_mels, F1 = (F - 1) / 2, F2 = (F1 - 1) / 2;
+    const int T1 = (T - 1) / 2, Tq = (T1 - 1) / 2;
+    if (T < 7 || Tq <= 0) return fail("input too short for Conv2dSubsampling4Pure (need >= 7 frames)");
+    if (st && ndir != 1) return fail("deepspeech2: stateful chunks need the uni-directional (streaming) model");
+    const int M = nseq * Tq;
+    CHK(e->x1.ensure((size_t)nseq * T1 * F1 * C * sizeof(float)));
+    CHK(e->x2.ensure((size_t)M * F2 * C * sizeof(float)));
+    CHK(e->gx.ensure((size_t)M * ndir * 4 * H * sizeof(float)));
+    CHK(e->rnn_out.ensure((size_t)M * D * sizeof(float)));
+    CHK(e->ln.ensure((size_t)M * D * sizeof(float)));
+    CHK(e->hstate.ensure((size_t)2 * ndir * nseq * H * sizeof(float)));
+    CHK(e->cstate.ensure((size_t)ndir * nseq * H * sizeof(float)));
+    const int* xl = nullptr;
+    if (lens) {
+        CHK(e->ds2_lens.ensure(sizeof(int) * nseq));
+        launch_ds2_lens(lens, nseq, Tq, e->ds2_lens.as<int>(), s);
+        xl = e->ds2_lens.as<int>();
+    }
+    launch_conv1(feats, e->cmvn_mean, e->cmvn_istd, e->conv1_w, e->conv1_b, e->x1.as<float>(), nseq, T, F, C, s);
+    {
+        GemmArgs a{};
+        a.A = e->x1.as<float>(); a.W = e->conv2_w; a.bias = e->conv2_b; a.C = e->x2.as<float>();
+        a.M = M * F2; a.N = C; a.K = 9 * C; a.ldc = C; a.act = ACT_RELU; a.alpha = 1.f;
+        a.T1 = T1; a.F1 = F1; a.T2 = Tq; a.F2 = F2; a.Cc = C;
+        ProfScope ps(e, s, PROF_CONV2, 2.0 * a.M * (double)a.N * a.K);
+        launch_gemm(a, A_CONV2, EPI_STD, s);
+    }
+    const float* in = e->x2.as<float>();
+    const size_t hsz = (size_t)ndir * nseq * H;
+    float* hbuf = e->hstate.as<float>();
+    float* cbuf = e->cstate.as<float>();
+    for (int l = 0; l < L; ++l) {
+        const Ds2LayerW& w = e->ds2_layers[l];
+        gemm(e, s, in, w.kin, w.wih, w.bih, e->gx.as<float>(), ndir * 4 * H, M, ndir * 4 * H, w.kin, ACT_NONE, 1.f, nullptr, 0);
+        if (st) {
+            for (int i = 0; i < nseq; ++i) {
+                const float* hc = st[i]->cnn.as<float>() + (size_t)l * 2 * H;
+                HIPCHK(hipMemcpyAsync(hbuf + (size_t)i * H, hc, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(cbuf + (size_t)i * H, hc + H, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
+            }
+        } else {
+            HIPCHK(hipMemsetAsync(hbuf, 0, sizeof(float) * hsz, s));
+            HIPCHK(hipMemsetAsync(cbuf, 0, sizeof(float) * hsz, s));
+        }
+        for (int step = 0; step < Tq; ++step)
+            launch_lstm_step(e->gx.as<float>(), w.whh, hbuf + (size_t)(step & 1) * hsz, hbuf + (size_t)((step + 1) & 1) * hsz,
+                             cbuf, e->rnn_out.as<float>(), xl, nseq, Tq, H, step, ndir, s);
+        if (st) {
+            const float* hfin = hbuf + (size_t)(Tq & 1) * hsz;
+            for (int i = 0; i < nseq; ++i) {
+                float* hc = st[i]->cnn.as<float>() + (size_t)l * 2 * H;
+                HIPCHK(hipMemcpyAsync(hc, hfin + (size_t)i * H, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(hc + H, cbuf + (size_t)i * H, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
+            }
+        }
+        float* out = l == L - 1 ? enc_out : e->ln.as<float>();
+        launch_layernorm_generic(e->rnn_out.as<float>(), w.ln_w, w.ln_b, out, M, D, 1e-5f, s);
+        in = out;
+    }
+    HIPCHK(hipGetLastError());
+    if (Tq_out) *Tq_out = Tq;
+    return 0;
+}
+
 extern "C" {
 
 int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat_lens_dev, int32_t B, int32_t T,
@@ -874,6 +1031,7 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     if (!e || !e->finalized) return fail("engine not finalized");
     if (B <= 0) return fail("empty batch");
     hipStream_t s = (hipStream_t)stream;
+    if (e->cfg.model_kind == 3) return ds2_forward(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev, nullptr, nullptr);
     if (e->cfg.model_kind == 1) {
         if (decoding_chunk_size > 0) return fail("squeezeformer (non-streaming): chunk masks are not available");
         return encode_full_squeezeformer(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev);
@@ -912,7 +1070,7 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
 
 static int ctc_head(masr_engine* e, const float* enc_dev, int M, float* probs_dev, int write_probs, int32_t* argmax_dev,
                     float* maxprob_dev, hipStream_t s) {
-    const int d = e->cfg.d_model, V = e->cfg.vocab_size;
+    const int d = enc_dim(e), V = e->cfg.vocab_size;
     float* logits = probs_dev;
     if (!logits) {
         CHK(e->logits.ensure((size_t)M * V * sizeof(float)));
@@ -935,6 +1093,8 @@ int masr_ctc_probs(masr_engine* e, const float* enc_dev, int32_t M, float* probs
 int masr_ctc_greedy_frames(masr_engine* e, const float* enc_dev, int32_t M, int32_t* argmax_dev, float* maxprob_dev,
                            void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
+    if (e->cfg.model_kind == 3)      // K = 1024 / 2048 rows: generic GEMM + softmax statistics (logits stay in a workspace)
+        return ctc_head(e, enc_dev, M, nullptr, 0, argmax_dev, maxprob_dev, (hipStream_t)stream);
     // fused: logits GEMM + online softmax statistics + argmax, nothing but (idx, prob) leaves the chip
     rowgemm(e, (hipStream_t)stream, RG_PRO_PLAIN, RG_EPI_CTC, enc_dev, e->cfg.d_model, nullptr, nullptr, e->ctc_w,
             e->ctc_b, nullptr, 0, M, e->cfg.vocab_size, nullptr, 0, 1.f, nullptr, 0, 0, 0, argmax_dev, maxprob_dev);
@@ -998,7 +1158,7 @@ int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t*
     if (!e || !e->finalized) return fail("engine not finalized");
     if (n_max < 400) return fail("n_max < 400 samples: no frame");
     hipStream_t s = (hipStream_t)stream;
-    const int d = e->cfg.d_model, F = e->cfg.n_mels;
+    const int d = enc_dim(e), F = e->cfg.n_mels;
     const int T = 1 + (n_max - 400) / 160, T1 = (T - 1) / 2, Tsub = (T1 - 1) / 2;
     const bool halved = e->cfg.model_kind == 2 && e->stride_idx >= 0;      // efficient conformer: one more stride-2 stage
     const int Tq = halved ? (Tsub + 1) / 2 : Tsub;
@@ -1024,7 +1184,11 @@ int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t*
 
 int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id) {
     if (!e || !e->finalized) return fail("engine not finalized");
-    if (e->cfg.model_kind != 0) return fail("streaming is implemented for the conformer only");
+    if (e->cfg.model_kind == 3) {
+        if (!e->cfg.causal) return fail("deepspeech2: streaming needs the uni-directional model");
+    } else if (e->cfg.model_kind != 0) {
+        return fail("streaming is implemented for the conformer and deepspeech2");
+    }
     if (max_frames_out <= 0 || max_frames_out > e->cfg.max_pos) max_frames_out = e->cfg.max_pos;
     int id = -1;
     for (size_t i = 0; i < e->streams.size(); ++i)
@@ -1036,6 +1200,15 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     Stream& st = e->streams[id];
     const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
     st.cap = max_frames_out;
+    if (e->cfg.model_kind == 3) {      // LSTM state (h, c) per layer; no attention cache, no frame limit
+        st.cap = 1 << 30;
+        CHK(st.cnn.ensure((size_t)L * 2 * d * sizeof(float)));
+        HIPCHK(hipMemset(st.cnn.p, 0, (size_t)L * 2 * d * sizeof(float)));
+        st.offset = 0;
+        st.open = true;
+        *stream_id = id;
+        return 0;
+    }
     CHK(st.att.ensure((size_t)L * st.cap * 2 * d * sizeof(float)));
     CHK(st.cnn.ensure((size_t)L * pad * d * sizeof(float)));
     HIPCHK(hipMemset(st.cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
@@ -1057,7 +1230,7 @@ int masr_stream_reset(masr_engine* e, int32_t stream_id) {
     CHK(stream_of(e, stream_id, &st));
     const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(st->cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
+    HIPCHK(hipMemset(st->cnn.p, 0, (e->cfg.model_kind == 3 ? (size_t)L * 2 * d : (size_t)L * pad * d) * sizeof(float)));
     st->offset = 0;
     return 0;
 }
@@ -1088,6 +1261,19 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
     std::vector<Stream*> st(n);
     for (int i = 0; i < n; ++i) CHK(stream_of(e, stream_ids[i], &st[i]));
     int Tq = 0;
+    if (e->cfg.model_kind == 3) {       // deepspeech2/model.py:79-108: chunk conv + LSTM stack with carried (h, c)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < i; ++j)
+                if (st[i] == st[j]) return fail("duplicate stream id in one call");
+        const int Tq3 = ((Tc - 1) / 2 - 1) / 2;
+        if (Tq3 <= 0) return fail("chunk too short");
+        CHK(e->enc.ensure((size_t)n * Tq3 * enc_dim(e) * sizeof(float)));
+        CHK(ds2_forward(e, s, feats_dev, nullptr, n, Tc, e->enc.as<float>(), st.data(), &Tq));
+        if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+        CHK(ctc_head(e, e->enc.as<float>(), n * Tq, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
+        for (int i = 0; i < n; ++i) st[i]->offset += Tq;
+        return 0;
+    }
     CHK(embed(e, s, feats_dev, n, Tc, &Tq));
     for (int i = 0; i < n; ++i)
         if (st[i]->offset + Tq > st[i]->cap) return fail("stream exceeds its max_frames_out / max_pos");
@@ -1147,6 +1333,14 @@ int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, 
     CHK(stream_of(e, stream_id, &st));
     hipStream_t s = (hipStream_t)stream;
     const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1, H = e->cfg.heads;
+    if (e->cfg.model_kind == 3) {       // att_dev <- h [L][rnn_size], cnn_dev <- c [L][rnn_size]
+        for (int l = 0; l < L; ++l) {
+            const float* hc = st->cnn.as<float>() + (size_t)l * 2 * d;
+            if (att_dev) HIPCHK(hipMemcpyAsync(att_dev + (size_t)l * d, hc, sizeof(float) * d, hipMemcpyDeviceToDevice, s));
+            if (cnn_dev) HIPCHK(hipMemcpyAsync(cnn_dev + (size_t)l * d, hc + d, sizeof(float) * d, hipMemcpyDeviceToDevice, s));
+        }
+        return 0;
+    }
     if (att_dev && st->offset > 0)
         launch_export_att(st->att.as<float>(), att_dev, L, H, st->cap, st->offset, d / H, s);
     if (cnn_dev) launch_export_cnn(st->cnn.as<float>(), cnn_dev, L, pad, d, s);

@@ -1,0 +1,141 @@
+// DeepSpeech2 recurrent stack pieces (reference masr/model_utils/deepspeech2/encoder.py:36-45,96-129):
+// nn.LSTM(batch_first, 1 layer, uni- or bi-directional) over a packed sequence + LayerNorm.
+//
+// The input projection W_ih . x_t + b_ih + b_hh of ALL timesteps is one MFMA GEMM (gemm_f32.hip); what is
+// left is the recurrence  gates_t = Gx_t + W_hh . h_{t-1}  (PyTorch gate order i, f, g, o),
+// c_t = sigma(f) c_{t-1} + sigma(i) tanh(g),  h_t = sigma(o) tanh(c_t).  One launch per timestep, both
+// directions in it (blockIdx.y): a wave owns ONE hidden unit (its 4 gate rows of W_hh stay in registers,
+// 16 values per lane) and walks over the batch; 1024 units / 4 waves = 256 workgroups = one per CU.
+// W_hh (16 MB per direction) is re-streamed from L2 / Infinity Cache every step -- the recurrence is
+// HBM/L2-bound by construction at batch 1; a persistent cross-CU kernel is the next step.
+// pack_padded_sequence semantics: a sequence advances only while t < len (the reverse direction therefore
+// starts at its own last frame), padded outputs are zero.
+#include "common.h"
+
+namespace masr {
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int H>
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                        const float* __restrict__ h_prev, float* __restrict__ h_next,
+                                                        float* __restrict__ c, float* __restrict__ out,
+                                                        const int* __restrict__ lens, int B, int T, int step, int ndir) {
+    constexpr int PL = H / 64;                      // W_hh values per lane and gate
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dir = blockIdx.y;
+    const int j = blockIdx.x * 4 + wave;
+    const int t = dir ? T - 1 - step : step;
+    float w[4][PL];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float* wr = whh + ((size_t)dir * 4 * H + (size_t)g * H + j) * H + lane * PL;
+#pragma unroll
+        for (int k = 0; k < PL; k += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wr + k);
+            w[g][k] = v[0]; w[g][k + 1] = v[1]; w[g][k + 2] = v[2]; w[g][k + 3] = v[3];
+        }
+    }
+    for (int b = 0; b < B; ++b) {
+        const float* hp = h_prev + ((size_t)dir * B + b) * H + lane * PL;
+        float hv[PL];
+#pragma unroll
+        for (int k = 0; k < PL; k += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(hp + k);
+            hv[k] = v[0]; hv[k + 1] = v[1]; hv[k + 2] = v[2]; hv[k + 3] = v[3];
+        }
+        float dot[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < PL; ++k) a = fmaf(w[g][k], hv[k], a);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            dot[g] = a;
+        }
+        if (lane == 0) {
+            const size_t sidx = ((size_t)dir * B + b) * H + j;
+            const bool active = !lens || t < lens[b];
+            const float* gr = gx + ((size_t)b * T + t) * (ndir * 4 * H) + (size_t)dir * 4 * H + j;
+            const float gi = gr[0] + dot[0], gf = gr[H] + dot[1], gg = gr[2 * H] + dot[2], go = gr[3 * H] + dot[3];
+            const float c_old = c[sidx];
+            const float c_new = sigm(gf) * c_old + sigm(gi) * tanhf(gg);
+            const float h_new = sigm(go) * tanhf(c_new);
+            float* o = out + ((size_t)b * T + t) * (ndir * H) + dir * H + j;
+            if (active) {
+                c[sidx] = c_new;
+                h_next[sidx] = h_new;
+                *o = h_new;
+            } else {
+                h_next[sidx] = h_prev[sidx];
+                *o = 0.f;
+            }
+        }
+    }
+}
+
+void launch_lstm_step(const float* gx, const float* whh, const float* h_prev, float* h_next, float* c, float* out,
+                      const int* lens, int B, int T, int H, int step, int ndir, hipStream_t s) {
+    if (H != 1024) return;
+    hipLaunchKernelGGL(lstm_step_kernel<1024>, dim3(H / 4, ndir), dim3(256), 0, s, gx, whh, h_prev, h_next, c, out, lens, B,
+                       T, step, ndir);
+}
+
+// LayerNorm over rows of arbitrary width N <= 8192 (deepspeech2/encoder.py:33,44): one workgroup per row
+__global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float* y, int N, float eps) {
+    __shared__ float red[4];
+    const float* xr = x + (size_t)blockIdx.x * N;
+    float v[32];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int k = threadIdx.x + i * 256;
+        v[i] = k < N ? xr[k] : 0.f;
+        s += v[i];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)N;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int k = threadIdx.x + i * 256;
+        const float d = k < N ? v[i] - mean : 0.f;
+        v[i] = d;
+        q += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);
+    float* yr = y + (size_t)blockIdx.x * N;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int k = threadIdx.x + i * 256;
+        if (k < N) yr[k] = v[i] * rstd * w[k] + b[k];
+    }
+}
+
+void launch_layernorm_generic(const float* x, const float* w, const float* b, float* y, int M, int N, float eps,
+                              hipStream_t s) {
+    if (M <= 0 || N > 8192) return;
+    hipLaunchKernelGGL(layernorm_generic_kernel, dim3(M), dim3(256), 0, s, x, w, b, y, N, eps);
+}
+
+// encoder frame counts of Conv2dSubsampling4Pure (conv.py:21): ((len - 1) / 2 - 1) / 2
+__global__ void ds2_lens_kernel(const int* __restrict__ lens, int B, int Tq, int* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = max(0, min(Tq, ((lens[b] - 1) / 2 - 1) / 2));
+}
+void launch_ds2_lens(const int* lens, int B, int Tq, int* out, hipStream_t s) {
+    hipLaunchKernelGGL(ds2_lens_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lens, B, Tq, out);
+}
+
+}  // namespace masr

@@ -44,7 +44,8 @@ class HipEngine:
         self.lib = _lib.lib()
         enc = dict(encoder_conf or {})
         if vocab_size is None:
-            vocab_size = int(state_dict['ctc.ctc_lo.weight'].shape[0]) if state_dict is not None else 1
+            ctc_key = 'decoder.ctc_lo.weight' if use_model == 'deepspeech2' else 'ctc.ctc_lo.weight'
+            vocab_size = int(state_dict[ctc_key].shape[0]) if state_dict is not None else 1
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
         if use_model == 'conformer':
@@ -84,11 +85,21 @@ class HipEngine:
             cfg.reserved[0] = int(stride_idx[0])
             cfg.reserved[1] = len(groups)
             cfg.reserved[2] = int(eff.get('group_size', 3))
+        elif use_model == 'deepspeech2':
+            # configs/deepspeech2.yml encoder_conf: rnn_size, num_rnn_layers; streaming <=> uni-directional LSTMs
+            # (deepspeech2/encoder.py:14-19: rnn_direction = 'forward' if streaming else 'bidirect')
+            cfg = MasrConfig(model_kind=3, d_model=int(enc.get('rnn_size', 1024)), heads=0, d_ff=0,
+                             num_blocks=int(enc.get('num_rnn_layers', 5)), cnn_kernel=0, n_mels=n_mels,
+                             vocab_size=int(vocab_size), causal=1 if streaming else 0, max_pos=max_pos,
+                             device_id=device)
         else:
-            raise _lib.MasrError(f'use_model={use_model}: conformer, squeezeformer, efficient_conformer are implemented')
+            raise _lib.MasrError(f'use_model={use_model}: conformer, squeezeformer, efficient_conformer, deepspeech2 '
+                                 f'are implemented')
         self.use_model = use_model
         self.cfg = cfg
         self.d_model, self.vocab_size, self.n_mels = cfg.d_model, cfg.vocab_size, n_mels
+        # width of the encoder output rows (DeepSpeech2: rnn_size x directions)
+        self.enc_dim = cfg.d_model * (1 if streaming else 2) if use_model == 'deepspeech2' else cfg.d_model
         self.num_blocks, self.heads, self.cnn_kernel = cfg.num_blocks, cfg.heads, cfg.cnn_kernel
         h = C.c_void_p()
         check(self.lib.masr_create(C.byref(cfg), C.byref(h)))
@@ -97,10 +108,11 @@ class HipEngine:
         if state_dict is None:      # weight-less engine: fbank / argmax / collapse kernels only
             return
         for name, t in state_dict.items():
-            if not (name.startswith('encoder.') or name.startswith('ctc.')):
+            if not (name.startswith('encoder.') or name.startswith('ctc.') or name.startswith('decoder.ctc_lo.')):
                 continue
             self._load(name, t)
-        self._load('__pos_table__', positional_table(max_pos, cfg.d_model))
+        if use_model != 'deepspeech2':
+            self._load('__pos_table__', positional_table(max_pos, cfg.d_model))
         check(self.lib.masr_finalize(self.h, _stream()))
 
     def _load(self, name, t):
@@ -147,7 +159,7 @@ class HipEngine:
         """feats f32 [B,T,80] (device, zero padded), lens int32 [B] (device) -> enc [B,T',d]."""
         B, T, _ = feats.shape
         Tp = self.out_frames(T)
-        enc = torch.empty(B, Tp, self.d_model, dtype=torch.float32, device=self.device)
+        enc = torch.empty(B, Tp, self.enc_dim, dtype=torch.float32, device=self.device)
         check(self.lib.masr_encode_full(self.h, _ptr(feats), _ptr(lens), B, T, int(decoding_chunk_size), _ptr(enc),
                                         _stream()))
         return enc
@@ -158,7 +170,7 @@ class HipEngine:
         return (Tp + 1) // 2 if getattr(self, 'use_model', 'conformer') == 'efficient_conformer' else Tp
 
     def ctc_probs(self, enc, want_argmax=False):
-        M = enc.numel() // self.d_model
+        M = enc.numel() // self.enc_dim
         probs = torch.empty(*enc.shape[:-1], self.vocab_size, dtype=torch.float32, device=self.device)
         idx = torch.empty(M, dtype=torch.int32, device=self.device) if want_argmax else None
         mp = torch.empty(M, dtype=torch.float32, device=self.device) if want_argmax else None
@@ -166,7 +178,7 @@ class HipEngine:
         return (probs, idx, mp) if want_argmax else probs
 
     def ctc_greedy_frames(self, enc):
-        M = enc.numel() // self.d_model
+        M = enc.numel() // self.enc_dim
         idx = torch.empty(enc.shape[:-1], dtype=torch.int32, device=self.device)
         mp = torch.empty(enc.shape[:-1], dtype=torch.float32, device=self.device)
         check(self.lib.masr_ctc_greedy_frames(self.h, _ptr(enc), M, _ptr(idx), _ptr(mp), _stream()))
@@ -233,6 +245,11 @@ class HipEngine:
         return probs, idx, mp
 
     def stream_export_cache(self, sid):
+        if self.use_model == 'deepspeech2':       # (h, c), each [num_rnn_layers, 1, 1, rnn_size] like the reference state
+            h = torch.zeros(self.num_blocks, 1, 1, self.d_model, dtype=torch.float32, device=self.device)
+            c = torch.zeros_like(h)
+            check(self.lib.masr_stream_export_cache(self.h, sid, _ptr(h), _ptr(c), _stream()))
+            return h, c
         t = self.stream_offset(sid)
         dk = self.d_model // self.heads
         att = torch.zeros(self.num_blocks, self.heads, t, 2 * dk, dtype=torch.float32, device=self.device)

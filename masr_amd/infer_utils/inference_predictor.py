@@ -39,8 +39,9 @@ class InferencePredictor:
         if not use_gpu:
             raise Exception('masr_amd is the MI355X path: use_gpu=False is not available (no CPU fallback)')
         assert (torch.cuda.is_available()), 'GPU不可用'
-        if use_model not in ('conformer', 'squeezeformer', 'efficient_conformer'):
-            raise Exception(f'masr_amd implements conformer / squeezeformer / efficient_conformer; got use_model={use_model}')
+        if use_model not in ('conformer', 'squeezeformer', 'efficient_conformer', 'deepspeech2'):
+            raise Exception(f'masr_amd implements conformer / squeezeformer / efficient_conformer / deepspeech2; '
+                            f'got use_model={use_model}')
         if use_model == 'squeezeformer' and streaming:
             raise Exception('masr_amd implements the non-streaming squeezeformer (streaming: False) only')
         self.device = torch.device('cuda')
@@ -55,12 +56,21 @@ class InferencePredictor:
         audio_data = torch.as_tensor(np.asarray(speech), dtype=torch.float32).to(self.device).contiguous()
         audio_len = torch.as_tensor(np.asarray(speech_lengths)).to(torch.int32).to(self.device).contiguous()
         enc = self.engine.encode_full(audio_data, audio_len, -1)
-        return self.engine.ctc_probs(enc).cpu().numpy()
+        probs = self.engine.ctc_probs(enc)
+        if self.use_model == 'deepspeech2':      # pad_packed_sequence trims to the longest sequence (encoder.py:42)
+            longest = int(((np.asarray(speech_lengths).astype(np.int64) - 1) // 2 - 1).max() // 2)
+            probs = probs[:, :longest]
+        return probs.cpu().numpy()
 
     def predict_chunk_deepspeech(self, x_chunk):
         if not (self.use_model == 'deepspeech2' and self.streaming):
             raise Exception(f'当前模型不支持该方法，当前模型为：{self.use_model}，参数streaming为：{self.streaming}')
-        raise NotImplementedError
+        # inference_predictor.py:66-78: the (h, c) state of every LSTM layer lives in the engine's stream
+        if self._sid is None:
+            self._sid = self.engine.stream_open(0)
+        x = torch.as_tensor(np.asarray(x_chunk), dtype=torch.float32).to(self.device).contiguous()
+        probs, _, _ = self.engine.encode_chunk([self._sid], x)
+        return probs.cpu().numpy(), np.array([probs.shape[1]], dtype=np.int64)
 
     # streaming (inference_predictor.py:80-94): att_cache / cnn_cache / offset live in the engine
     def predict_chunk_conformer(self, x_chunk, required_cache_size):

@@ -170,11 +170,16 @@ class MASRPredictor:
         for cur in range(0, num_frames - left_frames + 1, stride):
             end = min(cur + decoding_window, num_frames)
             x_chunk = self.cached_feat[:, cur:end, :]
-            num_decoding_left_chunks = -1
-            required_cache_size = decoding_chunk_size * num_decoding_left_chunks
-            output_chunk_probs = self.predictor.predict_chunk_conformer(x_chunk=x_chunk,
-                                                                        required_cache_size=required_cache_size)
-            output_lens = np.array([output_chunk_probs.shape[1]])
+            if self.configs.use_model == 'deepspeech2':
+                output_chunk_probs, output_lens = self.predictor.predict_chunk_deepspeech(x_chunk=x_chunk)
+            elif 'former' in self.configs.use_model:
+                num_decoding_left_chunks = -1
+                required_cache_size = decoding_chunk_size * num_decoding_left_chunks
+                output_chunk_probs = self.predictor.predict_chunk_conformer(x_chunk=x_chunk,
+                                                                            required_cache_size=required_cache_size)
+                output_lens = np.array([output_chunk_probs.shape[1]])
+            else:
+                raise Exception(f'当前模型不支持该方法，当前模型为：{self.configs.use_model}')
             if self.configs.decoder == 'ctc_beam_search':
                 score, text = self.beam_search_decoder.decode_chunk(probs=output_chunk_probs, logits_lens=output_lens)
             else:

@@ -172,3 +172,33 @@ def efficient_conformer_state_dict(seed=0, vocab_size=4233, d=256, heads=4, d_ff
         if i in stride_layer_idx:
             k = k // stride[list(stride_layer_idx).index(i)]
     return sd
+
+
+def deepspeech2_state_dict(seed=0, vocab_size=4233, rnn_size=1024, num_rnn_layers=5, bidirectional=True, n_mels=80,
+                           ctc_gain=2.0):
+    """Keys/shapes == reference DeepSpeech2Model state_dict (masr/model_utils/deepspeech2/): conv front-end
+    1->32->32, ``num_rnn_layers`` x (LSTM(rnn_size) [+ reverse] + LayerNorm), CTC head under ``decoder.ctc_lo``."""
+    sd = {}
+    f2 = ((n_mels - 1) // 2 - 1) // 2
+    sd['encoder.global_cmvn.mean'] = 13.5 + _uniform(seed, 'cmvn.mean', (n_mels,), 1.0)
+    sd['encoder.global_cmvn.istd'] = 0.3 + _uniform(seed, 'cmvn.istd', (n_mels,), 0.05)
+    sd['encoder.conv.conv.0.weight'] = _uniform(seed, 'ds2.c0.w', (32, 1, 3, 3), math.sqrt(3.0 / 9))
+    sd['encoder.conv.conv.0.bias'] = _uniform(seed, 'ds2.c0.b', (32,), 0.1)
+    sd['encoder.conv.conv.2.weight'] = _uniform(seed, 'ds2.c2.w', (32, 32, 3, 3), math.sqrt(3.0 / (9 * 32)))
+    sd['encoder.conv.conv.2.bias'] = _uniform(seed, 'ds2.c2.b', (32,), 0.1)
+    ndir = 2 if bidirectional else 1
+    out = rnn_size * ndir
+    for i in range(num_rnn_layers):
+        isz = 32 * f2 if i == 0 else out
+        for suf in ([''] + (['_reverse'] if bidirectional else [])):
+            p = f'encoder.rnns.{i}.rnn.'
+            sd[p + 'weight_ih_l0' + suf] = _uniform(seed, p + 'wih' + suf, (4 * rnn_size, isz), math.sqrt(3.0 / isz))
+            sd[p + 'weight_hh_l0' + suf] = _uniform(seed, p + 'whh' + suf, (4 * rnn_size, rnn_size), math.sqrt(3.0 / rnn_size))
+            sd[p + 'bias_ih_l0' + suf] = _uniform(seed, p + 'bih' + suf, (4 * rnn_size,), 0.1)
+            sd[p + 'bias_hh_l0' + suf] = _uniform(seed, p + 'bhh' + suf, (4 * rnn_size,), 0.1)
+        sd[f'encoder.rnns.{i}.layer_norm.weight'] = 1.0 + _uniform(seed, f'ds2.ln{i}.w', (out,), 0.2)
+        sd[f'encoder.rnns.{i}.layer_norm.bias'] = _uniform(seed, f'ds2.ln{i}.b', (out,), 0.1)
+    b = ctc_gain / math.sqrt(out)
+    sd['decoder.ctc_lo.weight'] = _uniform(seed, 'ds2.ctc.w', (vocab_size, out), b * math.sqrt(3.0))
+    sd['decoder.ctc_lo.bias'] = _uniform(seed, 'ds2.ctc.b', (vocab_size,), 0.1)
+    return sd

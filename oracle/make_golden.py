@@ -10,6 +10,9 @@ Fixtures (all inputs are either stored or re-derivable from seeds):
                        synthetic weights seed 0, V=512): get_encoder_out probs, encoder output,
                        chunk-16 masked encoder output, and a 5-step get_encoder_out_chunk run.
 * ``conformer_v4233.npz`` same model family at V=4233: per-frame top-4 (index, prob).
+* ``deepspeech2_v300.npz`` reference DeepSpeech2Model (configs/deepspeech2.yml: 5 x LSTM-1024), V=300, synthetic weights:
+                       bi-directional (streaming=False) get_encoder_out on the ragged batch, and the uni-directional
+                       (streaming=True) model: get_encoder_out + a 5-chunk get_encoder_out_chunk run with carried (h, c).
 * ``predictor.npz``    reference MASRPredictor(use_gpu=False) on TorchScript export of the
                        synthetic model: predict(test.wav) and every predict_stream partial.
 * ``greedy.npz``       reference greedy_decoder / greedy_decoder_chunk outputs on seeded probs.
@@ -51,11 +54,52 @@ def golden_inputs():
     return feats, lens
 
 
+def build_reference_deepspeech2(sd, vocab_size, streaming, tmp):
+    from masr.model_utils.deepspeech2.model import DeepSpeech2Model
+    cfg = yaml.safe_load(open(os.path.join(REF, 'configs', 'deepspeech2.yml'), encoding='utf-8'))
+    p = os.path.join(tmp, 'mean_istd_ds2.json')
+    json.dump({'mean': sd['encoder.global_cmvn.mean'].tolist(), 'istd': sd['encoder.global_cmvn.istd'].tolist(),
+               'feature_method': 'fbank'}, open(p, 'w'))
+    m = DeepSpeech2Model(input_dim=80, vocab_size=vocab_size, mean_istd_path=p, streaming=streaming,
+                         encoder_conf=cfg['encoder_conf'], decoder_conf=cfg['decoder_conf'])
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    return m.eval()
+
+
+def deepspeech2_fixture(tmp):
+    feats, lens = golden_inputs()
+    out = {}
+    sd = weights.deepspeech2_state_dict(0, 300, bidirectional=True)
+    m = build_reference_deepspeech2(sd, 300, False, tmp)
+    out['bi_probs'] = m.get_encoder_out(feats, lens).numpy()
+    sd = weights.deepspeech2_state_dict(0, 300, bidirectional=False)
+    m = build_reference_deepspeech2(sd, 300, True, tmp)
+    out['uni_probs'] = m.get_encoder_out(feats, lens).numpy()
+    h = torch.zeros(0, 0, 0, 0)
+    c = torch.zeros(0, 0, 0, 0)
+    chunks = []
+    for cur in range(0, 331 - 67 + 1, 64):
+        x = feats[:1, cur:cur + 67]
+        r, _, h, c = m.get_encoder_out_chunk(x, torch.tensor([x.shape[1]]), h, c)
+        chunks.append(r[0].numpy())
+    out['chunk_probs'] = np.stack(chunks)
+    out['h'] = h.numpy()
+    out['c'] = c.numpy()
+    np.savez_compressed(os.path.join(OUT, 'deepspeech2_v300.npz'), **out)
+
+
 def main():
+    import sys
     shims.install()
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp()
     torch.set_grad_enabled(False)
+    if '--only-deepspeech2' in sys.argv:
+        deepspeech2_fixture(tmp)
+        print('deepspeech2 fixture written')
+        return
+    deepspeech2_fixture(tmp)
 
     # ---- test.wav ---------------------------------------------------------
     w = wave.open(os.path.join(REF, 'dataset', 'test.wav'))

@@ -438,3 +438,97 @@ def test_efficient_conformer_lengths_against_oracle(eff512, oracle_mods, T):
         ref = oe.encoder_full(sd, feats, lens)
     enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
     assert ref.shape == enc.shape and (ref - enc).abs().max() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# DeepSpeech2 (configs/deepspeech2.yml: conv front-end + 5 x LSTM-1024 + LayerNorm, CTC head)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def ds2_engines(oracle_mods):
+    from masr_amd.engine import HipEngine
+    weights = oracle_mods[3]
+    enc_conf = {'num_rnn_layers': 5, 'rnn_size': 1024}
+    sd_bi = weights.deepspeech2_state_dict(0, 300, bidirectional=True)
+    sd_uni = weights.deepspeech2_state_dict(0, 300, bidirectional=False)
+    e_bi = HipEngine(sd_bi, encoder_conf=enc_conf, streaming=False, use_model='deepspeech2')
+    e_uni = HipEngine(sd_uni, encoder_conf=enc_conf, streaming=True, use_model='deepspeech2')
+    yield e_bi, e_uni, sd_bi, sd_uni
+    e_bi.close()
+    e_uni.close()
+
+
+def test_deepspeech2_against_reference_fixture(ds2_engines, oracle_mods):
+    e_bi, e_uni, _, _ = ds2_engines
+    z = g('deepspeech2_v300.npz')
+    feats, lens = oracle_mods[4]()
+    for e, key in ((e_bi, 'bi_probs'), (e_uni, 'uni_probs')):
+        enc = e.encode_full(dev(feats), dev(lens, torch.int32))
+        probs = e.ctc_probs(enc).cpu().numpy()
+        ref = z[key]                                   # [3, 82, 300]; padded rows of the shorter utterances included
+        assert probs.shape == ref.shape
+        assert np.abs(probs - ref).max() < 1e-3
+        valid = [82, 49, 23]
+        for b in range(3):
+            assert (probs[b, :valid[b]].argmax(-1) == ref[b, :valid[b]].argmax(-1)).mean() > 0.995
+        idx, mp = e.ctc_greedy_frames(enc)
+        assert np.array_equal(idx.cpu().numpy(), probs.argmax(-1))
+        np.testing.assert_allclose(mp.cpu().numpy(), probs.max(-1), atol=1e-6)
+
+
+def test_deepspeech2_stream_chunks_against_reference_fixture(ds2_engines, oracle_mods):
+    _, e, _, _ = ds2_engines
+    z = g('deepspeech2_v300.npz')
+    feats, _ = oracle_mods[4]()
+    sid = e.stream_open(0)
+    for i, cur in enumerate(range(0, 331 - 67 + 1, 64)):
+        probs, _, _ = e.encode_chunk([sid], dev(feats[:1, cur:cur + 67]))
+        assert np.abs(probs[0].cpu().numpy() - z['chunk_probs'][i]).max() < 1e-3
+    h, c = e.stream_export_cache(sid)
+    assert np.abs(h.cpu().numpy() - z['h']).max() < 1e-3
+    assert np.abs(c.cpu().numpy() - z['c']).max() < 1e-3
+    # reset -> the first chunk repeats bit-for-bit
+    e.stream_reset(sid)
+    p0, _, _ = e.encode_chunk([sid], dev(feats[:1, :67]))
+    assert np.abs(p0[0].cpu().numpy() - z['chunk_probs'][0]).max() < 1e-3
+    e.stream_close(sid)
+
+
+def test_deepspeech2_two_streams_against_oracle(ds2_engines, oracle_mods):
+    # two interleaved streams with different audio == each one alone (state isolation), and == the oracle
+    from oracle import deepspeech2 as ods
+    _, e, _, sd = ds2_engines
+    torch.manual_seed(11)
+    xa = torch.randn(1, 131, 80) * 3 + 13
+    xb = torch.randn(1, 131, 80) * 3 + 13
+    s0, s1 = e.stream_open(0), e.stream_open(0)
+    ha = ca = hb = cb = None
+    for cur in (0, 64):
+        both = torch.cat([xa[:, cur:cur + 67], xb[:, cur:cur + 67]])
+        probs, _, _ = e.encode_chunk([s0, s1], dev(both))
+        with torch.no_grad():
+            pa, _, ha, ca = ods.get_encoder_out_chunk(sd, xa[:, cur:cur + 67], torch.tensor([67]), ha, ca)
+            pb, _, hb, cb = ods.get_encoder_out_chunk(sd, xb[:, cur:cur + 67], torch.tensor([67]), hb, cb)
+        assert np.abs(probs[0].cpu().numpy() - pa[0].numpy()).max() < 1e-3
+        assert np.abs(probs[1].cpu().numpy() - pb[0].numpy()).max() < 1e-3
+    e.stream_close(s0)
+    e.stream_close(s1)
+
+
+def test_deepspeech2_transcribe_batch_against_oracle(ds2_engines, oracle_mods):
+    from oracle import deepspeech2 as ods
+    oc, od, ofb, weights, _ = oracle_mods
+    e, _, sd, _ = ds2_engines
+    n = [32000, 21000, 9000]
+    pcm = np.zeros((3, max(n)), np.int16)
+    for b in range(3):
+        pcm[b, :n[b]] = weights.synthetic_pcm(20 + b, n[b] / 16000)
+    tok, ntok, score = e.transcribe_batch(dev(pcm), dev(np.array(n, np.int32)))
+    feats, frames = e.fbank_batch(dev(pcm), dev(np.array(n, np.int32)))
+    with torch.no_grad():
+        probs = ods.get_encoder_out(sd, feats.cpu(), frames.cpu().long()).numpy()
+    xl = ((frames.cpu().numpy() - 1) // 2 - 1) // 2
+    vocab = weights.synthetic_vocab(300)
+    for b in range(3):
+        s_ref, t_ref = od.greedy_decoder(probs[b, :xl[b]], vocab)
+        ids = tok[b, :int(ntok[b])].cpu().numpy()
+        assert ''.join(vocab[i] for i in ids).replace('<space>', ' ') == t_ref

@@ -146,3 +146,22 @@ def test_oracle_against_live_reference():
     lens = torch.tensor([150, 99])
     with torch.no_grad():
         assert (m.get_encoder_out(x, lens) - oc.get_encoder_out(sd, x, lens)).abs().max() < 1e-6
+
+
+def test_deepspeech2_fixture():
+    # oracle LSTM stack (cell written out, pack/pad semantics) vs the reference nn.LSTM model, bi- and uni-directional
+    from oracle import deepspeech2 as ods
+    z = g('deepspeech2_v300.npz')
+    feats, lens = golden_inputs()
+    with torch.no_grad():
+        sd = weights.deepspeech2_state_dict(0, 300, bidirectional=True)
+        np.testing.assert_allclose(ods.get_encoder_out(sd, feats, lens).numpy(), z['bi_probs'], atol=5e-6)
+        sd = weights.deepspeech2_state_dict(0, 300, bidirectional=False)
+        np.testing.assert_allclose(ods.get_encoder_out(sd, feats, lens).numpy(), z['uni_probs'], atol=5e-6)
+        h = c = None
+        for i, cur in enumerate(range(0, 331 - 67 + 1, 64)):
+            x = feats[:1, cur:cur + 67]
+            p, xl, h, c = ods.get_encoder_out_chunk(sd, x, torch.tensor([67]), h, c)
+            np.testing.assert_allclose(p[0].numpy(), z['chunk_probs'][i], atol=5e-6)
+        np.testing.assert_allclose(h.numpy(), z['h'], atol=5e-6)
+        np.testing.assert_allclose(c.numpy(), z['c'], atol=5e-6)
