@@ -137,6 +137,18 @@ def other_workload(args, device):
                 lat.append(time.perf_counter() - t0)
         audio = ns * 15 * 0.64
         desc = 'configs[4] shard: conformer.yml streaming, 16 concurrent streams per GPU in lock-step, 67-frame windows / 64 stride'
+    elif args.workload in ('deepspeech2_b1', 'deepspeech2_b32'):
+        # configs[0] is CPU plumbing in BASELINE.json; timed here on the GPU for DESIGN.md (bi-directional, one 8.39 s
+        # utterance the length of dataset/test.wav) and at batch 32 x 10 s
+        B = 1 if args.workload == 'deepspeech2_b1' else BATCH
+        ns = 134240 if B == 1 else N_SAMPLES
+        eng = HipEngine(synthetic.deepspeech2_state_dict(0, VOCAB, bidirectional=True), vocab_size=VOCAB, streaming=False,
+                        encoder_conf={'num_rnn_layers': 5, 'rnn_size': 1024}, use_model='deepspeech2', device=device)
+        pcm = torch.from_numpy(synthetic.synthetic_pcm(B, ns, seed=1234)).cuda()
+        n = torch.full((B,), ns, dtype=torch.int32, device='cuda')
+        step = lambda: eng.transcribe_batch(pcm, n)
+        audio = B * ns / 16000.0
+        desc = f'configs[0] on the GPU: deepspeech2.yml non-streaming (5 x bi-LSTM-1024), batch {B} x {ns / 16000:.2f} s, ctc_greedy'
     else:
         raise SystemExit(f'unknown workload {args.workload}')
     for _ in range(args.warmup):
@@ -166,7 +178,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='conformer_b32',
                     help='conformer_b32 (BASELINE configs[1], the contract line) | squeezeformer_b64_beam (configs[2]) | '
-                         'efficient_b32 (configs[3] per-GPU shard) | stream16 (configs[4] per-GPU shard)')
+                         'efficient_b32 (configs[3] per-GPU shard) | stream16 (configs[4] per-GPU shard) | deepspeech2_b1 | deepspeech2_b32')
     ap.add_argument('--profile-kind', type=int, default=2, help='kernel class timed with HIP events (2 = fused FFN)')
     args = ap.parse_args()
 

@@ -13,6 +13,8 @@ Fixtures (all inputs are either stored or re-derivable from seeds):
 * ``deepspeech2_v300.npz`` reference DeepSpeech2Model (configs/deepspeech2.yml: 5 x LSTM-1024), V=300, synthetic weights:
                        bi-directional (streaming=False) get_encoder_out on the ragged batch, and the uni-directional
                        (streaming=True) model: get_encoder_out + a 5-chunk get_encoder_out_chunk run with carried (h, c).
+* ``predictor_deepspeech2.npz`` BASELINE config 1: reference MASRPredictor(use_gpu=False) on the TorchScript export of the
+                       synthetic DeepSpeech2 models (V=4233): predict(test.wav) for bi/uni + every predict_stream partial.
 * ``predictor.npz``    reference MASRPredictor(use_gpu=False) on TorchScript export of the
                        synthetic model: predict(test.wav) and every predict_stream partial.
 * ``greedy.npz``       reference greedy_decoder / greedy_decoder_chunk outputs on seeded probs.
@@ -87,6 +89,45 @@ def deepspeech2_fixture(tmp):
     out['h'] = h.numpy()
     out['c'] = c.numpy()
     np.savez_compressed(os.path.join(OUT, 'deepspeech2_v300.npz'), **out)
+
+    # BASELINE config 1: deepspeech2.yml, streaming False, ctc_greedy, B=1 on dataset/test.wav through the reference
+    # MASRPredictor(use_gpu=False); plus the streaming (uni-directional) model through predict_stream
+    from masr.predict import MASRPredictor
+    w = wave.open(os.path.join(REF, 'dataset', 'test.wav'))
+    pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16).copy()
+    vocab = weights.synthetic_vocab(4233)
+    vpath = os.path.join(tmp, 'vocabulary_ds2.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in vocab:
+            f.write(f'{t}\t1\n')
+    res = {}
+    for streaming in (False, True):
+        sd = weights.deepspeech2_state_dict(0, 4233, bidirectional=not streaming)
+        m = build_reference_deepspeech2(sd, 4233, streaming, tmp)
+        mdir = os.path.join(tmp, 'models', f'deepspeech2_{streaming}')
+        os.makedirs(mdir)
+        torch.jit.save(m.export(), os.path.join(mdir, 'inference.pt'))
+        cfg = yaml.safe_load(open(os.path.join(REF, 'configs', 'deepspeech2.yml'), encoding='utf-8'))
+        cfg['dataset_conf']['dataset_vocab'] = vpath
+        cfg['dataset_conf']['mean_istd_path'] = os.path.join(tmp, 'mean_istd_ds2.json')
+        cfg['decoder'] = 'ctc_greedy'
+        cfg['streaming'] = streaming
+        pred = MASRPredictor(configs=cfg, model_path=os.path.join(mdir, 'inference.pt'), use_gpu=False)
+        r = pred.predict(audio_data=pcm.copy())
+        key = 'uni' if streaming else 'bi'
+        res[key + '_text'] = np.array(r['text'])
+        res[key + '_score'] = np.array(r['score'], np.float64)
+        if streaming:
+            texts, scores, valid = [], [], []
+            for s0 in range(0, len(pcm), 8000):
+                q = pred.predict_stream(audio_data=pcm[s0:s0 + 8000].tobytes(), is_end=(s0 + 8000 >= len(pcm)))
+                valid.append(q is not None and q['text'] is not None)
+                texts.append('' if not valid[-1] else q['text'])
+                scores.append(0.0 if not valid[-1] else float(q['score']))
+            pred.reset_stream()
+            res['stream_text'], res['stream_score'], res['stream_valid'] = np.array(texts), np.array(scores), np.array(valid)
+    np.savez_compressed(os.path.join(OUT, 'predictor_deepspeech2.npz'), **res)
+    print('deepspeech2 facade:', res['bi_text'], res['bi_score'], '| stream:', res['stream_text'][-1], res['stream_score'][-1])
 
 
 def main():

@@ -158,3 +158,62 @@ def test_squeezeformer_beam_search_facade(tmp_path):
     assert batch[0]['text'] == batch[1]['text'] and _close(res['text'], batch[0]['text']) <= 0.05
     with pytest.raises(Exception):
         pred.predict_stream(audio_data=pcm[:8000].tobytes())       # streaming: False (predict.py:253-255)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE config 1: deepspeech2.yml, B=1 on dataset/test.wav, ctc_greedy (fixture: predictor_deepspeech2.npz)
+# ---------------------------------------------------------------------------------------------------
+DS2_CONFIG = """
+encoder_conf: {num_rnn_layers: 5, rnn_size: 1024, use_gru: False}
+preprocess_conf: {feature_method: fbank, n_mels: 80, n_mfcc: 40, sample_rate: 16000, use_dB_normalization: True, target_dB: -20}
+dataset_conf: {dataset_vocab: VOCAB}
+use_model: deepspeech2
+streaming: STREAMING
+decoder: ctc_greedy
+metrics_type: cer
+"""
+
+
+def _ds2_predictor(d, streaming):
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.utils import synthetic
+    vpath = os.path.join(d, 'vocabulary.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in synthetic.synthetic_vocab(4233):
+            f.write(f'{t}\t1\n')
+    cfg = yaml.safe_load(DS2_CONFIG.replace('VOCAB', vpath).replace('STREAMING', str(streaming)))
+    sd = synthetic.deepspeech2_state_dict(0, 4233, bidirectional=not streaming)
+    mpath = os.path.join(d, f'model_{streaming}.pt')
+    torch.save(sd, mpath)
+    return MASRPredictor(configs=cfg, model_path=mpath, use_gpu=True)
+
+
+def test_deepspeech2_config1_matches_reference_facade(tmp_path):
+    z = np.load(os.path.join(GOLDEN, 'predictor_deepspeech2.npz'))
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    p = _ds2_predictor(str(tmp_path), False)
+    res = p.predict(audio_data=pcm.copy())
+    assert _close(str(z['bi_text']), res['text']) <= 0.1, (res['text'], str(z['bi_text']))
+    assert abs(res['score'] - float(z['bi_score'])) < 0.5
+    with pytest.raises(Exception):
+        p.predict_stream(audio_data=pcm[:8000].tobytes())       # non-streaming model: predict.py:262-263
+
+
+def test_deepspeech2_stream_matches_reference_facade(tmp_path):
+    z = np.load(os.path.join(GOLDEN, 'predictor_deepspeech2.npz'))
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    p = _ds2_predictor(str(tmp_path), True)
+    res = p.predict(audio_data=pcm.copy())
+    assert _close(str(z['uni_text']), res['text']) <= 0.1
+    assert abs(res['score'] - float(z['uni_score'])) < 0.5
+    p.reset_stream()
+    k = 0
+    for s in range(0, len(pcm), 8000):
+        r = p.predict_stream(audio_data=pcm[s:s + 8000].tobytes(), is_end=(s + 8000 >= len(pcm)))
+        valid = r is not None and r['text'] is not None
+        assert valid == bool(z['stream_valid'][k]), f'call {k}: validity differs'
+        if valid:
+            assert _close(str(z['stream_text'][k]), r['text']) <= 0.1, (k, r['text'], str(z['stream_text'][k]))
+            assert abs(r['score'] - float(z['stream_score'][k])) < 0.5
+        k += 1
+    p.reset_stream()

@@ -521,7 +521,7 @@ def test_deepspeech2_transcribe_batch_against_oracle(ds2_engines, oracle_mods):
     n = [32000, 21000, 9000]
     pcm = np.zeros((3, max(n)), np.int16)
     for b in range(3):
-        pcm[b, :n[b]] = weights.synthetic_pcm(20 + b, n[b] / 16000)
+        pcm[b, :n[b]] = weights.synthetic_pcm(1, n[b], seed=20 + b)[0]
     tok, ntok, score = e.transcribe_batch(dev(pcm), dev(np.array(n, np.int32)))
     feats, frames = e.fbank_batch(dev(pcm), dev(np.array(n, np.int32)))
     with torch.no_grad():
