@@ -125,6 +125,18 @@ int masr_beam_search_batch(const int32_t* idx_host, const float* logp_host, cons
                            int32_t blank, int32_t num_threads, int32_t* tokens_host, int32_t max_len, int32_t* len_host,
                            float* score_host);
 
+/* CTC prefix beam search of a whole batch ON THE GPU (one workgroup per utterance; live prefixes, candidate scores and
+ * the top-`beam_size` selection live in LDS, trie nodes of survivors in HBM).  Same inputs as masr_beam_search_batch but
+ * DEVICE pointers (the outputs of masr_ctc_topk stay on the device), same outputs (token ids of the best prefix, its
+ * length and log probability) as device arrays.  Replaces ctc_beam_search_decoding_batch of the third-party
+ * paddlespeech_ctcdecoders (masr/decoders/swig_wrapper.py:67-103, beam_search_decoder.py:59-73), LM-free.
+ * Limits: cutoff_top_n <= 64, beam_size <= 512, beam_size * (cutoff_top_n + 1) * 4 B + tables <= 160 KB LDS,
+ * T_stride * beam_size <= 524000; returns non-zero (masr_last_error) beyond them -- use masr_beam_search_batch then. */
+int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* logp_dev, const int32_t* count_dev,
+                         const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
+                         int32_t blank, int32_t* tokens_dev, int32_t max_len, int32_t* len_dev, float* score_dev,
+                         void* stream);
+
 /* One call for the whole offline hot path (MASRPredictor.predict semantics, masr/predict.py:167-192,
  * batched like MASRTrainer.evaluate, trainer.py:632): PCM -> fbank -> encoder -> CTC greedy.
  * decode_all_frames != 0 reproduces the reference batch quirk of decoding padded frames. */

@@ -104,6 +104,26 @@ void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float*
 
 void set_ffn_variant(int v);   // diagnostic ablations of the fused FFN kernel (0 = production)
 
+// ---- CTC prefix beam search on the GPU (beam_gpu.hip) ---------------------------------------------
+struct BeamGpuArgs {
+    const int* cidx;       // [B * T_stride, K]
+    const float* clp;      // [B * T_stride, K]
+    const int* ccount;     // [B * T_stride]
+    const int* frames;     // [B] frames to consume per utterance (nullptr: T_stride)
+    int T_stride, K, beam, blank, max_len;
+    int* pool_parent;      // [B][pool_cap]
+    int* pool_ch;          // [B][pool_cap]
+    int pool_cap;
+    int* state_i;          // [B][2 + 3 * beam]: n_live, pool_count, node[], pnode[], ch[]       (persistent streams)
+    float* state_f;        // [B][3 * beam]:     b[], nb[], score[]
+    int init;              // 1: start from the empty prefix; 0: continue from state_*
+    int* tokens;           // [B][max_len]
+    int* len;              // [B]
+    float* score;          // [B]
+};
+size_t beam_gpu_lds_bytes(int beam, int K);
+int launch_beam_search(const BeamGpuArgs& a, int B, hipStream_t s);   // 1: sizes not supported
+
 // ---- DeepSpeech2 (lstm.hip) --------------------------------------------------------------------
 void launch_lstm_step(const float* gx, const float* whh, const float* h_prev, float* h_next, float* c, float* out,
                       const int* lens, int B, int T, int H, int step, int ndir, hipStream_t s);

@@ -105,7 +105,8 @@ struct masr_engine {
     std::vector<LayerW> layers;
     std::vector<SqLayerW> sq_layers;
     std::vector<Ds2LayerW> ds2_layers;
-    DevBuf gx, rnn_out, hstate, cstate, ds2_lens;                               // DeepSpeech2 workspaces
+    DevBuf gx, rnn_out, hstate, cstate, ds2_lens;
+    DevBuf beam_pool, beam_state;                                               // GPU beam search scratch                               // DeepSpeech2 workspaces
     float *preln_w = nullptr, *preln_b = nullptr, *tr_dw_w = nullptr, *tr_dw_b = nullptr, *tr_pw_w = nullptr,
           *tr_pw_b = nullptr, *rec_w = nullptr, *rec_b = nullptr;
     int reduce_idx = -1, recover_idx = -1;
@@ -313,7 +314,7 @@ void masr_destroy(masr_engine* e) {
     DevBuf* bufs[] = {&e->x1, &e->x2, &e->x, &e->ln, &e->hid, &e->qkv, &e->att, &e->lnpad, &e->glu, &e->dwo,
                       &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens, &e->xsave,
                       &e->xred, &e->qplanes, &e->attp, &e->cnnptrs, &e->ffpart, &e->gx, &e->rnn_out, &e->hstate, &e->cstate,
-                      &e->ds2_lens};
+                      &e->ds2_lens, &e->beam_pool, &e->beam_state};
     for (DevBuf* b : bufs) b->release();
     for (auto& s : e->streams) {
         s.att.release();
@@ -1127,6 +1128,32 @@ int masr_ctc_topk(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, 
     if (V > 8192) return fail("V > 8192 not supported");
     if (top_n <= 0) return fail("top_n must be positive");
     launch_topk_prune(probs_dev, M, V, top_n, cutoff_prob, idx_dev, logp_dev, count_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* logp_dev, const int32_t* count_dev,
+                         const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size, int32_t blank,
+                         int32_t* tokens_dev, int32_t max_len, int32_t* len_dev, float* score_dev, void* stream) {
+    if (!e) return fail("null engine");
+    if (B <= 0 || T_stride <= 0) return fail("empty batch");
+    if (e->cfg.vocab_size > 8192 && e->finalized) return fail("vocab_size > 8192 not supported");
+    BeamGpuArgs a{};
+    a.cidx = idx_dev; a.clp = logp_dev; a.ccount = count_dev; a.frames = frames_dev;
+    a.T_stride = T_stride; a.K = K; a.beam = beam_size; a.blank = blank; a.max_len = max_len;
+    a.pool_cap = T_stride * beam_size + 1;
+    if (K > 64 || beam_size > 512 || beam_size < 1 || a.pool_cap > 524000 || beam_gpu_lds_bytes(beam_size, K) > 160 * 1024)
+        return fail("beam search on the GPU needs cutoff_top_n <= 64, beam_size <= 512, beam_size*(cutoff_top_n+1) entries in "
+                    "160 KB of LDS and T*beam_size <= 524000 trie nodes; use masr_beam_search_batch (host threads) beyond that");
+    CHK(e->beam_pool.ensure((size_t)B * a.pool_cap * 2 * sizeof(int)));
+    CHK(e->beam_state.ensure((size_t)B * (2 + 6 * (size_t)beam_size) * sizeof(int)));
+    a.pool_parent = e->beam_pool.as<int>();
+    a.pool_ch = a.pool_parent + (size_t)B * a.pool_cap;
+    a.state_i = e->beam_state.as<int>();
+    a.state_f = reinterpret_cast<float*>(a.state_i + (size_t)B * (2 + 3 * (size_t)beam_size));
+    a.init = 1;
+    a.tokens = tokens_dev; a.len = len_dev; a.score = score_dev;
+    if (launch_beam_search(a, B, (hipStream_t)stream)) return fail("beam search launch rejected the sizes");
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -1,8 +1,9 @@
 """BeamSearchDecoder with the reference's constructor / method contract
 (masr/decoders/beam_search_decoder.py:9-96).  The reference hands the search to the third-party SWIG
 module ``paddlespeech_ctcdecoders`` (+ a KenLM language model); here the per-frame vocabulary pruning runs
-on the GPU (masr_ctc_topk) and the LM-free CTC prefix beam search runs on host threads inside
-libmasr_hip.so (masr_beam_*).  The external LM scorer (alpha / beta) is NOT implemented: a missing
+on the GPU (masr_ctc_topk) and so does the LM-free CTC prefix beam search of whole utterances
+(masr_beam_search_gpu: one workgroup per utterance); the streaming decode_chunk path and sizes beyond the kernel's
+limits use the host-thread search inside libmasr_hip.so (masr_beam_*).  The external LM scorer (alpha / beta) is NOT implemented: a missing
 language model file is not an error, scores are the log probability of the best prefix (alpha = 0 path)."""
 import ctypes as C
 import logging
@@ -26,6 +27,7 @@ class BeamSearchDecoder:
         self.vocab_list = vocab_list
         self.num_processes = int(num_processes)
         self.blank_id = int(blank_id)
+        self.use_gpu_search = True       # False: prefix search on host threads (masr_beam_search_batch)
         if alpha or beta:
             logger.warning('masr_amd BeamSearchDecoder: the external language-model scorer is not implemented; '
                            'decoding with the acoustic CTC scores only (alpha = beta = 0)')
@@ -44,8 +46,8 @@ class BeamSearchDecoder:
             pass
 
     # ---- GPU: per-frame candidate pruning ----------------------------------------------------------
-    def _candidates(self, probs):
-        """probs np/torch [M, V] -> host arrays idx [M,K] int32, logp [M,K] f32, count [M] int32."""
+    def _candidates(self, probs, to_host=True):
+        """probs np/torch [M, V] -> idx [M,K] int32, logp [M,K] f32, count [M] int32 (host arrays, or device tensors)."""
         eng = runtime.aux_engine()
         p = torch.as_tensor(np.asarray(probs) if not torch.is_tensor(probs) else probs, dtype=torch.float32)
         p = p.to(eng.device).contiguous()
@@ -59,7 +61,15 @@ class BeamSearchDecoder:
                                           C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
                                           C.c_void_p(cnt.data_ptr()),
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        if not to_host:
+            return idx, logp, cnt, K
         return idx.cpu().numpy(), logp.cpu().numpy(), cnt.cpu().numpy(), K
+
+    def gpu_search_supported(self, T, V):
+        """limits of masr_beam_search_gpu (include/masr_hip.h): LDS-resident entry table and 32-bit trie keys."""
+        K = min(self.cutoff_top_n, V)
+        lds = self.beam_size * (K + 1) * 4 + 56 * self.beam_size + 17500
+        return K <= 64 and 1 <= self.beam_size <= 512 and lds <= 160 * 1024 and T * self.beam_size + 1 <= 524000
 
     def _text(self, toks):
         return ''.join(self.vocab_list[t] for t in toks).replace('<space>', ' ')
@@ -85,8 +95,23 @@ class BeamSearchDecoder:
             stacked = np.zeros((B, Ts, V), np.float32)
         for i, p in enumerate(probs_list):
             stacked[i, :p.shape[0]] = p
-        idx, logp, cnt, K = self._candidates(stacked.reshape(B * Ts, V))
         max_len = max(Ts, 1)
+        if B and Ts and self.use_gpu_search and self.gpu_search_supported(Ts, V):
+            # whole search on the device: candidates never leave HBM, one workgroup per utterance
+            eng = runtime.aux_engine()
+            idx, logp, cnt, K = self._candidates(stacked.reshape(B * Ts, V), to_host=False)
+            fr = torch.from_numpy(frames).to(eng.device)
+            toks = torch.zeros(B, max_len, dtype=torch.int32, device=eng.device)
+            lens = torch.zeros(B, dtype=torch.int32, device=eng.device)
+            scores = torch.zeros(B, dtype=torch.float32, device=eng.device)
+            check(self._lib.masr_beam_search_gpu(eng.h, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                                 C.c_void_p(cnt.data_ptr()), C.c_void_p(fr.data_ptr()), B, Ts, K,
+                                                 self.beam_size, self.blank_id, C.c_void_p(toks.data_ptr()), max_len,
+                                                 C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
+            return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(B)]
+        idx, logp, cnt, K = self._candidates(stacked.reshape(B * Ts, V))
         toks = np.zeros((B, max_len), np.int32)
         lens = np.zeros(B, np.int32)
         scores = np.zeros(B, np.float32)

@@ -113,3 +113,48 @@ def test_gpu_pruning_and_decoder_api():
         out = dec.decode_chunk(probs[0][None, lo:lo + 16], np.array([min(16, 37 - lo)]))
     assert out[1] == texts[0]
     dec.reset_decoder()
+
+
+def _gpu_vs_host(probs_list, beam, cut, topn):
+    """GPU search (masr_beam_search_gpu) and host search (masr_beam_search_batch) on the same pruned candidates"""
+    import torch
+    from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    V = probs_list[0].shape[1]
+    vocab = ['<blank>'] + [chr(0x4e00 + i) for i in range(V - 1)]
+    dec = BeamSearchDecoder(alpha=0, beta=0, beam_size=beam, cutoff_prob=cut, cutoff_top_n=topn, vocab_list=vocab,
+                            num_processes=4)
+    assert dec.gpu_search_supported(max(p.shape[0] for p in probs_list), V)
+    gpu = dec._batch(probs_list)
+    dec.use_gpu_search = False
+    host = dec._batch(probs_list)
+    return gpu, host
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed,V,Ts,beam,cut,topn,conc', [
+    (0, 6, (12, 5, 9), 4, 1.0, 40, 0.4), (1, 50, (30, 30), 8, 0.99, 5, 0.4), (2, 300, (60, 41, 1), 20, 0.99, 40, 0.05),
+    (3, 5, (40,), 300, 1.0, 40, 0.4), (4, 4233, (120, 77, 33, 120), 300, 0.99, 40, 0.002), (5, 600, (90, 64), 64, 0.95, 64, 0.01)])
+def test_gpu_prefix_search_matches_host_search(seed, V, Ts, beam, cut, topn, conc):
+    rng = np.random.default_rng(seed)
+    probs = [rng.dirichlet(np.ones(V) * conc, size=T).astype(np.float32) for T in Ts]
+    gpu, host = _gpu_vs_host(probs, beam, cut, topn)
+    for (sg, tg), (sh, th) in zip(gpu, host):
+        assert tg == th
+        assert abs(sg - sh) < 1e-3 * max(1.0, abs(sh))
+
+
+@pytest.mark.gpu
+def test_gpu_prefix_search_peaked_equals_greedy_and_oracle():
+    rng = np.random.default_rng(3)
+    V, T = 40, 200
+    ids = rng.integers(0, V, T)
+    ids[rng.random(T) < 0.5] = 0                       # plenty of blanks and repeats
+    probs = np.full((T, V), 2e-4, np.float32)
+    probs[np.arange(T), ids] = 1.0 - 2e-4 * (V - 1)
+    vocab = ['<blank>'] + [chr(0x4e00 + i) for i in range(V - 1)]
+    _, t_greedy = od.greedy_decoder(probs, vocab)
+    gpu, host = _gpu_vs_host([probs], 300, 0.99, 40)
+    assert gpu[0][1] == t_greedy == host[0][1]
+    s_ref, t_ref = obs.decode(probs[:60], vocab, 16, 1.0, 40)
+    g2, _ = _gpu_vs_host([probs[:60]], 16, 1.0, 40)
+    assert g2[0][1] == t_ref and abs(g2[0][0] - s_ref) < 1e-3
