@@ -117,7 +117,7 @@ def other_workload(args, device):
             return dec._batch([probs[i, :nenc[i]] for i in range(64)])
         audio = float(lens.sum()) / 16000.0
         desc = f'configs[2]: squeezeformer.yml non-streaming, 64 utterances 2-20 s padded ({audio:.1f} audio-s), ctc_beam_search ' \
-               f'(LM-free, beam 300, {dec.num_processes} host threads)'
+               f'(LM-free, beam 300, cutoff_top_n 40; pruning and prefix search on the GPU)'
     elif args.workload == 'stream16':
         eng = HipEngine(synthetic.conformer_state_dict(0, VOCAB), vocab_size=VOCAB, device=device)
         ns = 16

@@ -130,8 +130,7 @@ int masr_beam_search_batch(const int32_t* idx_host, const float* logp_host, cons
  * DEVICE pointers (the outputs of masr_ctc_topk stay on the device), same outputs (token ids of the best prefix, its
  * length and log probability) as device arrays.  Replaces ctc_beam_search_decoding_batch of the third-party
  * paddlespeech_ctcdecoders (masr/decoders/swig_wrapper.py:67-103, beam_search_decoder.py:59-73), LM-free.
- * Limits: cutoff_top_n <= 64, beam_size <= 512, beam_size * (cutoff_top_n + 1) * 4 B + tables <= 160 KB LDS,
- * T_stride * beam_size <= 524000; returns non-zero (masr_last_error) beyond them -- use masr_beam_search_batch then. */
+ * Limits: cutoff_top_n <= 64, beam_size <= 512, beam_size * cutoff_top_n * 6 B + tables <= 160 KB of LDS; returns non-zero (masr_last_error) beyond them -- use masr_beam_search_batch then. */
 int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* logp_dev, const int32_t* count_dev,
                          const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
                          int32_t blank, int32_t* tokens_dev, int32_t max_len, int32_t* len_dev, float* score_dev,

@@ -2,18 +2,22 @@
 // masr/decoders/beam_search_decoder.py:45-96 -> third-party paddlespeech_ctcdecoders, see beam_search.cpp for the
 // host restatement of the same algorithm and the "parity unpinned" note).
 //
-// One workgroup (512 threads) per utterance walks the frames sequentially; everything a step needs lives in LDS:
-//   live prefixes  (<= beam):  trie node id, parent node id, last character, log P(blank end), log P(non-blank end), score
+// One workgroup (1024 threads) per utterance walks the frames sequentially; everything a step needs lives in LDS:
+//   live prefixes  (<= beam):  trie node id, parent node id, live index of the parent (or -1), last character,
+//                              log P(blank end), log P(non-blank end), score
 //   candidates     (<= K):     the pruned vocabulary of the frame (topk_prune_kernel), descending probability
-//   entry scores   (<= beam * (K + 1)): the live prefixes themselves + every (prefix, character) extension
+//   entry scores   (<= beam * K): every (prefix, character) extension, as order-preserving integer keys
 // Step (== Beam::step of beam_search.cpp, reformulated without a pointer trie):
 //   A  every live prefix p:  b_cur = lp(blank) + score(p);  nb_cur = lp(ch(p)) + nb_prev(p)        (repeat of its last char)
 //   B  every pair (p, c != blank): add = c == ch(p) ? lp(c) + b_prev(p) : lp(c) + score(p).  If the child (p, c) is itself a
-//      live prefix (hash lookup keyed by (node(p), c)) the term is merged into its nb_cur -- a node has one parent, so at
-//      most one such term per live prefix and the two-term log-sum-exp is order independent -- otherwise it is a new entry.
-//   C  score = logsumexp(b_cur, nb_cur); keep the `beam` best entries: 4-pass radix select on the order-preserving integer
-//      image of the scores, then an index-ordered compaction (deterministic).  Survivors that are new get trie nodes
-//      (parent pointer + character) appended to the utterance's node pool in HBM -- only survivors ever get a node.
+//      live prefix (p's list of live children, linked through the carried parent indices) the term is merged into that
+//      prefix's nb_cur -- a node has one parent, so at most one such term per live prefix and the two-term log-sum-exp is
+//      order independent -- otherwise it is a new entry.  Threads own (prefix, k-range): the prefix state is read once.
+//   C  score = logsumexp(b_cur, nb_cur); keep the `beam` best entries.  A valid lower bound of the beam-th best score
+//      (the beam-th best of the 1024 per-thread maxima over a strided sample, 3 radix passes on one value per thread)
+//      discards ~95 % of the entries; an exact 4-pass radix select over the survivors gives the threshold; ordered
+//      (deterministic) compaction.  Survivors that are new get trie nodes (parent pointer + character) appended to the
+//      utterance's node pool in HBM -- only survivors ever get a node.
 // Entries with score -inf are never revived except through their parent's extension, which re-creates them, so dropping
 // them is equivalent to the pointer trie that keeps them.
 // The best prefix is read back by walking parent pointers.
@@ -23,9 +27,8 @@
 
 namespace masr {
 
-static constexpr int BS_THREADS = 512;
+static constexpr int BS_THREADS = 1024;
 static constexpr int BS_WAVES = BS_THREADS / 64;
-static constexpr int BS_HASH = 1024;
 static constexpr int BS_KMAX = 64;
 
 __device__ __forceinline__ float lse2(float x, float y) {
@@ -34,43 +37,115 @@ __device__ __forceinline__ float lse2(float x, float y) {
     const float m = fmaxf(x, y);
     return m + logf(expf(x - m) + expf(y - m));
 }
-__device__ __forceinline__ unsigned okey(float f) {       // larger float -> larger unsigned
+__device__ __forceinline__ unsigned okey(float f) {       // larger float -> larger unsigned; never 0 for a real score
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__device__ __forceinline__ unsigned hash32(unsigned k) {
-    k *= 0x9E3779B1u;
-    return (k >> 22) & (BS_HASH - 1);
+
+// inclusive wave64 prefix sum with DPP row shifts / row broadcasts (6 VALU ops, no LDS crossbar traffic)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
 }
 
+// exclusive block scan of one int per thread (packed counters); `wsum` must be a scratch row [BS_WAVES] that nobody
+// else touches during this step (one barrier per scan); returns the exclusive prefix, total in `total`
+__device__ __forceinline__ int block_scan(int v, int* wsum, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = wave_scan_incl(v);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BS_WAVES; ++w) {
+        const int x = wsum[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    total = tot;
+    return base + incl - v;
+}
 
+// histogram update with wave aggregation: scores of one frame share their leading bytes, so whole waves usually hit
+// one bin -- one atomic per wave instead of a 64-way serialised one
+__device__ __forceinline__ void hist_add(int* hist, bool active, int bin) {
+    const unsigned long long act = __ballot(active);
+    if (!act) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const int b0 = __builtin_amdgcn_readlane(bin, leader);
+    const unsigned long long same = __ballot(active && bin == b0);
+    if (same == act) {
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b0], __popcll(act));
+    } else if (active) {
+        atomicAdd(&hist[bin], 1);
+    }
+}
+
+// every wave: find the bin (scanning from 255 down) in which the cumulative count reaches `need`, and how many are
+// still needed inside that bin
+__device__ __forceinline__ void pick_bin(const int* hist, int need, int& bin, int& rem) {
+    const int lane = threadIdx.x & 63;
+    int c4[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c4[j] = hist[255 - (4 * lane + j)];
+        s += c4[j];
+    }
+    const int incl = wave_scan_incl(s);
+    const int excl = incl - s;
+    const bool mine = excl < need && need <= incl;
+    int b = 0, r = 0, acc = excl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (acc < need && need <= acc + c4[j]) {
+            b = 255 - (4 * lane + j);
+            r = need - acc;
+        }
+        acc += c4[j];
+    }
+    const unsigned long long m = __ballot(mine);
+    const int leader = m ? __ffsll((long long)m) - 1 : 0;
+    bin = __builtin_amdgcn_readlane(b, leader);
+    rem = __builtin_amdgcn_readlane(r, leader);
+}
+
+// NPT = extension entries per thread in the selection phase, strided (beam * K <= 1024 * NPT)
+template <int NPT>
 __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = blockIdx.x;
     const int beam = a.beam, K = a.K;
-    const int Emax = beam * (K + 1);
     // ---- LDS carve-up --------------------------------------------------------------------------------
-    unsigned* keys = reinterpret_cast<unsigned*>(smem_raw);              // [Emax]
-    int* lv_node = reinterpret_cast<int*>(keys + Emax);                  // [2][beam] each
+    unsigned* ekeys = reinterpret_cast<unsigned*>(smem_raw);             // [beam * K] extension keys, index p * cnt + k
+    int* lv_node = reinterpret_cast<int*>(ekeys + beam * K);             // [2][beam] each
     int* lv_pnode = lv_node + 2 * beam;
-    int* lv_ch = lv_pnode + 2 * beam;
+    int* lv_par = lv_pnode + 2 * beam;
+    int* lv_ch = lv_par + 2 * beam;
     float* lv_b = reinterpret_cast<float*>(lv_ch + 2 * beam);
     float* lv_nb = lv_b + 2 * beam;
     float* lv_sc = lv_nb + 2 * beam;
     float* bcur = lv_sc + 2 * beam;                                     // [beam]
-    float* nbcur = bcur + beam;                                         // [beam]
-    unsigned* hkey = reinterpret_cast<unsigned*>(nbcur + beam);          // [BS_HASH]
-    int* hval = reinterpret_cast<int*>(hkey + BS_HASH);                                          // [BS_HASH]
-    int* c_idx = hval + BS_HASH;                                         // [BS_KMAX]
+    float* rep = bcur + beam;                                           // [beam] repeat term of nb_cur
+    float* ext = rep + beam;                                            // [beam] parent-extension term of nb_cur
+    int* head = reinterpret_cast<int*>(ext + beam);                      // [beam] first live child
+    int* next = head + beam;                                             // [beam] next live child of the same parent
+    int* newslot = next + beam;                                          // [beam] old live index -> new live index / -1
+    int* c_idx = newslot + beam;                                         // [BS_KMAX]
     float* c_lp = reinterpret_cast<float*>(c_idx + BS_KMAX);             // [BS_KMAX]
-    int* hist = reinterpret_cast<int*>(c_lp + BS_KMAX);                  // [BS_WAVES][256]
-    int* wsum = hist + BS_WAVES * 256;                                   // [BS_WAVES] scan scratch
-    int* misc = wsum + BS_WAVES;                                         // [8]: 0 blank_k, 1 sel_bin, 2 need, 3 n_sel_exist
+    int* hist = reinterpret_cast<int*>(c_lp + BS_KMAX);                  // [7][256]: one per radix pass of a step
+    int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
+    int* misc = wsum + (6 + NPT) * BS_WAVES;                                         // [8]: 0 blank_k, 1 sel_bin, 2 need
+    unsigned short* slist = reinterpret_cast<unsigned short*>(misc + 8);  // [beam * K] surviving extension entries
 
     int* pool_parent = a.pool_parent + (size_t)u * a.pool_cap;
     int* pool_ch = a.pool_ch + (size_t)u * a.pool_cap;
-    int* st_i = a.state_i + (size_t)u * (2 + 3 * beam);
+    int* st_i = a.state_i + (size_t)u * (2 + 4 * beam);
     float* st_f = a.state_f + (size_t)u * (3 * beam);
 
     int n, pool_count, cur = 0;
@@ -80,7 +155,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         if (tid == 0) {
             pool_parent[0] = -1;
             pool_ch[0] = -1;
-            lv_node[0] = 0; lv_pnode[0] = -1; lv_ch[0] = -1;
+            lv_node[0] = 0; lv_pnode[0] = -1; lv_par[0] = -1; lv_ch[0] = -1;
             lv_b[0] = 0.f; lv_nb[0] = -INFINITY; lv_sc[0] = 0.f;
         }
     } else {
@@ -88,214 +163,246 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         pool_count = st_i[1];
         for (int i = tid; i < n; i += BS_THREADS) {
             lv_node[i] = st_i[2 + i]; lv_pnode[i] = st_i[2 + beam + i]; lv_ch[i] = st_i[2 + 2 * beam + i];
+            lv_par[i] = st_i[2 + 3 * beam + i];
             lv_b[i] = st_f[i]; lv_nb[i] = st_f[beam + i]; lv_sc[i] = st_f[2 * beam + i];
         }
     }
+    const unsigned NEG = okey(-INFINITY);
+    const int T = a.frames ? min(a.frames[u], a.T_stride) : a.T_stride;
+    const int G = BS_THREADS / beam;                  // threads per prefix in the extension phase (>= 2)
+    const int my_p = tid / G, my_g = tid - my_p * G;
+    // candidates of the next frame are fetched one step ahead (registers of threads 0..K-1)
+    const size_t row0 = (size_t)u * a.T_stride;
+    int nx_cnt = 0, nx_c = 0;
+    float nx_lp = 0.f;
+    if (T > 0) {
+        nx_cnt = min(a.ccount[row0], K);
+        if (tid < K) { nx_c = a.cidx[row0 * K + tid]; nx_lp = a.clp[row0 * K + tid]; }
+    }
+    long long pc[6] = {0, 0, 0, 0, 0, 0};
+    const bool prof = a.prof && u == 0 && tid == 0;
+#define BS_TICK(i) do { if (prof) { const long long now_ = clock64(); pc[i] += now_ - tick_; tick_ = now_; } } while (0)
+    long long tick_ = prof ? clock64() : 0;
     __syncthreads();
 
-    const int T = a.frames ? min(a.frames[u], a.T_stride) : a.T_stride;
     for (int t = 0; t < T; ++t) {
-        const size_t row = (size_t)u * a.T_stride + t;
-        const int cnt = min(a.ccount[row], K);
+        const int cnt = nx_cnt;
         const int o = cur * beam, o2 = (cur ^ 1) * beam;
-        // ---- 0. candidates, hash clear ----------------------------------------------------------------
-        if (tid == 0) { misc[0] = -1; misc[3] = 0; }
-        for (int i = tid; i < BS_HASH; i += BS_THREADS) hkey[i] = 0xffffffffu;
-        __syncthreads();
-        if (tid < cnt) {
-            const int c = a.cidx[row * K + tid];
-            c_idx[tid] = c;
-            c_lp[tid] = a.clp[row * K + tid];
-            if (c == a.blank) misc[0] = tid;
+        // ---- 0. candidates -> LDS, clear tables; prefetch the next frame -------------------------------------
+        for (int i = tid; i < 7 * 256; i += BS_THREADS) hist[i] = 0;
+        if (tid < n) { rep[tid] = -INFINITY; ext[tid] = -INFINITY; head[tid] = -1; }
+        if (wave == 0) {
+            const bool isb = lane < cnt && nx_c == a.blank;
+            const unsigned long long bm = __ballot(isb);
+            if (lane < cnt) { c_idx[lane] = nx_c; c_lp[lane] = nx_lp; }
+            if (lane == 0) misc[0] = bm ? __ffsll((long long)bm) - 1 : -1;
         }
-        // ---- 1. hash of the live prefixes: (parent node, char) -> live index ----------------------------
-        if (tid < n && lv_pnode[o + tid] >= 0) {
-            const unsigned key = (unsigned)lv_pnode[o + tid] * 8192u + (unsigned)lv_ch[o + tid];
-            unsigned h = hash32(key);
-            while (atomicCAS(&hkey[h], 0xffffffffu, key) != 0xffffffffu) h = (h + 1) & (BS_HASH - 1);
-            hval[h] = tid;
+        if (t + 1 < T) {
+            nx_cnt = min(a.ccount[row0 + t + 1], K);
+            if (tid < K) { nx_c = a.cidx[(row0 + t + 1) * K + tid]; nx_lp = a.clp[(row0 + t + 1) * K + tid]; }
         }
         __syncthreads();
-        // ---- 2. phase A: the prefixes themselves ------------------------------------------------------------
+        // ---- 1. live children lists; blank term ------------------------------------------------------------------
         const int blank_k = misc[0];
         if (tid < n) {
-            const float sc = lv_sc[o + tid];
-            bcur[tid] = blank_k >= 0 ? c_lp[blank_k] + sc : -INFINITY;
-            float nb = -INFINITY;
-            const int ch = lv_ch[o + tid];
-            for (int k = 0; k < cnt; ++k)
-                if (c_idx[k] == ch && ch != a.blank) nb = c_lp[k] + lv_nb[o + tid];
-            nbcur[tid] = nb;
+            const int par = lv_par[o + tid];
+            if (par >= 0) next[tid] = atomicExch(&head[par], tid);
+            bcur[tid] = blank_k >= 0 ? c_lp[blank_k] + lv_sc[o + tid] : -INFINITY;
         }
         __syncthreads();
-        // ---- 3. phase B: extensions ------------------------------------------------------------------------
-        const int E = n + n * cnt;
-        for (int e = tid; e < n * cnt; e += BS_THREADS) {
-            const int p = e / cnt, k = e - p * cnt;
-            const int c = c_idx[k];
-            float val = -INFINITY;
-            if (c != a.blank) {
+        BS_TICK(0);
+        // ---- 2. extensions (p, c): G threads per prefix, each a strided set of candidates ------------------------
+        const int nq = n * cnt;
+        if (my_p < n) {
+            const float sc = lv_sc[o + my_p], pb = lv_b[o + my_p], pnb = lv_nb[o + my_p];
+            const int ch = lv_ch[o + my_p], hd = head[my_p];
+            for (int k = my_g; k < cnt; k += G) {
+                const int c = c_idx[k];
                 const float lp = c_lp[k];
-                const float add = c == lv_ch[o + p] ? (lv_b[o + p] > -INFINITY ? lp + lv_b[o + p] : -INFINITY) : lp + lv_sc[o + p];
-                const unsigned key = (unsigned)lv_node[o + p] * 8192u + (unsigned)c;
-                unsigned h = hash32(key);
-                int found = -1;
-                while (true) {
-                    const unsigned hk = hkey[h];
-                    if (hk == key) { found = hval[h]; break; }
-                    if (hk == 0xffffffffu) break;
-                    h = (h + 1) & (BS_HASH - 1);
+                float val = -INFINITY;
+                if (c != a.blank) {
+                    if (c == ch) {
+                        rep[my_p] = lp + pnb;                       // only this k repeats the last character of p
+                        val = pb > -INFINITY ? lp + pb : -INFINITY;
+                    } else {
+                        val = lp + sc;
+                    }
+                    for (int j = hd; j >= 0; j = next[j])
+                        if (lv_ch[o + j] == c) {                    // the child (p, c) is a live prefix: merge into it
+                            ext[j] = val;
+                            val = -INFINITY;
+                        }
                 }
-                if (found >= 0) nbcur[found] = lse2(nbcur[found], add);   // unique writer: a node has one parent
-                else val = add;
+                ekeys[my_p * cnt + k] = okey(val);
             }
-            keys[n + e] = okey(val);
         }
         __syncthreads();
-        if (tid < n) keys[tid] = okey(lse2(bcur[tid], nbcur[tid]));
-        __syncthreads();
-        // ---- 4. radix select of the beam-th best key ---------------------------------------------------------
-        unsigned thr = 0;          // select key > thr, plus `need_eq` of the keys == thr
-        int need_eq = 0;
-        const unsigned NEG = okey(-INFINITY);
-        int fin = 0;               // entries with a finite score; if they all fit, keep exactly those
-        for (int e = tid; e < E; e += BS_THREADS) fin += keys[e] != NEG;
+        BS_TICK(1);
+        // ---- 3. the prefixes themselves; this thread's strided sample of the extension keys -------------------------
+        unsigned kex = 0;
+        float my_nb = -INFINITY, my_sc = -INFINITY;
+        if (tid < n) {
+            my_nb = lse2(rep[tid], ext[tid]);
+            my_sc = lse2(bcur[tid], my_nb);
+            kex = okey(my_sc);
+        }
+        unsigned keys[NPT];
+        unsigned tmax = kex;
+        int fin = kex > NEG;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) fin += __shfl_xor(fin, off, 64);
-        if (lane == 0) wsum[wave] = fin;
+        for (int i = 0; i < NPT; ++i) {
+            const int e = tid + i * BS_THREADS;
+            keys[i] = e < nq ? ekeys[e] : 0u;                           // 0 = no entry
+            tmax = max(tmax, keys[i]);
+            fin += keys[i] > NEG;
+        }
+        int tot;
+        block_scan(fin, wsum + 0 * BS_WAVES, tot);
+        BS_TICK(2);
+        // ---- 4a. lower bound of the beam-th best key: the beam-th best of the per-thread maxima, to 24 bits ---------------
+        unsigned low = NEG + 1;                                         // every finite entry
+        const bool overflow = tot > beam;
+        if (overflow) {
+            unsigned prefix = 0, mask = 0;
+            int need = beam;
+            for (int pass = 0; pass < 3; ++pass) {
+                const int shift = 24 - 8 * pass;
+                int* hp = hist + pass * 256;
+                hist_add(hp, (tmax & mask) == prefix, (tmax >> shift) & 255);
+                __syncthreads();
+                int bin, rem;
+                pick_bin(hp, need, bin, rem);
+                prefix |= (unsigned)bin << shift;
+                mask |= 255u << shift;
+                need = rem;
+            }
+            low = max(prefix, NEG + 1);                                 // >= beam entries are >= low
+        }
+        // ---- 4b. survivors (extension entries >= low) -> ordered list, re-dealt one per thread ----------------------------
+        int ns = 0;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) ns += keys[i] >= low;
+        int nsurv;
+        int pos = block_scan(ns, wsum + 1 * BS_WAVES, nsurv);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+            if (keys[i] >= low) slist[pos++] = (unsigned short)(tid + i * BS_THREADS);
         __syncthreads();
-        fin = 0;
-        for (int w = 0; w < BS_WAVES; ++w) fin += wsum[w];
-        __syncthreads();
-        const bool take_all = fin <= beam;
-        if (!take_all) {
+        unsigned ke[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            ke[i] = 0u;
+            if (i * BS_THREADS < nsurv) {
+                const int idx = tid + i * BS_THREADS;
+                if (idx < nsurv) ke[i] = ekeys[slist[idx]];
+            }
+        }
+        const unsigned kx = kex >= low ? kex : 0u;                       // live prefixes take part with their own score
+        // ---- 4c. exact radix select among the survivors -------------------------------------------------------------------
+        unsigned thr = NEG;        // select key > thr, plus `need_eq` of the keys == thr
+        int need_eq = 0;
+        if (overflow) {
             unsigned prefix = 0, mask = 0;
             int need = beam;
             for (int pass = 0; pass < 4; ++pass) {
                 const int shift = 24 - 8 * pass;
-                for (int i = tid; i < BS_WAVES * 256; i += BS_THREADS) hist[i] = 0;
+                int* hp = hist + (3 + pass) * 256;
+                hist_add(hp, kx != 0 && (kx & mask) == prefix, (kx >> shift) & 255);
+#pragma unroll
+                for (int i = 0; i < NPT; ++i)
+                    if (i * BS_THREADS < nsurv) hist_add(hp, ke[i] != 0 && (ke[i] & mask) == prefix, (ke[i] >> shift) & 255);
                 __syncthreads();
-                for (int e = tid; e < E; e += BS_THREADS) {
-                    const unsigned kk = keys[e];
-                    if ((kk & mask) == prefix) atomicAdd(&hist[wave * 256 + ((kk >> shift) & 255)], 1);
-                }
-                __syncthreads();
-                if (wave == 0) {
-                    int c4[4], s = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int bin = 255 - (4 * lane + j);
-                        int v = 0;
-#pragma unroll
-                        for (int w = 0; w < BS_WAVES; ++w) v += hist[w * 256 + bin];
-                        c4[j] = v;
-                        s += v;
-                    }
-                    int incl = s;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const int v = __shfl_up(incl, off, 64);
-                        if (lane >= off) incl += v;
-                    }
-                    int excl = incl - s;
-                    if (excl < need && need <= incl) {
-                        int acc = excl;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (acc < need && need <= acc + c4[j]) {
-                                misc[1] = 255 - (4 * lane + j);
-                                misc[2] = need - acc;
-                            }
-                            acc += c4[j];
-                        }
-                    }
-                }
-                __syncthreads();
-                prefix |= (unsigned)misc[1] << shift;
+                int bin, rem;
+                pick_bin(hp, need, bin, rem);
+                prefix |= (unsigned)bin << shift;
                 mask |= 255u << shift;
-                need = misc[2];
-                __syncthreads();
+                need = rem;
             }
             thr = prefix;
             need_eq = need;
         }
-        // ---- 5. index-ordered compaction into the other live buffer -------------------------------------------
-        const int per = (E + BS_THREADS - 1) / BS_THREADS;
-        const int e0 = min(tid * per, E), e1 = min(e0 + per, E);
-        int gt = 0, eq = 0;
-        for (int e = e0; e < e1; ++e) {
-            const unsigned kk = keys[e];
-            if (take_all) gt += kk != NEG;
-            else { gt += kk > thr; eq += kk == thr; }
+        BS_TICK(3);
+        // ---- 5. ordered compaction into the other live buffer: live prefixes first (by index), then extensions ------
+        int totE;
+        const int exE = block_scan((kx > thr) | ((kx == thr && kx != 0) << 16), wsum + 2 * BS_WAVES, totE);
+        const int gtE = totE & 0xffff, eqE = totE >> 16;
+        const int eq_take_E = min(eqE, need_eq);
+        const int n_exist = gtE + eq_take_E;
+        int my_slot = -1;
+        if (tid < n) {
+            const int gb = exE & 0xffff, eb = exE >> 16;
+            if (kx > thr || (kx == thr && kx != 0 && eb < need_eq)) my_slot = gb + min(eb, need_eq);
+            newslot[tid] = my_slot;
         }
-        int packed = gt | (eq << 16), incl = packed;
+        const int need_eq_new = need_eq - eq_take_E;
+        // list order = index order of the re-dealt items: item idx = tid + i * 1024 -> scan row by row
+        int n_new = 0;
+        int gbase = 0, ebase = 0;                                       // selected / equal counts of the previous rows
+        int row_ex[NPT];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        int total = 0;
-        for (int w = 0; w < BS_WAVES; ++w) total += wsum[w];
-        const int excl = base + incl - packed;
-        int gt_before = excl & 0xffff, eq_before = excl >> 16;
-        const int n_new_total = take_all ? fin : beam;
-        (void)total;
-        // first pass: survivors that already are live prefixes (entries < n come first in index order)
-        for (int e = e0; e < e1; ++e) {
-            const unsigned kk = keys[e];
-            bool sel;
-            if (take_all) sel = kk != NEG;
-            else sel = kk > thr || (kk == thr && eq_before < need_eq);
-            const int slot = gt_before + (take_all ? 0 : min(eq_before, need_eq));
-            if (take_all) gt_before += sel;
-            else { gt_before += kk > thr; eq_before += kk == thr; }
-            if (!sel) { keys[e] = 0xffffffffu; continue; }     // mark: not selected
-            keys[e] = (unsigned)slot;                          // selected: remember the slot
-            if (e < n) {
-                lv_node[o2 + slot] = lv_node[o + e];
-                lv_pnode[o2 + slot] = lv_pnode[o + e];
-                lv_ch[o2 + slot] = lv_ch[o + e];
-                lv_b[o2 + slot] = bcur[e];
-                lv_nb[o2 + slot] = nbcur[e];
-                lv_sc[o2 + slot] = lse2(bcur[e], nbcur[e]);
-                atomicAdd(&misc[3], 1);
+        for (int i = 0; i < NPT; ++i) {
+            row_ex[i] = 0;
+            if (i * BS_THREADS < nsurv) {
+                int totR;
+                const int ex = block_scan((ke[i] > thr) | ((ke[i] == thr && ke[i] != 0) << 16), wsum + (3 + i) * BS_WAVES, totR);
+                row_ex[i] = (gbase + (ex & 0xffff)) | ((ebase + (ex >> 16)) << 16);
+                gbase += totR & 0xffff;
+                ebase += totR >> 16;
             }
         }
-        __syncthreads();
-        const int n_exist = misc[3];
-        for (int e = max(e0, n); e < e1; ++e) {
-            const unsigned slot = keys[e];
-            if (slot == 0xffffffffu) continue;
-            const int q = e - n;
-            const int p = q / cnt, k = q - p * cnt;
-            const int node = pool_count + ((int)slot - n_exist);
-            const float add = c_idx[k] == lv_ch[o + p] ? c_lp[k] + lv_b[o + p] : c_lp[k] + lv_sc[o + p];
-            if (node < a.pool_cap) {
-                pool_parent[node] = lv_node[o + p];
-                pool_ch[node] = c_idx[k];
-            }
-            lv_node[o2 + slot] = node;
-            lv_pnode[o2 + slot] = lv_node[o + p];
-            lv_ch[o2 + slot] = c_idx[k];
-            lv_b[o2 + slot] = -INFINITY;
-            lv_nb[o2 + slot] = add;
-            lv_sc[o2 + slot] = add;
+        n_new = gbase + min(ebase, need_eq_new);
+        if (nsurv == 0) __syncthreads();                                // publish newslot[] even without a scan
+        if (my_slot >= 0) {
+            const int par = lv_par[o + tid];
+            lv_node[o2 + my_slot] = lv_node[o + tid];
+            lv_pnode[o2 + my_slot] = lv_pnode[o + tid];
+            lv_par[o2 + my_slot] = par >= 0 ? newslot[par] : -1;
+            lv_ch[o2 + my_slot] = lv_ch[o + tid];
+            lv_b[o2 + my_slot] = bcur[tid];
+            lv_nb[o2 + my_slot] = my_nb;
+            lv_sc[o2 + my_slot] = my_sc;
         }
-        pool_count += n_new_total - n_exist;
-        n = n_new_total;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            if (i * BS_THREADS < nsurv) {
+                const unsigned kk = ke[i];
+                const int gb = row_ex[i] & 0xffff, eb = row_ex[i] >> 16;
+                if (kk > thr || (kk == thr && kk != 0 && eb < need_eq_new)) {
+                    const int r = gb + min(eb, need_eq_new);            // rank among the selected extensions
+                    const int slot = n_exist + r, node = pool_count + r;
+                    const int e = slist[tid + i * BS_THREADS];
+                    const int p = e / cnt, k = e - p * cnt;
+                    const int c = c_idx[k];
+                    const float add = c == lv_ch[o + p] ? c_lp[k] + lv_b[o + p] : c_lp[k] + lv_sc[o + p];
+                    if (node < a.pool_cap) {
+                        pool_parent[node] = lv_node[o + p];
+                        pool_ch[node] = c;
+                    }
+                    lv_node[o2 + slot] = node;
+                    lv_pnode[o2 + slot] = lv_node[o + p];
+                    lv_par[o2 + slot] = newslot[p];
+                    lv_ch[o2 + slot] = c;
+                    lv_b[o2 + slot] = -INFINITY;
+                    lv_nb[o2 + slot] = add;
+                    lv_sc[o2 + slot] = add;
+                }
+            }
+        }
+        pool_count += n_new;
+        n = n_exist + n_new;
         cur ^= 1;
         __syncthreads();
+        BS_TICK(4);
     }
+    if (prof)
+        for (int i = 0; i < 5; ++i) a.prof[i] = pc[i];
 
     // ---- persist the live set (streams), pick the best prefix, walk the parent pointers ----------------------
     const int o = cur * beam;
     if (tid == 0) { st_i[0] = n; st_i[1] = pool_count; }
     for (int i = tid; i < n; i += BS_THREADS) {
         st_i[2 + i] = lv_node[o + i]; st_i[2 + beam + i] = lv_pnode[o + i]; st_i[2 + 2 * beam + i] = lv_ch[o + i];
+        st_i[2 + 3 * beam + i] = lv_par[o + i];
         st_f[i] = lv_b[o + i]; st_f[beam + i] = lv_nb[o + i]; st_f[2 * beam + i] = lv_sc[o + i];
     }
     if (wave == 0) {
@@ -328,23 +435,31 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 }
 
 size_t beam_gpu_lds_bytes(int beam, int K) {
-    const size_t Emax = (size_t)beam * (K + 1);
-    return Emax * 4 + (size_t)12 * beam * 4 + (size_t)2 * beam * 4 + 2 * BS_HASH * 4 + 2 * BS_KMAX * 4 + BS_WAVES * 256 * 4 +
-           BS_WAVES * 4 + 8 * 4 + 64;
+    return (size_t)beam * K * 6 + (size_t)20 * beam * 4 + 2 * BS_KMAX * 4 + 7 * 256 * 4 + (6 + 32) * BS_WAVES * 4 + 8 * 4 + 64;
+}
+
+template <int NPT>
+static void launch_beam_t(const BeamGpuArgs& a, int B, size_t lds, hipStream_t s) {
+    auto k = beam_search_kernel<NPT>;
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL(k, dim3(B), dim3(BS_THREADS), lds, s, a);
 }
 
 int launch_beam_search(const BeamGpuArgs& a, int B, hipStream_t s) {
     if (B <= 0) return 0;
-    if (a.K > BS_KMAX || a.beam > 512 || a.beam < 1 || a.pool_cap > 524000) return 1;
+    if (a.K > BS_KMAX || a.beam > 512 || a.beam < 1 || a.pool_cap > (1 << 30)) return 1;
     const size_t lds = beam_gpu_lds_bytes(a.beam, a.K);
     if (lds > 160 * 1024) return 1;
-    static size_t attr = 0;
-    if (lds > attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(beam_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-        attr = lds;
-    }
-    hipLaunchKernelGGL(beam_search_kernel, dim3(B), dim3(BS_THREADS), lds, s, a);
+    const int per = (a.beam * a.K + BS_THREADS - 1) / BS_THREADS;
+    if (per <= 4) launch_beam_t<4>(a, B, lds, s);
+    else if (per <= 12) launch_beam_t<12>(a, B, lds, s);
+    else if (per <= 20) launch_beam_t<20>(a, B, lds, s);
+    else if (per <= 32) launch_beam_t<32>(a, B, lds, s);
+    else return 1;
     return 0;
 }
 

@@ -114,12 +114,13 @@ struct BeamGpuArgs {
     int* pool_parent;      // [B][pool_cap]
     int* pool_ch;          // [B][pool_cap]
     int pool_cap;
-    int* state_i;          // [B][2 + 3 * beam]: n_live, pool_count, node[], pnode[], ch[]       (persistent streams)
+    int* state_i;          // [B][2 + 4 * beam]: n_live, pool_count, node[], pnode[], ch[], parent live index[]
     float* state_f;        // [B][3 * beam]:     b[], nb[], score[]
     int init;              // 1: start from the empty prefix; 0: continue from state_*
     int* tokens;           // [B][max_len]
     int* len;              // [B]
     float* score;          // [B]
+    long long* prof;       // optional [8] cycle counters of workgroup 0 (phase breakdown), or nullptr
 };
 size_t beam_gpu_lds_bytes(int beam, int K);
 int launch_beam_search(const BeamGpuArgs& a, int B, hipStream_t s);   // 1: sizes not supported

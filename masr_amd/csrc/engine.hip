@@ -106,7 +106,8 @@ struct masr_engine {
     std::vector<SqLayerW> sq_layers;
     std::vector<Ds2LayerW> ds2_layers;
     DevBuf gx, rnn_out, hstate, cstate, ds2_lens;
-    DevBuf beam_pool, beam_state;                                               // GPU beam search scratch                               // DeepSpeech2 workspaces
+    DevBuf beam_pool, beam_state;
+    long long* beam_prof = nullptr;                                             // debug: phase cycle counters (masr_debug_set key 2)                                               // GPU beam search scratch                               // DeepSpeech2 workspaces
     float *preln_w = nullptr, *preln_b = nullptr, *tr_dw_w = nullptr, *tr_dw_b = nullptr, *tr_pw_w = nullptr,
           *tr_pw_b = nullptr, *rec_w = nullptr, *rec_b = nullptr;
     int reduce_idx = -1, recover_idx = -1;
@@ -1142,16 +1143,17 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
     a.cidx = idx_dev; a.clp = logp_dev; a.ccount = count_dev; a.frames = frames_dev;
     a.T_stride = T_stride; a.K = K; a.beam = beam_size; a.blank = blank; a.max_len = max_len;
     a.pool_cap = T_stride * beam_size + 1;
-    if (K > 64 || beam_size > 512 || beam_size < 1 || a.pool_cap > 524000 || beam_gpu_lds_bytes(beam_size, K) > 160 * 1024)
-        return fail("beam search on the GPU needs cutoff_top_n <= 64, beam_size <= 512, beam_size*(cutoff_top_n+1) entries in "
-                    "160 KB of LDS and T*beam_size <= 524000 trie nodes; use masr_beam_search_batch (host threads) beyond that");
+    if (K > 64 || beam_size > 512 || beam_size < 1 || beam_gpu_lds_bytes(beam_size, K) > 160 * 1024)
+        return fail("beam search on the GPU needs cutoff_top_n <= 64, beam_size <= 512 and beam_size*cutoff_top_n*4 B + tables "
+                    "within 160 KB of LDS; use masr_beam_search_batch (host threads) beyond that");
     CHK(e->beam_pool.ensure((size_t)B * a.pool_cap * 2 * sizeof(int)));
-    CHK(e->beam_state.ensure((size_t)B * (2 + 6 * (size_t)beam_size) * sizeof(int)));
+    CHK(e->beam_state.ensure((size_t)B * (2 + 7 * (size_t)beam_size) * sizeof(int)));
     a.pool_parent = e->beam_pool.as<int>();
     a.pool_ch = a.pool_parent + (size_t)B * a.pool_cap;
     a.state_i = e->beam_state.as<int>();
-    a.state_f = reinterpret_cast<float*>(a.state_i + (size_t)B * (2 + 3 * (size_t)beam_size));
+    a.state_f = reinterpret_cast<float*>(a.state_i + (size_t)B * (2 + 4 * (size_t)beam_size));
     a.init = 1;
+    a.prof = e->beam_prof;
     a.tokens = tokens_dev; a.len = len_dev; a.score = score_dev;
     if (launch_beam_search(a, B, (hipStream_t)stream)) return fail("beam search launch rejected the sizes");
     HIPCHK(hipGetLastError());
@@ -1397,6 +1399,22 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
 int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     if (!e) return fail("null engine");
     if (key == 1) set_ffn_variant(value);
+    else if (key == 2) {            // beam search phase profile of workgroup 0: value 1 = on, 0 = print + off
+        if (value) {
+            if (!e->beam_prof) {
+                void* p = nullptr;
+                HIPCHK(hipMalloc(&p, 8 * sizeof(long long)));
+                e->owned.push_back(p);
+                e->beam_prof = (long long*)p;
+            }
+        } else if (e->beam_prof) {
+            long long h[8];
+            HIPCHK(hipMemcpy(h, e->beam_prof, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "beam phases (cycles, wg 0): setup+hash %lld  extensions %lld  prefixes+count %lld  select %lld  compact %lld\n",
+                    h[0], h[1], h[2], h[3], h[4]);
+            e->beam_prof = nullptr;
+        }
+    }
     else return fail("unknown debug key");
     return 0;
 }

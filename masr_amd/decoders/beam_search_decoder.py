@@ -68,8 +68,7 @@ class BeamSearchDecoder:
     def gpu_search_supported(self, T, V):
         """limits of masr_beam_search_gpu (include/masr_hip.h): LDS-resident entry table and 32-bit trie keys."""
         K = min(self.cutoff_top_n, V)
-        lds = self.beam_size * (K + 1) * 4 + 56 * self.beam_size + 17500
-        return K <= 64 and 1 <= self.beam_size <= 512 and lds <= 160 * 1024 and T * self.beam_size + 1 <= 524000
+        return K <= 64 and 2 <= self.beam_size <= 512 and self.beam_size * K * 6 + 80 * self.beam_size + 2048 <= 160 * 1024
 
     def _text(self, toks):
         return ''.join(self.vocab_list[t] for t in toks).replace('<space>', ' ')
