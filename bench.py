@@ -186,11 +186,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
-    if world > 1:
+    # MASR_BENCH_FORCE_DIST=1: take the RCCL path (init, all-gather, barriers, max over ranks) even with one rank --
+    # lets a 1-GPU box exercise the code the multi-GPU launch runs
+    force_dist = os.environ.get('MASR_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))   # RCCL
     n_gpus = world if world > 1 else 1
+    use_dist = world > 1 or force_dist
 
     from masr_amd.engine import HipEngine, subsampled_len
     from masr_amd.utils import synthetic
@@ -205,18 +209,18 @@ def main():
     Tp = subsampled_len(1 + (N_SAMPLES - 400) // 160)
     out = (torch.empty(BATCH, Tp, dtype=torch.int32, device='cuda'), torch.empty(BATCH, dtype=torch.int32, device='cuda'),
            torch.empty(BATCH, dtype=torch.float32, device='cuda'))
-    gathered = torch.empty(world * BATCH, Tp, dtype=torch.int32, device='cuda') if world > 1 else None
+    gathered = torch.empty(world * BATCH, Tp, dtype=torch.int32, device='cuda') if use_dist else None
 
     def step():
         eng.transcribe_batch(pcm, n, out=out)
-        if world > 1:   # the only exchange step: hypotheses (token ids, -1 padded), ~32 KB per rank
+        if use_dist:   # the only exchange step: hypotheses (token ids, -1 padded), ~32 KB per rank
             dist.all_gather_into_tensor(gathered, out[0])
 
     log(f'rank {rank}: engine ready, warmup {args.warmup}')
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     eng.profile_select(args.profile_kind)
     eng.profile_read(reset=True)
@@ -225,13 +229,13 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     log(f'rank {rank}: timed region done: {dt * 1e3 / args.steps:.2f} ms/step')
     prof_ms, prof_n, prof_flops = eng.profile_read(reset=True)
     eng.profile_select(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -261,7 +265,7 @@ def main():
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

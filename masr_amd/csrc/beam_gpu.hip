@@ -3,14 +3,16 @@
 // host restatement of the same algorithm and the "parity unpinned" note).
 //
 // One workgroup (1024 threads) per utterance walks the frames sequentially; everything a step needs lives in LDS:
-//   live prefixes  (<= beam):  trie node id, parent node id, live index of the parent (or -1), last character,
-//                              log P(blank end), log P(non-blank end), score
+//   live prefixes  (<= beam):  64-bit identity of the prefix STRING (hash chain over its characters) and of its parent,
+//                              back-pointer node in HBM, last character, log P(blank end), log P(non-blank end), score
 //   candidates     (<= K):     the pruned vocabulary of the frame (topk_prune_kernel), descending probability
 //   entry scores   (<= beam * K): every (prefix, character) extension, as order-preserving integer keys
 // Step (== Beam::step of beam_search.cpp, reformulated without a pointer trie):
 //   A  every live prefix p:  b_cur = lp(blank) + score(p);  nb_cur = lp(ch(p)) + nb_prev(p)        (repeat of its last char)
 //   B  every pair (p, c != blank): add = c == ch(p) ? lp(c) + b_prev(p) : lp(c) + score(p).  If the child (p, c) is itself a
-//      live prefix (p's list of live children, linked through the carried parent indices) the term is merged into that
+//      live prefix (p's list of live children: every step the live prefixes find their parent through an LDS hash of
+//      the string identities -- a prefix that was dropped and is re-created later is the SAME prefix, as in the
+//      reference's trie where dead nodes with live descendants are kept) the term is merged into that
 //      prefix's nb_cur -- a node has one parent, so at most one such term per live prefix and the two-term log-sum-exp is
 //      order independent -- otherwise it is a new entry.  Threads own (prefix, k-range): the prefix state is read once.
 //   C  score = logsumexp(b_cur, nb_cur); keep the `beam` best entries.  A valid lower bound of the beam-th best score
@@ -41,6 +43,16 @@ __device__ __forceinline__ unsigned okey(float f) {       // larger float -> lar
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+
+// identity of the prefix string: hash chain over its characters (64 bits; never 0)
+__device__ __forceinline__ unsigned long long str_hash(unsigned long long parent, int ch) {
+    unsigned long long z = parent * 0x9E3779B97F4A7C15ull + (unsigned long long)(ch + 2) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z ? z : 1ull;
+}
+static constexpr int BS_HASH = 1024;
 
 // inclusive wave64 prefix sum with DPP row shifts / row broadcasts (6 VALU ops, no LDS crossbar traffic)
 __device__ __forceinline__ int wave_scan_incl(int v) {
@@ -123,10 +135,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     const int beam = a.beam, K = a.K;
     // ---- LDS carve-up --------------------------------------------------------------------------------
     unsigned* ekeys = reinterpret_cast<unsigned*>(smem_raw);             // [beam * K] extension keys, index p * cnt + k
-    int* lv_node = reinterpret_cast<int*>(ekeys + beam * K);             // [2][beam] each
-    int* lv_pnode = lv_node + 2 * beam;
-    int* lv_par = lv_pnode + 2 * beam;
-    int* lv_ch = lv_par + 2 * beam;
+    unsigned long long* lv_hid = reinterpret_cast<unsigned long long*>(ekeys + ((beam * K + 1) & ~1));   // [2][beam] each
+    unsigned long long* lv_phid = lv_hid + 2 * beam;
+    unsigned long long* hkey = lv_phid + 2 * beam;                       // [BS_HASH] string identity -> live index
+    int* hval = reinterpret_cast<int*>(hkey + BS_HASH);                  // [BS_HASH]
+    int* lv_node = hval + BS_HASH;
+    int* lv_ch = lv_node + 2 * beam;
     float* lv_b = reinterpret_cast<float*>(lv_ch + 2 * beam);
     float* lv_nb = lv_b + 2 * beam;
     float* lv_sc = lv_nb + 2 * beam;
@@ -135,8 +149,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     float* ext = rep + beam;                                            // [beam] parent-extension term of nb_cur
     int* head = reinterpret_cast<int*>(ext + beam);                      // [beam] first live child
     int* next = head + beam;                                             // [beam] next live child of the same parent
-    int* newslot = next + beam;                                          // [beam] old live index -> new live index / -1
-    int* c_idx = newslot + beam;                                         // [BS_KMAX]
+    int* c_idx = next + beam;                                            // [BS_KMAX]
     float* c_lp = reinterpret_cast<float*>(c_idx + BS_KMAX);             // [BS_KMAX]
     int* hist = reinterpret_cast<int*>(c_lp + BS_KMAX);                  // [7][256]: one per radix pass of a step
     int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
@@ -145,8 +158,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 
     int* pool_parent = a.pool_parent + (size_t)u * a.pool_cap;
     int* pool_ch = a.pool_ch + (size_t)u * a.pool_cap;
-    int* st_i = a.state_i + (size_t)u * (2 + 4 * beam);
+    int* st_i = a.state_i + (size_t)u * (2 + 2 * beam);
     float* st_f = a.state_f + (size_t)u * (3 * beam);
+    unsigned long long* st_h = a.state_h + (size_t)u * (2 * beam);
 
     int n, pool_count, cur = 0;
     if (a.init) {
@@ -155,15 +169,15 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         if (tid == 0) {
             pool_parent[0] = -1;
             pool_ch[0] = -1;
-            lv_node[0] = 0; lv_pnode[0] = -1; lv_par[0] = -1; lv_ch[0] = -1;
+            lv_node[0] = 0; lv_ch[0] = -1; lv_hid[0] = 0x1234567887654321ull; lv_phid[0] = 0ull;
             lv_b[0] = 0.f; lv_nb[0] = -INFINITY; lv_sc[0] = 0.f;
         }
     } else {
         n = st_i[0];
         pool_count = st_i[1];
         for (int i = tid; i < n; i += BS_THREADS) {
-            lv_node[i] = st_i[2 + i]; lv_pnode[i] = st_i[2 + beam + i]; lv_ch[i] = st_i[2 + 2 * beam + i];
-            lv_par[i] = st_i[2 + 3 * beam + i];
+            lv_node[i] = st_i[2 + i]; lv_ch[i] = st_i[2 + beam + i];
+            lv_hid[i] = st_h[i]; lv_phid[i] = st_h[beam + i];
             lv_b[i] = st_f[i]; lv_nb[i] = st_f[beam + i]; lv_sc[i] = st_f[2 * beam + i];
         }
     }
@@ -191,6 +205,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         // ---- 0. candidates -> LDS, clear tables; prefetch the next frame -------------------------------------
         for (int i = tid; i < 7 * 256; i += BS_THREADS) hist[i] = 0;
         if (tid < n) { rep[tid] = -INFINITY; ext[tid] = -INFINITY; head[tid] = -1; }
+        if (tid < BS_HASH) hkey[tid] = 0ull;
         if (wave == 0) {
             const bool isb = lane < cnt && nx_c == a.blank;
             const unsigned long long bm = __ballot(isb);
@@ -205,9 +220,24 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         // ---- 1. live children lists; blank term ------------------------------------------------------------------
         const int blank_k = misc[0];
         if (tid < n) {
-            const int par = lv_par[o + tid];
-            if (par >= 0) next[tid] = atomicExch(&head[par], tid);
+            const unsigned long long key = lv_hid[o + tid];
+            unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
+            while (atomicCAS(&hkey[h], 0ull, key) != 0ull) h = (h + 1) & (BS_HASH - 1);
+            hval[h] = tid;
             bcur[tid] = blank_k >= 0 ? c_lp[blank_k] + lv_sc[o + tid] : -INFINITY;
+        }
+        __syncthreads();
+        if (tid < n) {                                  // is my parent prefix live?  then I am on its children list
+            const unsigned long long key = lv_phid[o + tid];
+            unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
+            int par = -1;
+            while (key != 0ull) {
+                const unsigned long long hk = hkey[h];
+                if (hk == key) { par = hval[h]; break; }
+                if (hk == 0ull) break;
+                h = (h + 1) & (BS_HASH - 1);
+            }
+            if (par >= 0) next[tid] = atomicExch(&head[par], tid);
         }
         __syncthreads();
         BS_TICK(0);
@@ -332,7 +362,6 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         if (tid < n) {
             const int gb = exE & 0xffff, eb = exE >> 16;
             if (kx > thr || (kx == thr && kx != 0 && eb < need_eq)) my_slot = gb + min(eb, need_eq);
-            newslot[tid] = my_slot;
         }
         const int need_eq_new = need_eq - eq_take_E;
         // list order = index order of the re-dealt items: item idx = tid + i * 1024 -> scan row by row
@@ -351,12 +380,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             }
         }
         n_new = gbase + min(ebase, need_eq_new);
-        if (nsurv == 0) __syncthreads();                                // publish newslot[] even without a scan
         if (my_slot >= 0) {
-            const int par = lv_par[o + tid];
             lv_node[o2 + my_slot] = lv_node[o + tid];
-            lv_pnode[o2 + my_slot] = lv_pnode[o + tid];
-            lv_par[o2 + my_slot] = par >= 0 ? newslot[par] : -1;
+            lv_hid[o2 + my_slot] = lv_hid[o + tid];
+            lv_phid[o2 + my_slot] = lv_phid[o + tid];
             lv_ch[o2 + my_slot] = lv_ch[o + tid];
             lv_b[o2 + my_slot] = bcur[tid];
             lv_nb[o2 + my_slot] = my_nb;
@@ -379,8 +406,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                         pool_ch[node] = c;
                     }
                     lv_node[o2 + slot] = node;
-                    lv_pnode[o2 + slot] = lv_node[o + p];
-                    lv_par[o2 + slot] = newslot[p];
+                    lv_hid[o2 + slot] = str_hash(lv_hid[o + p], c);
+                    lv_phid[o2 + slot] = lv_hid[o + p];
                     lv_ch[o2 + slot] = c;
                     lv_b[o2 + slot] = -INFINITY;
                     lv_nb[o2 + slot] = add;
@@ -401,8 +428,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     const int o = cur * beam;
     if (tid == 0) { st_i[0] = n; st_i[1] = pool_count; }
     for (int i = tid; i < n; i += BS_THREADS) {
-        st_i[2 + i] = lv_node[o + i]; st_i[2 + beam + i] = lv_pnode[o + i]; st_i[2 + 2 * beam + i] = lv_ch[o + i];
-        st_i[2 + 3 * beam + i] = lv_par[o + i];
+        st_i[2 + i] = lv_node[o + i]; st_i[2 + beam + i] = lv_ch[o + i];
+        st_h[i] = lv_hid[o + i]; st_h[beam + i] = lv_phid[o + i];
         st_f[i] = lv_b[o + i]; st_f[beam + i] = lv_nb[o + i]; st_f[2 * beam + i] = lv_sc[o + i];
     }
     if (wave == 0) {
@@ -435,7 +462,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 }
 
 size_t beam_gpu_lds_bytes(int beam, int K) {
-    return (size_t)beam * K * 6 + (size_t)20 * beam * 4 + 2 * BS_KMAX * 4 + 7 * 256 * 4 + (6 + 32) * BS_WAVES * 4 + 8 * 4 + 64;
+    return (size_t)beam * K * 6 + (size_t)26 * beam * 4 + BS_HASH * 12 + 2 * BS_KMAX * 4 + 7 * 256 * 4 + (6 + 32) * BS_WAVES * 4 + 8 * 4 + 128;
 }
 
 template <int NPT>

@@ -43,8 +43,9 @@ void launch_conv1(const float* feats, const float* mean, const float* istd, cons
                   float* out, int B, int T, int F, int C, hipStream_t s);
 // depthwise causal conv (k taps) + LayerNorm(C=256) + SiLU on padded layout [nseq, pad+Tq, 256] -> [nseq*Tq, 256]
 void launch_dwconv_ln_silu(const float* g, const float* wkc, const float* bias, const float* lnw, const float* lnb,
-                           float* out, int nseq, int Tq, int ktaps, float eps, hipStream_t s);
+                           float* out, int nseq, int Tq, int ktaps, float eps, hipStream_t s, const float* gconst = nullptr);
 // same with an eval-mode BatchNorm folded into a per-channel scale/shift instead of the LayerNorm
+void launch_glu_const(const float* bias512, float* out256, hipStream_t s);
 void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, const float* scale, const float* shift,
                            float* out, int nseq, int Tq, int ktaps, hipStream_t s);
 // Efficient-Conformer stride layer: depthwise causal conv with stride 2 (+ LayerNorm + SiLU) on the padded layout
@@ -114,7 +115,8 @@ struct BeamGpuArgs {
     int* pool_parent;      // [B][pool_cap]
     int* pool_ch;          // [B][pool_cap]
     int pool_cap;
-    int* state_i;          // [B][2 + 4 * beam]: n_live, pool_count, node[], pnode[], ch[], parent live index[]
+    int* state_i;          // [B][2 + 2 * beam]: n_live, pool_count, node[], ch[]                (persistent streams)
+    unsigned long long* state_h;   // [B][2 * beam]: string identity of the prefix and of its parent
     float* state_f;        // [B][3 * beam]:     b[], nb[], score[]
     int init;              // 1: start from the empty prefix; 0: continue from state_*
     int* tokens;           // [B][max_len]

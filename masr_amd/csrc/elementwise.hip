@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const float* __rest
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ lnw,
                                                              const float* __restrict__ lnb, float* __restrict__ out,
-                                                             int Tq, float eps) {
+                                                             int Tq, float eps, const float* __restrict__ gconst) {
     __shared__ __align__(16) float tile[DW_TT][256 + 4];
     const int tiles = (Tq + DW_TT - 1) / DW_TT;
     const int seq = blockIdx.x / tiles;
@@ -134,8 +134,11 @@ __global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const float* __rest
     const float bv = bias[c];
     const int nrows = min(DW_TT, Tq - t0);
     win[0] = 0.f;
+    // gconst != nullptr (offline causal conv): the KT-1 history rows of every sequence are not materialised -- they all
+    // equal glu(pointwise_conv1.bias), the image of the reference's zero left-padding (convolution.py:101-104,118-119)
+    const float gc = gconst ? gconst[c] : 0.f;
 #pragma unroll
-    for (int j = 0; j < KT - 1; ++j) win[j + 1] = gin[(size_t)j * 256];
+    for (int j = 0; j < KT - 1; ++j) win[j + 1] = (gconst && t0 + j < pad) ? gc : gin[(size_t)j * 256];
     for (int r = 0; r < nrows; ++r) {
 #pragma unroll
         for (int j = 0; j < KT - 1; ++j) win[j] = win[j + 1];
@@ -172,13 +175,23 @@ __global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const float* __rest
 }
 
 void launch_dwconv_ln_silu(const float* g, const float* wkc, const float* bias, const float* lnw, const float* lnb,
-                           float* out, int nseq, int Tq, int ktaps, float eps, hipStream_t s) {
+                           float* out, int nseq, int Tq, int ktaps, float eps, hipStream_t s, const float* gconst) {
     if (nseq * Tq <= 0) return;
     const int tiles = (Tq + DW_TT - 1) / DW_TT;
     const dim3 grid(nseq * tiles), blk(256);
-    if (ktaps == 15) hipLaunchKernelGGL((dwconv_ln_silu_kernel<15, 0>), grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
-    else if (ktaps == 7) hipLaunchKernelGGL((dwconv_ln_silu_kernel<7, 0>), grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
-    else if (ktaps == 31) hipLaunchKernelGGL((dwconv_ln_silu_kernel<31, 0>), grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps);
+    if (ktaps == 15) hipLaunchKernelGGL((dwconv_ln_silu_kernel<15, 0>), grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps, gconst);
+    else if (ktaps == 7) hipLaunchKernelGGL((dwconv_ln_silu_kernel<7, 0>), grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps, gconst);
+    else if (ktaps == 31) hipLaunchKernelGGL((dwconv_ln_silu_kernel<31, 0>), grid, blk, 0, s, g, wkc, bias, lnw, lnb, out, Tq, eps, gconst);
+}
+
+// glu(bias) of pointwise_conv1 with the arithmetic of the rowgemm GLU epilogue: the constant history rows of the offline
+// causal conv module
+__global__ void glu_const_kernel(const float* __restrict__ bias, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    out[c] = bias[c] * __builtin_amdgcn_rcpf(1.0f + __expf(-bias[256 + c]));
+}
+void launch_glu_const(const float* bias512, float* out256, hipStream_t s) {
+    hipLaunchKernelGGL(glu_const_kernel, dim3(1), dim3(256), 0, s, bias512, out256);
 }
 
 void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, const float* scale, const float* shift,
@@ -186,8 +199,8 @@ void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, 
     if (nseq * Tq <= 0) return;
     const int tiles = (Tq + DW_TT - 1) / DW_TT;
     const dim3 grid(nseq * tiles), blk(256);
-    if (ktaps == 31) hipLaunchKernelGGL((dwconv_ln_silu_kernel<31, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f);
-    else if (ktaps == 15) hipLaunchKernelGGL((dwconv_ln_silu_kernel<15, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f);
+    if (ktaps == 31) hipLaunchKernelGGL((dwconv_ln_silu_kernel<31, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f, (const float*)nullptr);
+    else if (ktaps == 15) hipLaunchKernelGGL((dwconv_ln_silu_kernel<15, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f, (const float*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

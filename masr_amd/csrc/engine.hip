@@ -59,7 +59,7 @@ struct DevBuf {
 struct LayerW {
     float *ln_ffm_w, *ln_ffm_b, *ffm_w1, *ffm_b1, *ffm_w2, *ffm_b2;
     float *ln_mha_w, *ln_mha_b, *wqkv, *bqkv, *wo, *bo, *pos_u, *pos_v, *wpos, *ptab;
-    float *ln_conv_w, *ln_conv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *cln_w, *cln_b, *pw2_w, *pw2_b;
+    float *ln_conv_w, *ln_conv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *cln_w, *cln_b, *pw2_w, *pw2_b, *gconst;
     float *ln_ff_w, *ln_ff_b, *ff_w1, *ff_b1, *ff_w2, *ff_b2;
     float *ln_fin_w, *ln_fin_b;
 };
@@ -451,6 +451,11 @@ int masr_finalize(masr_engine* e, void* stream) {
         CHK(up(e, p + "self_attn.pos_bias_v", {H, gk}, &w.pos_v));
         CHK(up(e, p + "conv_module.pointwise_conv1.weight", {2 * d, d, 1}, &w.pw1_w));   // rows: value c, gate d + c
         CHK(up(e, p + "conv_module.pointwise_conv1.bias", {2 * d}, &w.pw1_b));
+        {   // glu(bias): what the zero left-padding of the causal conv turns into behind pointwise_conv1 + GLU
+            std::vector<float> z(d, 0.f);
+            CHK(upload(e, z, &w.gconst));
+            launch_glu_const(w.pw1_b, w.gconst, (hipStream_t)stream);
+        }
         {   // depthwise [d,1,K_i] -> [K_i][d]
             const int K = layer_kernel(e, i);
             CHK(get(e, p + "conv_module.depthwise_conv.weight", {d, 1, K}, &t));
@@ -567,11 +572,13 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
                 e->glu.as<float>(), d, Mp, 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
     } else {
+        // only the real rows go through the GEMM (M = nseq*Tq: 248 workgroups at B=32 x 10 s, one per CU); they land in the
+        // padded layout, whose history rows are the constant glu(bias) that the depthwise kernel substitutes itself
         rowgemm(e, s, RG_PRO_LN_PAD, RG_EPI_GLU, x, d, w.ln_conv_w, w.ln_conv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d,
-                Mp, 2 * d, nullptr, 0, 1.f, c.lens, 0, c.Tq, pad, nullptr, nullptr, PROF_GEMM, mstride);
+                M, 2 * d, nullptr, 0, 1.f, c.lens, 0, c.Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, c.Tq, pad, pad);
     }
     launch_dwconv_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), c.nseq, c.Tq, K,
-                          1e-5f, s);
+                          1e-5f, s, hist ? nullptr : w.gconst);
     rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x, d,
             1.f, c.lens, c.lens ? c.Tq : 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
     return 0;
@@ -1147,11 +1154,12 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
         return fail("beam search on the GPU needs cutoff_top_n <= 64, beam_size <= 512 and beam_size*cutoff_top_n*4 B + tables "
                     "within 160 KB of LDS; use masr_beam_search_batch (host threads) beyond that");
     CHK(e->beam_pool.ensure((size_t)B * a.pool_cap * 2 * sizeof(int)));
-    CHK(e->beam_state.ensure((size_t)B * (2 + 7 * (size_t)beam_size) * sizeof(int)));
+    CHK(e->beam_state.ensure((size_t)B * (4 + 9 * (size_t)beam_size) * sizeof(int)));
     a.pool_parent = e->beam_pool.as<int>();
     a.pool_ch = a.pool_parent + (size_t)B * a.pool_cap;
-    a.state_i = e->beam_state.as<int>();
-    a.state_f = reinterpret_cast<float*>(a.state_i + (size_t)B * (2 + 4 * (size_t)beam_size));
+    a.state_h = e->beam_state.as<unsigned long long>();                    // [B][2*beam] u64, then ints, then floats
+    a.state_i = reinterpret_cast<int*>(a.state_h + (size_t)B * 2 * beam_size);
+    a.state_f = reinterpret_cast<float*>(a.state_i + (size_t)B * (2 + 2 * (size_t)beam_size));
     a.init = 1;
     a.prof = e->beam_prof;
     a.tokens = tokens_dev; a.len = len_dev; a.score = score_dev;

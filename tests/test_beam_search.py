@@ -158,3 +158,19 @@ def test_gpu_prefix_search_peaked_equals_greedy_and_oracle():
     s_ref, t_ref = obs.decode(probs[:60], vocab, 16, 1.0, 40)
     g2, _ = _gpu_vs_host([probs[:60]], 16, 1.0, 40)
     assert g2[0][1] == t_ref and abs(g2[0][0] - s_ref) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed,beam', [(0, 2), (1, 3), (2, 5), (3, 10), (4, 10), (5, 16)])
+def test_gpu_prefix_search_small_beam_revived_prefixes(seed, beam):
+    """few dominant symbols + a small beam: prefixes are dropped and re-created all the time while their extensions stay
+    live -- a re-created prefix must be the SAME prefix (the reference keeps dead trie nodes that have live descendants)"""
+    rng = np.random.default_rng(100 + seed)
+    V, T = 24, 150
+    alpha = np.full(V, 0.03)
+    alpha[[0, 3, 7]] = 1.5
+    probs = [rng.dirichlet(alpha, size=T).astype(np.float32), rng.dirichlet(alpha, size=T // 2).astype(np.float32)]
+    gpu, host = _gpu_vs_host(probs, beam, 0.99, 40)
+    for (sg, tg), (sh, th) in zip(gpu, host):
+        assert tg == th
+        assert abs(sg - sh) < 1e-3 * max(1.0, abs(sh))
