@@ -45,7 +45,7 @@ __device__ __forceinline__ float wsum64(float v) {
 // (Measured with per-slab barriers: 54-57 % MFMA-busy, ~450 cycles of barrier skew + ~800 cycles of
 //  exposed L2 latency per 2048-cycle slab.)
 // VAR (diagnostic ablations, production = 0): 1 = no global weight loads, 2 = no MFMA, 3 = no LDS stores of weights
-template <int VAR, int AFFINE>
+template <int VAR, int AFFINE, int SPLIT>
 __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* __restrict__ lnw,
                                                         const float* __restrict__ lnb, const float* __restrict__ w1,
                                                         const float* __restrict__ b1, const float* __restrict__ w2,
@@ -103,8 +103,9 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
     //   j >= 4 : W2[32*wave + r][chunk*128 + 32(j-4) .. +31]
     // NSET register sets in rotation: in iteration s set (s+1)%NSET (slab s+1) is written to LDS buffer (s+1)&1
     // and then refilled with slab s+1+NSET; the other sets hold slabs s+2 .. s+NSET in flight.
-    const int chunk_lo = partial ? blockIdx.y * chunks_per_block : 0;
-    const int chunk_hi = partial ? min(chunk_lo + chunks_per_block, dff / FF_CH) : dff / FF_CH;
+    // SPLIT is a template parameter so that the full-M kernel keeps compile-time chunk bookkeeping (chunk_lo == 0)
+    const int chunk_lo = SPLIT ? blockIdx.y * chunks_per_block : 0;
+    const int chunk_hi = SPLIT ? min(chunk_lo + chunks_per_block, dff / FF_CH) : dff / FF_CH;
     const int lr8 = lane >> 3, lc4 = (lane & 7) * 4;
     f32x4 pre[NSET][4];   // register sets in rotation: slab s+1 (-> LDS), s+2 .. s+NSET in flight
     auto src_of = [&](int chunk, int j, int i) -> const float* {   // j is a compile-time constant at every call
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
     // ---- epilogue: x <- x + scale * (acc2 + b2) ---------------------------------------------------------
     {
         const int col = wave * 32 + frow;
-        if (partial) {
+        if (SPLIT) {
             float* pp = partial + (size_t)blockIdx.y * M * FF_D;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -282,7 +283,9 @@ static void launch_ffn_t(float* x, const float* lnw, const float* lnb, const flo
     const size_t lds = (size_t)(FF_BM * XN_LD + 2 * FF_BM * HS_LD + 8 * 2 * WSLAB + 8 * 8 * 64) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fused_kernel<VAR, AFFINE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fused_kernel<VAR, AFFINE, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fused_kernel<VAR, AFFINE, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
@@ -290,12 +293,12 @@ static void launch_ffn_t(float* x, const float* lnw, const float* lnb, const flo
     if (partial && nsplit > 1) {
         const int cpb = (nchunk + nsplit - 1) / nsplit;
         const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
-        hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE>), dim3((M + FF_BM - 1) / FF_BM, ny), dim3(512), lds, s, x, lnw,
+        hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE, 1>), dim3((M + FF_BM - 1) / FF_BM, ny), dim3(512), lds, s, x, lnw,
                            lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, cpb);
         hipLaunchKernelGGL(ffn_reduce_kernel, dim3((unsigned)(((size_t)M * FF_D / 4 + 255) / 256)), dim3(256), 0, s, x, partial,
                            b2, M, ny, scale);
     } else {
-        hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE>), dim3((M + FF_BM - 1) / FF_BM), dim3(512), lds, s, x, lnw, lnb, w1,
+        hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE, 0>), dim3((M + FF_BM - 1) / FF_BM), dim3(512), lds, s, x, lnw, lnb, w1,
                            b1, w2, b2, M, dff, eps, scale, (float*)nullptr, 0);
     }
 }
