@@ -12,7 +12,7 @@ namespace masr {
 // ---- GEMM: C[M,N] = epilogue(A[M,K] * W[N,K]^T) on v_mfma_f32_32x32x2_f32 ----------------
 enum GemmAct { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 enum GemmAMode { A_PLAIN = 0, A_CONV2 = 1 };
-enum GemmEpi { EPI_STD = 0, EPI_GLU = 1 };
+enum GemmEpi { EPI_STD = 0, EPI_GLU = 1, EPI_SPLITK = 2 };
 
 struct GemmArgs {
     const float* A;      // [M, lda] row-major (A_PLAIN) or conv1 activations [B,T1,F1,C] (A_CONV2)
@@ -29,9 +29,12 @@ struct GemmArgs {
     int bias_after_alpha; // 1: out = R + alpha*act(acc) + bias  (Squeezeformer input_proj: scaling precedes the Linear)
     // A_CONV2 geometry: row m -> (b, t2, f2) with m = (b*T2 + t2)*F2 + f2 ; k -> (kh, kw*C + c)
     int T1, F1, T2, F2, Cc;
+    int nsplit, ksplit;  // EPI_SPLITK: number of K ranges (gridDim.y) and BK-slabs per range
 };
 
 void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s);
+// deep-K, few-row GEMM: split K over workgroups into `partial` [nsplit][M][N], then reduce + epilogue into a.C
+void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream_t s);
 
 // ---- elementwise / reductions ------------------------------------------------------------
 // LayerNorm over rows of width 256.  If seq_t > 0 the output row is remapped to

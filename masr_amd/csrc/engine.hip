@@ -539,7 +539,14 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
         a.M = M; a.N = d; a.K = F2 * d; a.act = ACT_NONE; a.alpha = sqrtf((float)d);
         a.bias_after_alpha = e->cfg.model_kind == 1 ? 1 : 0;
         ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)d * F2 * d);
-        launch_gemm(a, A_PLAIN, EPI_STD, s);
+        const int tiles = ((M + 63) / 64) * ((d + 63) / 64);
+        if (tiles < 128) {              // few rows, K = 4864: split K so that ~256 workgroups share the weight stream
+            const int nsplit = std::min(F2 * d / 32, std::max(2, 256 / tiles));
+            CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
+            launch_gemm_splitk(a, e->ffpart.as<float>(), nsplit, s);
+        } else {
+            launch_gemm(a, A_PLAIN, EPI_STD, s);
+        }
     }
     *Tq_out = Tq;
     return 0;

@@ -23,6 +23,9 @@ static constexpr int LDP = 36;   // padded LDS row (floats)
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// EPI_SPLITK: blockIdx.y owns a contiguous range of K slabs and stores its raw partial tile to p.C + blockIdx.y*M*ldc
+// (p.ksplit slabs per range); splitk_reduce_kernel applies the epilogue.  For M so small that the tile grid cannot fill
+// the chip while K is deep (embed projection of a streaming chunk step: M = 256, K = 4864).
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     static_assert(WM * WN == 4, "4 waves");
@@ -115,15 +118,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const int KT = p.K / BK;
-    load_slab(0);
+    const int kt_lo = EPI == EPI_SPLITK ? (int)blockIdx.y * p.ksplit : 0;
+    const int KT = EPI == EPI_SPLITK ? min(kt_lo + p.ksplit, p.K / BK) : p.K / BK;
+    load_slab(kt_lo);
     store_slab(0);
     __syncthreads();
 
     const int frow = lane & 31;
     const int fcol = (lane >> 5) * 4;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt_lo; kt < KT; ++kt) {
+        const int buf = (kt - kt_lo) & 1;
         if (kt + 1 < KT) load_slab(kt + 1);
         const float* Ab = &As[(buf * BM + wm * (BM / WM) + frow) * LDP + fcol];
         const float* Wb = &Ws[(buf * BN + wn * (BN / WN) + frow) * LDP + fcol];
@@ -150,6 +154,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     const int ccol = lane & 31;
     const int rbase = 4 * (lane >> 5);
+    if (EPI == EPI_SPLITK) {
+        float* cp = p.C + (size_t)blockIdx.y * p.M * p.ldc;
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = bn + wn * (BN / WN) + n * 32 + ccol;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = bm + wm * (BM / WM) + m * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (row < p.M) cp[(size_t)row * p.ldc + col] = acc[m][n][r];
+                }
+        }
+    }
     if (EPI == EPI_STD) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
@@ -193,13 +212,34 @@ static void launch_t(const GemmArgs& a, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(nbm * nbn), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(nbm * nbn, EPI == EPI_SPLITK ? a.nsplit : 1), dim3(256), lds, s, a);
+}
+
+// out = R + alpha * act(sum_s partial[s] + bias) [+ bias after alpha]; partials added in ascending s (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p, const float* __restrict__ partial, float* out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)p.M * p.N) return;
+    const int row = (int)(i / p.N), col = (int)(i - (size_t)row * p.N);
+    float acc = 0.f;
+    for (int sp = 0; sp < p.nsplit; ++sp) acc += partial[((size_t)sp * p.M + row) * p.N + col];
+    const float bv = p.bias ? p.bias[col] : 0.f;
+    float v = acc + (p.bias_after_alpha ? 0.f : bv);
+    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (p.act == ACT_SILU) v = silu_f(v);
+    const float r = p.R ? p.R[(size_t)row * p.ldr + col] : 0.f;
+    out[(size_t)row * p.ldc + col] = r + v * p.alpha + (p.bias_after_alpha ? bv : 0.f);
 }
 
 void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
     if (amode == A_CONV2) {
-        launch_t<128, 128, 2, 2, A_CONV2, EPI_STD>(a, s);
+        // few output rows (streaming chunk steps): 64x64 tiles so that the grid still covers the chip
+        if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 200) launch_t<64, 64, 2, 2, A_CONV2, EPI_STD>(a, s);
+        else launch_t<128, 128, 2, 2, A_CONV2, EPI_STD>(a, s);
+        return;
+    }
+    if (epi == EPI_SPLITK) {            // caller set a.C = partial buffer, a.nsplit, a.ksplit
+        launch_t<64, 64, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
         return;
     }
     // Tile choice: fill >= 256 CUs.  128x128 when that already yields enough workgroups,
@@ -209,6 +249,20 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     if (t128 >= 384) launch_t<128, 128, 2, 2, A_PLAIN, EPI_STD>(a, s);
     else if (t64 >= 200) launch_t<64, 128, 2, 2, A_PLAIN, EPI_STD>(a, s);
     else launch_t<64, 64, 2, 2, A_PLAIN, EPI_STD>(a, s);
+}
+
+void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return;
+    GemmArgs b = a;
+    const int kts = a.K / BK;
+    b.ksplit = (kts + nsplit - 1) / nsplit;
+    b.nsplit = (kts + b.ksplit - 1) / b.ksplit;          // every range owns at least one slab
+    b.C = partial;
+    b.ldc = a.N;
+    launch_gemm(b, A_PLAIN, EPI_SPLITK, s);
+    GemmArgs r = a;
+    r.nsplit = b.nsplit;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)a.M * a.N + 255) / 256)), dim3(256), 0, s, r, partial, a.C);
 }
 
 }  // namespace masr

@@ -32,7 +32,9 @@ __device__ __forceinline__ float rg_wsum(float v) {
     return v;
 }
 
-template <int PRO, int EPI>
+// GSPLIT = 1 (few row blocks, streaming chunk steps): blockIdx.y owns ONE column group of 256, so that e.g. the fused
+// QKV projection of 16 streams x 16 frames runs on 8 x 3 workgroups with one MFMA tile (8 weight slabs) per wave
+template <int PRO, int EPI, int GSPLIT>
 __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
     extern __shared__ __align__(16) float sm[];
     float* at = sm;                               // [32][260] A tile
@@ -114,10 +116,11 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
     // ---- weight tile stream: tile t = 32 weight rows starting at wrow(t), 8 slabs of 32 k -------------
     // EPI_GLU: tiles come in (value, gate) pairs -> tile 2g = rows 32w.., tile 2g+1 = rows 256 + 32w..
     const int ngroups = (EPI == RG_EPI_GLU) ? 1 : (p.N + 255) / 256;
-    const int ntiles = (EPI == RG_EPI_GLU) ? 2 : ngroups;
+    const int ntiles = (EPI == RG_EPI_GLU) ? 2 : (GSPLIT ? 1 : ngroups);
+    const int tbase = GSPLIT ? (int)blockIdx.y : 0;
     auto wrow_of = [&](int t) -> int {
         if (EPI == RG_EPI_GLU) return (t & 1) * 256 + wave * 32;
-        return t * 256 + wave * 32;
+        return (tbase + t) * 256 + wave * 32;
     };
     const int lr8 = lane >> 3, lc4 = (lane & 7) * 4;
     f32x4 pre[RG_NSET][4];
@@ -308,13 +311,21 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
 template <int PRO, int EPI>
 static void launch_rg(const RowGemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(RG_BM * RG_ALD + 8 * 2 * RG_WSLAB + 8 * RG_BM * 3) * sizeof(float);
+    constexpr bool can_split = EPI == RG_EPI_STORE || EPI == RG_EPI_RESID;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_kernel<PRO, EPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_kernel<PRO, EPI, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (can_split)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_kernel<PRO, EPI, can_split ? 1 : 0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI>), dim3((a.M + RG_BM - 1) / RG_BM), dim3(512), lds, s, a);
+    const int rowblocks = (a.M + RG_BM - 1) / RG_BM, ngroups = (a.N + 255) / 256;
+    if (can_split && ngroups > 1 && rowblocks < 64)
+        hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI, can_split ? 1 : 0>), dim3(rowblocks, ngroups), dim3(512), lds, s, a);
+    else
+        hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI, 0>), dim3(rowblocks), dim3(512), lds, s, a);
 }
 
 void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
