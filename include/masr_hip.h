@@ -136,6 +136,18 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
                          int32_t blank, int32_t* tokens_dev, int32_t max_len, int32_t* len_dev, float* score_dev,
                          void* stream);
 
+/* Streaming variant: a device-resident search per stream.  masr_gbeam_advance consumes the pruned candidates of the next T
+ * frames (device arrays from masr_ctc_topk) and returns the best prefix so far (tokens/len/score device arrays); the
+ * live prefixes and the trie nodes stay on the device between calls.  Replaces CTCBeamSearchDecoder.next / decode / reset
+ * of the third-party module (masr/decoders/swig_wrapper.py:106-121, beam_search_decoder.py:75-96), LM-free.
+ * max_frames bounds the number of frames of one utterance (trie node pool = max_frames * beam_size). */
+int masr_gbeam_open(masr_engine* e, int32_t beam_size, int32_t blank, int32_t max_frames, int32_t* handle);
+int masr_gbeam_advance(masr_engine* e, int32_t handle, const int32_t* idx_dev, const float* logp_dev,
+                       const int32_t* count_dev, int32_t T, int32_t K, int32_t* tokens_dev, int32_t max_len,
+                       int32_t* len_dev, float* score_dev, void* stream);
+int masr_gbeam_reset(masr_engine* e, int32_t handle);
+int masr_gbeam_close(masr_engine* e, int32_t handle);
+
 /* One call for the whole offline hot path (MASRPredictor.predict semantics, masr/predict.py:167-192,
  * batched like MASRTrainer.evaluate, trainer.py:632): PCM -> fbank -> encoder -> CTC greedy.
  * decode_all_frames != 0 reproduces the reference batch quirk of decoding padded frames. */

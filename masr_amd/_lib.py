@@ -48,6 +48,10 @@ SIGNATURES = {
     'masr_beam_result': [_P, _P, _I, C.POINTER(_I), C.POINTER(_F)],
     'masr_beam_search_batch': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     'masr_beam_search_gpu': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P],
+    'masr_gbeam_open': [_P, _I, _I, _I, C.POINTER(_I)],
+    'masr_gbeam_advance': [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P],
+    'masr_gbeam_reset': [_P, _I],
+    'masr_gbeam_close': [_P, _I],
     'masr_transcribe_batch': [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     'masr_stream_open': [_P, _I, C.POINTER(_I)],
     'masr_stream_reset': [_P, _I],

@@ -89,6 +89,12 @@ struct Stream {
     DevBuf cnn;  // [L][kernel-1][d]   (DeepSpeech2: LSTM state [L][2 (h, c)][rnn_size])
 };
 
+struct GBeam {        // device-resident streaming CTC prefix beam search (masr_gbeam_*)
+    bool open = false, started = false;
+    int beam = 0, blank = 0, cap = 0;
+    DevBuf pool, state;
+};
+
 enum ProfKind { PROF_NONE = 0, PROF_GEMM = 1, PROF_FFN1 = 2, PROF_CONV2 = 3, PROF_ATT = 4, PROF_FBANK = 5 };
 
 }  // namespace
@@ -106,6 +112,7 @@ struct masr_engine {
     std::vector<SqLayerW> sq_layers;
     std::vector<Ds2LayerW> ds2_layers;
     DevBuf gx, rnn_out, hstate, cstate, ds2_lens;
+    std::vector<GBeam> gbeams;
     DevBuf beam_pool, beam_state;
     long long* beam_prof = nullptr;                                             // debug: phase cycle counters (masr_debug_set key 2)                                               // GPU beam search scratch                               // DeepSpeech2 workspaces
     float *preln_w = nullptr, *preln_b = nullptr, *tr_dw_w = nullptr, *tr_dw_b = nullptr, *tr_pw_w = nullptr,
@@ -320,6 +327,10 @@ void masr_destroy(masr_engine* e) {
     for (auto& s : e->streams) {
         s.att.release();
         s.cnn.release();
+    }
+    for (auto& g : e->gbeams) {
+        g.pool.release();
+        g.state.release();
     }
     for (auto& ev : e->prof_events) {
         (void)hipEventDestroy(ev.first);
@@ -1172,6 +1183,83 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
     a.tokens = tokens_dev; a.len = len_dev; a.score = score_dev;
     if (launch_beam_search(a, B, (hipStream_t)stream)) return fail("beam search launch rejected the sizes");
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- streaming beam search on the device (BeamSearchDecoder.decode_chunk / reset_decoder) -----------------------------
+static void gbeam_args(GBeam& g, BeamGpuArgs& a) {
+    a.pool_cap = g.cap;
+    a.pool_parent = g.pool.as<int>();
+    a.pool_ch = a.pool_parent + g.cap;
+    a.state_h = g.state.as<unsigned long long>();
+    a.state_i = reinterpret_cast<int*>(a.state_h + 2 * (size_t)g.beam);
+    a.state_f = reinterpret_cast<float*>(a.state_i + 2 + 2 * (size_t)g.beam);
+}
+
+int masr_gbeam_open(masr_engine* e, int32_t beam_size, int32_t blank, int32_t max_frames, int32_t* handle) {
+    if (!e || !handle) return fail("null argument");
+    if (beam_size < 1 || beam_size > 512) return fail("beam_size must be in [1, 512]");
+    if (max_frames <= 0) max_frames = 5000;
+    int id = -1;
+    for (size_t i = 0; i < e->gbeams.size(); ++i)
+        if (!e->gbeams[i].open) { id = (int)i; break; }
+    if (id < 0) {
+        e->gbeams.emplace_back();
+        id = (int)e->gbeams.size() - 1;
+    }
+    GBeam& g = e->gbeams[id];
+    g.beam = beam_size;
+    g.blank = blank;
+    g.cap = max_frames * beam_size + 1;
+    CHK(g.pool.ensure((size_t)g.cap * 2 * sizeof(int)));
+    CHK(g.state.ensure((4 + 9 * (size_t)beam_size) * sizeof(int)));
+    g.open = true;
+    g.started = false;
+    *handle = id;
+    return 0;
+}
+
+static int gbeam_of(masr_engine* e, int id, GBeam** out) {
+    if (!e) return fail("null engine");
+    if (id < 0 || id >= (int)e->gbeams.size() || !e->gbeams[id].open) return fail("bad beam handle");
+    *out = &e->gbeams[id];
+    return 0;
+}
+
+int masr_gbeam_reset(masr_engine* e, int32_t handle) {
+    GBeam* g;
+    CHK(gbeam_of(e, handle, &g));
+    g->started = false;
+    return 0;
+}
+
+int masr_gbeam_close(masr_engine* e, int32_t handle) {
+    GBeam* g;
+    CHK(gbeam_of(e, handle, &g));
+    HIPCHK(hipDeviceSynchronize());
+    g->pool.release();
+    g->state.release();
+    g->open = false;
+    return 0;
+}
+
+int masr_gbeam_advance(masr_engine* e, int32_t handle, const int32_t* idx_dev, const float* logp_dev,
+                       const int32_t* count_dev, int32_t T, int32_t K, int32_t* tokens_dev, int32_t max_len,
+                       int32_t* len_dev, float* score_dev, void* stream) {
+    GBeam* g;
+    CHK(gbeam_of(e, handle, &g));
+    if (T < 0 || K > 64 || beam_gpu_lds_bytes(g->beam, K) > 160 * 1024) return fail("unsupported chunk / cutoff_top_n");
+    BeamGpuArgs a{};
+    a.cidx = idx_dev; a.clp = logp_dev; a.ccount = count_dev; a.frames = nullptr;
+    a.T_stride = T; a.K = K; a.beam = g->beam; a.blank = g->blank; a.max_len = max_len;
+    gbeam_args(*g, a);
+    a.init = g->started ? 0 : 1;
+    a.prof = nullptr;
+    a.tokens = tokens_dev; a.len = len_dev; a.score = score_dev;
+    // (the kernel stops allocating trie nodes at the pool capacity; max_frames bounds the utterance length)
+    if (launch_beam_search(a, 1, (hipStream_t)stream)) return fail("beam search launch rejected the sizes");
+    HIPCHK(hipGetLastError());
+    g->started = true;
     return 0;
 }
 

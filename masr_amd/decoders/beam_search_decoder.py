@@ -2,8 +2,9 @@
 (masr/decoders/beam_search_decoder.py:9-96).  The reference hands the search to the third-party SWIG
 module ``paddlespeech_ctcdecoders`` (+ a KenLM language model); here the per-frame vocabulary pruning runs
 on the GPU (masr_ctc_topk) and so does the LM-free CTC prefix beam search of whole utterances
-(masr_beam_search_gpu: one workgroup per utterance); the streaming decode_chunk path and sizes beyond the kernel's
-limits use the host-thread search inside libmasr_hip.so (masr_beam_*).  The external LM scorer (alpha / beta) is NOT implemented: a missing
+(masr_beam_search_gpu: one workgroup per utterance) and of streams (masr_gbeam_*: the live prefixes stay on the device
+between decode_chunk calls); sizes beyond the kernel's limits use the host-thread search inside libmasr_hip.so
+(masr_beam_*).  The external LM scorer (alpha / beta) is NOT implemented: a missing
 language model file is not an error, scores are the log probability of the best prefix (alpha = 0 path)."""
 import ctypes as C
 import logging
@@ -28,6 +29,8 @@ class BeamSearchDecoder:
         self.num_processes = int(num_processes)
         self.blank_id = int(blank_id)
         self.use_gpu_search = True       # False: prefix search on host threads (masr_beam_search_batch)
+        self._gstream = None             # device-resident streaming search (masr_gbeam_*), opened on first use
+        self._gout = None
         if alpha or beta:
             logger.warning('masr_amd BeamSearchDecoder: the external language-model scorer is not implemented; '
                            'decoding with the acoustic CTC scores only (alpha = beta = 0)')
@@ -127,6 +130,8 @@ class BeamSearchDecoder:
         """streaming: feed a chunk probs [1, T, V]; returns (score, text) of the best prefix so far
         (beam_search_decoder.py:75-91)."""
         p = np.asarray(probs)[0][:int(np.asarray(logits_lens).reshape(-1)[0])]
+        if self.use_gpu_search and self.gpu_search_supported(1, p.shape[1]):
+            return self._decode_chunk_gpu(p)
         idx, logp, cnt, K = self._candidates(p)
         if p.shape[0]:
             self._lib.masr_beam_advance(self._stream, idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
@@ -136,6 +141,30 @@ class BeamSearchDecoder:
         self._lib.masr_beam_result(self._stream, toks.ctypes.data_as(C.c_void_p), 4096, C.byref(n), C.byref(sc))
         return float(sc.value), self._text(toks[:n.value])
 
+    def _decode_chunk_gpu(self, p):
+        """device-resident search state (masr_gbeam_*): only the best prefix travels back per chunk"""
+        eng = runtime.aux_engine()
+        if self._gstream is None:
+            h = C.c_int32()
+            check(self._lib.masr_gbeam_open(eng.h, self.beam_size, self.blank_id, 5000, C.byref(h)))
+            self._gstream = h.value
+        T = p.shape[0]
+        idx, logp, cnt, K = self._candidates(p, to_host=False)
+        max_len = 5000
+        if self._gout is None:
+            self._gout = (torch.zeros(1, max_len, dtype=torch.int32, device=eng.device),
+                          torch.zeros(1, dtype=torch.int32, device=eng.device),
+                          torch.zeros(1, dtype=torch.float32, device=eng.device))
+        toks, lens, scores = self._gout
+        check(self._lib.masr_gbeam_advance(eng.h, self._gstream, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                           C.c_void_p(cnt.data_ptr()), T, K, C.c_void_p(toks.data_ptr()), max_len,
+                                           C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        n = int(lens.item())
+        return float(scores.item()), self._text(toks[0, :n].cpu().numpy())
+
     def reset_decoder(self):
         """beam_search_decoder.py:93-96."""
         self._lib.masr_beam_reset(self._stream)
+        if self._gstream is not None:
+            check(self._lib.masr_gbeam_reset(runtime.aux_engine().h, self._gstream))

@@ -174,3 +174,28 @@ def test_gpu_prefix_search_small_beam_revived_prefixes(seed, beam):
     for (sg, tg), (sh, th) in zip(gpu, host):
         assert tg == th
         assert abs(sg - sh) < 1e-3 * max(1.0, abs(sh))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('beam', [5, 300])
+def test_gpu_streaming_search_equals_offline_and_host(beam):
+    """decode_chunk with the device-resident search state (masr_gbeam_*) == whole-utterance search == host stream"""
+    from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    rng = np.random.default_rng(77)
+    V, T = 60, 131
+    alpha = np.full(V, 0.02)
+    alpha[[0, 5, 9, 11]] = 1.0
+    probs = rng.dirichlet(alpha, size=T).astype(np.float32)
+    vocab = ['<blank>'] + [chr(0x4e00 + i) for i in range(V - 1)]
+    dec = BeamSearchDecoder(0, 0, beam, 0.99, 40, vocab)
+    off = dec.decode_beam_search_offline(probs)
+    for use_gpu in (True, False, True):                 # the second GPU pass also checks reset_decoder on a used stream
+        dec.use_gpu_search = use_gpu
+        dec.reset_decoder()
+        out = None
+        for lo in range(0, T, 16):
+            n = min(16, T - lo)
+            out = dec.decode_chunk(probs[None, lo:lo + n], np.array([n]))
+        assert out[1] == off[1]
+        assert abs(out[0] - off[0]) < 1e-3 * max(1.0, abs(off[0]))
+    dec.reset_decoder()
