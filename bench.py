@@ -245,7 +245,7 @@ def main():
         roofline = None
         if prof_n > 0 and prof_ms > 0:
             achieved = prof_flops / (prof_ms * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'ffn_fused_kernel (LN + [B*T\',256]x[256,2048] + SiLU + x[2048,256] + residual)',
+            roofline = {'bound': 'mfma', 'kernel': 'ffn_pc_kernel (LN + [B*T\',256]x[256,2048] + SiLU + x[2048,256] + residual)',
                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': committed_traffic(),
                         'traffic_note': 'HBM bytes per launch from committed PMC passes (profiles/r01_hbm_traffic.json); '

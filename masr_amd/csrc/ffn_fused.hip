@@ -176,6 +176,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
                         if (VAR == 2) acc1[q & 1][q] = fmaf(a[g & 1][q], b[g & 1][q], acc1[q & 1][q]);
                         else acc1[q & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc1[q & 1], 0, 0, 0);
                         side_work(s, j, (j + 1) % NSET, g * 4 + q);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 if (j == 3) {
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
                         if (VAR == 2) acc2[q & 1][q] = fmaf(a[g & 1][q], b[g & 1][q], acc2[q & 1][q]);
                         else acc2[q & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc2[q & 1], 0, 0, 0);
                         side_work(s, j, (j + 1) % NSET, g * 4 + q);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -273,6 +275,14 @@ __global__ __launch_bounds__(256) void ffn_reduce_kernel(float* x, const float* 
     reinterpret_cast<f32x4*>(x)[i] = xv;
 }
 
+void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(ffn_reduce_kernel, dim3((unsigned)(((size_t)M * FF_D / 4 + 255) / 256)), dim3(256), 0, s, x, partial, b2,
+                       M, nsplit, scale);
+}
+void launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
+                   hipStream_t s, int variant);
+
 static int g_ffn_variant = 0;
 void set_ffn_variant(int v) { g_ffn_variant = v; }
 
@@ -307,6 +317,13 @@ void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float*
                       const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
                       int nsplit, hipStream_t s) {
     if (M <= 0) return;
+    // production path: producer/consumer kernel (ffn_pc.hip).  masr_debug_set(1, v): 9 = this file's kernel (k-split GEMM1,
+    // two barriers per chunk), 1 / 2 / 4 = its ablations, 81 = producer/consumer kernel without weight loads
+    if (g_ffn_variant == 0 || g_ffn_variant == 81) {
+        launch_ffn_pc(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, affine_prologue, partial, nsplit, s,
+                      g_ffn_variant == 81 ? 1 : 0);
+        return;
+    }
     if (affine_prologue) {
         launch_ffn_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);
         return;

@@ -1,0 +1,279 @@
+// Fused position-wise feed-forward block, producer/consumer wave specialisation (same math, layout and interface as
+// ffn_fused.hip; reference conformer/positionwise.py:30-37, conformer/encoder.py:113-121,150-158):
+//     x <- x + scale * ( W2 . silu( W1 . LayerNorm(x) + b1 ) + b2 )
+// One workgroup = 32 rows, 8 waves = 2 per SIMD.  The two waves of a SIMD have DIFFERENT jobs:
+//   producer  wave p (0..3): hidden tile  h[32 rows, 32 units]  = silu(xn . W1[chunk*128 + 32p .. +31, 0..255]^T + b1)
+//                            (128 MFMA 32x32x2 per chunk, K = 256 from the LayerNorm tile in LDS) -> hs[phase & 1]
+//   consumer  wave c (0..3): output tiles acc2[32 rows, 64 cols] += h(prev chunk) . W2[64c .. 64c+63, chunk]^T
+//                            (128 MFMA per chunk, K = 128 from hs[(phase-1) & 1])
+// In phase k the producers work on chunk k while the consumers work on chunk k-1: the bias + SiLU + LDS traffic of one
+// wave overlaps with the matrix work of the other wave on the same SIMD, and there is ONE workgroup barrier per chunk
+// (the k-split partial-sum exchange of ffn_fused.hip is gone).  Weights stream through the same wave-private,
+// double-buffered LDS slabs with a 4-deep register prefetch rotation; no barrier on the weight path.
+#include "common.h"
+
+namespace masr {
+
+static constexpr int PC_BM = 32;
+static constexpr int PC_D = 256;
+static constexpr int PC_CH = 128;          // hidden units per chunk
+static constexpr int PC_XLD = PC_D + 4;    // 260
+static constexpr int PC_HLD = PC_CH + 4;   // 132
+static constexpr int PC_WLD = 32 + 4;
+static constexpr int PC_WSLAB = 32 * PC_WLD;
+static constexpr int PC_NSET = 4;
+
+__device__ __forceinline__ float pc_wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int AFFINE, int SPLIT, int VAR>
+__global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2, int M,
+                                                     int dff, float eps, float scale, float* partial,
+                                                     int chunks_per_block) {
+    extern __shared__ __align__(16) float sm[];
+    float* xn = sm;                              // [32][260]   LayerNorm(x) tile (A operand of GEMM1)
+    float* hs = xn + PC_BM * PC_XLD;             // [2][32][132] hidden tile (A operand of GEMM2), double-buffered
+    float* wpv = hs + 2 * PC_BM * PC_HLD;        // [8 waves][2][32][36] wave-private weight slabs
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, idx = wave & 3;  // waves w and w+4 share a SIMD: producer idx and consumer idx
+    const int row0 = blockIdx.x * PC_BM;
+    const int frow = lane & 31, fh = lane >> 5;
+    float* wmine = wpv + wave * 2 * PC_WSLAB;
+
+    // ---- LayerNorm prologue: wave w normalises rows 4w..4w+3 ----------------------------------------
+    {
+        const f32x4 gw = *reinterpret_cast<const f32x4*>(lnw + lane * 4);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
+        f32x4 v4[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = min(row0 + wave * 4 + rr, M - 1);
+            v4[rr] = *reinterpret_cast<const f32x4*>(x + (size_t)row * PC_D + lane * 4);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = wave * 4 + rr;
+            const f32x4 v = v4[rr];
+            f32x4 o;
+            if (AFFINE) {          // Squeezeformer: ada_scale * x + ada_bias (positionwise.py:57-58), no LayerNorm
+                o[0] = gw[0] * v[0] + gb[0];
+                o[1] = gw[1] * v[1] + gb[1];
+                o[2] = gw[2] * v[2] + gb[2];
+                o[3] = gw[3] * v[3] + gb[3];
+            } else {
+                const float mean = pc_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                const float var = pc_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + eps);
+                o[0] = d0 * rstd * gw[0] + gb[0];
+                o[1] = d1 * rstd * gw[1] + gb[1];
+                o[2] = d2 * rstd * gw[2] + gb[2];
+                o[3] = d3 * rstd * gw[3] + gb[3];
+            }
+            if (row0 + lr >= M) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&xn[lr * PC_XLD + lane * 4]) = o;
+        }
+    }
+
+    // ---- this wave's weight slab stream: 8 slabs (32 rows x 32 k) per chunk -----------------------------------------
+    //   producer p, slab j : W1[chunk*128 + 32p + r][32j .. 32j+31]
+    //   consumer c, slab j : W2[64c + 32(j&1) + r][chunk*128 + 32(j>>1) .. +31]     (tile n = j&1, k-slab j>>1)
+    const int chunk_lo = SPLIT ? blockIdx.y * chunks_per_block : 0;
+    const int chunk_hi = SPLIT ? min(chunk_lo + chunks_per_block, dff / PC_CH) : dff / PC_CH;
+    const int nchunk = chunk_hi - chunk_lo;
+    const int lr8 = lane >> 3, lc4 = (lane & 7) * 4;
+    f32x4 pre[PC_NSET][4];
+    // branch-free addressing: role-dependent strides are wave-uniform scalars
+    const float* wbase = role == 0 ? w1 + (size_t)(idx * 32) * PC_D : w2 + (size_t)(idx * 64) * dff;
+    const size_t rs = role == 0 ? (size_t)PC_D : (size_t)dff;            // row stride of my weight matrix
+    const size_t cs = role == 0 ? (size_t)PC_CH * PC_D : (size_t)PC_CH;  // offset of one chunk
+    const float* wlane = wbase + (size_t)lr8 * rs + lc4;
+    auto src_of = [&](int chunk, int j, int i) -> const float* {   // j, i are compile-time constants at every call
+        const size_t joff = role == 0 ? (size_t)(j * 32) : (size_t)((j & 1) * 32) * dff + (size_t)((j >> 1) * 32);
+        return wlane + (size_t)(8 * i) * rs + (size_t)chunk * cs + joff;
+    };
+    auto dst_of = [&](int s, int i) -> float* { return wmine + (s & 1) * PC_WSLAB + (lr8 + 8 * i) * PC_WLD + lc4; };
+    const int nlast = chunk_hi - 1;
+    // side work in the MFMA issue slots of slab (c, j): store slab s+1 (set (j+1)%NSET) to LDS, refill that set with slab
+    // s+1+NSET (chunk index clamped past the end: re-fetches land in buffers nobody reads any more)
+    auto side_work = [&](int chunk, int j, int slot) {
+        const int p = (j + 1) % PC_NSET;
+        if (slot < 8) {
+            if ((slot & 1) == 0) *reinterpret_cast<f32x4*>(dst_of(j + 1, slot >> 1)) = pre[p][slot >> 1];
+        } else if ((slot & 1) == 0 && VAR != 1) {
+            pre[p][(slot - 8) >> 1] = *reinterpret_cast<const f32x4*>(
+                src_of(min(chunk + (j + 1 + PC_NSET) / 8, nlast), (j + 1 + PC_NSET) & 7, (slot - 8) >> 1));
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, 0, i));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+#pragma unroll
+    for (int k = 1; k <= PC_NSET; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, k, i));
+    __syncthreads();                                 // xn tile complete
+
+    const float* wfrag = wmine + frow * PC_WLD + 4 * fh;
+    // Phases p = 0 .. nchunk+1, one workgroup barrier at the end of each:
+    //   producer: MFMAs of chunk p (p < nchunk) with the bias + SiLU + LDS store of chunk p-1 spread over the free issue
+    //             slots between them (the raw sums of chunk p-1 wait in accp) -> hs[(p-1) & 1]
+    //   consumer: chunk p-2 from hs[(p-2) & 1]
+    // The two roles run separate loops (wave-uniform branch, same number of barriers), so each keeps only its own
+    // accumulators live.
+    if (role == 0) {
+        const float* xa = xn + frow * PC_XLD + 4 * fh;
+        f32x16 accp;                       // raw sums of the previous chunk
+        float bvp = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+        for (int phase = 0; phase <= nchunk + 1; ++phase) {
+            float* hprev = hs + ((phase + 1) & 1) * PC_BM * PC_HLD + idx * 32 + frow;     // buffer (phase-1) & 1
+            auto finish = [&](int r) {     // bias + SiLU of element r of the previous chunk (C layout: row = (r&3)+8(r>>2)+4fh)
+                const float v = accp[r] + bvp;
+                hprev[((r & 3) + 8 * (r >> 2) + 4 * fh) * PC_HLD] = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+            };
+            if (phase < nchunk) {
+                const int chunk = chunk_lo + phase;
+                const float bv1 = b1[chunk * PC_CH + idx * 32 + frow];
+                f32x16 acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float* wp = wfrag + (j & 1) * PC_WSLAB;
+                    f32x4 a[2], b[2];
+                    a[0] = *reinterpret_cast<const f32x4*>(xa + j * 32);
+                    b[0] = *reinterpret_cast<const f32x4*>(wp);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (g + 1 < 4) {
+                            a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(xa + j * 32 + 8 * (g + 1));
+                            b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc1, 0, 0, 0);
+                            side_work(chunk, j, g * 4 + q);
+                            // odd slots 1 and 9 of every slab: one element of the previous chunk's epilogue each
+                            if (phase > 0 && g * 4 + q == 1) finish(2 * j);
+                            if (phase > 0 && g * 4 + q == 9) finish(2 * j + 1);
+                            __builtin_amdgcn_sched_barrier(0);   // keep the written MFMA / load / LDS-store interleave
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[r] = acc1[r];
+                bvp = bv1;
+            } else if (phase == nchunk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) finish(r);
+            }
+            __syncthreads();
+        }
+    } else {
+        f32x16 acc2[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
+        for (int phase = 0; phase <= nchunk + 1; ++phase) {
+            if (phase >= 2) {
+                const int chunk = chunk_lo + phase - 2;
+                const float* ha = hs + (phase & 1) * PC_BM * PC_HLD + frow * PC_HLD + 4 * fh;       // buffer (phase-2) & 1
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float* wp = wfrag + (j & 1) * PC_WSLAB;
+                    f32x4 a[2], b[2];
+                    a[0] = *reinterpret_cast<const f32x4*>(ha + (j >> 1) * 32);
+                    b[0] = *reinterpret_cast<const f32x4*>(wp);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (g + 1 < 4) {
+                            a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(ha + (j >> 1) * 32 + 8 * (g + 1));
+                            b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc2[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc2[j & 1], 0, 0, 0);
+                            side_work(chunk, j, g * 4 + q);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- epilogue (consumers): x <- x + scale * (acc2 + b2) ---------------------------------------------------
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = idx * 64 + n * 32 + frow;
+            if (SPLIT) {
+                float* pp = partial + (size_t)blockIdx.y * M * PC_D;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (row < M) pp[(size_t)row * PC_D + col] = acc2[n][r];
+                }
+            } else {
+                const float bv2 = b2[col];
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, M - 1);
+                    res[r] = x[(size_t)row * PC_D + col];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (row < M) x[(size_t)row * PC_D + col] = res[r] + scale * (acc2[n][r] + bv2);
+                }
+            }
+        }
+    }
+}
+
+void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s);
+
+template <int AFFINE, int VAR>
+static void launch_pc_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                        const float* b2, int M, int dff, float eps, float scale, float* partial, int nsplit, hipStream_t s) {
+    const size_t lds = (size_t)(PC_BM * PC_XLD + 2 * PC_BM * PC_HLD + 8 * 2 * PC_WSLAB) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 0, VAR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int nchunk = dff / PC_CH;
+    if (partial && nsplit > 1) {
+        const int cpb = (nchunk + nsplit - 1) / nsplit;
+        const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
+        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
+                           b1, w2, b2, M, dff, eps, scale, partial, cpb);
+        launch_ffn_reduce(x, partial, b2, M, ny, scale, s);
+    } else {
+        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 0, VAR>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1,
+                           w2, b2, M, dff, eps, scale, (float*)nullptr, 0);
+    }
+}
+
+void launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
+                   hipStream_t s, int variant) {
+    if (M <= 0) return;
+    if (affine_prologue) launch_pc_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);
+    else if (variant == 1) launch_pc_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);
+    else launch_pc_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);
+}
+
+}  // namespace masr
