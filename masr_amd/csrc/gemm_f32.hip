@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     for (int kt = kt_lo; kt < KT; ++kt) {
         const int buf = (kt - kt_lo) & 1;
         if (kt + 1 < KT) load_slab(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);       // the loads stay ahead of this slab's MFMAs (the scheduler would sink them)
         const float* Ab = &As[(buf * BM + wm * (BM / WM) + frow) * LDP + fcol];
         const float* Wb = &Ws[(buf * BN + wn * (BN / WN) + frow) * LDP + fcol];
 #pragma unroll
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                     for (int n = 0; n < TN; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][s], wf[n][s], acc[m][n], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < KT) store_slab(buf ^ 1);
         __syncthreads();
     }

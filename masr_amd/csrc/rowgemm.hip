@@ -182,6 +182,7 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
                         pre[(j + 1) % RG_NSET][(slot - 8) >> 1] = *reinterpret_cast<const f32x4*>(
                             src_of(t + (j + 1 + RG_NSET) / 8, (j + 1 + RG_NSET) & 7, (slot - 8) >> 1));
                     }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the written MFMA / load / LDS-store interleave
                 }
             }
         }
