@@ -4,8 +4,8 @@
 //     attn = softmax_j(mask(score)),  masked entries -> 0 ;  out_i = sum_j attn[i,j] v_j
 //
 // MI355X mapping (fp32, v_mfma_f32_32x32x2_f32, wave64):
-//  * one wave owns 32 queries of one (sequence, head); 4 waves (128 queries) per workgroup share
-//    LDS tiles of 32 keys: K, P (positional keys, from the table precomputed at weight load) and V.
+//  * one wave owns 32 queries of one (sequence, head) and every second tile of 32 keys; 8 waves (128 queries x 2 key
+//    parities) per workgroup share LDS tiles: K, P (positional keys, from the table precomputed at weight load) and V.
 //  * both score terms are ONE contraction over a concatenated 128-wide dimension:
 //        S^T[key, query] = [k_j | p_j] . [q_i + u | q_i + v]
 //    computed TRANSPOSED (A operand = keys, B operand = queries) so that every lane owns ONE query
@@ -23,21 +23,27 @@ static constexpr int DK = 64;
 static constexpr int KP_LD = 68;   // padded row of the K / P tiles (floats): 16B slot = (17*row + ..) mod 16
 static constexpr int V_LD = 68;
 
-__global__ __launch_bounds__(256) void attention_kernel(const AttSeq* __restrict__ seqs, int q_stride, int kv_stride,
+// 8 waves per workgroup: wave w = (query group w & 3, key parity w >> 2).  The two waves of a query group walk the even and the
+// odd key tiles with their own online-softmax state and are merged once at the end, so every SIMD holds two waves (the softmax
+// VALU work of one overlaps the MFMAs of the other) although B*H*T'/32 is only ~4 waves per CU at B = 32 x 10 s.
+__global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict__ seqs, int q_stride, int kv_stride,
                                                         const float* __restrict__ ptab,
                                                         const float* __restrict__ bias_u,
                                                         const float* __restrict__ bias_v, int chunk_size,
                                                         int pos_stride) {
-    __shared__ __align__(16) float Ks[32 * KP_LD];
-    __shared__ __align__(16) float Ps[32 * KP_LD];
-    __shared__ __align__(16) float Vs[32 * V_LD];
+    __shared__ __align__(16) float lds_att[2 * 32 * KP_LD * 2 + 2 * 32 * V_LD];
+    float* Ks = lds_att;                       // [2 tiles][32][68]
+    float* Ps = Ks + 2 * 32 * KP_LD;
+    float* Vs = Ps + 2 * 32 * KP_LD;
 
     const AttSeq sq = seqs[blockIdx.z];
     const int head = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave & 3, kh = wave >> 2;
     const int q0 = blockIdx.x * 128;
     if (q0 >= sq.nq) return;                 // whole workgroup exits together
-    const int qi = q0 + wave * 32 + (lane & 31);
+    const int qi = q0 + qg * 32 + (lane & 31);
     const int h = lane >> 5;
     const bool q_ok = qi < sq.nq;
     const int q_abs = sq.q_abs0 + (q_ok ? qi : sq.nq - 1);
@@ -67,17 +73,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttSeq* __restrict
     // visible keys for this query: j < klen and (chunk mask) j < (q_abs / cs + 1) * cs
     int jlim = sq.klen;
     if (chunk_size > 0) jlim = min(jlim, (q_abs / chunk_size + 1) * chunk_size);
-
     const int ntile = (sq.nk + 31) / 32;
-    // staging assignment: 512 float4 per 32x64 tile, 2 per thread
-    const int srow = tid >> 4;            // 0..15 (+16)
+    const int npair = (ntile + 1) / 2;
+    // staging assignment: two 32x64 tiles per iteration; thread t -> tile t >> 8, 512 float4 per tile, 2 per thread
+    const int sti = tid >> 8;             // which tile of the pair this thread stages
+    const int srow = (tid & 255) >> 4;    // 0..15 (+16)
     const int sc4 = (tid & 15) * 4;       // float offset 0..60
-    // register-prefetched staging: tile kt+1 is fetched from global memory while tile kt is multiplied
+    // register-prefetched staging: pair kp+1 is fetched from global memory while pair kp is multiplied
     f32x4 pk[2], pp[2], pv[2];
-    auto fetch = [&](int kt) {
+    auto fetch = [&](int kp) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int j = kt * 32 + srow + 16 * i;
+            const int j = (2 * kp + sti) * 32 + srow + 16 * i;
             const int jc = min(j, sq.nk - 1);                      // clamped address, masked below
             pk[i] = *reinterpret_cast<const f32x4*>(sq.k + (size_t)jc * kv_stride + head * DK + sc4);
             pv[i] = *reinterpret_cast<const f32x4*>(sq.v + (size_t)jc * kv_stride + head * DK + sc4);
@@ -86,25 +93,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttSeq* __restrict
         }
     };
     fetch(0);
-    for (int kt = 0; kt < ntile; ++kt) {
-        const int j0 = kt * 32;
-        __syncthreads();   // previous tile fully consumed
+    for (int kp = 0; kp < npair; ++kp) {
+        const int j0 = (2 * kp + kh) * 32;     // first key of this wave's tile
+        __syncthreads();   // previous pair fully consumed
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = srow + 16 * i;
-            *reinterpret_cast<f32x4*>(&Ks[r * KP_LD + sc4]) = pk[i];
-            *reinterpret_cast<f32x4*>(&Ps[r * KP_LD + sc4]) = pp[i];
-            *reinterpret_cast<f32x4*>(&Vs[r * V_LD + sc4]) = pv[i];
+            *reinterpret_cast<f32x4*>(&Ks[sti * 32 * KP_LD + r * KP_LD + sc4]) = pk[i];
+            *reinterpret_cast<f32x4*>(&Ps[sti * 32 * KP_LD + r * KP_LD + sc4]) = pp[i];
+            *reinterpret_cast<f32x4*>(&Vs[sti * 32 * V_LD + r * V_LD + sc4]) = pv[i];
         }
         __syncthreads();
-        if (kt + 1 < ntile) fetch(kt + 1);
+        if (kp + 1 < npair) fetch(kp + 1);
+        if (j0 >= sq.nk) continue;             // (wave-uniform) odd tile past the end: nothing to add
 
         // ---- S^T tile: rows = 32 keys, cols = this wave's 32 queries -------------------------
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
-        const float* kb = &Ks[(lane & 31) * KP_LD + 4 * h];
-        const float* pb = &Ps[(lane & 31) * KP_LD + 4 * h];
+        const float* kb = &Ks[kh * 32 * KP_LD + (lane & 31) * KP_LD + 4 * h];
+        const float* pb = &Ps[kh * 32 * KP_LD + (lane & 31) * KP_LD + 4 * h];
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const f32x4 kf = *reinterpret_cast<const f32x4*>(kb + 8 * g);
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttSeq* __restrict
         for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
 
         // ---- O^T += V^T . P^T ---------------------------------------------------------------------
-        const float* vb = &Vs[(4 * h) * V_LD + (lane & 31)];
+        const float* vb = &Vs[kh * 32 * V_LD + (4 * h) * V_LD + (lane & 31)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int krow = (r & 3) + 8 * (r >> 2);       // + 4h folded into vb
@@ -151,6 +159,33 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttSeq* __restrict
             const float vb2 = vb[krow * V_LD + 32];
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va, st[r], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb2, st[r], o1, 0, 0, 0);
+        }
+    }
+
+    // ---- merge the odd-tile state into the even-tile wave of the same query group (through the tile LDS) -------------
+    __syncthreads();
+    float* mg = lds_att;                                // [4 query groups][34][64 lanes] floats (34.8 KB <= Ks + Ps)
+    static_assert(4 * 34 * 64 <= 2 * 2 * 32 * KP_LD, "merge buffer must fit into the K and P tiles");
+    if (kh == 1) {
+        float* d = mg + (size_t)qg * 34 * 64 + lane;
+        d[0] = m_run;
+        d[64] = l_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d[(2 + r) * 64] = o0[r]; d[(18 + r) * 64] = o1[r]; }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    {
+        const float* d = mg + (size_t)qg * 34 * 64 + lane;
+        const float m1 = d[0], l1 = d[64];
+        const float m = fmaxf(m_run, m1);
+        const float ms = (m == -INFINITY) ? 0.f : m;
+        const float c0 = expf(m_run - ms), c1 = expf(m1 - ms);     // -inf -> 0
+        l_run = l_run * c0 + l1 * c1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] = o0[r] * c0 + d[(2 + r) * 64] * c1;
+            o1[r] = o1[r] * c0 + d[(18 + r) * 64] * c1;
         }
     }
 
@@ -174,7 +209,7 @@ void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q
                       const float* ptab, const float* bias_u, const float* bias_v, int chunk_size, int pos_stride,
                       hipStream_t s) {
     if (nseq <= 0 || max_nq <= 0) return;
-    hipLaunchKernelGGL(attention_kernel, dim3((max_nq + 127) / 128, heads, nseq), dim3(256), 0, s, seqs, q_stride,
+    hipLaunchKernelGGL(attention_kernel, dim3((max_nq + 127) / 128, heads, nseq), dim3(512), 0, s, seqs, q_stride,
                        kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride);
 }
 
