@@ -49,6 +49,7 @@ __device__ float pw_leaf(const ST* x, int off, int len) {
     for (int j = 0; j < 8; ++j) r[j] = sq_unit(x, off + j);
     int i = 8;
     const int m = len - (len % 8);
+#pragma unroll 4
     for (; i < m; i += 8) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], sq_unit(x, off + i + j));
@@ -57,6 +58,46 @@ __device__ float pw_leaf(const ST* x, int off, int len) {
                           __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
     for (; i < len; ++i) res = __fadd_rn(res, sq_unit(x, off + i));
     return res;
+}
+
+// the 128-element leaf of a full chunk, same add order as pw_leaf, but the 8 strided accumulators are fed by one
+// 16-byte (int16) / two 16-byte (float) vector loads per step instead of 8 scalar loads (leaf starts are 256-B aligned
+// relative to the utterance, and utterance rows are 16-B aligned when n_max is a multiple of 8 -- checked by the caller)
+__device__ __forceinline__ float pw_leaf128(const int16_t* x, int off) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8* p = reinterpret_cast<const s16x8*>(x + off);
+    s16x8 v[16];                           // all 16 loads in flight before the (ordered) add chain starts
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = p[i];
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = (float)v[0][j] * (1.0f / 32768.0f); r[j] = __fmul_rn(f, f); }
+#pragma unroll
+    for (int i = 1; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = (float)v[i][j] * (1.0f / 32768.0f); r[j] = __fadd_rn(r[j], __fmul_rn(f, f)); }
+    return __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                     __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+}
+__device__ __forceinline__ float pw_leaf128(const float* x, int off) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(x + off);
+    float r[8];
+    {
+        const f32x4 a = p[0], b = p[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { r[j] = __fmul_rn(a[j], a[j]); r[4 + j] = __fmul_rn(b[j], b[j]); }
+    }
+#pragma unroll 5
+    for (int i = 1; i < 16; ++i) {
+        const f32x4 a = p[2 * i], b = p[2 * i + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = __fadd_rn(r[j], __fmul_rn(a[j], a[j]));
+            r[4 + j] = __fadd_rn(r[4 + j], __fmul_rn(b[j], b[j]));
+        }
+    }
+    return __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                     __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
 }
 
 static constexpr int NP_BUF = 8192;       // numpy's default ufunc buffer size (elements)
@@ -79,7 +120,7 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__
     // full chunk: 64 leaves of 128 elements, balanced tree == xor-butterfly (fp add is commutative)
     const int c = blockIdx.x * 4 + wave;
     if (c < nc) {
-        float v = pw_leaf(x, c * NP_BUF + lane * 128, 128);
+        float v = (n_max & 7) == 0 ? pw_leaf128(x, c * NP_BUF + lane * 128) : pw_leaf(x, c * NP_BUF + lane * 128, 128);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) v = __fadd_rn(v, __shfl_xor(v, o, 64));
         if (lane == 0) out[c] = v;
