@@ -32,7 +32,7 @@ def committed_traffic():
     (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if absent."""
     try:
         k = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
-        return k['masr::ffn_fused_kernel<0, 0>']['hbm_bytes']
+        return k['masr::ffn_pc_kernel<0, 0, 0>']['hbm_bytes']
     except Exception:
         return None
 
@@ -249,7 +249,8 @@ def main():
                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': committed_traffic(),
                         'traffic_note': 'HBM bytes per launch from committed PMC passes (profiles/r01_hbm_traffic.json); '
-                                        'algorithmic bytes per launch = 20.4 MB (x in/out + W1 + W2)',
+                                        'algorithmic bytes per launch = 20.4 MB (x in/out + W1 + W2); measured = x in/out 16.3 MB + the 4.2 MB of weights '
+                                        'fetched once by each of the 8 XCD L2s (Infinity Cache hits after the first)',
                         'launches': int(prof_n), 'avg_us': round(prof_ms * 1e3 / prof_n, 2),
                         'flops_per_launch': prof_flops / prof_n}
         res = {'metric': 'audio-seconds/sec (RTF^-1), conformer_streaming_fbank b32x10s, PCM->fbank->encoder->ctc_greedy',
