@@ -36,29 +36,35 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
             w[g][k] = v[0]; w[g][k + 1] = v[1]; w[g][k + 2] = v[2]; w[g][k + 3] = v[3];
         }
     }
-    for (int b = 0; b < B; ++b) {
-        const float* hp = h_prev + ((size_t)dir * B + b) * H + lane * PL;
-        float hv[PL];
+    // batch loop: the four gate pre-activations of (unit j, sequence b) end up in lane (b & 63); the gate epilogue then
+    // runs once per 64 sequences with one sequence per lane, so its dependent global loads cost one latency, not B
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int nb = min(64, B - b0);
+        float mine[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int bb = 0; bb < nb; ++bb) {
+            const float* hp = h_prev + ((size_t)dir * B + b0 + bb) * H + lane * PL;
+            float hv[PL];
 #pragma unroll
-        for (int k = 0; k < PL; k += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(hp + k);
-            hv[k] = v[0]; hv[k + 1] = v[1]; hv[k + 2] = v[2]; hv[k + 3] = v[3];
+            for (int k = 0; k < PL; k += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(hp + k);
+                hv[k] = v[0]; hv[k + 1] = v[1]; hv[k + 2] = v[2]; hv[k + 3] = v[3];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < PL; ++k) a = fmaf(w[g][k], hv[k], a);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                if (lane == bb) mine[g] = a;
+            }
         }
-        float dot[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < PL; ++k) a = fmaf(w[g][k], hv[k], a);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-            dot[g] = a;
-        }
-        if (lane == 0) {
+        if (lane < nb) {
+            const int b = b0 + lane;
             const size_t sidx = ((size_t)dir * B + b) * H + j;
             const bool active = !lens || t < lens[b];
             const float* gr = gx + ((size_t)b * T + t) * (ndir * 4 * H) + (size_t)dir * 4 * H + j;
-            const float gi = gr[0] + dot[0], gf = gr[H] + dot[1], gg = gr[2 * H] + dot[2], go = gr[3 * H] + dot[3];
+            const float gi = gr[0] + mine[0], gf = gr[H] + mine[1], gg = gr[2 * H] + mine[2], go = gr[3 * H] + mine[3];
             const float c_old = c[sidx];
             const float c_new = sigm(gf) * c_old + sigm(gi) * tanhf(gg);
             const float h_new = sigm(go) * tanhf(c_new);
