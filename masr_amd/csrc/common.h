@@ -101,7 +101,7 @@ struct RowGemmArgs {
 };
 void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);
 
-// Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_fused.hip)
+// Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_pc.hip; ffn_fused.hip = previous kernel, kept for A/B)
 void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                       const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
                       int nsplit, hipStream_t s);   // partial/nsplit: split-d_ff mode for small M (streaming)

@@ -1,3 +1,5 @@
+// (Previous production kernel, kept for A/B measurements -- masr_debug_set(1, 9) -- and for ffn_reduce_kernel and the launcher;
+//  the production path is the producer/consumer kernel in ffn_pc.hip.)
 // Fused position-wise feed-forward block of the Conformer layer, in place on x:
 //     x <- x + scale * ( W2 . silu( W1 . LayerNorm(x) + b1 ) + b2 )        (scale = 0.5, macaron style)
 // Reference: ConformerEncoderLayer.forward (conformer/encoder.py:113-121,150-158) +

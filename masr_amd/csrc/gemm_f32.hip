@@ -11,7 +11,7 @@
 // * A operand modes: plain row-major, or implicit-GEMM gather for the 3x3/stride-2 subsampling
 //   conv over channels-last activations (reference conformer/subsampling.py:86-110).
 // * Epilogue: bias, ReLU/SiLU, alpha, residual, row masking.  (The K = 256 projections of the layers use
-//   rowgemm.hip, the FFN ffn_fused.hip; this kernel serves conv2, the embed projection, the positional-key
+//   rowgemm.hip, the FFN ffn_pc.hip; this kernel serves conv2, the embed projection, the positional-key
 //   precompute and the full-probability CTC head.)
 #include "common.h"
 

@@ -4,7 +4,7 @@
 // tile is built once in LDS and stays resident while the workgroup walks over the column groups of 256;
 // wave w owns columns [32w, 32w+32) of every group, so its B operand (32 weight rows) is private to
 // it and streamed through a wave-private, double-buffered LDS region with a 4-deep register prefetch
-// (same machinery as ffn_fused.hip, no workgroup barrier in the main loop).  M = B*T' = 7936 rows give
+// (same machinery as ffn_pc.hip, no workgroup barrier in the main loop).  M = B*T' = 7936 rows give
 // 248 workgroups ~ one per CU.  v_mfma_f32_32x32x2_f32 (exact fp32) throughout.
 //
 // Prologues: plain rows | per-channel affine (Squeezeformer adaptive scale/bias, optional pad masking) |
