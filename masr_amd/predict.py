@@ -6,6 +6,7 @@ AudioFeaturizer (fbank), InferencePredictor (Conformer encoder + CTC head) and t
 decoders.  ``predict_batch`` is an addition: the whole PCM -> text path for a padded batch in one
 device call (no host round trip of probabilities).
 """
+import logging
 import os
 from io import BufferedReader
 
@@ -20,6 +21,8 @@ from masr_amd.data_utils.featurizer.text_featurizer import TextFeaturizer
 from masr_amd.decoders.ctc_greedy_decoder import greedy_decoder, greedy_decoder_chunk
 from masr_amd.infer_utils.inference_predictor import InferencePredictor
 from masr_amd.utils.utils import dict_to_object
+
+logger = logging.getLogger(__name__)
 
 
 class MASRPredictor:
@@ -128,6 +131,38 @@ class MASRPredictor:
             text = ''.join(vocab[j] for j in tok[i, :ntok[i]]).replace('<space>', ' ')
             out.append({'text': text, 'score': float(score[i]) * 100.0 if ntok[i] > 0 or score[i] > 0 else 0})
         return out
+
+    def evaluate(self, manifest, batch_size=32, display_result=False, decode_all_frames=False):
+        """Batched offline evaluation on the engine (the reference's batch > 1 consumer: MASRTrainer.evaluate,
+        trainer.py:592-651): ``manifest`` is the reference's txt manifest (one JSON object per line with ``audio_filepath``
+        and ``text``, data_utils/reader.py:32-40,55), utterances are sorted by duration, padded per batch and decoded with
+        the configured decoder; returns (loss, error_rate) like the reference with loss = -1 (no CTC loss on this path) and
+        error_rate = mean CER or WER over utterances (configs.metrics_type).  ``decode_all_frames=True`` reproduces the
+        reference's decoding of the padded frames (trainer.py:340-344)."""
+        import json
+        from masr_amd.utils.metrics import cer, wer
+        items = []
+        with open(manifest, 'r', encoding='utf-8') as f:
+            for line in f:
+                line = line.strip()
+                if line:
+                    d = json.loads(line)
+                    items.append((d['audio_filepath'], d['text'], float(d.get('duration', 0.0))))
+        items.sort(key=lambda it: it[2])
+        metric = wer if self.configs.metrics_type == 'wer' else cer
+        errors = []
+        for lo in range(0, len(items), batch_size):
+            chunk = items[lo:lo + batch_size]
+            results = self.predict_batch([it[0] for it in chunk], decode_all_frames=decode_all_frames)
+            for (path, label, _), res in zip(chunk, results):
+                err = metric(res['text'], label)
+                errors.append(err)
+                if display_result:
+                    logger.info(f'预测结果为：{res["text"]}')
+                    logger.info(f'实际标签为：{label}')
+                    logger.info(f'这条数据的{self.configs.metrics_type}：{round(err, 6)}，'
+                                f'当前{self.configs.metrics_type}：{round(sum(errors) / len(errors), 6)}')
+        return -1, (float(sum(errors) / len(errors)) if errors else -1)
 
     def predict_stream(self, audio_data, is_end=False, use_pun=False, is_itn=False, channels=1, samp_width=2,
                        sample_rate=16000):

@@ -217,3 +217,32 @@ def test_deepspeech2_stream_matches_reference_facade(tmp_path):
             assert abs(r['score'] - float(z['stream_score'][k])) < 0.5
         k += 1
     p.reset_stream()
+
+
+def test_evaluate_manifest_matches_per_utterance_cer(predictor, tmp_path):
+    """batched evaluation over a reference-format manifest == per-utterance predict + CER"""
+    import json
+    import wave
+    from masr_amd.utils.metrics import cer
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    pieces = [pcm[:32000], pcm[20000:68000], pcm[40000:56000], pcm[60000:124000]]
+    labels = ['丁丂七丄', '丅丆万丈三上下', '丌不', '与丏丐丑丒专且丕世']
+    man = os.path.join(tmp_path, 'manifest.test')
+    with open(man, 'w', encoding='utf-8') as f:
+        for i, (p, t) in enumerate(zip(pieces, labels)):
+            path = os.path.join(tmp_path, f'u{i}.wav')
+            with wave.open(path, 'wb') as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+                w.writeframes(p.astype('<i2').tobytes())
+            f.write(json.dumps({'audio_filepath': path, 'text': t, 'duration': len(p) / 16000}, ensure_ascii=False) + '\n')
+    loss, err = predictor.evaluate(man, batch_size=3, display_result=True)
+    assert loss == -1
+    # same batches by hand: sorted by duration -> [u2, u0, u1], [u3]
+    paths = [os.path.join(tmp_path, f'u{i}.wav') for i in range(4)]
+    r1 = predictor.predict_batch([paths[2], paths[0], paths[1]])
+    r2 = predictor.predict_batch([paths[3]])
+    want = np.mean([cer(r1[0]['text'], labels[2]), cer(r1[1]['text'], labels[0]), cer(r1[2]['text'], labels[1]),
+                    cer(r2[0]['text'], labels[3])])
+    assert err == pytest.approx(float(want))
+    # a batch of one is the single-utterance path
+    assert r2[0]['text'] == predictor.predict(audio_data=paths[3])['text']

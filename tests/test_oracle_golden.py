@@ -165,3 +165,17 @@ def test_deepspeech2_fixture():
             np.testing.assert_allclose(p[0].numpy(), z['chunk_probs'][i], atol=5e-6)
         np.testing.assert_allclose(h.numpy(), z['h'], atol=5e-6)
         np.testing.assert_allclose(c.numpy(), z['c'], atol=5e-6)
+
+
+def test_metrics_match_reference_definitions():
+    # masr/utils/metrics.py:4-29 (Levenshtein package) restated with a numpy DP; KATs by hand + the oracle's plain DP
+    from masr_amd.utils.metrics import cer, wer
+    assert cer('a b c', 'abd') == pytest.approx(1 / 3)
+    assert cer('今天天气', '今天天气') == 0.0
+    assert cer('', 'abc') == 1.0
+    assert wer('the cat sat', 'the bat sat down') == 0.5
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = ''.join(rng.choice(list('abcd'), rng.integers(0, 12)))
+        b = ''.join(rng.choice(list('abcd'), rng.integers(1, 12)))
+        assert cer(a, b) == pytest.approx(od.cer(b, a))          # oracle signature is (ref, hyp)
