@@ -75,7 +75,7 @@ void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hi
 
 // ---- row-block GEMM for the K = 256 projections (rowgemm.hip) -------------------------------------
 enum RowGemmPro { RG_PRO_PLAIN = 0, RG_PRO_LN = 1, RG_PRO_LN_PAD = 2, RG_PRO_AFFINE = 3 };
-enum RowGemmEpi { RG_EPI_STORE = 0, RG_EPI_RESID = 1, RG_EPI_GLU = 2, RG_EPI_CTC = 3 };
+enum RowGemmEpi { RG_EPI_STORE = 0, RG_EPI_RESID = 1, RG_EPI_GLU = 2, RG_EPI_CTC = 3, RG_EPI_CHAIN = 4 };
 struct RowGemmArgs {
     const float* A;       // [rows, lda] source rows (K = 256)
     const float* lnw;     // LayerNorm weight / bias (PRO_LN*)
@@ -84,6 +84,7 @@ struct RowGemmArgs {
     const float* bias;    // [N]
     float* C;             // output [M, ldc]
     const float* R;       // residual [M, ldr] (EPI_RESID; may alias C)
+    float* R2;            // EPI_CHAIN: where the updated residual stream x + out-proj goes (may alias R); C = GLU output
     const int* lens;      // per-sequence feature lengths (pad masks), or nullptr
     int* out_idx;         // EPI_CTC: per-row argmax
     float* out_maxp;      // EPI_CTC: per-row softmax probability of the argmax

@@ -32,6 +32,8 @@ static int fail(const std::string& m) {
         if (_r) return _r;     \
     } while (0)
 
+static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
+
 namespace {
 
 struct DevBuf {
@@ -60,6 +62,7 @@ struct LayerW {
     float *ln_ffm_w, *ln_ffm_b, *ffm_w1, *ffm_b1, *ffm_w2, *ffm_b2;
     float *ln_mha_w, *ln_mha_b, *wqkv, *bqkv, *wo, *bo, *pos_u, *pos_v, *wpos, *ptab;
     float *ln_conv_w, *ln_conv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *cln_w, *cln_b, *pw2_w, *pw2_b, *gconst;
+    float *chain_w, *chain_b;     // [Wo; W_pw1] [768,256] and [bo; b_pw1] for the fused out-proj -> LN -> pw1 -> GLU kernel
     float *ln_ff_w, *ln_ff_b, *ff_w1, *ff_b1, *ff_w2, *ff_b2;
     float *ln_fin_w, *ln_fin_b;
 };
@@ -462,6 +465,18 @@ int masr_finalize(masr_engine* e, void* stream) {
         CHK(up(e, p + "self_attn.pos_bias_v", {H, gk}, &w.pos_v));
         CHK(up(e, p + "conv_module.pointwise_conv1.weight", {2 * d, d, 1}, &w.pw1_w));   // rows: value c, gate d + c
         CHK(up(e, p + "conv_module.pointwise_conv1.bias", {2 * d}, &w.pw1_b));
+        {   // [Wo; W_pw1] and [bo; b_pw1]: one continuous weight stream for the fused kernel of the offline path
+            const HostTensor *a, *b, *c2, *d2;
+            CHK(get(e, p + "self_attn.linear_out.weight", {d, d}, &a));
+            CHK(get(e, p + "self_attn.linear_out.bias", {d}, &b));
+            CHK(get(e, p + "conv_module.pointwise_conv1.weight", {2 * d, d, 1}, &c2));
+            CHK(get(e, p + "conv_module.pointwise_conv1.bias", {2 * d}, &d2));
+            std::vector<float> cw(a->v), cb(b->v);
+            cw.insert(cw.end(), c2->v.begin(), c2->v.end());
+            cb.insert(cb.end(), d2->v.begin(), d2->v.end());
+            CHK(upload(e, cw, &w.chain_w));
+            CHK(upload(e, cb, &w.chain_b));
+        }
         {   // glu(bias): what the zero left-padding of the causal conv turns into behind pointwise_conv1 + GLU
             std::vector<float> z(d, 0.f);
             CHK(upload(e, z, &w.gconst));
@@ -580,12 +595,15 @@ int ensure_layer_ws(masr_engine* e, int nseq, int Tq) {
 //                            GEMM's A-tile prologue (rowgemm PRO_LN_PAD); lnpad is not used.
 //  streaming (hist == true): lnpad rows [0,pad) of every sequence already hold the cnn cache; LayerNorm writes
 //                            the new rows behind them (needed for the next cache) and the GEMM reads lnpad.
-int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, bool hist, int K = 0, int mstride = 4) {
+int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, bool hist, int K = 0, int mstride = 4,
+                bool pw1_done = false) {
     if (K <= 0) K = e->cfg.cnn_kernel;
     const int d = e->cfg.d_model, pad = K - 1;
     const int M = c.nseq * c.Tq, Mp = c.nseq * (c.Tq + pad);
     float* x = e->x.as<float>();
-    if (hist) {
+    if (pw1_done) {
+        // glu buffer already filled by mhsa_out_pw1 (fused out-projection -> LayerNorm -> pointwise_conv1 -> GLU)
+    } else if (hist) {
         launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, c.Tq, pad, c.lens, s);
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
                 e->glu.as<float>(), d, Mp, 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
@@ -613,6 +631,20 @@ void mhsa_out(masr_engine* e, hipStream_t s, const LayerW& w, int M) {
     float* x = e->x.as<float>();
     rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->att.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d, 1.f,
             nullptr, 0, 0, 0, nullptr, nullptr);
+}
+
+// offline conformer layer: attention out-projection + residual and the conv module's LayerNorm + pointwise_conv1 + GLU in ONE
+// kernel (rowgemm EPI_CHAIN): the updated rows go to x (global) and, without leaving the CU, through the second GEMM
+void mhsa_out_pw1(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, int mstride = 4) {
+    const int d = e->cfg.d_model, pad = e->cfg.cnn_kernel - 1, M = c.nseq * c.Tq;
+    float* x = e->x.as<float>();
+    RowGemmArgs a{};
+    a.A = e->att.as<float>(); a.lda = d; a.lnw = w.ln_conv_w; a.lnb = w.ln_conv_b; a.W = w.chain_w; a.bias = w.chain_b;
+    a.C = e->glu.as<float>(); a.ldc = d; a.M = M; a.N = 3 * d; a.R = x; a.R2 = x; a.ldr = d; a.alpha = 1.f;
+    a.lens = c.lens; a.seq_t = c.Tq; a.mstride = mstride; a.eps = 1e-5f;
+    a.out_seq_t = c.Tq; a.out_pad_l = pad; a.out_pad_tot = pad;
+    ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)(3 * d) * d);
+    launch_rowgemm(a, RG_PRO_PLAIN, RG_EPI_CHAIN, s);
 }
 
 }  // namespace
@@ -1085,8 +1117,13 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
             launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v,
                              decoding_chunk_size > 0 ? decoding_chunk_size : 0, 1, s);
         }
-        mhsa_out(e, s, w, M);
-        CHK(conv_module(e, s, w, ctx, false));
+        if (g_no_chain) {
+            mhsa_out(e, s, w, M);
+            CHK(conv_module(e, s, w, ctx, false));
+        } else {
+            mhsa_out_pw1(e, s, w, ctx);
+            CHK(conv_module(e, s, w, ctx, false, 0, 4, true));
+        }
         CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
         launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
     }
@@ -1502,6 +1539,7 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
 int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     if (!e) return fail("null engine");
     if (key == 1) set_ffn_variant(value);
+    else if (key == 5) g_no_chain = value;
     else if (key == 2) {            // beam search phase profile of workgroup 0: value 1 = on, 0 = print + off
         if (value) {
             if (!e->beam_prof) {

@@ -15,6 +15,9 @@
 //            GLU (pointwise_conv1: value rows c, gate rows 256+c) -- convolution.py:117-118
 //            CTC greedy: online (max, argmax, sum exp) over all V columns, never writing logits --
 //            loss/ctc.py:62-70 + ctc_greedy_decoder.py:20-21
+//            CHAIN (offline conformer layer): attention out-projection + residual, then -- the 32 updated rows never leaving
+//            the CU -- LayerNorm + pad mask + pointwise_conv1 + GLU in the same kernel (weights [Wo; W_pw1] concatenated,
+//            one continuous slab stream): encoder.py:123-131 + convolution.py:98-119
 #include "common.h"
 
 namespace masr {
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
     extern __shared__ __align__(16) float sm[];
     float* at = sm;                               // [32][260] A tile
     float* wpv = at + RG_BM * RG_ALD;             // [8][2][32][36] wave-private weight slabs
-    float* red = wpv + 8 * 2 * RG_WSLAB;          // CTC: [8 waves][32 rows][3]
+    float* red = wpv + 8 * 2 * RG_WSLAB;          // CTC: [8 waves][32 rows][3];  CHAIN: second A tile [32][260] (the updated x rows)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
     // ---- weight tile stream: tile t = 32 weight rows starting at wrow(t), 8 slabs of 32 k -------------
     // EPI_GLU: tiles come in (value, gate) pairs -> tile 2g = rows 32w.., tile 2g+1 = rows 256 + 32w..
     const int ngroups = (EPI == RG_EPI_GLU) ? 1 : (p.N + 255) / 256;
-    const int ntiles = (EPI == RG_EPI_GLU) ? 2 : (GSPLIT ? 1 : ngroups);
+    const int ntiles = (EPI == RG_EPI_GLU) ? 2 : (EPI == RG_EPI_CHAIN) ? 3 : (GSPLIT ? 1 : ngroups);
     const int tbase = GSPLIT ? (int)blockIdx.y : 0;
     auto wrow_of = [&](int t) -> int {
         if (EPI == RG_EPI_GLU) return (t & 1) * 256 + wave * 32;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
         for (int i = 0; i < 4; ++i) pre[k % RG_NSET][i] = *reinterpret_cast<const f32x4*>(src_of(k / 8, k & 7, i));
     __syncthreads();                                  // A tile complete
 
-    const float* aa = at + frow * RG_ALD + 4 * fh;
+    const float* aa = at + frow * RG_ALD + 4 * fh;     // (CHAIN: switched to the second tile after tile 0)
     const float* wfrag = wmine + frow * RG_WLD + 4 * fh;
 
     // CTC running state of this lane's row (row = lane & 31; the two half-waves hold different columns)
@@ -232,6 +235,69 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
                     }
                 }
             }
+        } else if (EPI == RG_EPI_CHAIN) {
+            const int ch = wave * 32 + frow;
+            if (t == 0) {
+                // x <- x + (att . Wo^T + bo): to global (residual base of pointwise_conv2) and, raw, into the second LDS tile
+                const float bv = p.bias[ch];
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, p.M - 1);
+                    res[r] = p.R[(size_t)row * p.ldr + ch];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const float v = res[r] + (acc[r] + bv);
+                    if (row0 + lr < p.M) p.R2[(size_t)(row0 + lr) * p.ldr + ch] = v;
+                    red[lr * RG_ALD + ch] = v;
+                }
+                __syncthreads();
+                {   // LayerNorm (conv module) + pad mask in place: wave w owns rows 4w .. 4w+3
+                    const f32x4 gw = *reinterpret_cast<const f32x4*>(p.lnw + lane * 4);
+                    const f32x4 gb = *reinterpret_cast<const f32x4*>(p.lnb + lane * 4);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int lr = wave * 4 + rr, row = row0 + lr;
+                        bool live = row < p.M;
+                        if (live && p.lens && p.seq_t > 0) {
+                            const int b = row / p.seq_t, tt = row - b * p.seq_t;
+                            live = p.mstride * tt < p.lens[b];
+                        }
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(&red[lr * RG_ALD + lane * 4]);
+                        const float mean = rg_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                        const float var = rg_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                        const float rstd = 1.0f / sqrtf(var + p.eps);
+                        f32x4 o;
+                        o[0] = d0 * rstd * gw[0] + gb[0];
+                        o[1] = d1 * rstd * gw[1] + gb[1];
+                        o[2] = d2 * rstd * gw[2] + gb[2];
+                        o[3] = d3 * rstd * gw[3] + gb[3];
+                        if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<f32x4*>(&red[lr * RG_ALD + lane * 4]) = o;
+                    }
+                }
+                __syncthreads();
+                aa = red + frow * RG_ALD + 4 * fh;
+            } else if (t == 1) {
+                accv = acc;
+            } else {
+                const float bva = p.bias[256 + ch], bvg = p.bias[512 + ch];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (row >= p.M) continue;
+                    size_t crow = row;
+                    if (p.out_seq_t > 0) {
+                        const int b = row / p.out_seq_t, tt = row - b * p.out_seq_t;
+                        crow = (size_t)b * (p.out_seq_t + p.out_pad_tot) + p.out_pad_l + tt;
+                    }
+                    const float g = acc[r] + bvg;
+                    p.C[crow * p.ldc + ch] = (accv[r] + bva) * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+                }
+            }
         } else if (EPI == RG_EPI_GLU) {
             if (t == 0) {
                 accv = acc;
@@ -311,7 +377,7 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
 
 template <int PRO, int EPI>
 static void launch_rg(const RowGemmArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)(RG_BM * RG_ALD + 8 * 2 * RG_WSLAB + 8 * RG_BM * 3) * sizeof(float);
+    const size_t lds = (size_t)(RG_BM * RG_ALD + 8 * 2 * RG_WSLAB + (EPI == RG_EPI_CHAIN ? RG_BM * RG_ALD : 8 * RG_BM * 3)) * sizeof(float);
     constexpr bool can_split = EPI == RG_EPI_STORE || EPI == RG_EPI_RESID;
     static bool attr_done = false;
     if (!attr_done) {
@@ -340,6 +406,7 @@ void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
     else if (pro == RG_PRO_AFFINE && epi == RG_EPI_GLU) launch_rg<RG_PRO_AFFINE, RG_EPI_GLU>(a, s);
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_CTC) launch_rg<RG_PRO_PLAIN, RG_EPI_CTC>(a, s);
     else if (pro == RG_PRO_LN && epi == RG_EPI_CTC) launch_rg<RG_PRO_LN, RG_EPI_CTC>(a, s);
+    else if (pro == RG_PRO_PLAIN && epi == RG_EPI_CHAIN) launch_rg<RG_PRO_PLAIN, RG_EPI_CHAIN>(a, s);
 }
 
 }  // namespace masr
