@@ -532,3 +532,42 @@ def test_deepspeech2_transcribe_batch_against_oracle(ds2_engines, oracle_mods):
         s_ref, t_ref = od.greedy_decoder(probs[b, :xl[b]], vocab)
         ids = tok[b, :int(ntok[b])].cpu().numpy()
         assert ''.join(vocab[i] for i in ids).replace('<space>', ' ') == t_ref
+
+
+# ---------------------------------------------------------------------------------------------------
+# engine reuse: grow-only workspaces, stream slots, mixed call sequences
+# ---------------------------------------------------------------------------------------------------
+def test_engine_reuse_across_shapes_and_streams(eng512, oracle_mods):
+    """one engine, changing batch sizes / lengths / stream counts: results do not depend on the call history"""
+    e, _ = eng512
+    torch.manual_seed(21)
+    x_small = torch.randn(1, 131, 80) * 3 + 13
+    l_small = torch.tensor([131], dtype=torch.int32)
+    ref = e.encode_full(dev(x_small), dev(l_small)).cpu()
+    for B, T in ((5, 400), (2, 67), (9, 203), (1, 998)):
+        x = torch.randn(B, T, 80) * 3 + 13
+        lens = torch.randint(T // 2, T + 1, (B,), dtype=torch.int32)
+        lens[0] = T
+        enc = e.encode_full(dev(x), dev(lens))
+        assert torch.isfinite(enc).all()
+    again = e.encode_full(dev(x_small), dev(l_small)).cpu()
+    assert torch.equal(ref, again)
+    # streams: open / close many times, ids are recycled, a fresh stream behaves like the first one
+    chunk = dev(x_small[:, :67])
+    sid = e.stream_open(0)
+    first, _, _ = e.encode_chunk([sid], chunk)
+    first = first.cpu()
+    e.stream_close(sid)
+    seen = set()
+    for _ in range(6):
+        ids = [e.stream_open(64) for _ in range(5)]
+        seen.update(ids)
+        p, _, _ = e.encode_chunk(ids, chunk.repeat(5, 1, 1))
+        for k in range(5):
+            # (the d_ff / K splits depend on the number of rows: same values up to the summation order)
+            assert (p[k].cpu() - first[0]).abs().max() < 1e-5
+        for i in ids:
+            e.stream_close(i)
+    assert len(seen) <= 5                      # slots are reused
+    with pytest.raises(Exception):
+        e.encode_chunk([sid + 100], chunk)      # unknown stream id fails loudly
