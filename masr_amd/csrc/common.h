@@ -50,7 +50,7 @@ void launch_dwconv_ln_silu(const float* g, const float* wkc, const float* bias, 
 // same with an eval-mode BatchNorm folded into a per-channel scale/shift instead of the LayerNorm
 void launch_glu_const(const float* bias512, float* out256, hipStream_t s);
 void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, const float* scale, const float* shift,
-                           float* out, int nseq, int Tq, int ktaps, hipStream_t s);
+                           float* out, int nseq, int Tq, int ktaps, hipStream_t s, const float* gconst = nullptr);
 // Efficient-Conformer stride layer: depthwise causal conv with stride 2 (+ LayerNorm + SiLU) on the padded layout
 // [nseq][ktaps-1 + Tin][256] -> [nseq * ceil(Tin/2), 256]; and the AvgPool1d(2, ceil_mode) residual path
 void launch_dwconv_stride2_ln_silu(const float* g, const float* wkc, const float* bias, const float* lnw,

@@ -195,12 +195,12 @@ void launch_glu_const(const float* bias512, float* out256, hipStream_t s) {
 }
 
 void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, const float* scale, const float* shift,
-                           float* out, int nseq, int Tq, int ktaps, hipStream_t s) {
+                           float* out, int nseq, int Tq, int ktaps, hipStream_t s, const float* gconst) {
     if (nseq * Tq <= 0) return;
     const int tiles = (Tq + DW_TT - 1) / DW_TT;
     const dim3 grid(nseq * tiles), blk(256);
-    if (ktaps == 31) hipLaunchKernelGGL((dwconv_ln_silu_kernel<31, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f, (const float*)nullptr);
-    else if (ktaps == 15) hipLaunchKernelGGL((dwconv_ln_silu_kernel<15, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f, (const float*)nullptr);
+    if (ktaps == 31) hipLaunchKernelGGL((dwconv_ln_silu_kernel<31, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f, gconst);
+    else if (ktaps == 15) hipLaunchKernelGGL((dwconv_ln_silu_kernel<15, 1>), grid, blk, 0, s, g, wkc, bias, scale, shift, out, Tq, 0.f, gconst);
 }
 
 // ------------------------------------------------------------------------------------------

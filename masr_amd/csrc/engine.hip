@@ -70,7 +70,7 @@ struct LayerW {
 struct SqLayerW {   // Squeezeformer block (post-LN, adaptive scale/bias, BatchNorm conv module)
     float *att_s, *att_b, *wqkv, *bqkv, *wo, *bo, *pos_u, *pos_v, *wpos, *ptab, *ln1_w, *ln1_b;
     float *f1_s, *f1_b, *f1_w1, *f1_b1, *f1_w2, *f1_b2, *ln2_w, *ln2_b;
-    float *cv_s, *cv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *bn_scale, *bn_shift, *pw2_w, *pw2_b, *ln3_w, *ln3_b;
+    float *cv_s, *cv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *bn_scale, *bn_shift, *pw2_w, *pw2_b, *ln3_w, *ln3_b, *gconst;
     float *f2_s, *f2_b, *f2_w1, *f2_b1, *f2_w2, *f2_b2, *ln4_w, *ln4_b;
 };
 
@@ -294,7 +294,6 @@ int masr_create(const masr_config* cfg, masr_engine** out) {
         if (!cfg->causal) return fail("only the streaming-trained (causal conv) conformer is implemented");
     } else {
         if (cfg->cnn_kernel != 31) return fail("squeezeformer: cnn_module_kernel must be 31");
-        if (cfg->causal) return fail("only the non-streaming squeezeformer (symmetric conv + BatchNorm) is implemented");
     }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -758,6 +757,11 @@ static int finalize_squeezeformer(masr_engine* e, hipStream_t s) {
         CHK(vec("conv_module.ada_scale", &w.cv_s)); CHK(vec("conv_module.ada_bias", &w.cv_b));
         CHK(up(e, p + "conv_module.pointwise_conv1.weight", {2 * d, d, 1}, &w.pw1_w));
         CHK(up(e, p + "conv_module.pointwise_conv1.bias", {2 * d}, &w.pw1_b));
+        {   // streaming-trained build (causal conv): the K-1 zero frames padded in front of pointwise_conv1 become glu(bias)
+            std::vector<float> z(d, 0.f);
+            CHK(upload(e, z, &w.gconst));
+            launch_glu_const(w.pw1_b, w.gconst, s);
+        }
         {
             CHK(get(e, p + "conv_module.depthwise_conv.weight", {d, 1, K}, &t));
             std::vector<float> wd((size_t)K * d);
@@ -784,10 +788,13 @@ static int finalize_squeezeformer(masr_engine* e, hipStream_t s) {
         CHK(up(e, p + "conv_module.pointwise_conv2.bias", {d}, &w.pw2_b));
     }
     {
-        CHK(get(e, "encoder.time_reduction_layer.dw_conv.weight", {d, 1, 5}, &t));
-        std::vector<float> wd((size_t)5 * d);
+        // TimeReductionLayer1D: depthwise k = 5, stride 2, padding 3; TimeReductionLayerStream (streaming-trained build,
+        // squeezeformer/model.py:37-41): k = 1, stride 2, no padding == the k = 5 kernel with only tap 3 (t = 2j) non-zero
+        const int tk = e->cfg.causal ? 1 : 5;
+        CHK(get(e, "encoder.time_reduction_layer.dw_conv.weight", {d, 1, tk}, &t));
+        std::vector<float> wd((size_t)5 * d, 0.f);
         for (int c = 0; c < d; ++c)
-            for (int j = 0; j < 5; ++j) wd[(size_t)j * d + c] = t->v[(size_t)c * 5 + j];
+            for (int j = 0; j < tk; ++j) wd[(size_t)(tk == 1 ? 3 : j) * d + c] = t->v[(size_t)c * tk + j];
         CHK(upload(e, wd, &e->tr_dw_w));
         CHK(up(e, "encoder.time_reduction_layer.dw_conv.bias", {d}, &e->tr_dw_b));
         CHK(up(e, "encoder.time_reduction_layer.pw_conv.weight", {d, d, 1}, &e->tr_pw_w));
@@ -817,8 +824,10 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
     float* x = e->x.as<float>();
     launch_layernorm(x, e->preln_w, e->preln_b, x, B * T0, 1e-5f, 0, 0, nullptr, s);
     int Tq = T0, mstride = 4, pstride = 1;
+    const bool causal = e->cfg.causal != 0;   // streaming-trained build: K-1 history rows in front (constant glu(bias))
+    const int pad_l = causal ? K - 1 : half;
     auto new_resolution = [&]() -> int {     // zero the symmetric pad rows of the GLU buffer, rebuild the descriptors
-        HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + 2 * half) * d * sizeof(float), s));
+        if (!causal) HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + 2 * half) * d * sizeof(float), s));
         launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), lens, B, Tq, mstride, s);
         return 0;
     };
@@ -860,8 +869,9 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
         launch_layernorm(x, w.ln2_w, w.ln2_b, x, M, 1e-5f, 0, 0, nullptr, s);
         // x = LN3(x + Conv(ada(x)))   symmetric depthwise conv: (K-1)/2 zero rows on both sides of the GLU output
         rowgemm(e, s, RG_PRO_AFFINE, RG_EPI_GLU, x, d, w.cv_s, w.cv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d, M, 2 * d,
-                nullptr, 0, 1.f, lens, 0, Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, Tq, half, 2 * half);
-        launch_dwconv_bn_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.bn_scale, w.bn_shift, e->dwo.as<float>(), B, Tq, K, s);
+                nullptr, 0, 1.f, lens, 0, Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, Tq, pad_l, 2 * half);
+        launch_dwconv_bn_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.bn_scale, w.bn_shift, e->dwo.as<float>(), B, Tq, K, s,
+                              causal ? w.gconst : nullptr);
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x,
                 d, 1.f, lens, Tq, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
         launch_layernorm(x, w.ln3_w, w.ln3_b, x, M, 1e-5f, 0, 0, nullptr, s);

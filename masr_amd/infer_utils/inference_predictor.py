@@ -42,8 +42,6 @@ class InferencePredictor:
         if use_model not in ('conformer', 'squeezeformer', 'efficient_conformer', 'deepspeech2'):
             raise Exception(f'masr_amd implements conformer / squeezeformer / efficient_conformer / deepspeech2; '
                             f'got use_model={use_model}')
-        if use_model == 'squeezeformer' and streaming:
-            raise Exception('masr_amd implements the non-streaming squeezeformer (streaming: False) only')
         self.device = torch.device('cuda')
         enc_conf = dict(configs.get('encoder_conf', {})) if configs is not None else {}
         n_mels = int(configs.get('preprocess_conf', {}).get('n_mels', 80)) if configs is not None else 80

@@ -90,9 +90,10 @@ def synthetic_pcm(batch, n_samples, seed=1234):
 
 
 def squeezeformer_state_dict(seed=0, vocab_size=4233, d=256, heads=4, ff_factor=8, num_blocks=12, kernel=31,
-                             n_mels=80, ctc_gain=6.0):
-    """Keys/shapes == reference SqueezeformerModel ``encoder.*`` + ``ctc.*`` (non-streaming build:
-    TimeReductionLayer1D, BatchNorm conv module; masr/model_utils/squeezeformer/)."""
+                             n_mels=80, ctc_gain=6.0, streaming=False):
+    """Keys/shapes == reference SqueezeformerModel ``encoder.*`` + ``ctc.*`` (masr/model_utils/squeezeformer/):
+    BatchNorm conv module; ``streaming=False`` -> TimeReductionLayer1D (kernel 5), ``streaming=True`` (the shipped YAML
+    default) -> TimeReductionLayerStream (kernel 1) -- the causal convolution changes no shapes."""
     sd = {}
     f2 = ((n_mels - 1) // 2 - 1) // 2
     d_ff = d * ff_factor
@@ -145,7 +146,8 @@ def squeezeformer_state_dict(seed=0, vocab_size=4233, d=256, heads=4, ff_factor=
         sd[p + 'conv_module.pointwise_conv2.bias'] = _uniform(seed, p + 'pw2.b', (d,), 0.1)
         for n in ('layer_norm1', 'layer_norm2', 'layer_norm3', 'layer_norm4'):
             ln(p + n)
-    sd['encoder.time_reduction_layer.dw_conv.weight'] = _uniform(seed, 'tr.dw.w', (d, 1, 5), math.sqrt(3.0 / 5))
+    tk = 1 if streaming else 5
+    sd['encoder.time_reduction_layer.dw_conv.weight'] = _uniform(seed, 'tr.dw.w', (d, 1, tk), math.sqrt(3.0 / tk))
     sd['encoder.time_reduction_layer.dw_conv.bias'] = _uniform(seed, 'tr.dw.b', (d,), 0.1)
     sd['encoder.time_reduction_layer.pw_conv.weight'] = _uniform(seed, 'tr.pw.w', (d, d, 1), math.sqrt(3.0 / d))
     sd['encoder.time_reduction_layer.pw_conv.bias'] = _uniform(seed, 'tr.pw.b', (d,), 0.1)

@@ -69,6 +69,23 @@ def build_reference_deepspeech2(sd, vocab_size, streaming, tmp):
     return m.eval()
 
 
+def squeezeformer_streaming_fixture(mean_istd):
+    """squeezeformer.yml as shipped (streaming: True -> causal conv module + TimeReductionLayerStream), full-context
+    get_encoder_out on the ragged batch"""
+    from masr.model_utils.squeezeformer.model import SqueezeformerModel
+    feats, lens = golden_inputs()
+    cfg = yaml.safe_load(open(os.path.join(REF, 'configs', 'squeezeformer.yml'), encoding='utf-8'))
+    sd = weights.squeezeformer_state_dict(0, 512, streaming=True)
+    m = SqueezeformerModel(input_dim=80, vocab_size=512, mean_istd_path=mean_istd, streaming=True,
+                           encoder_conf=cfg['encoder_conf'], decoder_conf=cfg['decoder_conf'], **cfg['model_conf'])
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith('decoder.') for k in missing), (missing[:4], unexpected[:4])
+    m.eval()
+    enc, _ = m.encoder(feats, lens, -1, -1)
+    probs = m.get_encoder_out(feats, lens)
+    np.savez_compressed(os.path.join(OUT, 'squeezeformer_streaming_v512.npz'), enc=enc.numpy(), probs=probs.numpy())
+
+
 def deepspeech2_fixture(tmp):
     feats, lens = golden_inputs()
     out = {}
@@ -136,6 +153,14 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp()
     torch.set_grad_enabled(False)
+    if '--only-squeezeformer-streaming' in sys.argv:
+        p = os.path.join(tmp, 'mean_istd_sq.json')
+        sd0 = weights.squeezeformer_state_dict(0, 512, streaming=True)
+        json.dump({'mean': sd0['encoder.global_cmvn.mean'].tolist(), 'istd': sd0['encoder.global_cmvn.istd'].tolist(),
+                   'feature_method': 'fbank'}, open(p, 'w'))
+        squeezeformer_streaming_fixture(p)
+        print('squeezeformer streaming fixture written')
+        return
     if '--only-deepspeech2' in sys.argv:
         deepspeech2_fixture(tmp)
         print('deepspeech2 fixture written')
@@ -193,6 +218,7 @@ def main():
     sq_enc, _ = sq.encoder(feats, lens, -1, -1)
     sq_probs = sq.get_encoder_out(feats, lens)
     np.savez_compressed(os.path.join(OUT, 'squeezeformer_v512.npz'), enc=sq_enc.numpy(), probs=sq_probs.numpy())
+    squeezeformer_streaming_fixture(mean_istd)
 
     # ---- efficient conformer (configs/efficient_conformer.yml, streaming: True) V=512 ------------------
     from masr.model_utils.efficient_conformer.model import EfficientConformerModel

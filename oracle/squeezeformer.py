@@ -58,14 +58,17 @@ def _ffn(sd, p, x):
     return F.linear(h, sd[p + '.w_2.weight'], sd[p + '.w_2.bias'])
 
 
-def _conv_module(sd, p, x, pad_mask, kernel):
-    """squeezeformer/convolution.py:92-148, non-causal + BatchNorm1d in eval mode."""
+def _conv_module(sd, p, x, pad_mask, kernel, causal=False):
+    """squeezeformer/convolution.py:92-148, BatchNorm1d in eval mode; causal (streaming-trained model): the input is
+    left-padded with kernel-1 zero frames BEFORE pointwise_conv1 (:117-120), symmetric otherwise (Conv1d padding)."""
     x = _ada(sd, p, x).transpose(1, 2)
     x = x.masked_fill(~pad_mask.unsqueeze(1), 0.0)
+    if causal:
+        x = F.pad(x, (kernel - 1, 0), 'constant', 0.0)
     x = F.conv1d(x, sd[p + '.pointwise_conv1.weight'], sd[p + '.pointwise_conv1.bias'])
     x = F.glu(x, dim=1)
-    x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], padding=(kernel - 1) // 2,
-                 groups=x.shape[1])
+    x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'],
+                 padding=0 if causal else (kernel - 1) // 2, groups=x.shape[1])
     x = F.batch_norm(x, sd[p + '.norm.running_mean'], sd[p + '.norm.running_var'], sd[p + '.norm.weight'],
                      sd[p + '.norm.bias'], False, 0.1, 1e-5)
     x = F.silu(x)
@@ -74,21 +77,23 @@ def _conv_module(sd, p, x, pad_mask, kernel):
     return x.transpose(1, 2)
 
 
-def _layer(sd, i, x, pos_emb, pad_mask, heads, kernel):
+def _layer(sd, i, x, pos_emb, pad_mask, heads, kernel, causal=False):
     """SqueezeformerEncoderLayer.forward, normalize_before=False (squeezeformer/encoder.py:412-463)."""
     p = f'encoder.encoders.{i}'
     x = _ln(sd, p + '.layer_norm1', x + _attention(sd, p + '.self_attn', x, pos_emb, pad_mask.unsqueeze(1), heads))
     x = _ln(sd, p + '.layer_norm2', x + _ffn(sd, p + '.ffn1', x))
-    x = _ln(sd, p + '.layer_norm3', x + _conv_module(sd, p + '.conv_module', x, pad_mask, kernel))
+    x = _ln(sd, p + '.layer_norm3', x + _conv_module(sd, p + '.conv_module', x, pad_mask, kernel, causal))
     x = _ln(sd, p + '.layer_norm4', x + _ffn(sd, p + '.ffn2', x))
     return x
 
 
 def _time_reduce(sd, x, pad_mask):
-    """TimeReductionLayer1D.forward (squeezeformer/time_reduction.py:53-76): dw k=5 s=2 pad=3 + pw."""
+    """TimeReductionLayer1D.forward (squeezeformer/time_reduction.py:53-76): dw k=5 s=2 pad=3 + pw; the streaming build
+    uses TimeReductionLayerStream (:131-200): dw k=1 s=2 pad=0 -- told apart by the depthwise kernel size."""
     p = 'encoder.time_reduction_layer'
     y = x.transpose(1, 2).masked_fill(~pad_mask.unsqueeze(1), 0.0)
-    y = F.conv1d(y, sd[p + '.dw_conv.weight'], sd[p + '.dw_conv.bias'], stride=2, padding=3, groups=y.shape[1])
+    k = sd[p + '.dw_conv.weight'].shape[-1]
+    y = F.conv1d(y, sd[p + '.dw_conv.weight'], sd[p + '.dw_conv.bias'], stride=2, padding=max(0, k - 2), groups=y.shape[1])
     y = F.conv1d(y, sd[p + '.pw_conv.weight'], sd[p + '.pw_conv.bias']).transpose(1, 2)
     pm = pad_mask[:, ::2]
     L, T = pm.shape[1], y.shape[1]
@@ -103,8 +108,9 @@ def num_blocks_of(sd):
     return 1 + max(int(k.split('.')[2]) for k in sd if k.startswith('encoder.encoders.'))
 
 
-def encoder_full(sd, feats, lens, heads=4, kernel=31, reduce_idx=5, recover_idx=11):
-    """SqueezeformerEncoder.forward, streaming=False (squeezeformer/encoder.py:168-216)."""
+def encoder_full(sd, feats, lens, heads=4, kernel=31, reduce_idx=5, recover_idx=11, causal=False):
+    """SqueezeformerEncoder.forward, full context (squeezeformer/encoder.py:168-216); ``causal=True`` for the
+    streaming-trained build (model.py:37-41: causal convolution + stream time reduction)."""
     B, T, _ = feats.shape
     pad = torch.arange(T)[None, :] < lens[:, None]
     x = embed(sd, feats)
@@ -124,7 +130,7 @@ def encoder_full(sd, feats, lens, heads=4, kernel=31, reduce_idx=5, recover_idx=
             y = F.linear(y, sd['encoder.time_recover_layer.weight'], sd['encoder.time_recover_layer.bias'])
             x = rx + y[:, :rx.shape[1], :]
             pad_s, pos_emb = rpad, rpos
-        x = _layer(sd, i, x, pos_emb, pad_s, heads, kernel)
+        x = _layer(sd, i, x, pos_emb, pad_s, heads, kernel, causal)
     return x
 
 

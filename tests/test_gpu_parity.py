@@ -381,6 +381,33 @@ def test_squeezeformer_against_reference_fixture(sq512, oracle_mods):
     assert (idx.cpu().numpy()[safe] == z['probs'].argmax(-1)[safe]).all()
 
 
+def test_squeezeformer_streaming_build_against_reference_fixture(oracle_mods):
+    """squeezeformer.yml as shipped (streaming: True): causal conv module (history rows = glu(bias)) + stream time reduction"""
+    from masr_amd.engine import HipEngine
+    from oracle import squeezeformer as osq
+    weights, golden_inputs = oracle_mods[3], oracle_mods[4]
+    sd = weights.squeezeformer_state_dict(0, 512, streaming=True)
+    enc_conf = {'encoder_dim': 256, 'attention_heads': 4, 'num_blocks': 12, 'reduce_idx': 5, 'recover_idx': 11,
+                'feed_forward_expansion_factor': 8, 'cnn_module_kernel': 31}
+    e = HipEngine(sd, encoder_conf=enc_conf, vocab_size=512, streaming=True, use_model='squeezeformer')
+    z = g('squeezeformer_streaming_v512.npz')
+    feats, lens = golden_inputs()
+    enc = e.encode_full(dev(feats), dev(lens, torch.int32))
+    assert np.abs(enc.cpu().numpy() - z['enc']).max() < 1e-3
+    probs = e.ctc_probs(enc).cpu().numpy()
+    assert np.abs(probs - z['probs']).max() < 1e-3
+    # odd frame counts (time reduction / recovery edge) against the oracle
+    torch.manual_seed(4)
+    x = torch.randn(2, 203, 80) * 3 + 13
+    l2 = torch.tensor([203, 150])
+    x = x * (torch.arange(203)[None, :, None] < l2[:, None, None])
+    with torch.no_grad():
+        ref = osq.encoder_full(sd, x, l2, causal=True).numpy()
+    got = e.encode_full(dev(x), dev(l2, torch.int32)).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-3
+    e.close()
+
+
 def test_squeezeformer_odd_lengths_against_oracle(sq512, oracle_mods):
     """odd T' (time reduction trims, recovery slices) and a ragged batch."""
     from oracle import squeezeformer as osq

@@ -179,3 +179,15 @@ def test_metrics_match_reference_definitions():
         a = ''.join(rng.choice(list('abcd'), rng.integers(0, 12)))
         b = ''.join(rng.choice(list('abcd'), rng.integers(1, 12)))
         assert cer(a, b) == pytest.approx(od.cer(b, a))          # oracle signature is (ref, hyp)
+
+
+def test_squeezeformer_streaming_build_fixture():
+    # squeezeformer.yml as shipped (streaming: True): causal conv module + TimeReductionLayerStream, full-context decode
+    from oracle import squeezeformer as osq
+    z = g('squeezeformer_streaming_v512.npz')
+    feats, lens = golden_inputs()
+    sd = weights.squeezeformer_state_dict(0, 512, streaming=True)
+    with torch.no_grad():
+        enc = osq.encoder_full(sd, feats, lens, causal=True)
+        np.testing.assert_allclose(enc.numpy(), z['enc'], atol=2e-5)
+        np.testing.assert_allclose(osq.get_encoder_out(sd, feats, lens, causal=True).numpy(), z['probs'], atol=2e-6)
