@@ -291,7 +291,8 @@ int masr_create(const masr_config* cfg, masr_engine** out) {
     if (cfg->model_kind == 3) {
     } else if (cfg->model_kind == 0 || cfg->model_kind == 2) {
         if (cfg->cnn_kernel != 15) return fail("conformer: cnn_module_kernel must be 15");
-        if (!cfg->causal) return fail("only the streaming-trained (causal conv) conformer is implemented");
+        if (!cfg->causal && cfg->model_kind == 2)
+            return fail("efficient_conformer: only the streaming-trained (causal conv) build is implemented");
     } else {
         if (cfg->cnn_kernel != 31) return fail("squeezeformer: cnn_module_kernel must be 31");
     }
@@ -609,11 +610,14 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
     } else {
         // only the real rows go through the GEMM (M = nseq*Tq: 248 workgroups at B=32 x 10 s, one per CU); they land in the
         // padded layout, whose history rows are the constant glu(bias) that the depthwise kernel substitutes itself
+        // (non-causal build, streaming: False: the depthwise Conv1d pads the GLU output with (K-1)/2 zero rows on both sides --
+        //  those rows of the glu buffer are zeroed once per call by the caller)
         rowgemm(e, s, RG_PRO_LN_PAD, RG_EPI_GLU, x, d, w.ln_conv_w, w.ln_conv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d,
-                M, 2 * d, nullptr, 0, 1.f, c.lens, 0, c.Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, c.Tq, pad, pad);
+                M, 2 * d, nullptr, 0, 1.f, c.lens, 0, c.Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, c.Tq,
+                e->cfg.causal ? pad : pad / 2, pad);
     }
     launch_dwconv_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), c.nseq, c.Tq, K,
-                          1e-5f, s, hist ? nullptr : w.gconst);
+                          1e-5f, s, (hist || !e->cfg.causal) ? nullptr : w.gconst);
     rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x, d,
             1.f, c.lens, c.lens ? c.Tq : 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
     return 0;
@@ -641,7 +645,7 @@ void mhsa_out_pw1(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCt
     a.A = e->att.as<float>(); a.lda = d; a.lnw = w.ln_conv_w; a.lnb = w.ln_conv_b; a.W = w.chain_w; a.bias = w.chain_b;
     a.C = e->glu.as<float>(); a.ldc = d; a.M = M; a.N = 3 * d; a.R = x; a.R2 = x; a.ldr = d; a.alpha = 1.f;
     a.lens = c.lens; a.seq_t = c.Tq; a.mstride = mstride; a.eps = 1e-5f;
-    a.out_seq_t = c.Tq; a.out_pad_l = pad; a.out_pad_tot = pad;
+    a.out_seq_t = c.Tq; a.out_pad_l = e->cfg.causal ? pad : pad / 2; a.out_pad_tot = pad;
     ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)(3 * d) * d);
     launch_rowgemm(a, RG_PRO_PLAIN, RG_EPI_CHAIN, s);
 }
@@ -1119,13 +1123,15 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     float* x = e->x.as<float>();
     EncodeCtx ctx{B, Tq, feat_lens_dev};
     launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), feat_lens_dev, B, Tq, 4, s);
+    if (!e->cfg.causal)     // symmetric conv: the (K-1)/2 pad rows on both sides of every sequence stay zero for all layers
+        HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + pad) * d * sizeof(float), s));
     for (const LayerW& w : e->layers) {
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
         mhsa(e, s, w, M);
         {
             ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
             launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v,
-                             decoding_chunk_size > 0 ? decoding_chunk_size : 0, 1, s);
+                             (decoding_chunk_size > 0 && e->cfg.causal) ? decoding_chunk_size : 0, 1, s);   // use_dynamic_chunk only in the streaming build
         }
         if (g_no_chain) {
             mhsa_out(e, s, w, M);
@@ -1367,6 +1373,8 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
         if (!e->cfg.causal) return fail("deepspeech2: streaming needs the uni-directional model");
     } else if (e->cfg.model_kind != 0) {
         return fail("streaming is implemented for the conformer and deepspeech2");
+    } else if (!e->cfg.causal) {
+        return fail("chunked streaming needs the streaming-trained (causal conv) conformer");
     }
     if (max_frames_out <= 0 || max_frames_out > e->cfg.max_pos) max_frames_out = e->cfg.max_pos;
     int id = -1;

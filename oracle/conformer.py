@@ -79,23 +79,26 @@ def _attention(sd, p, x, pos_emb, key_mask, heads, cache=None):
     return F.linear(o, sd[p + '.linear_out.weight'], sd[p + '.linear_out.bias']), new_cache
 
 
-def _conv_module(sd, p, x, pad_mask, kernel, cache=None):
-    """ConvolutionModule.forward, causal + layer_norm variant
-    (conformer/convolution.py:76-132).  x [B,T,d]; pad_mask bool [B,T] (True=valid)
-    or None; cache [B,d,kernel-1] or None.  NB the left zero padding (or cache) is
-    concatenated BEFORE pointwise_conv1, so padded frames carry glu(bias)."""
+def _conv_module(sd, p, x, pad_mask, kernel, cache=None, causal=True):
+    """ConvolutionModule.forward, layer_norm variant (conformer/convolution.py:76-132).  x [B,T,d]; pad_mask bool [B,T]
+    (True=valid) or None; cache [B,d,kernel-1] or None.  causal (streaming-trained model): NB the left zero padding (or
+    cache) is concatenated BEFORE pointwise_conv1, so padded frames carry glu(bias).  Non-causal (streaming: False):
+    symmetric zero padding inside the depthwise Conv1d (:53-61)."""
     x = x.transpose(1, 2)
     if pad_mask is not None:
         x = x.masked_fill(~pad_mask.unsqueeze(1), 0.0)
     lorder = kernel - 1
-    if cache is None or cache.shape[2] == 0:
-        x = F.pad(x, (lorder, 0))
-    else:
-        x = torch.cat([cache, x], dim=2)
-    new_cache = x[:, :, -lorder:]
+    new_cache = None
+    if causal:
+        if cache is None or cache.shape[2] == 0:
+            x = F.pad(x, (lorder, 0))
+        else:
+            x = torch.cat([cache, x], dim=2)
+        new_cache = x[:, :, -lorder:]
     x = F.conv1d(x, sd[p + '.pointwise_conv1.weight'], sd[p + '.pointwise_conv1.bias'])
     x = F.glu(x, dim=1)
-    x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], groups=x.shape[1])
+    x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], groups=x.shape[1],
+                 padding=0 if causal else lorder // 2)
     x = F.silu(_ln(sd, p + '.norm', x.transpose(1, 2))).transpose(1, 2)
     x = F.conv1d(x, sd[p + '.pointwise_conv2.weight'], sd[p + '.pointwise_conv2.bias'])
     if pad_mask is not None:
@@ -103,14 +106,14 @@ def _conv_module(sd, p, x, pad_mask, kernel, cache=None):
     return x.transpose(1, 2), new_cache
 
 
-def _layer(sd, i, x, pos_emb, att_mask, pad_mask, heads, kernel, att_cache=None, cnn_cache=None):
+def _layer(sd, i, x, pos_emb, att_mask, pad_mask, heads, kernel, att_cache=None, cnn_cache=None, causal=True):
     """ConformerEncoderLayer.forward, normalize_before=True, macaron
     (conformer/encoder.py:82-163)."""
     p = f'encoder.encoders.{i}'
     x = x + 0.5 * _ffn(sd, p + '.feed_forward_macaron', _ln(sd, p + '.norm_ff_macaron', x))
     a, new_att = _attention(sd, p + '.self_attn', _ln(sd, p + '.norm_mha', x), pos_emb, att_mask, heads, att_cache)
     x = x + a
-    c, new_cnn = _conv_module(sd, p + '.conv_module', _ln(sd, p + '.norm_conv', x), pad_mask, kernel, cnn_cache)
+    c, new_cnn = _conv_module(sd, p + '.conv_module', _ln(sd, p + '.norm_conv', x), pad_mask, kernel, cnn_cache, causal)
     x = x + c
     x = x + 0.5 * _ffn(sd, p + '.feed_forward', _ln(sd, p + '.norm_ff', x))
     return _ln(sd, p + '.norm_final', x), new_att, new_cnn
@@ -126,7 +129,8 @@ def encoder_full(sd, feats, lens, decoding_chunk_size=-1, heads=4, kernel=15, st
     num_decoding_left_chunks=-1.  ``streaming`` (model.py:37-42) selects
     use_dynamic_chunk (=> (B,T',T') chunk mask, utils/mask.py:78-143).
     Returns encoder_out [B,T',d] (after_norm applied) [, per-layer outputs]."""
-    assert streaming, 'only the streaming-trained (causal conv) variant is restated'
+    if not streaming:                 # use_dynamic_chunk = False: decoding_chunk_size is ignored (mask.py:117-143)
+        decoding_chunk_size = -1
     B, T, _ = feats.shape
     pad = torch.arange(T)[None, :] < lens[:, None]                      # ~make_pad_mask (mask.py:146-172)
     x = embed(sd, feats)
@@ -141,7 +145,7 @@ def encoder_full(sd, feats, lens, decoding_chunk_size=-1, heads=4, kernel=15, st
     att_mask = pad_s[:, None, :] & chunk[None]                          # (B,T',T')
     outs = []
     for i in range(num_blocks_of(sd)):
-        x, _, _ = _layer(sd, i, x, pos_emb, att_mask, pad_s, heads, kernel)
+        x, _, _ = _layer(sd, i, x, pos_emb, att_mask, pad_s, heads, kernel, causal=streaming)
         outs.append(x)
     x = _ln(sd, 'encoder.after_norm', x)
     return (x, outs) if return_layers else x

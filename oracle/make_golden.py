@@ -69,6 +69,25 @@ def build_reference_deepspeech2(sd, vocab_size, streaming, tmp):
     return m.eval()
 
 
+def conformer_nonstreaming_fixture(tmp):
+    """conformer.yml with streaming: False (non-causal conv module, no dynamic chunk masks), ragged batch"""
+    from masr.model_utils.conformer.model import ConformerModel
+    feats, lens = golden_inputs()
+    sd = weights.conformer_state_dict(0, 512)
+    cfg = yaml.safe_load(open(os.path.join(REF, 'configs', 'conformer.yml'), encoding='utf-8'))
+    p = os.path.join(tmp, 'mean_istd_ns.json')
+    json.dump({'mean': sd['encoder.global_cmvn.mean'].tolist(), 'istd': sd['encoder.global_cmvn.istd'].tolist(),
+               'feature_method': 'fbank'}, open(p, 'w'))
+    m = ConformerModel(input_dim=80, vocab_size=512, mean_istd_path=p, streaming=False,
+                       encoder_conf=cfg['encoder_conf'], decoder_conf=cfg['decoder_conf'], **cfg['model_conf'])
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith('decoder.') for k in missing)
+    m.eval()
+    enc, _ = m.encoder(feats, lens, -1, -1)
+    np.savez_compressed(os.path.join(OUT, 'conformer_nonstreaming_v512.npz'), enc=enc.numpy(),
+                        probs=m.get_encoder_out(feats, lens).numpy())
+
+
 def squeezeformer_streaming_fixture(mean_istd):
     """squeezeformer.yml as shipped (streaming: True -> causal conv module + TimeReductionLayerStream), full-context
     get_encoder_out on the ragged batch"""
@@ -153,6 +172,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp()
     torch.set_grad_enabled(False)
+    if '--only-conformer-nonstreaming' in sys.argv:
+        conformer_nonstreaming_fixture(tmp)
+        print('conformer non-streaming fixture written')
+        return
     if '--only-squeezeformer-streaming' in sys.argv:
         p = os.path.join(tmp, 'mean_istd_sq.json')
         sd0 = weights.squeezeformer_state_dict(0, 512, streaming=True)
@@ -219,6 +242,7 @@ def main():
     sq_probs = sq.get_encoder_out(feats, lens)
     np.savez_compressed(os.path.join(OUT, 'squeezeformer_v512.npz'), enc=sq_enc.numpy(), probs=sq_probs.numpy())
     squeezeformer_streaming_fixture(mean_istd)
+    conformer_nonstreaming_fixture(tmp)
 
     # ---- efficient conformer (configs/efficient_conformer.yml, streaming: True) V=512 ------------------
     from masr.model_utils.efficient_conformer.model import EfficientConformerModel

@@ -381,6 +381,25 @@ def test_squeezeformer_against_reference_fixture(sq512, oracle_mods):
     assert (idx.cpu().numpy()[safe] == z['probs'].argmax(-1)[safe]).all()
 
 
+def test_conformer_nonstreaming_build_against_reference_fixture(oracle_mods):
+    """conformer.yml with streaming: False: symmetric conv module (zero rows on both sides of the GLU output)"""
+    from masr_amd.engine import HipEngine
+    weights, golden_inputs = oracle_mods[3], oracle_mods[4]
+    sd = weights.conformer_state_dict(0, 512)
+    e = HipEngine(sd, vocab_size=512, streaming=False)
+    z = g('conformer_nonstreaming_v512.npz')
+    feats, lens = golden_inputs()
+    enc = e.encode_full(dev(feats), dev(lens, torch.int32))
+    assert np.abs(enc.cpu().numpy() - z['enc']).max() < 1e-3
+    assert np.abs(e.ctc_probs(enc).cpu().numpy() - z['probs']).max() < 1e-3
+    # chunk masks do not exist in this build; chunked streaming is refused
+    enc16 = e.encode_full(dev(feats), dev(lens, torch.int32), decoding_chunk_size=16)
+    assert torch.equal(enc16, enc)
+    with pytest.raises(Exception):
+        e.stream_open(0)
+    e.close()
+
+
 def test_squeezeformer_streaming_build_against_reference_fixture(oracle_mods):
     """squeezeformer.yml as shipped (streaming: True): causal conv module (history rows = glu(bias)) + stream time reduction"""
     from masr_amd.engine import HipEngine

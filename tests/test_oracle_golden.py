@@ -191,3 +191,16 @@ def test_squeezeformer_streaming_build_fixture():
         enc = osq.encoder_full(sd, feats, lens, causal=True)
         np.testing.assert_allclose(enc.numpy(), z['enc'], atol=2e-5)
         np.testing.assert_allclose(osq.get_encoder_out(sd, feats, lens, causal=True).numpy(), z['probs'], atol=2e-6)
+
+
+def test_conformer_nonstreaming_build_fixture():
+    # conformer.yml with streaming: False -> non-causal conv module (symmetric padding), no chunk masks
+    z = g('conformer_nonstreaming_v512.npz')
+    feats, lens = golden_inputs()
+    sd = weights.conformer_state_dict(0, 512)
+    with torch.no_grad():
+        enc = oc.encoder_full(sd, feats, lens, streaming=False)
+        np.testing.assert_allclose(enc.numpy(), z['enc'], atol=2e-5)
+        np.testing.assert_allclose(oc.get_encoder_out(sd, feats, lens, streaming=False).numpy(), z['probs'], atol=2e-6)
+        # decoding_chunk_size is ignored by the non-streaming build
+        assert torch.equal(oc.encoder_full(sd, feats, lens, decoding_chunk_size=16, streaming=False), enc)
