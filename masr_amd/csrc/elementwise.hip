@@ -57,6 +57,28 @@ void launch_layernorm(const float* x, const float* w, const float* b, float* y, 
     hipLaunchKernelGGL(layernorm256_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, y, M, eps, seq_t, pad, lens);
 }
 
+// y[b][pad + t] = scale * x[b][t] + bias  (Squeezeformer adaptive scale / bias in front of the conv module,
+// convolution.py:109-110) written into the padded streaming layout [nseq][pad + seq_t][256] behind the cnn cache rows
+__global__ __launch_bounds__(256) void affine_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* y, int M, int seq_t, int pad) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int bb = row / seq_t, t = row - bb * seq_t;
+    const size_t orow = (size_t)bb * (seq_t + pad) + pad + t;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * 256 + lane * 4);
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(b + lane * 4);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = ww[i] * v[i] + bv[i];
+    *reinterpret_cast<f32x4*>(y + orow * 256 + lane * 4) = o;
+}
+void launch_affine_rows(const float* x, const float* w, const float* b, float* y, int M, int seq_t, int pad, hipStream_t s) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(affine_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, y, M, seq_t, pad);
+}
+
 // ------------------------------------------------------------------------------------------
 // GlobalCMVN (utils/cmvn.py:21-32) + Conv2d(1->256, 3x3, stride 2) + ReLU
 // (conformer/subsampling.py:86-87).  One workgroup per (b, t1) output row, thread = out channel;
@@ -490,16 +512,17 @@ void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, int halve
 }
 
 // stream caches -> reference layouts (encoder.py:404-419): att [L,H,t,2dk], cnn [L,1,d,pad]
+// rate = 2: the layer keeps its cache at half the frame rate; the reference layout repeats every entry (encoder.py:347)
 __global__ void export_att_kernel(const float* __restrict__ cache, float* __restrict__ out, int H, int cap, int t,
-                                  int dk) {
+                                  int dk, int rate) {
     const int l = blockIdx.z, h = blockIdx.y, j = blockIdx.x;
     const int d = H * dk;
-    const float* row = cache + ((size_t)l * cap + j) * 2 * d;
+    const float* row = cache + ((size_t)l * cap + j / rate) * 2 * d;
     float* o = out + (((size_t)l * H + h) * t + j) * 2 * dk;
     for (int i = threadIdx.x; i < 2 * dk; i += blockDim.x) o[i] = i < dk ? row[h * dk + i] : row[d + h * dk + (i - dk)];
 }
-void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s) {
-    hipLaunchKernelGGL(export_att_kernel, dim3(t, H, L), dim3(128), 0, s, cache, out, H, cap, t, dk);
+void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s, int rate) {
+    hipLaunchKernelGGL(export_att_kernel, dim3(t, H, L), dim3(128), 0, s, cache, out, H, cap, t, dk, rate);
 }
 __global__ void export_cnn_kernel(const float* __restrict__ cache, float* __restrict__ out, int pad, int d) {
     const int l = blockIdx.x;

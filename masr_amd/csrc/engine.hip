@@ -87,6 +87,7 @@ struct HostTensor {
 struct Stream {
     bool open = false;
     int offset = 0;
+    int offset_r = 0;   // frames emitted at the reduced rate (Squeezeformer blocks between time reduction and recovery)
     int cap = 0;
     DevBuf att;  // [L][cap][2*d]  (k | v per row)
     DevBuf cnn;  // [L][kernel-1][d]   (DeepSpeech2: LSTM state [L][2 (h, c)][rnn_size])
@@ -1371,10 +1372,10 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     if (!e || !e->finalized) return fail("engine not finalized");
     if (e->cfg.model_kind == 3) {
         if (!e->cfg.causal) return fail("deepspeech2: streaming needs the uni-directional model");
-    } else if (e->cfg.model_kind != 0) {
-        return fail("streaming is implemented for the conformer and deepspeech2");
+    } else if (e->cfg.model_kind == 2) {
+        return fail("streaming is implemented for the conformer, the squeezeformer and deepspeech2");
     } else if (!e->cfg.causal) {
-        return fail("chunked streaming needs the streaming-trained (causal conv) conformer");
+        return fail("chunked streaming needs the streaming-trained (causal conv) build");
     }
     if (max_frames_out <= 0 || max_frames_out > e->cfg.max_pos) max_frames_out = e->cfg.max_pos;
     int id = -1;
@@ -1400,6 +1401,7 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     CHK(st.cnn.ensure((size_t)L * pad * d * sizeof(float)));
     HIPCHK(hipMemset(st.cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
     st.offset = 0;
+    st.offset_r = 0;
     st.open = true;
     *stream_id = id;
     return 0;
@@ -1419,6 +1421,7 @@ int masr_stream_reset(masr_engine* e, int32_t stream_id) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(st->cnn.p, 0, (e->cfg.model_kind == 3 ? (size_t)L * 2 * d : (size_t)L * pad * d) * sizeof(float)));
     st->offset = 0;
+    st->offset_r = 0;
     return 0;
 }
 
@@ -1439,6 +1442,107 @@ int masr_stream_offset(masr_engine* e, int32_t stream_id, int32_t* offset) {
     return 0;
 }
 
+}  // extern "C"
+
+// Squeezeformer chunk step (streaming-trained build), n streams in lock-step: SqueezeformerEncoder.forward_chunk
+// (squeezeformer/encoder.py:240-362) with required_cache_size < 0.  Every layer keeps its key/value cache at its OWN frame
+// rate (the reference stores the half-rate layers repeat-interleaved and reads every second entry back, :338-347), the cnn
+// cache holds the last K-1 adaptive-scaled input rows of the conv module.  TimeReductionLayerStream (k = 1, stride 2) and the
+// recovery are chunk-local.
+static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector<Stream*>& st, const float* feats, int Tc,
+                                      float* probs_dev, int32_t* argmax_dev, float* maxprob_dev) {
+    const int n = (int)st.size();
+    const int d = e->cfg.d_model, H = e->cfg.heads, L = e->cfg.num_blocks, K = e->cfg.cnn_kernel, pad = K - 1;
+    int T0 = 0;
+    CHK(embed(e, s, feats, n, Tc, &T0));
+    const int Tr = (T0 + 1) / 2;
+    for (int i = 0; i < n; ++i)
+        if (st[i]->offset + T0 > st[i]->cap) return fail("stream exceeds its max_frames_out / max_pos");
+    CHK(ensure_layer_ws(e, n, T0));
+    CHK(e->xsave.ensure((size_t)n * T0 * d * sizeof(float)));
+    CHK(e->xred.ensure((size_t)n * Tr * d * sizeof(float)));
+    CHK(e->attseq.ensure(sizeof(AttSeq) * (size_t)n * L));
+    auto reduced = [&](int l) { return e->reduce_idx >= 0 && l >= e->reduce_idx && l < e->recover_idx; };
+    std::vector<AttSeq> hs((size_t)n * L);
+    std::vector<float*> hp((size_t)n * L);
+    for (int l = 0; l < L; ++l) {
+        const int Tl = reduced(l) ? Tr : T0;
+        for (int i = 0; i < n; ++i) {
+            AttSeq& a = hs[(size_t)l * n + i];
+            const int off = reduced(l) ? st[i]->offset_r : st[i]->offset;
+            float* cache = st[i]->att.as<float>() + (size_t)l * st[i]->cap * 2 * d;
+            a.q = e->qkv.as<float>() + (size_t)i * Tl * 3 * d;
+            a.k = cache;
+            a.v = cache + d;
+            a.out = e->att.as<float>() + (size_t)i * Tl * d;
+            a.nq = Tl;
+            a.nk = off + Tl;
+            a.klen = a.nk;
+            a.pos0 = 0;
+            a.q_abs0 = off;
+            a.pad_ = 0;
+            hp[(size_t)l * n + i] = st[i]->cnn.as<float>() + (size_t)l * pad * d;
+        }
+    }
+    CHK(e->cnnptrs.ensure(sizeof(float*) * hp.size()));
+    HIPCHK(hipMemcpyAsync(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float* x = e->x.as<float>();
+    launch_layernorm(x, e->preln_w, e->preln_b, x, n * T0, 1e-5f, 0, 0, nullptr, s);
+    CHK(e->enc.ensure((size_t)n * T0 * d * sizeof(float)));
+    int Tq = T0;
+    for (int l = 0; l < L; ++l) {
+        const SqLayerW& w = e->sq_layers[l];
+        if (l == e->reduce_idx) {
+            HIPCHK(hipMemcpyAsync(e->xsave.p, x, (size_t)n * T0 * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+            launch_time_reduce_dw(x, e->tr_dw_w, e->tr_dw_b, nullptr, e->xred.as<float>(), n, T0, 4, s);
+            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_STORE, e->xred.as<float>(), d, nullptr, nullptr, e->tr_pw_w, e->tr_pw_b, x, d,
+                    n * Tr, d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+            Tq = Tr;
+        }
+        if (l == e->recover_idx && e->reduce_idx >= 0) {
+            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_STORE, x, d, nullptr, nullptr, e->rec_w, e->rec_b, e->xred.as<float>(), d,
+                    n * Tq, d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+            launch_recover_add(e->xsave.as<float>(), e->xred.as<float>(), x, n, T0, Tq, s);
+            Tq = T0;
+        }
+        const int M = n * Tq;
+        const AttSeq* seqs = e->attseq.as<AttSeq>() + (size_t)l * n;
+        rowgemm(e, s, RG_PRO_AFFINE, RG_EPI_STORE, x, d, w.att_s, w.att_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M,
+                3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+        launch_kv_append(seqs, e->qkv.as<float>(), n, Tq, s);
+        launch_attention(seqs, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, reduced(l) ? 2 : 1, s);
+        rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->att.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d, 1.f,
+                nullptr, 0, 0, 0, nullptr, nullptr);
+        launch_layernorm(x, w.ln1_w, w.ln1_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        CHK(ffn(e, s, M, w.f1_s, w.f1_b, w.f1_w1, w.f1_b1, w.f1_w2, w.f1_b2, 1.0f, 1));
+        launch_layernorm(x, w.ln2_w, w.ln2_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        // conv module: [cnn cache | ada(x)] -> pointwise_conv1 + GLU -> causal depthwise + BatchNorm + SiLU -> pointwise_conv2
+        float* const* cptr = e->cnnptrs.as<float*>() + (size_t)l * n;
+        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 0, s);
+        launch_affine_rows(x, w.cv_s, w.cv_b, e->lnpad.as<float>(), M, Tq, pad, s);
+        rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
+                e->glu.as<float>(), d, n * (Tq + pad), 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 1, s);
+        launch_dwconv_bn_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.bn_scale, w.bn_shift, e->dwo.as<float>(), n, Tq, K, s);
+        rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x,
+                d, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+        launch_layernorm(x, w.ln3_w, w.ln3_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        CHK(ffn(e, s, M, w.f2_s, w.f2_b, w.f2_w1, w.f2_b1, w.f2_w2, w.f2_b2, 1.0f, 1));
+        launch_layernorm(x, w.ln4_w, w.ln4_b, l == L - 1 ? e->enc.as<float>() : x, M, 1e-5f, 0, 0, nullptr, s);
+    }
+    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+    CHK(ctc_head(e, e->enc.as<float>(), n * T0, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
+    for (int i = 0; i < n; ++i) {
+        st[i]->offset += T0;
+        st[i]->offset_r += Tr;
+    }
+    return 0;
+}
+
+extern "C" {
+
 int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, const float* feats_dev, int32_t Tc,
                       float* probs_dev, int32_t* argmax_dev, float* maxprob_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
@@ -1448,6 +1552,12 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
     std::vector<Stream*> st(n);
     for (int i = 0; i < n; ++i) CHK(stream_of(e, stream_ids[i], &st[i]));
     int Tq = 0;
+    if (e->cfg.model_kind == 1) {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < i; ++j)
+                if (st[i] == st[j]) return fail("duplicate stream id in one call");
+        return encode_chunk_squeezeformer(e, s, st, feats_dev, Tc, probs_dev, argmax_dev, maxprob_dev);
+    }
     if (e->cfg.model_kind == 3) {       // deepspeech2/model.py:79-108: chunk conv + LSTM stack with carried (h, c)
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < i; ++j)
@@ -1528,8 +1638,15 @@ int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, 
         }
         return 0;
     }
-    if (att_dev && st->offset > 0)
-        launch_export_att(st->att.as<float>(), att_dev, L, H, st->cap, st->offset, d / H, s);
+    if (att_dev && st->offset > 0) {
+        if (e->cfg.model_kind == 1) {     // half-rate layers: every cache entry twice, like the reference (encoder.py:347)
+            for (int l = 0; l < L; ++l)
+                launch_export_att(st->att.as<float>() + (size_t)l * st->cap * 2 * d, att_dev + (size_t)l * st->offset * 2 * d, 1, H,
+                                  st->cap, st->offset, d / H, s, (l >= e->reduce_idx && l < e->recover_idx) ? 2 : 1);
+        } else {
+            launch_export_att(st->att.as<float>(), att_dev, L, H, st->cap, st->offset, d / H, s);
+        }
+    }
     if (cnn_dev) launch_export_cnn(st->cnn.as<float>(), cnn_dev, L, pad, d, s);
     HIPCHK(hipGetLastError());
     return 0;

@@ -102,7 +102,17 @@ def squeezeformer_streaming_fixture(mean_istd):
     m.eval()
     enc, _ = m.encoder(feats, lens, -1, -1)
     probs = m.get_encoder_out(feats, lens)
-    np.savez_compressed(os.path.join(OUT, 'squeezeformer_streaming_v512.npz'), enc=enc.numpy(), probs=probs.numpy())
+    # chunked streaming: five 67-frame windows (stride 64) and a short last one (11 frames -> 2 output frames)
+    att = torch.zeros(0, 0, 0, 0)
+    cnn = torch.zeros(0, 0, 0, 0)
+    off = 0
+    chunks = []
+    for cur, n in [(c, 67) for c in range(0, 331 - 67 + 1, 64)] + [(320, 11)]:
+        r, att, cnn = m.get_encoder_out_chunk(feats[:1, cur:cur + n], off, -16, att, cnn)
+        off += r.shape[1]
+        chunks.append(r[0].numpy())
+    np.savez_compressed(os.path.join(OUT, 'squeezeformer_streaming_v512.npz'), enc=enc.numpy(), probs=probs.numpy(),
+                        chunk_probs=np.concatenate(chunks), att=att.numpy(), cnn=cnn.numpy())
 
 
 def deepspeech2_fixture(tmp):

@@ -138,3 +138,93 @@ def get_encoder_out(sd, feats, lens, **kw):
     """SqueezeformerModel.get_encoder_out (squeezeformer/model.py) -> CTC softmax probabilities."""
     enc = encoder_full(sd, feats, lens, **kw)
     return torch.softmax(F.linear(enc, sd['ctc.ctc_lo.weight'], sd['ctc.ctc_lo.bias']), dim=2)
+
+
+# ---- chunked streaming (streaming-trained build) ------------------------------------------------------------------------
+def _attention_chunk(sd, p, x, pos_emb, heads, cache):
+    """attention.py:88-167 with the key/value cache of forward_chunk: cache [1,H,t,2dk] or None; no masks (fake mask)."""
+    B, T, d = x.shape
+    dk = d // heads
+    xs = _ada(sd, p, x)
+    q = F.linear(xs, sd[p + '.linear_q.weight'], sd[p + '.linear_q.bias']).view(B, T, heads, dk)
+    k = F.linear(xs, sd[p + '.linear_k.weight'], sd[p + '.linear_k.bias']).view(B, T, heads, dk).transpose(1, 2)
+    v = F.linear(xs, sd[p + '.linear_v.weight'], sd[p + '.linear_v.bias']).view(B, T, heads, dk).transpose(1, 2)
+    if cache is not None and cache.shape[2] > 0:
+        k = torch.cat([cache[..., :dk], k], dim=2)
+        v = torch.cat([cache[..., dk:], v], dim=2)
+    new_cache = torch.cat([k, v], dim=-1)
+    pp = F.linear(pos_emb, sd[p + '.linear_pos.weight']).view(1, -1, heads, dk).transpose(1, 2)
+    qu = (q + sd[p + '.pos_bias_u']).transpose(1, 2)
+    qv = (q + sd[p + '.pos_bias_v']).transpose(1, 2)
+    scores = (qu @ k.transpose(-2, -1) + qv @ pp.transpose(-2, -1)) / math.sqrt(dk)
+    o = (torch.softmax(scores, dim=-1) @ v).transpose(1, 2).reshape(B, T, d)
+    return F.linear(o, sd[p + '.linear_out.weight'], sd[p + '.linear_out.bias']), new_cache
+
+
+def _conv_module_chunk(sd, p, x, kernel, cache):
+    """convolution.py:92-148, causal, with the left-context cache [1,d,kernel-1] (or None -> zero padding)."""
+    x = _ada(sd, p, x).transpose(1, 2)
+    if cache is None or cache.shape[2] == 0:
+        x = F.pad(x, (kernel - 1, 0), 'constant', 0.0)
+    else:
+        x = torch.cat([cache, x], dim=2)
+    new_cache = x[:, :, -(kernel - 1):]
+    x = F.conv1d(x, sd[p + '.pointwise_conv1.weight'], sd[p + '.pointwise_conv1.bias'])
+    x = F.glu(x, dim=1)
+    x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], groups=x.shape[1])
+    x = F.batch_norm(x, sd[p + '.norm.running_mean'], sd[p + '.norm.running_var'], sd[p + '.norm.weight'],
+                     sd[p + '.norm.bias'], False, 0.1, 1e-5)
+    x = F.conv1d(F.silu(x), sd[p + '.pointwise_conv2.weight'], sd[p + '.pointwise_conv2.bias'])
+    return x.transpose(1, 2), new_cache
+
+
+def get_encoder_out_chunk(sd, feats, offset, required_cache_size, att_cache, cnn_cache, heads=4, kernel=31, reduce_idx=5,
+                          recover_idx=11):
+    """SqueezeformerModel.get_encoder_out_chunk -> SqueezeformerEncoder.forward_chunk (squeezeformer/encoder.py:240-362):
+    att_cache [L,H,t,2dk] at the FULL frame rate (layers reduce_idx..recover_idx-1 read every second entry and write their
+    cache back repeat-interleaved), cnn_cache [L,1,d,kernel-1]; returns (probs, att_cache, cnn_cache)."""
+    assert feats.shape[0] == 1
+    x = embed(sd, feats)
+    L = num_blocks_of(sd)
+    have = att_cache.numel() > 0
+    cache_t1 = att_cache.shape[2] if have else 0
+    chunk = x.shape[1]
+    key_size = cache_t1 + chunk
+    pos_emb = positional_table(5000, x.shape[-1])[offset - cache_t1: offset - cache_t1 + key_size].unsqueeze(0)
+    if required_cache_size < 0:
+        start = 0
+    elif required_cache_size == 0:
+        start = key_size
+    else:
+        start = max(key_size - required_cache_size, 0)
+    x = _ln(sd, 'encoder.preln', x)
+    r_att, r_cnn = [], []
+    saved = None
+    max_att_len = 0
+    for i in range(L):
+        if i == reduce_idx:
+            saved = (x, pos_emb)
+            x, _ = _time_reduce(sd, x, torch.ones(1, x.shape[1], dtype=torch.bool))
+            pos_emb = pos_emb[:, ::2, :]
+        if i == recover_idx:
+            rx, rpos = saved
+            y = torch.repeat_interleave(x, repeats=2, dim=1)
+            y = F.linear(y, sd['encoder.time_recover_layer.weight'], sd['encoder.time_recover_layer.bias'])
+            x = rx + y[:, :rx.shape[1], :]
+            pos_emb = rpos
+        factor = 2 if reduce_idx <= i < recover_idx else 1
+        ac = att_cache[i:i + 1][:, :, ::factor, :][:, :, :pos_emb.shape[1] - x.shape[1], :] if have else None
+        p = f'encoder.encoders.{i}'
+        a, new_att = _attention_chunk(sd, p + '.self_attn', x, pos_emb, heads, ac)
+        x = _ln(sd, p + '.layer_norm1', x + a)
+        x = _ln(sd, p + '.layer_norm2', x + _ffn(sd, p + '.ffn1', x))
+        c, new_cnn = _conv_module_chunk(sd, p + '.conv_module', x, kernel, cnn_cache[i] if cnn_cache.numel() > 0 else None)
+        x = _ln(sd, p + '.layer_norm3', x + c)
+        x = _ln(sd, p + '.layer_norm4', x + _ffn(sd, p + '.ffn2', x))
+        cached = new_att[:, :, start // factor:, :].repeat_interleave(repeats=factor, dim=2)
+        if i == 0:
+            max_att_len = cached.shape[2]
+        r_att.append(cached[:, :, :max_att_len, :])
+        r_cnn.append(new_cnn.unsqueeze(0))
+    probs = torch.softmax(F.linear(x, sd['ctc.ctc_lo.weight'], sd['ctc.ctc_lo.bias']), dim=2)
+    return probs, torch.cat(r_att, dim=0), torch.cat(r_cnn, dim=0)

@@ -246,3 +246,39 @@ def test_evaluate_manifest_matches_per_utterance_cer(predictor, tmp_path):
     assert err == pytest.approx(float(want))
     # a batch of one is the single-utterance path
     assert r2[0]['text'] == predictor.predict(audio_data=paths[3])['text']
+
+
+def test_squeezeformer_predict_stream_facade(tmp_path):
+    """squeezeformer.yml as shipped (streaming: True) through MASRPredictor.predict_stream (engine-level parity of the chunk
+    path: test_gpu_parity.test_squeezeformer_stream_chunks_against_reference_fixture)"""
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.utils import synthetic
+    from oracle import decoders as od, fbank as ofb, squeezeformer as osq
+    V = 300
+    vocab = synthetic.synthetic_vocab(V)
+    vpath = os.path.join(tmp_path, 'vocabulary.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in vocab:
+            f.write(f'{t}\t1\n')
+    cfg = {'encoder_conf': {'encoder_dim': 256, 'output_size': 256, 'attention_heads': 4, 'num_blocks': 12, 'reduce_idx': 5,
+                            'recover_idx': 11, 'feed_forward_expansion_factor': 8, 'cnn_module_kernel': 31},
+           'preprocess_conf': {'feature_method': 'fbank', 'n_mels': 80, 'n_mfcc': 40, 'sample_rate': 16000,
+                               'use_dB_normalization': True, 'target_dB': -20},
+           'dataset_conf': {'dataset_vocab': vpath}, 'use_model': 'squeezeformer', 'streaming': True,
+           'decoder': 'ctc_greedy', 'metrics_type': 'cer'}
+    sd = synthetic.squeezeformer_state_dict(0, V, streaming=True)
+    pred = MASRPredictor(configs=cfg, use_gpu=True, state_dict=sd)
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm'][:64000]
+    def run():
+        pred.reset_stream()
+        last, parts = None, 0
+        for s in range(0, len(pcm), 8000):
+            r = pred.predict_stream(audio_data=pcm[s:s + 8000].tobytes(), is_end=(s + 8000 >= len(pcm)))
+            if r is not None and r['text'] is not None:
+                last, parts = r, parts + 1
+        pred.reset_stream()
+        return last, parts
+    a, na = run()
+    b, nb = run()                       # reset_stream gives a fresh stream: same partials again
+    assert a is not None and len(a['text']) > 0 and na >= 5
+    assert a == b and na == nb

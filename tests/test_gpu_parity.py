@@ -427,6 +427,47 @@ def test_squeezeformer_streaming_build_against_reference_fixture(oracle_mods):
     e.close()
 
 
+def test_squeezeformer_stream_chunks_against_reference_fixture(oracle_mods):
+    """Squeezeformer forward_chunk (streaming build): half-rate layers keep their own caches, stream time reduction"""
+    from masr_amd.engine import HipEngine
+    from oracle import squeezeformer as osq
+    weights, golden_inputs = oracle_mods[3], oracle_mods[4]
+    sd = weights.squeezeformer_state_dict(0, 512, streaming=True)
+    enc_conf = {'encoder_dim': 256, 'attention_heads': 4, 'num_blocks': 12, 'reduce_idx': 5, 'recover_idx': 11,
+                'feed_forward_expansion_factor': 8, 'cnn_module_kernel': 31}
+    e = HipEngine(sd, encoder_conf=enc_conf, vocab_size=512, streaming=True, use_model='squeezeformer')
+    z = g('squeezeformer_streaming_v512.npz')
+    feats, _ = golden_inputs()
+    sid = e.stream_open(0)
+    outs = []
+    for cur, n in [(c, 67) for c in range(0, 331 - 67 + 1, 64)] + [(320, 11)]:
+        p, _, _ = e.encode_chunk([sid], dev(feats[:1, cur:cur + n]))
+        outs.append(p[0].cpu().numpy())
+    got = np.concatenate(outs)
+    assert got.shape == z['chunk_probs'].shape == (82, 512)
+    assert np.abs(got - z['chunk_probs']).max() < 1e-3
+    att, cnn = e.stream_export_cache(sid)
+    assert att.shape == tuple(z['att'].shape) and np.abs(att.cpu().numpy() - z['att']).max() < 1e-3
+    assert np.abs(cnn.cpu().numpy() - z['cnn']).max() < 1e-3
+    # two streams in lock-step (different audio) == the oracle run stream by stream
+    torch.manual_seed(5)
+    xa, xb = torch.randn(1, 131, 80) * 3 + 13, torch.randn(1, 131, 80) * 3 + 13
+    s0, s1 = e.stream_open(0), e.stream_open(0)
+    ca = cb = (torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0))
+    oa = ob = 0
+    for cur in (0, 64):
+        both = torch.cat([xa[:, cur:cur + 67], xb[:, cur:cur + 67]])
+        p, _, _ = e.encode_chunk([s0, s1], dev(both))
+        with torch.no_grad():
+            pa, *ca = osq.get_encoder_out_chunk(sd, xa[:, cur:cur + 67], oa, -16, *ca)
+            pb, *cb = osq.get_encoder_out_chunk(sd, xb[:, cur:cur + 67], ob, -16, *cb)
+        oa += pa.shape[1]
+        ob += pb.shape[1]
+        assert np.abs(p[0].cpu().numpy() - pa[0].numpy()).max() < 1e-3
+        assert np.abs(p[1].cpu().numpy() - pb[0].numpy()).max() < 1e-3
+    e.close()
+
+
 def test_squeezeformer_odd_lengths_against_oracle(sq512, oracle_mods):
     """odd T' (time reduction trims, recovery slices) and a ragged batch."""
     from oracle import squeezeformer as osq
