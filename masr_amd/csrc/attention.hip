@@ -299,7 +299,8 @@ __global__ __launch_bounds__(64 * NW) void attention_grouped_kernel(const AttSeq
                 vv = *reinterpret_cast<const f32x4*>(sq.v + (size_t)j * row_stride + head * DKG + c4);
                 // flat element index of P'[j][head][c4] in the [T,256] positional-key matrix
                 const size_t e = (size_t)j * row_stride + head * DKG + c4;
-                if ((int)(e / 256) < t_true) pp = *reinterpret_cast<const f32x4*>(ptab + (size_t)sq.pos0 * 256 + e);
+                // (sq.pad_ > 0: per-sequence true key count -- streams in one lock-step call may have different histories)
+                if ((int)(e / 256) < (sq.pad_ > 0 ? sq.pad_ : t_true)) pp = *reinterpret_cast<const f32x4*>(ptab + (size_t)sq.pos0 * 256 + e);
             }
             *reinterpret_cast<f32x4*>(&Ks[r * LD + c4]) = kk;
             *reinterpret_cast<f32x4*>(&Ps[r * LD + c4]) = pp;

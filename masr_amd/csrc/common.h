@@ -70,7 +70,12 @@ void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff
                        int* out_cnt, hipStream_t s);
 void launch_argmax_rows(const float* probs, int M, int V, int* idx, float* maxp, hipStream_t s);
 void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, int halve, hipStream_t s);
-void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s, int rate = 1);
+void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s, int rate = 1,
+                       int shift = 0);   // rate 2: half-rate cache, entry (j + shift) / 2 (the reference repeat-interleaves)
+struct PlaneCopy { const float* src_k; const float* src_v; float* dst_k; float* dst_v; };
+void launch_kv_append_planar(const PlaneCopy* pc, int n, int Tq, hipStream_t s);
+void launch_export_cnn_layer(const float* cache, float* out, int used, int total, int d, hipStream_t s);
+void launch_export_att_planar(const float* kplane, const float* vplane, float* out, int H, int t, int dk, hipStream_t s);
 void launch_affine_rows(const float* x, const float* w, const float* b, float* y, int M, int seq_t, int pad, hipStream_t s);
 void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hipStream_t s);
 

@@ -514,15 +514,16 @@ void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, int halve
 // stream caches -> reference layouts (encoder.py:404-419): att [L,H,t,2dk], cnn [L,1,d,pad]
 // rate = 2: the layer keeps its cache at half the frame rate; the reference layout repeats every entry (encoder.py:347)
 __global__ void export_att_kernel(const float* __restrict__ cache, float* __restrict__ out, int H, int cap, int t,
-                                  int dk, int rate) {
+                                  int dk, int rate, int shift) {
     const int l = blockIdx.z, h = blockIdx.y, j = blockIdx.x;
     const int d = H * dk;
-    const float* row = cache + ((size_t)l * cap + j / rate) * 2 * d;
+    const float* row = cache + ((size_t)l * cap + (j + shift) / rate) * 2 * d;
     float* o = out + (((size_t)l * H + h) * t + j) * 2 * dk;
     for (int i = threadIdx.x; i < 2 * dk; i += blockDim.x) o[i] = i < dk ? row[h * dk + i] : row[d + h * dk + (i - dk)];
 }
-void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s, int rate) {
-    hipLaunchKernelGGL(export_att_kernel, dim3(t, H, L), dim3(128), 0, s, cache, out, H, cap, t, dk, rate);
+void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s, int rate,
+                       int shift) {
+    hipLaunchKernelGGL(export_att_kernel, dim3(t, H, L), dim3(128), 0, s, cache, out, H, cap, t, dk, rate, shift);
 }
 __global__ void export_cnn_kernel(const float* __restrict__ cache, float* __restrict__ out, int pad, int d) {
     const int l = blockIdx.x;
@@ -530,6 +531,16 @@ __global__ void export_cnn_kernel(const float* __restrict__ cache, float* __rest
         const int c = i / pad, j = i % pad;
         out[(size_t)l * pad * d + i] = cache[((size_t)l * pad + j) * d + c];
     }
+}
+// one layer whose cache has `used` rows, exported right-aligned into a [d][total] block (zeros in front, encoder.py:372)
+__global__ void export_cnn_layer_kernel(const float* __restrict__ cache, float* __restrict__ out, int used, int total, int d) {
+    for (int i = threadIdx.x; i < used * d; i += blockDim.x) {
+        const int c = i / used, j = i % used;
+        out[(size_t)c * total + (total - used) + j] = cache[(size_t)j * d + c];
+    }
+}
+void launch_export_cnn_layer(const float* cache, float* out, int used, int total, int d, hipStream_t s) {
+    hipLaunchKernelGGL(export_cnn_layer_kernel, dim3(1), dim3(256), 0, s, cache, out, used, total, d);
 }
 void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hipStream_t s) {
     hipLaunchKernelGGL(export_cnn_kernel, dim3(L), dim3(256), 0, s, cache, out, pad, d);
@@ -616,6 +627,33 @@ __global__ __launch_bounds__(128) void kv_append_kernel(const AttSeq* __restrict
 void launch_kv_append(const AttSeq* seqs, const float* qkv, int n, int Tq, hipStream_t s) {
     if (n * Tq <= 0) return;
     hipLaunchKernelGGL(kv_append_kernel, dim3(Tq, n), dim3(128), 0, s, seqs, qkv, Tq);
+}
+
+// Efficient-Conformer grouped layers keep PLANAR key / value caches ([cap][256] each, zero behind the last row) so that the
+// flat [T,256] -> [T/3,4,192] regrouping of cache + chunk (attention.py:147-155 before pad4group) is a plain reinterpretation
+__global__ __launch_bounds__(64) void kv_append_planar_kernel(const PlaneCopy* __restrict__ pc, int Tq) {
+    const PlaneCopy c = pc[blockIdx.y];
+    const int r = blockIdx.x;
+    reinterpret_cast<f32x4*>(c.dst_k + (size_t)r * 256)[threadIdx.x] = reinterpret_cast<const f32x4*>(c.src_k + (size_t)r * 256)[threadIdx.x];
+    reinterpret_cast<f32x4*>(c.dst_v + (size_t)r * 256)[threadIdx.x] = reinterpret_cast<const f32x4*>(c.src_v + (size_t)r * 256)[threadIdx.x];
+}
+void launch_kv_append_planar(const PlaneCopy* pc, int n, int Tq, hipStream_t s) {
+    if (n * Tq <= 0) return;
+    hipLaunchKernelGGL(kv_append_planar_kernel, dim3(Tq, n), dim3(64), 0, s, pc, Tq);
+}
+
+// stream cache (planar K | V planes) -> reference layout [H, t, 2dk] of one layer
+__global__ void export_att_planar_kernel(const float* __restrict__ kplane, const float* __restrict__ vplane,
+                                         float* __restrict__ out, int H, int t, int dk) {
+    const int h = blockIdx.y, j = blockIdx.x;
+    const int d = H * dk;
+    float* o = out + ((size_t)h * t + j) * 2 * dk;
+    for (int i = threadIdx.x; i < 2 * dk; i += blockDim.x)
+        o[i] = i < dk ? kplane[(size_t)j * d + h * dk + i] : vplane[(size_t)j * d + h * dk + (i - dk)];
+}
+void launch_export_att_planar(const float* kplane, const float* vplane, float* out, int H, int t, int dk, hipStream_t s) {
+    if (t <= 0) return;
+    hipLaunchKernelGGL(export_att_planar_kernel, dim3(t, H), dim3(128), 0, s, kplane, vplane, out, H, t, dk);
 }
 
 // dir 0: lnpad[i][0..pad) <- cache_i ;  dir 1: cache_i <- lnpad[i][Tq .. Tq+pad)

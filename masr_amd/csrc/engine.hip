@@ -1372,8 +1372,6 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     if (!e || !e->finalized) return fail("engine not finalized");
     if (e->cfg.model_kind == 3) {
         if (!e->cfg.causal) return fail("deepspeech2: streaming needs the uni-directional model");
-    } else if (e->cfg.model_kind == 2) {
-        return fail("streaming is implemented for the conformer, the squeezeformer and deepspeech2");
     } else if (!e->cfg.causal) {
         return fail("chunked streaming needs the streaming-trained (causal conv) build");
     }
@@ -1400,6 +1398,8 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     CHK(st.att.ensure((size_t)L * st.cap * 2 * d * sizeof(float)));
     CHK(st.cnn.ensure((size_t)L * pad * d * sizeof(float)));
     HIPCHK(hipMemset(st.cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
+    if (e->cfg.model_kind == 2)     // planar caches of the grouped layers: rows behind the last key must read as zero
+        HIPCHK(hipMemset(st.att.p, 0, (size_t)L * st.cap * 2 * d * sizeof(float)));
     st.offset = 0;
     st.offset_r = 0;
     st.open = true;
@@ -1420,6 +1420,7 @@ int masr_stream_reset(masr_engine* e, int32_t stream_id) {
     const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(st->cnn.p, 0, (e->cfg.model_kind == 3 ? (size_t)L * 2 * d : (size_t)L * pad * d) * sizeof(float)));
+    if (e->cfg.model_kind == 2) HIPCHK(hipMemset(st->att.p, 0, (size_t)L * st->cap * 2 * d * sizeof(float)));
     st->offset = 0;
     st->offset_r = 0;
     return 0;
@@ -1541,6 +1542,132 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
     return 0;
 }
 
+// Efficient-Conformer chunk step, n streams in lock-step: EfficientConformerEncoder.forward_chunk
+// (efficient_conformer/encoder.py:267-392) with required_cache_size < 0.  Grouped layers keep PLANAR key / value caches at the
+// input frame rate (the flat regrouping runs over cache + chunk), layers behind the stride layer keep interleaved k|v rows
+// at half the rate (the reference stores them repeat-interleaved, :370); cnn caches hold each layer's own K-1 rows.
+static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Stream*>& st, const float* feats, int Tc,
+                                  float* probs_dev, int32_t* argmax_dev, float* maxprob_dev) {
+    const int n = (int)st.size();
+    const int d = e->cfg.d_model, H = e->cfg.heads, L = e->cfg.num_blocks, G = e->group_size;
+    int T0 = 0;
+    CHK(embed(e, s, feats, n, Tc, &T0));
+    const int T2 = (T0 + 1) / 2, Tg = (T0 + G - 1) / G, Tpad = Tg * G;
+    for (int i = 0; i < n; ++i)
+        if (st[i]->offset + T0 + G > st[i]->cap) return fail("stream exceeds its max_frames_out / max_pos");
+    CHK(ensure_layer_ws(e, n, T0));
+    const size_t plane = (size_t)n * Tpad * d;
+    CHK(e->qplanes.ensure(3 * plane * sizeof(float)));
+    CHK(e->attp.ensure(plane * sizeof(float)));
+    CHK(e->xsave.ensure((size_t)n * T2 * d * sizeof(float)));
+    CHK(e->attseq.ensure(sizeof(AttSeq) * (size_t)n * L));
+    float* qp = e->qplanes.as<float>();
+    HIPCHK(hipMemsetAsync(qp, 0, 3 * plane * sizeof(float), s));      // time padding rows of the new q / k / v stay zero
+    auto rate = [&](int l) { return l > e->stride_idx ? 2 : 1; };
+    const int padmax = e->cfg.cnn_kernel - 1;
+    std::vector<AttSeq> hs((size_t)n * L);
+    std::vector<PlaneCopy> pcs((size_t)n * e->n_group_layers);
+    std::vector<float*> hp((size_t)n * L);
+    for (int l = 0; l < L; ++l) {
+        if (layer_grouped(e, l) && rate(l) != 1) return fail("grouped attention after the stride layer is not supported");
+        for (int i = 0; i < n; ++i) {
+            AttSeq& a = hs[(size_t)l * n + i];
+            float* cache = st[i]->att.as<float>() + (size_t)l * st[i]->cap * 2 * d;
+            if (layer_grouped(e, l)) {
+                float* kpl = cache;
+                float* vpl = cache + (size_t)st[i]->cap * d;
+                a.q = qp + (size_t)i * Tpad * d;
+                a.k = kpl;
+                a.v = vpl;
+                a.out = e->attp.as<float>() + (size_t)i * Tpad * d;
+                a.nq = Tg;
+                a.nk = (st[i]->offset + T0 + G - 1) / G;
+                a.klen = a.nk;
+                a.pos0 = 0;
+                a.q_abs0 = 0;
+                a.pad_ = st[i]->offset + T0;                   // true number of keys (rows of P behind it read as zero)
+                PlaneCopy& c = pcs[(size_t)l * n + i];
+                c.src_k = qp + plane + (size_t)i * Tpad * d;
+                c.src_v = qp + 2 * plane + (size_t)i * Tpad * d;
+                c.dst_k = kpl + (size_t)st[i]->offset * d;
+                c.dst_v = vpl + (size_t)st[i]->offset * d;
+            } else {
+                const int Tl = rate(l) == 2 ? T2 : T0;
+                const int off = rate(l) == 2 ? st[i]->offset_r : st[i]->offset;
+                a.q = e->qkv.as<float>() + (size_t)i * Tl * 3 * d;
+                a.k = cache;
+                a.v = cache + d;
+                a.out = e->att.as<float>() + (size_t)i * Tl * d;
+                a.nq = Tl;
+                a.nk = off + Tl;
+                a.klen = a.nk;
+                a.pos0 = 0;
+                a.q_abs0 = off;
+                a.pad_ = 0;
+            }
+            hp[(size_t)l * n + i] = st[i]->cnn.as<float>() + (size_t)l * padmax * d;
+        }
+    }
+    CHK(e->cnnptrs.ensure(sizeof(float*) * hp.size() + sizeof(PlaneCopy) * pcs.size()));
+    PlaneCopy* pc_dev = reinterpret_cast<PlaneCopy*>(e->cnnptrs.as<float*>() + hp.size());
+    HIPCHK(hipMemcpyAsync(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice, s));
+    if (!pcs.empty()) HIPCHK(hipMemcpyAsync(pc_dev, pcs.data(), sizeof(PlaneCopy) * pcs.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float* x = e->x.as<float>();
+    for (int l = 0; l < L; ++l) {
+        const LayerW& w = e->layers[l];
+        const int Tq = rate(l) == 2 ? T2 : T0;
+        int M = n * Tq;
+        const AttSeq* seqs = e->attseq.as<AttSeq>() + (size_t)l * n;
+        CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
+        if (layer_grouped(e, l)) {
+            rowgemm(e, s, RG_PRO_LN, RG_EPI_STORE, x, d, w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, qp, d, M, 3 * d, nullptr, 0,
+                    1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, 4, Tq, 0, Tpad - Tq, d, (long)plane);
+            launch_kv_append_planar(pc_dev + (size_t)l * n, n, Tq, s);
+            launch_attention_grouped(seqs, n, Tg, H, G, w.ptab, 0, w.pos_u, w.pos_v, s);
+            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->attp.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d,
+                    1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, 4, 0, 0, 0, 0, 0, Tq, Tpad);
+        } else {
+            mhsa(e, s, w, M);
+            launch_kv_append(seqs, e->qkv.as<float>(), n, Tq, s);
+            launch_attention(seqs, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, rate(l), s);
+            mhsa_out(e, s, w, M);
+        }
+        const int K = layer_kernel(e, l), pad = K - 1;
+        float* const* cptr = e->cnnptrs.as<float*>() + (size_t)l * n;
+        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 0, s);
+        if (l == e->stride_idx) {
+            // StrideConformerEncoderLayer (encoder.py:454-545): x = AvgPool(x) + conv_module_stride2([cache | LN(x)])
+            launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, Tq, pad, nullptr, s);
+            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
+                    e->glu.as<float>(), d, n * (Tq + pad), 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+            launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 1, s);
+            launch_dwconv_stride2_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), n, Tq, K,
+                                          1e-5f, s);
+            launch_avgpool2(x, e->xsave.as<float>(), n, Tq, s);
+            M = n * T2;
+            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d,
+                    e->xsave.as<float>(), d, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+        } else {
+            EncodeCtx ctx{n, Tq, nullptr};
+            CHK(conv_module(e, s, w, ctx, true, K));
+            launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 1, s);
+        }
+        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
+        launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
+    }
+    CHK(e->enc.ensure((size_t)n * T2 * d * sizeof(float)));
+    launch_layernorm(x, e->after_w, e->after_b, e->enc.as<float>(), n * T2, 1e-5f, 0, 0, nullptr, s);
+    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+    CHK(ctc_head(e, e->enc.as<float>(), n * T2, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
+    for (int i = 0; i < n; ++i) {
+        st[i]->offset += T0;
+        st[i]->offset_r += T2;
+    }
+    return 0;
+}
+
 extern "C" {
 
 int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, const float* feats_dev, int32_t Tc,
@@ -1552,11 +1679,12 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
     std::vector<Stream*> st(n);
     for (int i = 0; i < n; ++i) CHK(stream_of(e, stream_ids[i], &st[i]));
     int Tq = 0;
-    if (e->cfg.model_kind == 1) {
+    if (e->cfg.model_kind == 1 || e->cfg.model_kind == 2) {
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < i; ++j)
                 if (st[i] == st[j]) return fail("duplicate stream id in one call");
-        return encode_chunk_squeezeformer(e, s, st, feats_dev, Tc, probs_dev, argmax_dev, maxprob_dev);
+        return e->cfg.model_kind == 1 ? encode_chunk_squeezeformer(e, s, st, feats_dev, Tc, probs_dev, argmax_dev, maxprob_dev)
+                                      : encode_chunk_efficient(e, s, st, feats_dev, Tc, probs_dev, argmax_dev, maxprob_dev);
     }
     if (e->cfg.model_kind == 3) {       // deepspeech2/model.py:79-108: chunk conv + LSTM stack with carried (h, c)
         for (int i = 0; i < n; ++i)
@@ -1639,7 +1767,18 @@ int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, 
         return 0;
     }
     if (att_dev && st->offset > 0) {
-        if (e->cfg.model_kind == 1) {     // half-rate layers: every cache entry twice, like the reference (encoder.py:347)
+        if (e->cfg.model_kind == 2) {     // planar grouped layers; half-rate layers repeat-interleaved, last t entries (:370,380)
+            for (int l = 0; l < L; ++l) {
+                const float* base = st->att.as<float>() + (size_t)l * st->cap * 2 * d;
+                float* o = att_dev + (size_t)l * st->offset * 2 * d;
+                if (layer_grouped(e, l))
+                    launch_export_att_planar(base, base + (size_t)st->cap * d, o, H, st->offset, d / H, s);
+                else if (l > e->stride_idx)
+                    launch_export_att(base, o, 1, H, st->cap, st->offset, d / H, s, 2, 2 * st->offset_r - st->offset);
+                else
+                    launch_export_att(base, o, 1, H, st->cap, st->offset, d / H, s);
+            }
+        } else if (e->cfg.model_kind == 1) {     // half-rate layers: every cache entry twice, like the reference (encoder.py:347)
             for (int l = 0; l < L; ++l)
                 launch_export_att(st->att.as<float>() + (size_t)l * st->cap * 2 * d, att_dev + (size_t)l * st->offset * 2 * d, 1, H,
                                   st->cap, st->offset, d / H, s, (l >= e->reduce_idx && l < e->recover_idx) ? 2 : 1);
@@ -1647,7 +1786,14 @@ int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, 
             launch_export_att(st->att.as<float>(), att_dev, L, H, st->cap, st->offset, d / H, s);
         }
     }
-    if (cnn_dev) launch_export_cnn(st->cnn.as<float>(), cnn_dev, L, pad, d, s);
+    if (cnn_dev && e->cfg.model_kind == 2) {       // each layer's own K-1 rows, left-padded with zeros to cnn_module_kernel - 1
+        HIPCHK(hipMemsetAsync(cnn_dev, 0, (size_t)L * pad * d * sizeof(float), s));
+        for (int l = 0; l < L; ++l)
+            launch_export_cnn_layer(st->cnn.as<float>() + (size_t)l * pad * d, cnn_dev + (size_t)l * pad * d, layer_kernel(e, l) - 1,
+                                    pad, d, s);
+    } else if (cnn_dev) {
+        launch_export_cnn(st->cnn.as<float>(), cnn_dev, L, pad, d, s);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -236,7 +236,7 @@ class HipEngine:
     def encode_chunk(self, stream_ids, feats, want_probs=True, want_argmax=False):
         """feats f32 [n, Tc, 80] (device) -> probs [n, Tc', V] (+ argmax/maxprob [n, Tc'])."""
         n, Tc, _ = feats.shape
-        Tq = subsampled_len(Tc)
+        Tq = self.out_frames(Tc)
         ids = (C.c_int32 * n)(*stream_ids)
         probs = torch.empty(n, Tq, self.vocab_size, dtype=torch.float32, device=self.device) if want_probs else None
         idx = torch.empty(n, Tq, dtype=torch.int32, device=self.device) if want_argmax else None

@@ -74,8 +74,6 @@ class InferencePredictor:
     def predict_chunk_conformer(self, x_chunk, required_cache_size):
         if not ('former' in self.use_model and self.streaming):
             raise Exception(f'当前模型不支持该方法，当前模型为：{self.use_model}，参数streaming为：{self.streaming}')
-        if self.use_model not in ('conformer', 'squeezeformer'):
-            raise Exception(f'masr_amd: chunked streaming is implemented for conformer and squeezeformer (got {self.use_model})')
         if required_cache_size >= 0:
             raise Exception('only required_cache_size < 0 (keep all history, predict.py:312-313) is implemented')
         if self._sid is None:

@@ -69,6 +69,19 @@ def build_reference_deepspeech2(sd, vocab_size, streaming, tmp):
     return m.eval()
 
 
+def efficient_chunk_run(ef, feats):
+    """chunked streaming of the Efficient Conformer: five 67-frame windows (stride 64) + a short last one (11 frames)"""
+    att = torch.zeros(0, 0, 0, 0)
+    cnn = torch.zeros(0, 0, 0, 0)
+    off = 0
+    chunks = []
+    for cur, n in [(c, 67) for c in range(0, 331 - 67 + 1, 64)] + [(320, 11)]:
+        r, att, cnn = ef.get_encoder_out_chunk(feats[:1, cur:cur + n], off, -16, att, cnn)
+        off += r.shape[1]
+        chunks.append(r[0].numpy())
+    return np.concatenate(chunks), att.numpy(), cnn.numpy()
+
+
 def conformer_nonstreaming_fixture(tmp):
     """conformer.yml with streaming: False (non-causal conv module, no dynamic chunk masks), ragged batch"""
     from masr.model_utils.conformer.model import ConformerModel
@@ -182,6 +195,24 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp()
     torch.set_grad_enabled(False)
+    if '--only-efficient' in sys.argv:
+        from masr.model_utils.efficient_conformer.model import EfficientConformerModel
+        feats, lens = golden_inputs()
+        ef_cfg = yaml.safe_load(open(os.path.join(REF, 'configs', 'efficient_conformer.yml'), encoding='utf-8'))
+        ef_sd = weights.efficient_conformer_state_dict(0, 512)
+        p = os.path.join(tmp, 'mean_istd_ef.json')
+        json.dump({'mean': ef_sd['encoder.global_cmvn.mean'].tolist(), 'istd': ef_sd['encoder.global_cmvn.istd'].tolist(),
+                   'feature_method': 'fbank'}, open(p, 'w'))
+        ef = EfficientConformerModel(input_dim=80, vocab_size=512, mean_istd_path=p, streaming=True,
+                                     encoder_conf=ef_cfg['encoder_conf'], decoder_conf=ef_cfg['decoder_conf'],
+                                     **ef_cfg['model_conf']).eval()
+        ef.load_state_dict(ef_sd, strict=False)
+        ef_enc, _ = ef.encoder(feats, lens, -1, -1)
+        ef_chunks, ef_att, ef_cnn = efficient_chunk_run(ef, feats)
+        np.savez_compressed(os.path.join(OUT, 'efficient_conformer_v512.npz'), enc=ef_enc.numpy(),
+                            probs=ef.get_encoder_out(feats, lens).numpy(), chunk_probs=ef_chunks, att=ef_att, cnn=ef_cnn)
+        print('efficient conformer fixture written')
+        return
     if '--only-conformer-nonstreaming' in sys.argv:
         conformer_nonstreaming_fixture(tmp)
         print('conformer non-streaming fixture written')
@@ -266,7 +297,9 @@ def main():
     ef.eval()
     ef_enc, _ = ef.encoder(feats, lens, -1, -1)
     ef_probs = ef.get_encoder_out(feats, lens)
-    np.savez_compressed(os.path.join(OUT, 'efficient_conformer_v512.npz'), enc=ef_enc.numpy(), probs=ef_probs.numpy())
+    ef_chunks, ef_att, ef_cnn = efficient_chunk_run(ef, feats)
+    np.savez_compressed(os.path.join(OUT, 'efficient_conformer_v512.npz'), enc=ef_enc.numpy(), probs=ef_probs.numpy(),
+                        chunk_probs=ef_chunks, att=ef_att, cnn=ef_cnn)
 
     # ---- MASRPredictor facade on the TorchScript export ---------------------------
     from masr.predict import MASRPredictor

@@ -282,3 +282,40 @@ def test_squeezeformer_predict_stream_facade(tmp_path):
     b, nb = run()                       # reset_stream gives a fresh stream: same partials again
     assert a is not None and len(a['text']) > 0 and na >= 5
     assert a == b and na == nb
+
+
+def test_efficient_conformer_predict_stream_facade(tmp_path):
+    """efficient_conformer.yml (streaming: True) through MASRPredictor.predict_stream (engine-level parity of the chunk path:
+    test_gpu_parity.test_efficient_conformer_stream_chunks_against_reference_fixture)"""
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.utils import synthetic
+    V = 300
+    vocab = synthetic.synthetic_vocab(V)
+    vpath = os.path.join(tmp_path, 'vocabulary.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in vocab:
+            f.write(f'{t}\t1\n')
+    cfg = {'encoder_conf': {'output_size': 256, 'attention_heads': 4, 'linear_units': 2048, 'num_blocks': 12,
+                            'cnn_module_kernel': 15,
+                            'efficient_conf': {'stride_layer_idx': [3], 'stride': [2], 'group_layer_idx': [0, 1, 2, 3],
+                                               'group_size': 3, 'stride_kernel': True}},
+           'preprocess_conf': {'feature_method': 'fbank', 'n_mels': 80, 'n_mfcc': 40, 'sample_rate': 16000,
+                               'use_dB_normalization': True, 'target_dB': -20},
+           'dataset_conf': {'dataset_vocab': vpath}, 'use_model': 'efficient_conformer', 'streaming': True,
+           'decoder': 'ctc_greedy', 'metrics_type': 'cer'}
+    pred = MASRPredictor(configs=cfg, use_gpu=True, state_dict=synthetic.efficient_conformer_state_dict(0, V))
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm'][:64000]
+
+    def run():
+        pred.reset_stream()
+        last, parts = None, 0
+        for s in range(0, len(pcm), 8000):
+            r = pred.predict_stream(audio_data=pcm[s:s + 8000].tobytes(), is_end=(s + 8000 >= len(pcm)))
+            if r is not None and r['text'] is not None:
+                last, parts = r, parts + 1
+        pred.reset_stream()
+        return last, parts
+    a, na = run()
+    b, nb = run()
+    assert a is not None and len(a['text']) > 0 and na >= 5
+    assert a == b and na == nb

@@ -512,6 +512,49 @@ def test_efficient_conformer_against_reference_fixture(eff512, oracle_mods):
     assert np.abs(probs - z['probs']).max() < 1e-3
 
 
+def test_efficient_conformer_stream_chunks_against_reference_fixture(eff512, oracle_mods):
+    """EfficientConformerEncoder.forward_chunk: grouped attention over cache + chunk, stride layer with cnn cache, half-rate
+    layers with their own caches; probabilities and the exported caches against the reference run"""
+    from oracle import efficient_conformer as oe
+    e, sd = eff512
+    z = g('efficient_conformer_v512.npz')
+    feats, _ = oracle_mods[4]()
+    sid = e.stream_open(0)
+    outs = []
+    for cur, n in [(c, 67) for c in range(0, 331 - 67 + 1, 64)] + [(320, 11)]:
+        p, _, _ = e.encode_chunk([sid], dev(feats[:1, cur:cur + n]))
+        outs.append(p[0].cpu().numpy())
+    got = np.concatenate(outs)
+    assert got.shape == z['chunk_probs'].shape == (41, 512)
+    assert np.abs(got - z['chunk_probs']).max() < 1e-3
+    att, cnn = e.stream_export_cache(sid)
+    assert att.shape == tuple(z['att'].shape) and np.abs(att.cpu().numpy() - z['att']).max() < 1e-3
+    assert cnn.shape == tuple(z['cnn'].shape) and np.abs(cnn.cpu().numpy() - z['cnn']).max() < 1e-3
+    e.stream_close(sid)
+    # two streams with different histories in one lock-step call (one joins a chunk later) == the oracle stream by stream
+    torch.manual_seed(6)
+    xa, xb = torch.randn(1, 195, 80) * 3 + 13, torch.randn(1, 131, 80) * 3 + 13
+    s0, s1 = e.stream_open(0), e.stream_open(0)
+    ca = cb = (torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0))
+    with torch.no_grad():
+        pa, *ca = oe.get_encoder_out_chunk(sd, xa[:, :67], 0, -16, *ca)
+    p, _, _ = e.encode_chunk([s0], dev(xa[:, :67]))
+    assert np.abs(p[0].cpu().numpy() - pa[0].numpy()).max() < 1e-3
+    oa, ob = pa.shape[1], 0
+    for k, cur in enumerate((64, 128)):
+        both = torch.cat([xa[:, cur:cur + 67], xb[:, cur - 64:cur - 64 + 67]])
+        p, _, _ = e.encode_chunk([s0, s1], dev(both))
+        with torch.no_grad():
+            pa, *ca = oe.get_encoder_out_chunk(sd, xa[:, cur:cur + 67], oa, -16, *ca)
+            pb, *cb = oe.get_encoder_out_chunk(sd, xb[:, cur - 64:cur - 64 + 67], ob, -16, *cb)
+        oa += pa.shape[1]
+        ob += pb.shape[1]
+        assert np.abs(p[0].cpu().numpy() - pa[0].numpy()).max() < 1e-3
+        assert np.abs(p[1].cpu().numpy() - pb[0].numpy()).max() < 1e-3
+    e.stream_close(s0)
+    e.stream_close(s1)
+
+
 @pytest.mark.parametrize('T', [203, 204, 205, 331])
 def test_efficient_conformer_lengths_against_oracle(eff512, oracle_mods, T):
     """T' mod 3 = 0/1/2 (grouping pad) and odd / even T' (stride layer, AvgPool ceil mode), ragged batch."""
