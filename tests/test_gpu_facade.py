@@ -319,3 +319,50 @@ def test_efficient_conformer_predict_stream_facade(tmp_path):
     b, nb = run()
     assert a is not None and len(a['text']) > 0 and na >= 5
     assert a == b and na == nb
+
+
+def test_stream_pool_equals_independent_predict_stream(predictor):
+    """StreamPool (batched sessions): every session gets the partial results of its own predict_stream"""
+    from masr_amd.serving import StreamPool
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    audios = [pcm[:72000], pcm[30000:110000], pcm[50000:83000]]
+    step = 8000
+    # reference behaviour: one predictor, one stream at a time
+    want = []
+    for a in audios:
+        predictor.reset_stream()
+        parts = []
+        for s in range(0, len(a), step):
+            parts.append(predictor.predict_stream(audio_data=a[s:s + step].tobytes(), is_end=(s + step >= len(a))))
+        want.append(parts)
+    predictor.reset_stream()
+    # the same three streams concurrently
+    pool = StreamPool(predictor)
+    hs = [pool.open() for _ in audios]
+    got = [[] for _ in audios]
+    for k in range(max(len(a) for a in audios) // step + 1):
+        for i, a in enumerate(audios):
+            s = k * step
+            if s < len(a):
+                pool.feed(hs[i], a[s:s + step].tobytes(), is_end=(s + step >= len(a)))
+        out = pool.step()
+        for i, h in enumerate(hs):
+            if h in out:
+                got[i].append(out[h])
+    for i in range(len(audios)):
+        assert len(got[i]) == len(want[i])
+        for g_, w_ in zip(got[i], want[i]):
+            assert (g_ is None) == (w_ is None or w_['text'] is None)
+            if g_ is not None:
+                assert _close(w_['text'], g_['text']) <= 0.02, (w_['text'], g_['text'])
+                assert abs(g_['score'] - w_['score']) < 0.05
+    # a session can be reused for the next utterance
+    pool.reset(hs[0])
+    pool.feed(hs[0], audios[2].tobytes(), is_end=True)
+    again = pool.step()[hs[0]]
+    predictor.reset_stream()
+    one = predictor.predict_stream(audio_data=audios[2].tobytes(), is_end=True)       # same single-call feeding
+    predictor.reset_stream()
+    assert _close(one['text'], again['text']) <= 0.02 and abs(one['score'] - again['score']) < 0.05
+    for h in hs:
+        pool.close(h)
