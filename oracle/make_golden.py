@@ -79,7 +79,8 @@ def efficient_chunk_run(ef, feats):
         r, att, cnn = ef.get_encoder_out_chunk(feats[:1, cur:cur + n], off, -16, att, cnn)
         off += r.shape[1]
         chunks.append(r[0].numpy())
-    return np.concatenate(chunks), att.numpy(), cnn.numpy()
+    lay = np.array([0, 3, 4, 11])           # a grouped layer, the stride layer, two half-rate layers (keeps the file small)
+    return np.concatenate(chunks), (lay, att.numpy()[lay]), cnn.numpy()[lay]
 
 
 def conformer_nonstreaming_fixture(tmp):
@@ -124,8 +125,9 @@ def squeezeformer_streaming_fixture(mean_istd):
         r, att, cnn = m.get_encoder_out_chunk(feats[:1, cur:cur + n], off, -16, att, cnn)
         off += r.shape[1]
         chunks.append(r[0].numpy())
+    lay = np.array([0, 5, 10, 11])          # caches of a full-rate, two half-rate and the recovery layer (keeps the file small)
     np.savez_compressed(os.path.join(OUT, 'squeezeformer_streaming_v512.npz'), enc=enc.numpy(), probs=probs.numpy(),
-                        chunk_probs=np.concatenate(chunks), att=att.numpy(), cnn=cnn.numpy())
+                        chunk_probs=np.concatenate(chunks), att_layers=lay, att=att.numpy()[lay], cnn=cnn.numpy()[lay])
 
 
 def deepspeech2_fixture(tmp):
@@ -210,7 +212,8 @@ def main():
         ef_enc, _ = ef.encoder(feats, lens, -1, -1)
         ef_chunks, ef_att, ef_cnn = efficient_chunk_run(ef, feats)
         np.savez_compressed(os.path.join(OUT, 'efficient_conformer_v512.npz'), enc=ef_enc.numpy(),
-                            probs=ef.get_encoder_out(feats, lens).numpy(), chunk_probs=ef_chunks, att=ef_att, cnn=ef_cnn)
+                            probs=ef.get_encoder_out(feats, lens).numpy(), chunk_probs=ef_chunks, att_layers=ef_att[0],
+                            att=ef_att[1], cnn=ef_cnn)
         print('efficient conformer fixture written')
         return
     if '--only-conformer-nonstreaming' in sys.argv:
@@ -299,7 +302,7 @@ def main():
     ef_probs = ef.get_encoder_out(feats, lens)
     ef_chunks, ef_att, ef_cnn = efficient_chunk_run(ef, feats)
     np.savez_compressed(os.path.join(OUT, 'efficient_conformer_v512.npz'), enc=ef_enc.numpy(), probs=ef_probs.numpy(),
-                        chunk_probs=ef_chunks, att=ef_att, cnn=ef_cnn)
+                        chunk_probs=ef_chunks, att_layers=ef_att[0], att=ef_att[1], cnn=ef_cnn)
 
     # ---- MASRPredictor facade on the TorchScript export ---------------------------
     from masr.predict import MASRPredictor

@@ -447,8 +447,9 @@ def test_squeezeformer_stream_chunks_against_reference_fixture(oracle_mods):
     assert got.shape == z['chunk_probs'].shape == (82, 512)
     assert np.abs(got - z['chunk_probs']).max() < 1e-3
     att, cnn = e.stream_export_cache(sid)
-    assert att.shape == tuple(z['att'].shape) and np.abs(att.cpu().numpy() - z['att']).max() < 1e-3
-    assert np.abs(cnn.cpu().numpy() - z['cnn']).max() < 1e-3
+    lay = z['att_layers']                      # the fixture keeps the caches of four representative layers
+    assert att.shape == (12, 4, 82, 128) and np.abs(att.cpu().numpy()[lay] - z['att']).max() < 1e-3
+    assert np.abs(cnn.cpu().numpy()[lay] - z['cnn']).max() < 1e-3
     # two streams in lock-step (different audio) == the oracle run stream by stream
     torch.manual_seed(5)
     xa, xb = torch.randn(1, 131, 80) * 3 + 13, torch.randn(1, 131, 80) * 3 + 13
@@ -528,8 +529,9 @@ def test_efficient_conformer_stream_chunks_against_reference_fixture(eff512, ora
     assert got.shape == z['chunk_probs'].shape == (41, 512)
     assert np.abs(got - z['chunk_probs']).max() < 1e-3
     att, cnn = e.stream_export_cache(sid)
-    assert att.shape == tuple(z['att'].shape) and np.abs(att.cpu().numpy() - z['att']).max() < 1e-3
-    assert cnn.shape == tuple(z['cnn'].shape) and np.abs(cnn.cpu().numpy() - z['cnn']).max() < 1e-3
+    lay = z['att_layers']                      # the fixture keeps the caches of four representative layers
+    assert att.shape == (12, 4, 82, 128) and np.abs(att.cpu().numpy()[lay] - z['att']).max() < 1e-3
+    assert cnn.shape == (12, 1, 256, 14) and np.abs(cnn.cpu().numpy()[lay] - z['cnn']).max() < 1e-3
     e.stream_close(sid)
     # two streams with different histories in one lock-step call (one joins a chunk later) == the oracle stream by stream
     torch.manual_seed(6)
