@@ -4,7 +4,7 @@ other (infer_server.py:42-46,103-156).  Here every session keeps the reference's
 cached feature frames, greedy decoder history; predict.py:237-343) but the device work of all sessions that have audio
 pending is done together: ONE ragged fbank launch for the new samples of all sessions, and the 67-frame windows advance in
 lock-step through ``masr_encode_chunk`` (n streams per call).  Every session receives exactly the partial results it would
-get from its own ``MASRPredictor.predict_stream`` (greedy decoding; Conformer-family models).
+get from its own ``MASRPredictor.predict_stream`` (greedy decoding; Conformer-family models and streaming DeepSpeech2).
 """
 import numpy as np
 import torch
@@ -25,15 +25,15 @@ class _Session:
 
 
 class StreamPool:
-    """``pool = StreamPool(predictor)`` on a streaming MASRPredictor (conformer / squeezeformer / efficient_conformer,
-    ``decoder: ctc_greedy``).  ``open()`` -> handle; ``feed(handle, pcm_bytes, is_end)`` queues audio; ``step()`` processes
+    """``pool = StreamPool(predictor)`` on a streaming MASRPredictor (conformer / squeezeformer / efficient_conformer /
+    deepspeech2, ``decoder: ctc_greedy``).  ``open()`` -> handle; ``feed(handle, pcm_bytes, is_end)`` queues audio; ``step()`` processes
     everything queued since the last step and returns ``{handle: {'text', 'score'} or None}`` for the sessions that were fed;
     ``close(handle)`` releases the stream."""
 
     def __init__(self, predictor, max_frames_out=0):
         cfg = predictor.configs
-        if not cfg.streaming or 'former' not in cfg.use_model:
-            raise Exception('StreamPool needs a streaming Conformer-family model')
+        if not cfg.streaming or not ('former' in cfg.use_model or cfg.use_model == 'deepspeech2'):
+            raise Exception('StreamPool needs a streaming model (Conformer family or uni-directional DeepSpeech2)')
         if cfg.decoder != 'ctc_greedy':
             raise Exception('StreamPool decodes with ctc_greedy')
         self.predictor = predictor

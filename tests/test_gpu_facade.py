@@ -366,3 +366,36 @@ def test_stream_pool_equals_independent_predict_stream(predictor):
     assert _close(one['text'], again['text']) <= 0.02 and abs(one['score'] - again['score']) < 0.05
     for h in hs:
         pool.close(h)
+
+
+def test_stream_pool_deepspeech2(tmp_path):
+    """StreamPool over the streaming DeepSpeech2: two concurrent sessions == two sequential predict_stream runs"""
+    from masr_amd.serving import StreamPool
+    p = _ds2_predictor(str(tmp_path), True)
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    audios = [pcm[:64000], pcm[40000:96000]]
+    want = []
+    for a in audios:
+        p.reset_stream()
+        want.append([p.predict_stream(audio_data=a[s:s + 8000].tobytes(), is_end=(s + 8000 >= len(a)))
+                     for s in range(0, len(a), 8000)])
+    p.reset_stream()
+    pool = StreamPool(p)
+    hs = [pool.open() for _ in audios]
+    got = [[] for _ in audios]
+    for k in range(8):
+        for i, a in enumerate(audios):
+            if k * 8000 < len(a):
+                pool.feed(hs[i], a[k * 8000:(k + 1) * 8000].tobytes(), is_end=((k + 1) * 8000 >= len(a)))
+        out = pool.step()
+        for i, h in enumerate(hs):
+            if h in out:
+                got[i].append(out[h])
+    for i in range(2):
+        assert len(got[i]) == len(want[i])
+        for g_, w_ in zip(got[i], want[i]):
+            assert (g_ is None) == (w_ is None or w_['text'] is None)
+            if g_ is not None:
+                assert _close(w_['text'], g_['text']) <= 0.02 and abs(g_['score'] - w_['score']) < 0.05
+    for h in hs:
+        pool.close(h)
