@@ -703,3 +703,21 @@ def test_engine_reuse_across_shapes_and_streams(eng512, oracle_mods):
     assert len(seen) <= 5                      # slots are reused
     with pytest.raises(Exception):
         e.encode_chunk([sid + 100], chunk)      # unknown stream id fails loudly
+
+
+@pytest.mark.parametrize('B', [7, 20])
+def test_deepspeech2_batched_recurrence_against_oracle(ds2_engines, oracle_mods, B):
+    """batches above 4 sequences run the recurrence on the matrix cores (lstm_step_mfma_kernel): ragged batch vs the oracle"""
+    from oracle import deepspeech2 as ods
+    e_bi, e_uni, sd_bi, sd_uni = ds2_engines
+    torch.manual_seed(B)
+    T = 131
+    lens = torch.randint(40, T + 1, (B,))
+    lens[0] = T
+    x = (torch.randn(B, T, 80) * 3 + 13) * (torch.arange(T)[None, :, None] < lens[:, None, None])
+    for e, sd in ((e_bi, sd_bi), (e_uni, sd_uni)):
+        enc = e.encode_full(dev(x), dev(lens, torch.int32))
+        probs = e.ctc_probs(enc).cpu().numpy()
+        with torch.no_grad():
+            ref = ods.get_encoder_out(sd, x, lens).numpy()
+        assert probs.shape == ref.shape and np.abs(probs - ref).max() < 1e-3
