@@ -81,36 +81,39 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
     }
 }
 
-// Batched form of the step (B > 4): the 16 hidden units x 4 gates of a workgroup against the h_{t-1} rows of 16 * BT sequences
-// on the matrix cores (v_mfma_f32_16x16x4_f32: D[16 sequences, 16 units] += h[16, 4] . W_g^T[4, 16]).  8 waves split K = 1024
-// (128 each), partial tiles are summed through LDS, then one thread per (sequence, unit) applies the gate non-linearities.
-// Both operands are fetched as 16-byte vectors along k (lane l: row/col l % 16, k block 4 * (l / 16)); the k order inside an
-// MFMA sum is free, so element i of every lane's vector feeds MFMA i of a group of four.
+// Batched form of the step (B > 4): 8 hidden units x 4 gates of a workgroup against the h_{t-1} rows of 16 * BT sequences on
+// the matrix cores (v_mfma_f32_16x16x4_f32: D[16 sequences, 16 columns] += h[16, 4] . W^T[4, 16]; the 16 columns of tile p are
+// gate 2p of the 8 units followed by gate 2p+1 of the same units).  1024 / 8 units x directions = 256 workgroups at two
+// directions, one per CU, so the whole chip pulls W_hh.  8 waves split K = 1024 (128 each), partial tiles are summed through
+// LDS, then one thread per (sequence, unit) applies the gate non-linearities.  Both operands are fetched as 16-byte vectors
+// along k (lane l: row/col l % 16, k block 4 * (l / 16)); the k order inside an MFMA sum is free, so element i of every lane's
+// vector feeds MFMA i of a group of four.
 template <int H, int BT>
 __global__ __launch_bounds__(512) void lstm_step_mfma_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
                                                              const float* __restrict__ h_prev, float* __restrict__ h_next,
                                                              float* __restrict__ c, float* __restrict__ out,
                                                              const int* __restrict__ lens, int B, int T, int step, int ndir) {
     typedef float f32x4v __attribute__((ext_vector_type(4)));
-    __shared__ float red[8][BT * 4 * 4][64];          // [wave][tile, gate, acc reg][lane]
+    __shared__ float red[8][BT * 2 * 4][64];          // [wave][sequence tile, gate pair, acc reg][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dir = blockIdx.y;
-    const int j0 = blockIdx.x * 16;
+    const int j0 = blockIdx.x * 8;
     const int t = dir ? T - 1 - step : step;
     const int col = lane & 15, q = lane >> 4;
     const int k0 = wave * (H / 8);
-    f32x4v acc[BT][4];
+    f32x4v acc[BT][2];
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[bt][g] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    const float* wbase = whh + ((size_t)dir * 4 * H + j0 + col) * H + k0 + 4 * q;
+        for (int p = 0; p < 2; ++p) acc[bt][p] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // column `col` of gate-pair tile p: gate 2p + (col >> 3), unit j0 + (col & 7)
+    const float* wbase = whh + ((size_t)dir * 4 * H + (size_t)(col >> 3) * H + j0 + (col & 7)) * H + k0 + 4 * q;
     const float* hbase = h_prev + (size_t)dir * B * H + k0 + 4 * q;
 #pragma unroll
-    for (int kb = 0; kb < H / 8; kb += 16) {      // fully unrolled: all 8 x (4 + BT) vector loads can be in flight at once
-        f32x4 wv[4], hv[BT];
+    for (int kb = 0; kb < H / 8; kb += 16) {      // fully unrolled: all 8 x (2 + BT) vector loads can be in flight at once
+        f32x4 wv[2], hv[BT];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) wv[g] = *reinterpret_cast<const f32x4*>(wbase + (size_t)g * H * H + kb);
+        for (int p = 0; p < 2; ++p) wv[p] = *reinterpret_cast<const f32x4*>(wbase + (size_t)(2 * p) * H * H + kb);
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) {
             const int b = min(bt * 16 + col, B - 1);
@@ -121,29 +124,31 @@ __global__ __launch_bounds__(512) void lstm_step_mfma_kernel(const float* __rest
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    acc[bt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[bt][i], wv[g][i], acc[bt][g], 0, 0, 0);
+                for (int p = 0; p < 2; ++p)
+                    acc[bt][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[bt][i], wv[p][i], acc[bt][p], 0, 0, 0);
     }
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][(bt * 4 + g) * 4 + r][lane] = acc[bt][g][r];
+            for (int r = 0; r < 4; ++r) red[wave][(bt * 2 + p) * 4 + r][lane] = acc[bt][p][r];
     __syncthreads();
-    // D layout of the 16x16 tile: lane l, register r -> row (sequence) 4 * (l / 16) + r, column (unit) l % 16
-    for (int e = threadIdx.x; e < BT * 4 * 64; e += 512) {
-        const int bt = e / 256, r = (e >> 6) & 3, l = e & 63;
-        const int b = bt * 16 + 4 * (l >> 4) + r, j = j0 + (l & 15);
+    // D layout of the 16x16 tile: lane l, register r -> row (sequence) 4 * (l / 16) + r, column l % 16
+    for (int e = threadIdx.x; e < BT * 16 * 8; e += 512) {       // one thread per (sequence, unit)
+        const int b = e >> 3, u = e & 7;
         if (b >= B) continue;
+        const int bt = b >> 4, r = b & 3, lq = (b >> 2) & 3;      // b = 16 bt + 4 lq + r
         float dot[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            const int l = lq * 16 + (g & 1) * 8 + u;              // lane that holds column (gate g & 1, unit u) of tile g >> 1
             float a = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) a += red[w][(bt * 4 + g) * 4 + r][l];
+            for (int w = 0; w < 8; ++w) a += red[w][(bt * 2 + (g >> 1)) * 4 + r][l];
             dot[g] = a;
         }
+        const int j = j0 + u;
         const size_t sidx = ((size_t)dir * B + b) * H + j;
         const bool active = !lens || t < lens[b];
         const float* gr = gx + ((size_t)b * T + t) * (ndir * 4 * H) + (size_t)dir * 4 * H + j;
@@ -166,8 +171,8 @@ __global__ __launch_bounds__(512) void lstm_step_mfma_kernel(const float* __rest
 void launch_lstm_step(const float* gx, const float* whh, const float* h_prev, float* h_next, float* c, float* out,
                       const int* lens, int B, int T, int H, int step, int ndir, hipStream_t s) {
     if (H != 1024) return;
-    if (B > 4 && B <= 32) {           // matrix-core form: 16 units per workgroup, 16 * BT sequences (64 KB of LDS at BT = 2)
-        const dim3 grid(H / 16, ndir), blk(512);
+    if (B > 4 && B <= 32) {           // matrix-core form: 8 units per workgroup, 16 * BT sequences
+        const dim3 grid(H / 8, ndir), blk(512);
         if (B <= 16) hipLaunchKernelGGL((lstm_step_mfma_kernel<1024, 1>), grid, blk, 0, s, gx, whh, h_prev, h_next, c, out, lens, B, T, step, ndir);
         else hipLaunchKernelGGL((lstm_step_mfma_kernel<1024, 2>), grid, blk, 0, s, gx, whh, h_prev, h_next, c, out, lens, B, T, step, ndir);
         return;
