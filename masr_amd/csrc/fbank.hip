@@ -108,9 +108,8 @@ static constexpr int MAX_CHUNKS = 2048;   // 16.7 M samples (17 min @ 16 kHz) pe
 template <class ST>
 __global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp,
                                                           int n_max, float* __restrict__ chunk_sum /*[B][MAX_CHUNKS+1]*/) {
-    __shared__ int leaf_off[64], leaf_len[64], prog[128];
-    __shared__ float leaf_val[64];
-    __shared__ int n_leaf, n_prog;
+    __shared__ int lvl_child[8][64], lvl_split[8][64], tmp_off[64], tmp_len[64];
+    __shared__ float tmp_val[64];
     const int b = blockIdx.y;
     const int n = min(nsamp[b], NP_BUF * MAX_CHUNKS);
     const ST* x = pcm + (size_t)b * n_max;
@@ -125,51 +124,58 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__
         for (int o = 1; o < 64; o <<= 1) v = __fadd_rn(v, __shfl_xor(v, o, 64));
         if (lane == 0) out[c] = v;
     }
-    if (blockIdx.x != gridDim.x - 1) return;
-    // tail chunk: thread 0 lists the leaves in DFS order together with a postfix program
-    // (leaf index = push, -1 = add the two top values)
-    if (threadIdx.x == 0) {
-        int nl = 0, np = 0;
-        if (tail > 0) {
-            int s_off[16], s_len[16], s_stage[16], sp = 0;
-            s_off[0] = nc * NP_BUF; s_len[0] = tail; s_stage[0] = 0; sp = 1;
-            while (sp > 0) {
-                const int t = sp - 1;
-                if (s_len[t] <= 128) {
-                    leaf_off[nl] = s_off[t]; leaf_len[nl] = s_len[t];
-                    prog[np++] = nl++;
-                    --sp;
-                } else if (s_stage[t] == 0) {
-                    int n2 = s_len[t] / 2; n2 -= n2 % 8;
-                    s_stage[t] = 1;
-                    s_off[sp] = s_off[t]; s_len[sp] = n2; s_stage[sp] = 0; ++sp;
-                } else if (s_stage[t] == 1) {
-                    int n2 = s_len[t] / 2; n2 -= n2 % 8;
-                    s_stage[t] = 2;
-                    s_off[sp] = s_off[t] + n2; s_len[sp] = s_len[t] - n2; s_stage[sp] = 0; ++sp;
-                } else {
-                    prog[np++] = -1;
-                    --sp;
-                }
+    if (blockIdx.x != gridDim.x - 1 || wave != 0) return;
+    // tail chunk (< 8192 samples) on wave 0: numpy's pairwise recursion (split at n/2 rounded down to a multiple of 8, leaves of
+    // <= 128 elements) unrolled level by level -- at most 64 nodes per level, one per lane: a node that splits gets two slots
+    // in the next level, a leaf is carried down unchanged; the sums then fold back up level by level in the same tree order.
+    if (tail == 0) {
+        if (lane == 0) out[MAX_CHUNKS] = 0.f;
+        return;
+    }
+    int off = nc * NP_BUF, len = tail;
+    bool have = lane == 0;
+    int depth = 0;
+    while (true) {
+        const bool split = have && len > 128;
+        lvl_child[depth][lane] = 0;
+        lvl_split[depth][lane] = split ? 1 : 0;
+        if (!__ballot(split)) break;
+        const int width = have ? (split ? 2 : 1) : 0;
+        int incl = width;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        const int pos = incl - width;
+        const int total = __shfl(incl, 63, 64);
+        lvl_child[depth][lane] = pos;
+        if (have) {
+            if (split) {
+                int n2 = len / 2;
+                n2 -= n2 % 8;
+                tmp_off[pos] = off; tmp_len[pos] = n2;
+                tmp_off[pos + 1] = off + n2; tmp_len[pos + 1] = len - n2;
+            } else {
+                tmp_off[pos] = off; tmp_len[pos] = len;
             }
         }
-        n_leaf = nl; n_prog = np;
+        __builtin_amdgcn_wave_barrier();
+        have = lane < total;
+        off = have ? tmp_off[lane] : 0;
+        len = have ? tmp_len[lane] : 0;
+        __builtin_amdgcn_wave_barrier();
+        ++depth;
     }
-    __syncthreads();
-    if ((int)threadIdx.x < n_leaf) leaf_val[threadIdx.x] = pw_leaf(x, leaf_off[threadIdx.x], leaf_len[threadIdx.x]);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tv = 0.f;
-        if (n_prog > 0) {
-            float st[16]; int sp = 0;
-            for (int i = 0; i < n_prog; ++i) {
-                if (prog[i] >= 0) st[sp++] = leaf_val[prog[i]];
-                else { st[sp - 2] = __fadd_rn(st[sp - 2], st[sp - 1]); --sp; }
-            }
-            tv = st[0];
-        }
-        out[MAX_CHUNKS] = tv;
+    float val = have ? pw_leaf(x, off, len) : 0.f;
+    for (int d = depth - 1; d >= 0; --d) {
+        tmp_val[lane] = val;
+        __builtin_amdgcn_wave_barrier();
+        const int ch = lvl_child[d][lane];
+        val = lvl_split[d][lane] ? __fadd_rn(tmp_val[min(ch, 63)], tmp_val[min(ch + 1, 63)]) : tmp_val[min(ch, 63)];
+        __builtin_amdgcn_wave_barrier();
     }
+    if (lane == 0) out[MAX_CHUNKS] = val;
 }
 
 // pass 2: sequential float32 accumulation of the chunk sums (numpy's buffered reduction) + the gain
