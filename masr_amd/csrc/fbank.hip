@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const ST* __restrict__ pcm, 
         const int j = lane + 64 * i;
         if (j < WIN) Tm[j] = x[i] - mean;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();   // the four waves of a workgroup work on four independent frames: LDS traffic of a wave is in order
     // z[n] = y[2n] + i*y[2n+1], written at bit-reversed n for the in-place DIT FFT
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const ST* __restrict__ pcm, 
         const int br = __brev((unsigned)nn) >> 24;  // 8-bit reversal
         if (j & 1) I[br] = y; else R[br] = y;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();   // the four waves of a workgroup work on four independent frames: LDS traffic of a wave is in order
 
     // ---- 256-point complex FFT, radix-2 DIT, 8 stages, 2 butterflies per lane per stage ---------------
 #pragma unroll
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const ST* __restrict__ pcm, 
             R[i0] = ar + tr; I[i0] = ai + ti;
             R[i1] = ar - tr; I[i1] = ai - ti;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();   // the four waves of a workgroup work on four independent frames: LDS traffic of a wave is in order
     }
 
     // ---- real-split post-pass: X[k] = (Z[k] + conj(Z[N-k]))/2 - i/2 * W^k * (Z[k] - conj(Z[N-k])), N = 256 ---
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const ST* __restrict__ pcm, 
             P[k] = xr * xr + xi * xi;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();   // the four waves of a workgroup work on four independent frames: LDS traffic of a wave is in order
 
     // ---- mel filterbank + log --------------------------------------------------------------------------
     float* dst = feats + ((size_t)b * T_max + t) * NMEL;
