@@ -109,9 +109,17 @@ struct RowGemmArgs {
 void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);
 
 // Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_pc.hip; ffn_fused.hip = previous kernel, kept for A/B)
-void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
-                      int nsplit, hipStream_t s);   // partial/nsplit: split-d_ff mode for small M (streaming)
+// partial/nsplit: split-d_ff mode for small M (streaming).  post: LayerNorm that follows the block in the layer; it is fused into
+// the split-mode reduction (return value 1), otherwise the caller runs it (return value 0)
+struct FfnPostLn {
+    const float* lnw;
+    const float* lnb;
+    float* y;          // destination rows (may alias x)
+    float eps;
+};
+int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                     const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
+                     int nsplit, hipStream_t s, const FfnPostLn* post = nullptr);
 
 void set_ffn_variant(int v);   // diagnostic ablations of the fused FFN kernel (0 = production)
 
@@ -165,6 +173,9 @@ void launch_attseq_grouped(AttSeq* seqs, const float* q, const float* k, const f
                            int B, int Tg, int group, int mstride, hipStream_t s);
 void launch_kv_append(const AttSeq* seqs, const float* qkv, int n, int Tq, hipStream_t s);
 void launch_cnn_cache_move(float* const* caches, float* lnpad, int n, int Tq, int pad, int dir, hipStream_t s);
+// streaming conv-module front in one launch: history rows <- cache_rd, new rows <- LayerNorm / affine of x, cache_wr <- last pad rows
+void launch_conv_hist(const float* x, const float* w, const float* b, float* const* cache_rd, float* const* cache_wr,
+                      float* lnpad, int n, int Tq, int pad, int affine, float eps, hipStream_t s);
 void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, int mstride,
                         hipStream_t s);
 

@@ -670,4 +670,56 @@ void launch_cnn_cache_move(float* const* caches, float* lnpad, int n, int Tq, in
     hipLaunchKernelGGL(cnn_cache_move_kernel, dim3(pad, n), dim3(64), 0, s, caches, lnpad, Tq, pad, dir);
 }
 
+// Streaming conv module front, one launch instead of three (cache -> history rows | LayerNorm of the new rows | new cache):
+//   v(i, tp) = tp < pad ? cache_rd[i][tp] : f(x[i][tp - pad])          f = LayerNorm (Conformer) or scale * x + bias (Squeezeformer)
+//   lnpad[i][tp] = v(i, tp)   for tp in [0, pad + Tq)
+//   cache_wr[i][r] = v(i, Tq + r)   for r in [0, pad)                  (convolution.py:100-108: new_cache = x[:, :, -lorder:])
+// cache_rd / cache_wr are the two halves of a double-buffered cache (the caller flips them per call), so rows are independent:
+// one wave per padded row, no ordering between them.
+template <int AFFINE>
+__global__ __launch_bounds__(256) void conv_hist_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* const* __restrict__ cache_rd,
+                                                        float* const* __restrict__ cache_wr, float* __restrict__ lnpad,
+                                                        int n, int Tq, int pad, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int per = Tq + pad;
+    if (row >= n * per) return;
+    const int i = row / per, tp = row - i * per;
+    f32x4 o;
+    if (tp < pad) {
+        o = *reinterpret_cast<const f32x4*>(cache_rd[i] + (size_t)tp * 256 + lane * 4);
+    } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)i * Tq + tp - pad) * 256 + lane * 4);
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + lane * 4);
+        if (AFFINE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = ww[k] * v[k] + bb[k];
+        } else {
+            const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+            const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+            const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+            const float rstd = 1.0f / sqrtf(var + eps);
+            o[0] = d0 * rstd * ww[0] + bb[0];
+            o[1] = d1 * rstd * ww[1] + bb[1];
+            o[2] = d2 * rstd * ww[2] + bb[2];
+            o[3] = d3 * rstd * ww[3] + bb[3];
+        }
+    }
+    *reinterpret_cast<f32x4*>(lnpad + (size_t)row * 256 + lane * 4) = o;
+    if (tp >= Tq) *reinterpret_cast<f32x4*>(cache_wr[i] + (size_t)(tp - Tq) * 256 + lane * 4) = o;
+}
+void launch_conv_hist(const float* x, const float* w, const float* b, float* const* cache_rd, float* const* cache_wr,
+                      float* lnpad, int n, int Tq, int pad, int affine, float eps, hipStream_t s) {
+    const int rows = n * (Tq + pad);
+    if (rows <= 0) return;
+    if (affine)
+        hipLaunchKernelGGL(conv_hist_kernel<1>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, cache_rd, cache_wr, lnpad, n, Tq,
+                           pad, eps);
+    else
+        hipLaunchKernelGGL(conv_hist_kernel<0>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, cache_rd, cache_wr, lnpad, n, Tq,
+                           pad, eps);
+}
+
 }  // namespace masr

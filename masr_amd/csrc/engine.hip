@@ -91,6 +91,8 @@ struct Stream {
     int cap = 0;
     DevBuf att;  // [L][cap][2*d]  (k | v per row)
     DevBuf cnn;  // [L][kernel-1][d]   (DeepSpeech2: LSTM state [L][2 (h, c)][rnn_size])
+    DevBuf cnn2; // Conformer / Squeezeformer: second half of the double-buffered cnn cache (a chunk step reads `cnn`, writes
+                 // `cnn2`, then the two are swapped -- lets one kernel read the history and write the new cache without ordering)
 };
 
 struct GBeam {        // device-resident streaming CTC prefix beam search (masr_gbeam_*)
@@ -331,6 +333,7 @@ void masr_destroy(masr_engine* e) {
     for (auto& s : e->streams) {
         s.att.release();
         s.cnn.release();
+        s.cnn2.release();
     }
     for (auto& g : e->gbeams) {
         g.pool.release();
@@ -526,8 +529,10 @@ struct EncodeCtx {
     const int* lens; // device feature lengths for pad masking, or nullptr (streaming)
 };
 
+// post_*: the LayerNorm that follows the block (y <- LayerNorm(x), y may be x); fused into the split-mode reduction of small M
 int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb, const float* w1, const float* b1,
-        const float* w2, const float* b2, float scale = 0.5f, int affine = 0) {
+        const float* w2, const float* b2, float scale = 0.5f, int affine = 0, const float* post_w = nullptr,
+        const float* post_b = nullptr, float* post_y = nullptr) {
     const int d = e->cfg.d_model, dff = e->cfg.d_ff;
     // few rows (streaming chunk steps): split d_ff across workgroups so that >= ~128 CUs work on the block
     int nsplit = 1;
@@ -537,8 +542,10 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
     }
     ProfScope ps(e, s, PROF_FFN1, 4.0 * M * (double)dff * d);
-    launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine,
-                     nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s);
+    const FfnPostLn post{post_w, post_b, post_y, 1e-5f};
+    const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine,
+                                      nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s, post_y ? &post : nullptr);
+    if (post_y && !done) launch_layernorm(e->x.as<float>(), post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
     return 0;
 }
 
@@ -597,7 +604,7 @@ int ensure_layer_ws(masr_engine* e, int nseq, int Tq) {
 //  streaming (hist == true): lnpad rows [0,pad) of every sequence already hold the cnn cache; LayerNorm writes
 //                            the new rows behind them (needed for the next cache) and the GEMM reads lnpad.
 int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, bool hist, int K = 0, int mstride = 4,
-                bool pw1_done = false) {
+                bool pw1_done = false, bool ln_done = false) {
     if (K <= 0) K = e->cfg.cnn_kernel;
     const int d = e->cfg.d_model, pad = K - 1;
     const int M = c.nseq * c.Tq, Mp = c.nseq * (c.Tq + pad);
@@ -605,7 +612,7 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
     if (pw1_done) {
         // glu buffer already filled by mhsa_out_pw1 (fused out-projection -> LayerNorm -> pointwise_conv1 -> GLU)
     } else if (hist) {
-        launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, c.Tq, pad, c.lens, s);
+        if (!ln_done) launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, c.Tq, pad, c.lens, s);
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
                 e->glu.as<float>(), d, Mp, 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
     } else {
@@ -1398,6 +1405,10 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     CHK(st.att.ensure((size_t)L * st.cap * 2 * d * sizeof(float)));
     CHK(st.cnn.ensure((size_t)L * pad * d * sizeof(float)));
     HIPCHK(hipMemset(st.cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
+    if (e->cfg.model_kind != 2) {
+        CHK(st.cnn2.ensure((size_t)L * pad * d * sizeof(float)));
+        HIPCHK(hipMemset(st.cnn2.p, 0, (size_t)L * pad * d * sizeof(float)));
+    }
     if (e->cfg.model_kind == 2)     // planar caches of the grouped layers: rows behind the last key must read as zero
         HIPCHK(hipMemset(st.att.p, 0, (size_t)L * st.cap * 2 * d * sizeof(float)));
     st.offset = 0;
@@ -1432,6 +1443,7 @@ int masr_stream_close(masr_engine* e, int32_t stream_id) {
     HIPCHK(hipDeviceSynchronize());
     st->att.release();
     st->cnn.release();
+    st->cnn2.release();
     st->open = false;
     return 0;
 }
@@ -1465,7 +1477,7 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
     CHK(e->attseq.ensure(sizeof(AttSeq) * (size_t)n * L));
     auto reduced = [&](int l) { return e->reduce_idx >= 0 && l >= e->reduce_idx && l < e->recover_idx; };
     std::vector<AttSeq> hs((size_t)n * L);
-    std::vector<float*> hp((size_t)n * L);
+    std::vector<float*> hp((size_t)n * L * 2);    // cnn cache bases: current (read) | next (written)
     for (int l = 0; l < L; ++l) {
         const int Tl = reduced(l) ? Tr : T0;
         for (int i = 0; i < n; ++i) {
@@ -1483,6 +1495,7 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
             a.q_abs0 = off;
             a.pad_ = 0;
             hp[(size_t)l * n + i] = st[i]->cnn.as<float>() + (size_t)l * pad * d;
+            hp[(size_t)(L + l) * n + i] = st[i]->cnn2.as<float>() + (size_t)l * pad * d;
         }
     }
     CHK(e->cnnptrs.ensure(sizeof(float*) * hp.size()));
@@ -1517,27 +1530,25 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->att.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d, 1.f,
                 nullptr, 0, 0, 0, nullptr, nullptr);
         launch_layernorm(x, w.ln1_w, w.ln1_b, x, M, 1e-5f, 0, 0, nullptr, s);
-        CHK(ffn(e, s, M, w.f1_s, w.f1_b, w.f1_w1, w.f1_b1, w.f1_w2, w.f1_b2, 1.0f, 1));
-        launch_layernorm(x, w.ln2_w, w.ln2_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        CHK(ffn(e, s, M, w.f1_s, w.f1_b, w.f1_w1, w.f1_b1, w.f1_w2, w.f1_b2, 1.0f, 1, w.ln2_w, w.ln2_b, x));
         // conv module: [cnn cache | ada(x)] -> pointwise_conv1 + GLU -> causal depthwise + BatchNorm + SiLU -> pointwise_conv2
         float* const* cptr = e->cnnptrs.as<float*>() + (size_t)l * n;
-        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 0, s);
-        launch_affine_rows(x, w.cv_s, w.cv_b, e->lnpad.as<float>(), M, Tq, pad, s);
+        launch_conv_hist(x, w.cv_s, w.cv_b, cptr, cptr + (size_t)L * n, e->lnpad.as<float>(), n, Tq, pad, 1, 1e-5f, s);
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
                 e->glu.as<float>(), d, n * (Tq + pad), 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
-        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 1, s);
         launch_dwconv_bn_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.bn_scale, w.bn_shift, e->dwo.as<float>(), n, Tq, K, s);
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x,
                 d, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
         launch_layernorm(x, w.ln3_w, w.ln3_b, x, M, 1e-5f, 0, 0, nullptr, s);
-        CHK(ffn(e, s, M, w.f2_s, w.f2_b, w.f2_w1, w.f2_b1, w.f2_w2, w.f2_b2, 1.0f, 1));
-        launch_layernorm(x, w.ln4_w, w.ln4_b, l == L - 1 ? e->enc.as<float>() : x, M, 1e-5f, 0, 0, nullptr, s);
+        CHK(ffn(e, s, M, w.f2_s, w.f2_b, w.f2_w1, w.f2_b1, w.f2_w2, w.f2_b2, 1.0f, 1, w.ln4_w, w.ln4_b,
+                l == L - 1 ? e->enc.as<float>() : x));
     }
     if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
     CHK(ctc_head(e, e->enc.as<float>(), n * T0, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
     for (int i = 0; i < n; ++i) {
         st[i]->offset += T0;
         st[i]->offset_r += Tr;
+        std::swap(st[i]->cnn, st[i]->cnn2);
     }
     return 0;
 }
@@ -1654,8 +1665,7 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
             CHK(conv_module(e, s, w, ctx, true, K));
             launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 1, s);
         }
-        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
-        launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x));
     }
     CHK(e->enc.ensure((size_t)n * T2 * d * sizeof(float)));
     launch_layernorm(x, e->after_w, e->after_b, e->enc.as<float>(), n * T2, 1e-5f, 0, 0, nullptr, s);
@@ -1722,9 +1732,12 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
             a.q_abs0 = st[i]->offset;
             a.pad_ = 0;
         }
-    std::vector<float*> hp((size_t)n * L);        // cnn cache base of (layer, stream)
+    std::vector<float*> hp((size_t)n * L * 2);    // cnn cache base of (layer, stream): current (read) | next (written)
     for (int l = 0; l < L; ++l)
-        for (int i = 0; i < n; ++i) hp[(size_t)l * n + i] = st[i]->cnn.as<float>() + (size_t)l * pad * d;
+        for (int i = 0; i < n; ++i) {
+            hp[(size_t)l * n + i] = st[i]->cnn.as<float>() + (size_t)l * pad * d;
+            hp[(size_t)(L + l) * n + i] = st[i]->cnn2.as<float>() + (size_t)l * pad * d;
+        }
     CHK(e->cnnptrs.ensure(sizeof(float*) * hp.size()));
     HIPCHK(hipMemcpyAsync(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice, s));
@@ -1738,18 +1751,21 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
         launch_kv_append(e->attseq.as<AttSeq>() + (size_t)l * n, e->qkv.as<float>(), n, Tq, s);   // k|v rows -> caches
         launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, 1, s);
         mhsa_out(e, s, w, M);
+        // history rows <- cnn cache (zeros at first) | LayerNorm of the new rows | new cache = last kernel-1 rows
+        // (convolution.py:100-108), one launch
         float* const* cptr = e->cnnptrs.as<float*>() + (size_t)l * n;
-        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 0, s);   // history rows <- cnn cache (zeros at first)
-        CHK(conv_module(e, s, w, ctx, true));
-        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 1, s);   // new cache = last kernel-1 rows (convolution.py:108)
-        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
-        launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        launch_conv_hist(x, w.ln_conv_w, w.ln_conv_b, cptr, cptr + (size_t)L * n, e->lnpad.as<float>(), n, Tq, pad, 0, 1e-5f, s);
+        CHK(conv_module(e, s, w, ctx, true, 0, 4, false, true));
+        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x));
     }
     CHK(e->enc.ensure((size_t)M * d * sizeof(float)));
     launch_layernorm(x, e->after_w, e->after_b, e->enc.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
     if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
     CHK(ctc_head(e, e->enc.as<float>(), M, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
-    for (int i = 0; i < n; ++i) st[i]->offset += Tq;
+    for (int i = 0; i < n; ++i) {
+        st[i]->offset += Tq;
+        std::swap(st[i]->cnn, st[i]->cnn2);
+    }
     return 0;
 }
 

@@ -259,31 +259,67 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(float* x, const float* _
     }
 }
 
-// x <- x + scale * (sum_s partial[s] + b2), partials added in ascending s (deterministic)
+// x <- x + scale * (sum_s partial[s] + b2), partials added in ascending s (deterministic).  One wave per row; POSTLN: the
+// LayerNorm that follows the block in the layer (norm_final after the second macaron FFN, encoder.py:160-161; the post-norms of
+// Squeezeformer) is applied to the finished row while it is still in registers: y <- LayerNorm(x_new) (y may alias x)
+template <int POSTLN>
 __global__ __launch_bounds__(256) void ffn_reduce_kernel(float* x, const float* __restrict__ partial,
-                                                         const float* __restrict__ b2, int M, int nsplit, float scale) {
+                                                         const float* __restrict__ b2, int M, int nsplit, float scale,
+                                                         const float* __restrict__ lnw, const float* __restrict__ lnb, float* y,
+                                                         float eps) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;        // float4 index
     if (i >= (size_t)M * FF_D / 4) return;
-    f32x4 acc = reinterpret_cast<const f32x4*>(partial)[i];
-    for (int sp = 1; sp < nsplit; ++sp) {
-        const f32x4 p = reinterpret_cast<const f32x4*>(partial + (size_t)sp * M * FF_D)[i];
+    const size_t sstride = (size_t)M * FF_D / 4;
+    const f32x4* pp = reinterpret_cast<const f32x4*>(partial) + i;
+    f32x4 xv = reinterpret_cast<f32x4*>(x)[i];
+    const f32x4 bb = reinterpret_cast<const f32x4*>(b2)[i % (FF_D / 4)];
+    f32x4 acc = pp[0];
+    int sp = 1;
+    for (; sp + 4 <= nsplit; sp += 4) {          // four loads in flight, added in ascending order
+        const f32x4 p0 = pp[(size_t)sp * sstride], p1 = pp[(size_t)(sp + 1) * sstride];
+        const f32x4 p2 = pp[(size_t)(sp + 2) * sstride], p3 = pp[(size_t)(sp + 3) * sstride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = (((acc[k] + p0[k]) + p1[k]) + p2[k]) + p3[k];
+    }
+    for (; sp < nsplit; ++sp) {
+        const f32x4 p = pp[(size_t)sp * sstride];
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] += p[k];
     }
-    const f32x4 bb = reinterpret_cast<const f32x4*>(b2)[i % (FF_D / 4)];
-    f32x4 xv = reinterpret_cast<f32x4*>(x)[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) xv[k] = xv[k] + scale * (acc[k] + bb[k]);
-    reinterpret_cast<f32x4*>(x)[i] = xv;
+    if (POSTLN) {
+        const int lane = threadIdx.x & 63;
+        const f32x4 gw = *reinterpret_cast<const f32x4*>(lnw + lane * 4);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
+        const float mean = wsum64(xv[0] + xv[1] + xv[2] + xv[3]) * (1.0f / 256.0f);
+        const float d0 = xv[0] - mean, d1 = xv[1] - mean, d2 = xv[2] - mean, d3 = xv[3] - mean;
+        const float var = wsum64(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        f32x4 o;
+        o[0] = d0 * rstd * gw[0] + gb[0];
+        o[1] = d1 * rstd * gw[1] + gb[1];
+        o[2] = d2 * rstd * gw[2] + gb[2];
+        o[3] = d3 * rstd * gw[3] + gb[3];
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    } else {
+        reinterpret_cast<f32x4*>(x)[i] = xv;
+    }
 }
 
-void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(ffn_reduce_kernel, dim3((unsigned)(((size_t)M * FF_D / 4 + 255) / 256)), dim3(256), 0, s, x, partial, b2,
-                       M, nsplit, scale);
+void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
+                       const FfnPostLn* post) {
+    const dim3 grid((unsigned)(((size_t)M * FF_D / 4 + 255) / 256));
+    if (post && post->y)
+        hipLaunchKernelGGL(ffn_reduce_kernel<1>, grid, dim3(256), 0, s, x, partial, b2, M, nsplit, scale, post->lnw, post->lnb,
+                           post->y, post->eps);
+    else
+        hipLaunchKernelGGL(ffn_reduce_kernel<0>, grid, dim3(256), 0, s, x, partial, b2, M, nsplit, scale, (const float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, 0.f);
 }
-void launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
-                   hipStream_t s, int variant);
+int launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                  const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
+                  hipStream_t s, int variant, const FfnPostLn* post);
 
 static int g_ffn_variant = 0;
 void set_ffn_variant(int v) { g_ffn_variant = v; }
@@ -307,28 +343,26 @@ static void launch_ffn_t(float* x, const float* lnw, const float* lnb, const flo
         const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
         hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE, 1>), dim3((M + FF_BM - 1) / FF_BM, ny), dim3(512), lds, s, x, lnw,
                            lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, cpb);
-        hipLaunchKernelGGL(ffn_reduce_kernel, dim3((unsigned)(((size_t)M * FF_D / 4 + 255) / 256)), dim3(256), 0, s, x, partial,
-                           b2, M, ny, scale);
+        launch_ffn_reduce(x, partial, b2, M, ny, scale, s, nullptr);
     } else {
         hipLaunchKernelGGL((ffn_fused_kernel<VAR, AFFINE, 0>), dim3((M + FF_BM - 1) / FF_BM), dim3(512), lds, s, x, lnw, lnb, w1,
                            b1, w2, b2, M, dff, eps, scale, (float*)nullptr, 0);
     }
 }
 
-void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
-                      int nsplit, hipStream_t s) {
-    if (M <= 0) return;
+int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                     const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
+                     int nsplit, hipStream_t s, const FfnPostLn* post) {
+    if (M <= 0) return 0;
     // production path: producer/consumer kernel (ffn_pc.hip).  masr_debug_set(1, v): 9 = this file's kernel (k-split GEMM1,
     // two barriers per chunk), 1 / 2 / 4 = its ablations, 81 = producer/consumer kernel without weight loads
     if (g_ffn_variant == 0 || g_ffn_variant == 81) {
-        launch_ffn_pc(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, affine_prologue, partial, nsplit, s,
-                      g_ffn_variant == 81 ? 1 : 0);
-        return;
+        return launch_ffn_pc(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, affine_prologue, partial, nsplit, s,
+                             g_ffn_variant == 81 ? 1 : 0, post);
     }
     if (affine_prologue) {
         launch_ffn_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);
-        return;
+        return 0;
     }
     switch (g_ffn_variant) {
         case 1: launch_ffn_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s); break;
@@ -336,6 +370,7 @@ void launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float*
         case 4: launch_ffn_t<4, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s); break;
         default: launch_ffn_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s); break;
     }
+    return 0;
 }
 
 }  // namespace masr

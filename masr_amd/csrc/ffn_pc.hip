@@ -240,11 +240,13 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     }
 }
 
-void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s);
+void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
+                       const FfnPostLn* post);
 
 template <int AFFINE, int VAR>
-static void launch_pc_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                        const float* b2, int M, int dff, float eps, float scale, float* partial, int nsplit, hipStream_t s) {
+static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                       const float* b2, int M, int dff, float eps, float scale, float* partial, int nsplit, hipStream_t s,
+                       const FfnPostLn* post) {
     const size_t lds = (size_t)(PC_BM * PC_XLD + 2 * PC_BM * PC_HLD + 8 * 2 * PC_WSLAB) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -260,20 +262,23 @@ static void launch_pc_t(float* x, const float* lnw, const float* lnb, const floa
         const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
         hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
                            b1, w2, b2, M, dff, eps, scale, partial, cpb);
-        launch_ffn_reduce(x, partial, b2, M, ny, scale, s);
+        launch_ffn_reduce(x, partial, b2, M, ny, scale, s, post);
+        return post && post->y ? 1 : 0;
     } else {
         hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 0, VAR>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1,
                            w2, b2, M, dff, eps, scale, (float*)nullptr, 0);
     }
+    return 0;
 }
 
-void launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
-                   hipStream_t s, int variant) {
-    if (M <= 0) return;
-    if (affine_prologue) launch_pc_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);
-    else if (variant == 1) launch_pc_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);
-    else launch_pc_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);
+// returns 1 when the post LayerNorm was applied (split-d_ff path), 0 when the caller still has to run it
+int launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                  const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
+                  hipStream_t s, int variant, const FfnPostLn* post) {
+    if (M <= 0) return 0;
+    if (affine_prologue) return launch_pc_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post);
+    if (variant == 1) return launch_pc_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post);
+    return launch_pc_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post);
 }
 
 }  // namespace masr
