@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, 'csrc')
 LIB_DIR = os.path.join(ROOT, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmasr_hip.so')
-SOURCES = ['gemm_f32.hip', 'ffn_fused.hip', 'ffn_pc.hip', 'rowgemm.hip', 'elementwise.hip', 'attention.hip', 'lstm.hip', 'beam_gpu.hip', 'fbank.hip', 'engine.hip', 'beam_search.cpp']
+SOURCES = ['gemm_f32.hip', 'ffn_fused.hip', 'ffn_pc.hip', 'rowgemm.hip', 'rowgemm_small.hip', 'elementwise.hip', 'attention.hip', 'lstm.hip', 'beam_gpu.hip', 'fbank.hip', 'engine.hip', 'beam_search.cpp']
 
 
 def _hipcc():

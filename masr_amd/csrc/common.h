@@ -80,6 +80,7 @@ void launch_affine_rows(const float* x, const float* w, const float* b, float* y
 void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hipStream_t s);
 
 // ---- row-block GEMM for the K = 256 projections (rowgemm.hip) -------------------------------------
+struct AttSeq;
 enum RowGemmPro { RG_PRO_PLAIN = 0, RG_PRO_LN = 1, RG_PRO_LN_PAD = 2, RG_PRO_AFFINE = 3 };
 enum RowGemmEpi { RG_EPI_STORE = 0, RG_EPI_RESID = 1, RG_EPI_GLU = 2, RG_EPI_CTC = 3, RG_EPI_CHAIN = 4 };
 struct RowGemmArgs {
@@ -105,8 +106,12 @@ struct RowGemmArgs {
     int plane_cols;       // EPI_STORE: >0 -> column c goes to plane c / plane_cols (planar q | k | v buffers)
     long plane_stride;    //            floats between planes
     int a_seq_t, a_seq_stride;   // PRO_PLAIN: >0 -> source row of (b, t) = b * a_seq_stride + t, with (b, t) = divmod(row, a_seq_t)
+    const AttSeq* kv_seqs;       // EPI_STORE, small-M kernel: columns >= 256 (k | v of the fused QKV projection) of row (b, t) =
+    int kv_tq;                   //   divmod(row, kv_tq) go to stream b's key/value cache instead of C (replaces launch_kv_append)
 };
 void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);
+bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s);   // rowgemm_small.hip; false = not applicable
+void set_rowgemm_small(int on);                                                      // diagnostics (masr_debug_set key 6)
 
 // Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_pc.hip; ffn_fused.hip = previous kernel, kept for A/B)
 // partial/nsplit: split-d_ff mode for small M (streaming).  post: LayerNorm that follows the block in the layer; it is fused into

@@ -210,13 +210,15 @@ void rowgemm(masr_engine* e, hipStream_t s, int pro, int epi, const float* A, in
              const float* lnb, const float* W, const float* bias, float* C, int ldc, int M, int N, const float* R,
              int ldr, float alpha, const int* lens, int mask_tp, int seq_t, int pad, int* out_idx, float* out_maxp,
              int kind = PROF_GEMM, int mstride = 4, int out_seq_t = 0, int out_pad_l = 0, int out_pad_tot = 0,
-             int plane_cols = 0, long plane_stride = 0, int a_seq_t = 0, int a_seq_stride = 0) {
+             int plane_cols = 0, long plane_stride = 0, int a_seq_t = 0, int a_seq_stride = 0, const AttSeq* kv_seqs = nullptr,
+             int kv_tq = 0) {
     RowGemmArgs a{};
     a.A = A; a.lda = lda; a.lnw = lnw; a.lnb = lnb; a.W = W; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N;
     a.R = R; a.ldr = ldr; a.alpha = alpha; a.lens = lens; a.mask_tp = mask_tp; a.seq_t = seq_t; a.pad = pad;
     a.out_idx = out_idx; a.out_maxp = out_maxp; a.eps = 1e-5f; a.mstride = mstride;
     a.out_seq_t = out_seq_t; a.out_pad_l = out_pad_l; a.out_pad_tot = out_pad_tot;
     a.plane_cols = plane_cols; a.plane_stride = plane_stride; a.a_seq_t = a_seq_t; a.a_seq_stride = a_seq_stride;
+    a.kv_seqs = kv_seqs; a.kv_tq = kv_tq;
     ProfScope ps(e, s, kind, 2.0 * M * (double)N * 256);
     launch_rowgemm(a, pro, epi, s);
 }
@@ -632,10 +634,11 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
 }
 
 // multi-head self-attention block on x (in place residual); seqs describe where K/V live
-void mhsa(masr_engine* e, hipStream_t s, const LayerW& w, int M) {
+// kv_seqs (streaming): the k | v columns are appended to the streams' caches by the projection itself
+void mhsa(masr_engine* e, hipStream_t s, const LayerW& w, int M, const AttSeq* kv_seqs = nullptr, int kv_tq = 0) {
     const int d = e->cfg.d_model;
     rowgemm(e, s, RG_PRO_LN, RG_EPI_STORE, e->x.as<float>(), d, w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(),
-            3 * d, M, 3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+            3 * d, M, 3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, 4, 0, 0, 0, 0, 0, 0, 0, kv_seqs, kv_tq);
 }
 void mhsa_out(masr_engine* e, hipStream_t s, const LayerW& w, int M) {
     const int d = e->cfg.d_model;
@@ -1524,8 +1527,7 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
         const int M = n * Tq;
         const AttSeq* seqs = e->attseq.as<AttSeq>() + (size_t)l * n;
         rowgemm(e, s, RG_PRO_AFFINE, RG_EPI_STORE, x, d, w.att_s, w.att_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M,
-                3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
-        launch_kv_append(seqs, e->qkv.as<float>(), n, Tq, s);
+                3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, 4, 0, 0, 0, 0, 0, 0, 0, seqs, Tq);
         launch_attention(seqs, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, reduced(l) ? 2 : 1, s);
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->att.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d, 1.f,
                 nullptr, 0, 0, 0, nullptr, nullptr);
@@ -1747,8 +1749,7 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
     for (int l = 0; l < L; ++l) {
         const LayerW& w = e->layers[l];
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
-        mhsa(e, s, w, M);
-        launch_kv_append(e->attseq.as<AttSeq>() + (size_t)l * n, e->qkv.as<float>(), n, Tq, s);   // k|v rows -> caches
+        mhsa(e, s, w, M, e->attseq.as<AttSeq>() + (size_t)l * n, Tq);     // q -> qkv buffer, k|v rows -> the streams' caches
         launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, 1, s);
         mhsa_out(e, s, w, M);
         // history rows <- cnn cache (zeros at first) | LayerNorm of the new rows | new cache = last kernel-1 rows
@@ -1837,6 +1838,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     if (!e) return fail("null engine");
     if (key == 1) set_ffn_variant(value);
     else if (key == 5) g_no_chain = value;
+    else if (key == 6) set_rowgemm_small(value);
     else if (key == 2) {            // beam search phase profile of workgroup 0: value 1 = on, 0 = print + off
         if (value) {
             if (!e->beam_prof) {

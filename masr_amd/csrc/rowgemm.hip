@@ -395,8 +395,7 @@ static void launch_rg(const RowGemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI, 0>), dim3(rowblocks), dim3(512), lds, s, a);
 }
 
-void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0) return;
+static void launch_rowgemm_big(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
     if (pro == RG_PRO_LN && epi == RG_EPI_STORE) launch_rg<RG_PRO_LN, RG_EPI_STORE>(a, s);
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_STORE) launch_rg<RG_PRO_PLAIN, RG_EPI_STORE>(a, s);
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_RESID) launch_rg<RG_PRO_PLAIN, RG_EPI_RESID>(a, s);
@@ -407,6 +406,18 @@ void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_CTC) launch_rg<RG_PRO_PLAIN, RG_EPI_CTC>(a, s);
     else if (pro == RG_PRO_LN && epi == RG_EPI_CTC) launch_rg<RG_PRO_LN, RG_EPI_CTC>(a, s);
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_CHAIN) launch_rg<RG_PRO_PLAIN, RG_EPI_CHAIN>(a, s);
+}
+
+static int g_small = 1;
+void set_rowgemm_small(int on) { g_small = on; }
+
+void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return;
+    // few row blocks (streaming chunk steps, short utterances): K-split kernel with 4x more, 4x shorter workgroups
+    if (g_small && launch_rowgemm_small(a, pro, epi, s)) return;
+    launch_rowgemm_big(a, pro, epi, s);
+    // the big kernel stores all QKV columns to C; the streams' cache append is then its own launch
+    if (a.kv_seqs && epi == RG_EPI_STORE) launch_kv_append(a.kv_seqs, a.C, a.M / a.kv_tq, a.kv_tq, s);
 }
 
 }  // namespace masr

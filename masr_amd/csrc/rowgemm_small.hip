@@ -1,0 +1,217 @@
+// Small-M variant of the K = 256 row-block GEMM (rowgemm.hip) for streaming chunk steps, where M = n_streams * 16 rows gives
+// only M/32 = 8..15 row blocks: a 32-row x N-column workgroup with one 32x32 tile per wave then runs 128 dependent MFMAs
+// (~4 us) on a handful of the 256 CUs and its latency IS the kernel time (13-21 us per projection, 48 projections per
+// chunk step).  Here the work of one row block is cut into more, shorter pieces:
+//     workgroup = 32 rows x 64 columns;  wave (ct, kq) = column tile ct (32 columns) x K quarter kq (64 of the 256 k)
+//     -> 32 MFMAs per wave, 4x more workgroups, no LDS staging: every lane loads its own A / W fragments straight
+//        from global memory (all loads issued up front, one latency exposure), the four K-quarter partial tiles are
+//        summed through LDS in a fixed order, and each wave finishes 4 of the 16 accumulator registers.
+// Prologues: plain rows (optionally from a per-sequence padded buffer) | LayerNorm(256) | per-channel affine.
+// Epilogues: store (fused QKV; optionally the K|V columns go straight to the streams' key/value caches, which replaces
+//            the separate append launch) | residual + alpha * (.) | GLU (value tile ct = 0, gate tile ct = 1).
+// Same arithmetic as rowgemm.hip (v_mfma_f32_32x32x2_f32, fp32 throughout); only the order of the K summation differs.
+// References: conformer/attention.py:53-79 (QKV), encoder.py:123-145 (out-projection / residual),
+//             convolution.py:117-119,128 (pointwise_conv1 + GLU, pointwise_conv2), encoder.py:404-419 (cache append).
+#include "common.h"
+
+namespace masr {
+
+__device__ __forceinline__ float rs_wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
+    __shared__ __align__(16) float xch[4 * 2 * 16 * 64];     // [kq][ct][acc register][lane]
+    __shared__ float stat[32 * 2];                            // LayerNorm mean / rstd of the 32 rows
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wave & 1, kq = wave >> 1;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    // weight rows of my tile: STORE / RESID: 64 consecutive output columns per workgroup; GLU: 32 channels (value | gate)
+    const int col0 = (EPI == RG_EPI_GLU) ? (int)blockIdx.y * 32 + ct * 256 : (int)blockIdx.y * 64 + ct * 32;
+    const int kbase = kq * 64 + 4 * fh;
+
+    // ---- issue every global load of the kernel -----------------------------------------------------------------
+    const int arow = min(row0 + frow, p.M - 1);
+    size_t asrc = arow;
+    if (PRO == RG_PRO_PLAIN && p.a_seq_t > 0) {
+        const int b = arow / p.a_seq_t;
+        asrc = (size_t)b * p.a_seq_stride + (arow - b * p.a_seq_t);
+    }
+    const float* ap = p.A + asrc * p.lda + kbase;
+    const float* wp = p.W + (size_t)(col0 + frow) * 256 + kbase;
+    f32x4 a[8], b[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) a[g] = *reinterpret_cast<const f32x4*>(ap + 8 * g);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) b[g] = *reinterpret_cast<const f32x4*>(wp + 8 * g);
+    f32x4 gw[8], gb[8];
+    if (PRO != RG_PRO_PLAIN) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            gw[g] = *reinterpret_cast<const f32x4*>(p.lnw + kbase + 8 * g);
+            gb[g] = *reinterpret_cast<const f32x4*>(p.lnb + kbase + 8 * g);
+        }
+    }
+    f32x4 srow[4];
+    if (PRO == RG_PRO_LN) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = min(row0 + wave * 4 + rr, p.M - 1);
+            srow[rr] = *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + lane * 4);
+        }
+    }
+    // epilogue operands of the 4 (GLU: 2) accumulator registers this wave finishes
+    constexpr int NFIN = (EPI == RG_EPI_GLU) ? 2 : 4;
+    const int r0 = (EPI == RG_EPI_GLU) ? 4 * kq + 2 * ct : 4 * kq;
+    const int ocol = (EPI == RG_EPI_GLU) ? (int)blockIdx.y * 32 + frow : col0 + frow;      // GLU: channel
+    float res[NFIN];
+    if (EPI == RG_EPI_RESID) {
+#pragma unroll
+        for (int i = 0; i < NFIN; ++i) {
+            const int r = r0 + i;
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, p.M - 1);
+            res[i] = p.R[(size_t)row * p.ldr + ocol];
+        }
+    }
+    float bv = 0.f, bg = 0.f;
+    if (EPI == RG_EPI_GLU) {
+        bv = p.bias[ocol];
+        bg = p.bias[256 + ocol];
+    } else if (p.bias) {
+        bv = p.bias[ocol];
+    }
+    __builtin_amdgcn_sched_barrier(0);      // all loads above are in flight before anything waits (hipcc otherwise sinks them
+                                            // next to their use: eight exposed latencies instead of one)
+
+    // ---- prologue on the A fragments (registers) ------------------------------------------------------------------
+    if (PRO == RG_PRO_LN) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const f32x4 v = srow[rr];
+            const float mean = rs_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+            const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+            const float var = rs_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+            if (lane == 0) {
+                stat[(wave * 4 + rr) * 2] = mean;
+                stat[(wave * 4 + rr) * 2 + 1] = 1.0f / sqrtf(var + p.eps);
+            }
+        }
+        __syncthreads();
+        const float mean = stat[frow * 2], rstd = stat[frow * 2 + 1];
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[g][q] = (a[g][q] - mean) * rstd * gw[g][q] + gb[g][q];
+    } else if (PRO == RG_PRO_AFFINE) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[g][q] = gw[g][q] * a[g][q] + gb[g][q];
+    }
+
+    // ---- 32 MFMAs: my 32x32 tile over my K quarter ------------------------------------------------------------------
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][q], b[g][q], acc, 0, 0, 0);
+
+    // ---- K-quarter reduction through LDS (ascending kq: deterministic) ------------------------------------------------
+    float* mine = xch + ((kq * 2 + ct) * 16) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[r * 64] = acc[r];
+    __syncthreads();
+
+    if (EPI == RG_EPI_GLU) {
+#pragma unroll
+        for (int i = 0; i < NFIN; ++i) {
+            const int r = r0 + i;
+            float sv = 0.f, sg = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sv += xch[((k * 2 + 0) * 16 + r) * 64 + lane];
+                sg += xch[((k * 2 + 1) * 16 + r) * 64 + lane];
+            }
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (row >= p.M) continue;
+            size_t crow = row;
+            if (p.out_seq_t > 0) {
+                const int bq = row / p.out_seq_t, t = row - bq * p.out_seq_t;
+                crow = (size_t)bq * (p.out_seq_t + p.out_pad_tot) + p.out_pad_l + t;
+            }
+            const float gt = sg + bg;
+            p.C[crow * p.ldc + ocol] = (sv + bv) * __builtin_amdgcn_rcpf(1.0f + __expf(-gt));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NFIN; ++i) {
+            const int r = r0 + i;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += xch[((k * 2 + ct) * 16 + r) * 64 + lane];
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (row >= p.M) continue;
+            float v = sum + bv;
+            if (EPI == RG_EPI_RESID) {
+                if (p.mask_tp > 0) {
+                    const int bq = row / p.mask_tp, tt = row - bq * p.mask_tp;
+                    if (p.mstride * tt >= p.lens[bq]) v = 0.f;
+                }
+                p.C[(size_t)row * p.ldc + ocol] = res[i] + p.alpha * v;
+            } else {
+                if (p.kv_seqs && ocol >= 256) {
+                    // k | v columns of the fused QKV projection -> the stream's cache rows nk - nq .. nk - 1 ([k(256) | v(256)] per row)
+                    const int bq = row / p.kv_tq, t = row - bq * p.kv_tq;
+                    const AttSeq* sq = p.kv_seqs + bq;
+                    float* dst = const_cast<float*>(sq->k) + (size_t)(sq->nk - sq->nq + t) * 512;
+                    dst[ocol - 256] = v;
+                    continue;
+                }
+                size_t crow = row;
+                int ccol = ocol;
+                float* cb = p.C;
+                if (p.out_seq_t > 0) {
+                    const int bq = row / p.out_seq_t, t = row - bq * p.out_seq_t;
+                    crow = (size_t)bq * (p.out_seq_t + p.out_pad_tot) + p.out_pad_l + t;
+                }
+                if (p.plane_cols > 0) {
+                    cb += (size_t)(ocol / p.plane_cols) * p.plane_stride;
+                    ccol = ocol % p.plane_cols;
+                }
+                cb[crow * p.ldc + ccol] = v;
+            }
+        }
+    }
+}
+
+template <int PRO, int EPI>
+static void launch_rs(const RowGemmArgs& a, hipStream_t s) {
+    const int rowblocks = (a.M + 31) / 32;
+    const int ny = (EPI == RG_EPI_GLU) ? 8 : a.N / 64;
+    hipLaunchKernelGGL((rowgemm_small_kernel<PRO, EPI>), dim3(rowblocks, ny), dim3(512), 0, s, a);
+}
+
+// true when the small-M kernel took the launch
+bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
+    if (a.M <= 0 || a.M >= 64 * 32) return false;
+    if (epi == RG_EPI_GLU ? a.N != 512 : (a.N % 64) != 0) return false;
+    if (pro == RG_PRO_AFFINE && a.lens && a.seq_t > 0) return false;       // pad masking in the prologue: big kernel only
+    if (pro == RG_PRO_LN && epi == RG_EPI_STORE) launch_rs<RG_PRO_LN, RG_EPI_STORE>(a, s);
+    else if (pro == RG_PRO_AFFINE && epi == RG_EPI_STORE) launch_rs<RG_PRO_AFFINE, RG_EPI_STORE>(a, s);
+    else if (pro == RG_PRO_PLAIN && epi == RG_EPI_STORE) launch_rs<RG_PRO_PLAIN, RG_EPI_STORE>(a, s);
+    else if (pro == RG_PRO_PLAIN && epi == RG_EPI_RESID) launch_rs<RG_PRO_PLAIN, RG_EPI_RESID>(a, s);
+    else if (pro == RG_PRO_PLAIN && epi == RG_EPI_GLU) launch_rs<RG_PRO_PLAIN, RG_EPI_GLU>(a, s);
+    else if (pro == RG_PRO_AFFINE && epi == RG_EPI_GLU) launch_rs<RG_PRO_AFFINE, RG_EPI_GLU>(a, s);
+    else return false;
+    return true;
+}
+
+}  // namespace masr
