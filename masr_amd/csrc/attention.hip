@@ -205,10 +205,158 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
     }
 }
 
+// Few queries per sequence (streaming chunk steps: 16 new frames against a growing key cache).  attention_kernel gives
+// every query group of 32 its own wave pair and walks the key tiles two at a time, so with <= 32 queries six of the eight
+// waves multiply clamped duplicates and the time grows by ~4 us per 64 cached keys.  Here the eight waves of a workgroup
+// share the ONE query group and split the KEYS: wave w owns key tiles w, w+8, ... (one tile each up to 256 keys) with its own
+// online-softmax state; the eight states are merged once through LDS (each wave finishes 4 of the 32 output registers).
+// The K / P / V fragments are read straight from global memory in MFMA operand layout -- all loads of a tile are issued
+// before the first use, no LDS staging, no workgroup barrier before the merge.  Same arithmetic as attention_kernel.
+__global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __restrict__ seqs, int q_stride, int kv_stride,
+                                                             const float* __restrict__ ptab,
+                                                             const float* __restrict__ bias_u,
+                                                             const float* __restrict__ bias_v, int chunk_size,
+                                                             int pos_stride) {
+    __shared__ float mg[8 * 34 * 64];          // [wave][m, l, o0[16], o1[16]][lane]
+    const AttSeq sq = seqs[blockIdx.y];
+    const int head = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = lane & 31, h = lane >> 5;
+    const bool q_ok = qi < sq.nq;
+    const int qrow_i = q_ok ? qi : sq.nq - 1;
+    const int q_abs = sq.q_abs0 + qrow_i;
+
+    f32x4 qu[8], qv[8];
+    {
+        const float* qrow = sq.q + (size_t)qrow_i * q_stride + head * DK;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(qrow + 8 * g + 4 * h);
+            const f32x4 u = *reinterpret_cast<const f32x4*>(bias_u + head * DK + 8 * g + 4 * h);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bias_v + head * DK + 8 * g + 4 * h);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                qu[g][s] = (q[s] + u[s]) * 0.125f;
+                qv[g][s] = (q[s] + v[s]) * 0.125f;
+            }
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    int jlim = sq.klen;
+    if (chunk_size > 0) jlim = min(jlim, (q_abs / chunk_size + 1) * chunk_size);
+    const int ntile = (sq.nk + 31) / 32;
+
+    for (int t = wave; t < ntile; t += 8) {
+        const int j0 = t * 32;
+        // ---- all operand loads of this tile (clamped rows: masked keys get probability 0, times a finite value) ----------
+        const int jr = min(j0 + (lane & 31), sq.nk - 1);
+        const float* kp = sq.k + (size_t)jr * kv_stride + head * DK + 4 * h;
+        const float* pp = ptab + (size_t)(sq.pos0 + jr * pos_stride) * 256 + head * DK + 4 * h;
+        f32x4 kf[8], pf[8];
+        float va[16], vb[16];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) kf[g] = *reinterpret_cast<const f32x4*>(kp + 8 * g);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) pf[g] = *reinterpret_cast<const f32x4*>(pp + 8 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jv = min(j0 + (r & 3) + 8 * (r >> 2) + 4 * h, sq.nk - 1);
+            const float* vp = sq.v + (size_t)jv * kv_stride + head * DK + (lane & 31);
+            va[r] = vp[0];
+            vb[r] = vp[32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[g][s], qu[g][s], st, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[g][s], qv[g][s], st, 0, 0, 0);
+
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (j >= jlim) st[r] = -INFINITY;
+            tmax = fmaxf(tmax, st[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float corr = expf(m_run - m_safe);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = expf(st[r] - m_safe);
+            psum += st[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * corr + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], st[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[r], st[r], o1, 0, 0, 0);
+        }
+    }
+
+    // ---- merge the eight key-split states (ascending wave order) ----------------------------------------------------------
+    {
+        float* d = mg + (size_t)wave * 34 * 64 + lane;
+        d[0] = m_run;
+        d[64] = l_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d[(2 + r) * 64] = o0[r]; d[(18 + r) * 64] = o1[r]; }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) m = fmaxf(m, mg[(size_t)w * 34 * 64 + lane]);
+    const float ms = (m == -INFINITY) ? 0.f : m;
+    float l = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rbase = 2 + (wave >> 2) * 16 + (wave & 3) * 4;          // my 4 registers: o0 (waves 0-3) or o1 (waves 4-7), group wave & 3
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const float* d = mg + (size_t)w * 34 * 64 + lane;
+        const float c = expf(d[0] - ms);                                // -inf -> 0
+        l += d[64] * c;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] += d[(rbase + s) * 64] * c;
+    }
+    if (q_ok) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        float* orow = sq.out + (size_t)qi * 256 + head * DK + (wave >> 2) * 32 + 8 * (wave & 3) + 4 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] *= inv;
+        *reinterpret_cast<f32x4*>(orow) = acc;
+    }
+}
+
+static int g_fewq = 1;
+void set_attention_fewq(int on) { g_fewq = on; }
+
 void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q_stride, int kv_stride,
                       const float* ptab, const float* bias_u, const float* bias_v, int chunk_size, int pos_stride,
                       hipStream_t s) {
     if (nseq <= 0 || max_nq <= 0) return;
+    if (max_nq <= 32 && g_fewq) {
+        hipLaunchKernelGGL(attention_fewq_kernel, dim3(heads, nseq), dim3(512), 0, s, seqs, q_stride, kv_stride, ptab, bias_u,
+                           bias_v, chunk_size, pos_stride);
+        return;
+    }
     hipLaunchKernelGGL(attention_kernel, dim3((max_nq + 127) / 128, heads, nseq), dim3(512), 0, s, seqs, q_stride,
                        kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride);
 }

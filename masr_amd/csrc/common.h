@@ -9,6 +9,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace masr {
 
+#ifdef __HIPCC__
+// Sum over the 64 lanes of a wave, result in every lane.  DPP row shifts / row broadcasts (a scan whose last lane holds the
+// total) + one readlane: ~10 VALU instructions.  __shfl_xor lowers to ds_bpermute_b32, i.e. six dependent LDS round trips
+// (~600 cycles) per sum -- measurable in the LayerNorm prologues of the latency-bound streaming kernels.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define MASR_DPP_F(x, ctrl, rows) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rows), 0xf, false))
+    v += MASR_DPP_F(v, 0x111, 0xf);   // row_shr:1
+    v += MASR_DPP_F(v, 0x112, 0xf);   // row_shr:2
+    v += MASR_DPP_F(v, 0x114, 0xf);   // row_shr:4
+    v += MASR_DPP_F(v, 0x118, 0xf);   // row_shr:8
+    v += MASR_DPP_F(v, 0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+    v += MASR_DPP_F(v, 0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef MASR_DPP_F
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#endif
+
+
 // ---- GEMM: C[M,N] = epilogue(A[M,K] * W[N,K]^T) on v_mfma_f32_32x32x2_f32 ----------------
 enum GemmAct { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 enum GemmAMode { A_PLAIN = 0, A_CONV2 = 1 };
@@ -126,6 +145,8 @@ int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* 
                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
                      int nsplit, hipStream_t s, const FfnPostLn* post = nullptr);
 
+void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
+                       const FfnPostLn* post);
 void set_ffn_variant(int v);   // diagnostic ablations of the fused FFN kernel (0 = production)
 
 // ---- CTC prefix beam search on the GPU (beam_gpu.hip) ---------------------------------------------
@@ -172,6 +193,7 @@ struct AttSeq {            // one per sequence, device memory
 void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q_stride, int kv_stride,
                       const float* ptab /*[max_pos,256]*/, const float* bias_u, const float* bias_v,
                       int chunk_size, int pos_stride, hipStream_t s);
+void set_attention_fewq(int on);     // diagnostics (masr_debug_set key 7): 0 = always the query-tiled kernel
 void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int heads, int group, const float* ptab,
                               int t_true, const float* bias_u, const float* bias_v, hipStream_t s);
 void launch_attseq_grouped(AttSeq* seqs, const float* q, const float* k, const float* v, float* out, const int* lens,

@@ -5,9 +5,7 @@
 namespace masr {
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return wave_sum_dpp(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -539,12 +539,12 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
     // few rows (streaming chunk steps): split d_ff across workgroups so that >= ~128 CUs work on the block
     int nsplit = 1;
     const int rowblocks = (M + 31) / 32;
+    const FfnPostLn post{post_w, post_b, post_y, 1e-5f};
     if (rowblocks < 64) {
         nsplit = std::min(dff / 128, std::max(1, 128 / rowblocks));
         CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
     }
     ProfScope ps(e, s, PROF_FFN1, 4.0 * M * (double)dff * d);
-    const FfnPostLn post{post_w, post_b, post_y, 1e-5f};
     const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine,
                                       nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s, post_y ? &post : nullptr);
     if (post_y && !done) launch_layernorm(e->x.as<float>(), post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
@@ -1839,6 +1839,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     if (key == 1) set_ffn_variant(value);
     else if (key == 5) g_no_chain = value;
     else if (key == 6) set_rowgemm_small(value);
+    else if (key == 7) set_attention_fewq(value);
     else if (key == 2) {            // beam search phase profile of workgroup 0: value 1 = on, 0 = print + off
         if (value) {
             if (!e->beam_prof) {

@@ -28,9 +28,7 @@ static constexpr int WSLAB = 32 * W_LD;    // 1152 floats = 4.5 KB
 static constexpr int NSET = 4;             // prefetch register sets (must divide 8)
 
 __device__ __forceinline__ float wsum64(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return wave_sum_dpp(v);
 }
 
 // 512 threads = 8 waves = 2 waves per SIMD, and NO workgroup barrier on the weight stream:
@@ -273,13 +271,23 @@ __global__ __launch_bounds__(256) void ffn_reduce_kernel(float* x, const float* 
     const f32x4* pp = reinterpret_cast<const f32x4*>(partial) + i;
     f32x4 xv = reinterpret_cast<f32x4*>(x)[i];
     const f32x4 bb = reinterpret_cast<const f32x4*>(b2)[i % (FF_D / 4)];
-    f32x4 acc = pp[0];
-    int sp = 1;
-    for (; sp + 4 <= nsplit; sp += 4) {          // four loads in flight, added in ascending order
-        const f32x4 p0 = pp[(size_t)sp * sstride], p1 = pp[(size_t)(sp + 1) * sstride];
-        const f32x4 p2 = pp[(size_t)(sp + 2) * sstride], p3 = pp[(size_t)(sp + 3) * sstride];
+    f32x4 gw = f32x4{1.f, 1.f, 1.f, 1.f}, gb = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (POSTLN) {
+        const int lane = threadIdx.x & 63;
+        gw = *reinterpret_cast<const f32x4*>(lnw + lane * 4);
+        gb = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {          // eight loads in flight per round, added in ascending order
+        f32x4 q[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = (((acc[k] + p0[k]) + p1[k]) + p2[k]) + p3[k];
+        for (int j = 0; j < 8; ++j) q[j] = pp[(size_t)(sp + j) * sstride];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += q[j][k];
     }
     for (; sp < nsplit; ++sp) {
         const f32x4 p = pp[(size_t)sp * sstride];
@@ -289,9 +297,6 @@ __global__ __launch_bounds__(256) void ffn_reduce_kernel(float* x, const float* 
 #pragma unroll
     for (int k = 0; k < 4; ++k) xv[k] = xv[k] + scale * (acc[k] + bb[k]);
     if (POSTLN) {
-        const int lane = threadIdx.x & 63;
-        const f32x4 gw = *reinterpret_cast<const f32x4*>(lnw + lane * 4);
-        const f32x4 gb = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
         const float mean = wsum64(xv[0] + xv[1] + xv[2] + xv[3]) * (1.0f / 256.0f);
         const float d0 = xv[0] - mean, d1 = xv[1] - mean, d2 = xv[2] - mean, d3 = xv[3] - mean;
         const float var = wsum64(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);

@@ -24,9 +24,7 @@ static constexpr int PC_WSLAB = 32 * PC_WLD;
 static constexpr int PC_NSET = 4;
 
 __device__ __forceinline__ float pc_wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return wave_sum_dpp(v);
 }
 
 template <int AFFINE, int SPLIT, int VAR>
@@ -240,8 +238,6 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     }
 }
 
-void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
-                       const FfnPostLn* post);
 
 template <int AFFINE, int VAR>
 static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,

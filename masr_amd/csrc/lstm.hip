@@ -54,8 +54,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
                 float a = 0.f;
 #pragma unroll
                 for (int k = 0; k < PL; ++k) a = fmaf(w[g][k], hv[k], a);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                a = wave_sum_dpp(a);
                 if (lane == bb) mine[g] = a;
             }
         }
@@ -195,8 +194,7 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
         s += v[i];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = wave_sum_dpp(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
     const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)N;
@@ -209,8 +207,7 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
         v[i] = d;
         q += d * d;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    q = wave_sum_dpp(q);
     if (lane == 0) red[wave] = q;
     __syncthreads();
     const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);

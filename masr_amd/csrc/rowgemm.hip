@@ -30,9 +30,7 @@ static constexpr int RG_WSLAB = 32 * RG_WLD;
 static constexpr int RG_NSET = 4;
 
 __device__ __forceinline__ float rg_wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return wave_sum_dpp(v);
 }
 
 // GSPLIT = 1 (few row blocks, streaming chunk steps): blockIdx.y owns ONE column group of 256, so that e.g. the fused

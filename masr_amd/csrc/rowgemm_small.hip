@@ -17,9 +17,7 @@
 namespace masr {
 
 __device__ __forceinline__ float rs_wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return wave_sum_dpp(v);
 }
 
 template <int PRO, int EPI>
@@ -31,9 +29,11 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ct = wave & 1, kq = wave >> 1;
     const int frow = lane & 31, fh = lane >> 5;
-    const int row0 = blockIdx.x * 32;
+    // blockIdx.x = column block (fastest varying): consecutive workgroups go to consecutive XCDs, so all row blocks of one
+    // column block share an XCD and its weight rows are fetched from HBM once, not once per XCD (L2 is per XCD)
+    const int row0 = blockIdx.y * 32;
     // weight rows of my tile: STORE / RESID: 64 consecutive output columns per workgroup; GLU: 32 channels (value | gate)
-    const int col0 = (EPI == RG_EPI_GLU) ? (int)blockIdx.y * 32 + ct * 256 : (int)blockIdx.y * 64 + ct * 32;
+    const int col0 = (EPI == RG_EPI_GLU) ? (int)blockIdx.x * 32 + ct * 256 : (int)blockIdx.x * 64 + ct * 32;
     const int kbase = kq * 64 + 4 * fh;
 
     // ---- issue every global load of the kernel -----------------------------------------------------------------
@@ -46,6 +46,16 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
     const float* ap = p.A + asrc * p.lda + kbase;
     const float* wp = p.W + (size_t)(col0 + frow) * 256 + kbase;
     f32x4 a[8], b[8];
+    // rows for the LayerNorm statistics first: vmcnt retires in order, so their wait leaves the later loads in flight
+    f32x4 srow[4];
+    if (PRO == RG_PRO_LN) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = min(row0 + wave * 4 + rr, p.M - 1);
+            srow[rr] = *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + lane * 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keep them first (the scheduler otherwise mixes them into the later loads)
 #pragma unroll
     for (int g = 0; g < 8; ++g) a[g] = *reinterpret_cast<const f32x4*>(ap + 8 * g);
 #pragma unroll
@@ -58,18 +68,10 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
             gb[g] = *reinterpret_cast<const f32x4*>(p.lnb + kbase + 8 * g);
         }
     }
-    f32x4 srow[4];
-    if (PRO == RG_PRO_LN) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int row = min(row0 + wave * 4 + rr, p.M - 1);
-            srow[rr] = *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + lane * 4);
-        }
-    }
     // epilogue operands of the 4 (GLU: 2) accumulator registers this wave finishes
     constexpr int NFIN = (EPI == RG_EPI_GLU) ? 2 : 4;
     const int r0 = (EPI == RG_EPI_GLU) ? 4 * kq + 2 * ct : 4 * kq;
-    const int ocol = (EPI == RG_EPI_GLU) ? (int)blockIdx.y * 32 + frow : col0 + frow;      // GLU: channel
+    const int ocol = (EPI == RG_EPI_GLU) ? (int)blockIdx.x * 32 + frow : col0 + frow;      // GLU: channel
     float res[NFIN];
     if (EPI == RG_EPI_RESID) {
 #pragma unroll
@@ -77,6 +79,24 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
             const int r = r0 + i;
             const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, p.M - 1);
             res[i] = p.R[(size_t)row * p.ldr + ocol];
+        }
+    }
+    // fused cache append: destination rows of my NFIN output rows (pointer + counters fetched with everything else; a load in the
+    // epilogue would be a second, serial memory round trip per register)
+    const float* kvk[NFIN];      // loads only up here: arithmetic on the loaded values would force a wait per register
+    int kvnq[NFIN], kvnk[NFIN], kvt[NFIN];
+    const bool to_cache = EPI == RG_EPI_STORE && p.kv_seqs != nullptr && ocol >= 256;
+    if (EPI == RG_EPI_STORE && p.kv_seqs != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NFIN; ++i) {
+            const int r = r0 + i;
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, p.M - 1);
+            const int bq = row / p.kv_tq;
+            kvt[i] = row - bq * p.kv_tq;
+            const AttSeq* sq = p.kv_seqs + bq;
+            kvk[i] = sq->k;
+            kvnq[i] = sq->nq;
+            kvnk[i] = sq->nk;
         }
     }
     float bv = 0.f, bg = 0.f;
@@ -167,12 +187,9 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
                 }
                 p.C[(size_t)row * p.ldc + ocol] = res[i] + p.alpha * v;
             } else {
-                if (p.kv_seqs && ocol >= 256) {
+                if (to_cache) {
                     // k | v columns of the fused QKV projection -> the stream's cache rows nk - nq .. nk - 1 ([k(256) | v(256)] per row)
-                    const int bq = row / p.kv_tq, t = row - bq * p.kv_tq;
-                    const AttSeq* sq = p.kv_seqs + bq;
-                    float* dst = const_cast<float*>(sq->k) + (size_t)(sq->nk - sq->nq + t) * 512;
-                    dst[ocol - 256] = v;
+                    const_cast<float*>(kvk[i])[(size_t)(kvnk[i] - kvnq[i] + kvt[i]) * 512 + (ocol - 256)] = v;
                     continue;
                 }
                 size_t crow = row;
@@ -196,7 +213,7 @@ template <int PRO, int EPI>
 static void launch_rs(const RowGemmArgs& a, hipStream_t s) {
     const int rowblocks = (a.M + 31) / 32;
     const int ny = (EPI == RG_EPI_GLU) ? 8 : a.N / 64;
-    hipLaunchKernelGGL((rowgemm_small_kernel<PRO, EPI>), dim3(rowblocks, ny), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((rowgemm_small_kernel<PRO, EPI>), dim3(ny, rowblocks), dim3(512), 0, s, a);
 }
 
 // true when the small-M kernel took the launch
