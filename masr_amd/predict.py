@@ -48,6 +48,7 @@ class MASRPredictor:
         self.greedy_last_max_prob_list = None
         self.greedy_last_max_index_list = None
         self.beam_search_decoder = None
+        self.vad_predictor = None
         if self.configs.decoder == 'ctc_beam_search':
             # predict.py:96-109; here the search is masr_amd's own (GPU pruning + host prefix search, LM-free)
             from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
@@ -96,6 +97,51 @@ class MASRPredictor:
         output_data = self.predictor.predict(input_data, audio_len)[0]
         score, text = self.decode(output_data=output_data, use_pun=use_pun, is_itn=is_itn)
         return {'text': text, 'score': score}
+
+    def init_vad(self, vad_predictor=None):
+        """predict.py:110-115.  ``vad_predictor``: any object with the reference VADPredictor's ``get_speech_timestamps``;
+        default: the built-in energy VAD (Silero / onnxruntime are outside this path, see infer_utils/vad_predictor.py)."""
+        if vad_predictor is not None:
+            self.vad_predictor = vad_predictor
+        elif getattr(self, 'vad_predictor', None) is None:
+            from masr_amd.infer_utils.vad_predictor import EnergyVAD
+            self.vad_predictor = EnergyVAD()
+
+    def predict_long(self, audio_data, use_pun=False, is_itn=False, sample_rate=16000, vad_predictor=None, batch_size=32):
+        """predict.py:195-234: long audio -> VAD segments -> text.  The reference recognises the segments one after the
+        other (``self.predict`` per segment, :220); here they go through ``predict_batch`` in length-sorted batches of
+        ``batch_size`` (one device call per batch); texts are joined in time order exactly like the reference (:222-227,233).
+        A padded batch follows the reference's own batch > 1 semantics (its pad mask keeps one padding-contaminated key per
+        shorter utterance, trainer.py:632); ``batch_size=1`` is the reference's per-segment ``predict`` to the bit."""
+        if use_pun:
+            raise Exception('punctuation (PaddleNLP) is outside the hot path and not provided')
+        self.init_vad(vad_predictor)
+        audio_segment = self._load_audio(audio_data=audio_data, sample_rate=sample_rate)
+        if audio_segment.sample_rate != self.configs.preprocess_conf.sample_rate:
+            audio_segment.resample(self.configs.preprocess_conf.sample_rate)
+        samples = audio_segment.samples
+        stamps = self.vad_predictor.get_speech_timestamps(samples, audio_segment.sample_rate)
+        pieces = [samples[t['start']: t['end']] for t in stamps]
+        order = sorted(range(len(pieces)), key=lambda i: len(pieces[i]))
+        results = [None] * len(pieces)
+        for lo in range(0, len(order), batch_size):
+            idx = order[lo:lo + batch_size]
+            if len(idx) == 1:
+                results[idx[0]] = self.predict(audio_data=pieces[idx[0]], sample_rate=audio_segment.sample_rate)
+                continue
+            for i, res in zip(idx, self.predict_batch([pieces[i] for i in idx], sample_rate=audio_segment.sample_rate)):
+                results[i] = res
+        texts, scores = '', []
+        for res in results:
+            if is_itn:
+                raise Exception('inverse text normalisation (WeTextProcessing) is outside the hot path')
+            if res['text'] != '':
+                texts = texts + '，' + res['text']
+            scores.append(res['score'])
+            logger.info(f'长语音识别片段结果：{res["text"]}')
+        if texts[:1] == '，':
+            texts = texts[1:]
+        return {'text': texts, 'score': round(sum(scores) / len(scores), 2) if scores else 0}
 
     def predict_batch(self, audio_list, sample_rate=16000, decode_all_frames=False):
         """Batched offline path on the device: padded int16/float PCM -> fbank -> encoder -> greedy

@@ -1,0 +1,267 @@
+"""Batched serving front-end on one engine.
+
+The reference server owns ONE MASRPredictor and runs every request inline in the asyncio handler: one utterance per
+``predict`` call and at most one websocket stream at a time (``predictor.running``; infer_server.py:42-46,48-71,103-156).
+The MI355X engine only reaches its throughput with batches, so this front-end keeps the reference's wire protocol --
+
+    POST /recognition             multipart field ``audio``  -> {"code": 0, "msg": "success", "result": text, "score": s}
+    POST /recognition_long_audio  multipart field ``audio``  -> same, through ``predict_long``
+    websocket /                   binary PCM chunks, the last one ending in b'end' -> {"code": 0, "result": text} per chunk
+    failures                      {"error": 1, "msg": "audio read fail!"} / {"code": 2, "msg": "recognition fail!"}
+
+-- and puts an ``EngineWorker`` between the handlers and the predictor:
+
+* offline requests are collected for up to ``max_wait_ms`` (or until ``max_batch`` are waiting) and recognised in ONE
+  ``predict_batch`` call (dynamic batching);
+* every websocket is its own ``StreamPool`` session; chunks that arrive within a tick are fed together and advanced by ONE
+  ``StreamPool.step()`` (one ragged fbank launch, lock-step ``masr_encode_chunk`` calls);
+* the worker is the only thread that touches the engine (the C-ABI handle is not thread-safe, include/masr_hip.h).
+
+No static pages, templates or upload archive: the web UI is outside the hot path.  ``uvicorn`` needs the ``websockets`` or
+``wsproto`` package to serve the websocket route; the in-process test client does not.
+"""
+import asyncio
+import threading
+import time
+from concurrent.futures import Future
+from email.parser import BytesParser
+from email.policy import HTTP
+
+
+class EngineWorker(object):
+    """Single thread that owns the predictor (and its StreamPool): dynamic batching of offline requests, lock-step stepping
+    of stream sessions.  All public methods are thread-safe and return ``concurrent.futures.Future`` objects."""
+
+    def __init__(self, predictor, pool=None, max_batch=32, max_wait_ms=10.0):
+        self.predictor = predictor
+        self.pool = pool
+        self.max_batch = int(max_batch)
+        self.max_wait = float(max_wait_ms) / 1000.0
+        self._cv = threading.Condition()
+        self._offline = []          # (arrival time, audio, future)
+        self._calls = []            # (fn, args, future): run on the worker thread as they are (stream open/close, predict_long)
+        self._feeds = []            # (handle, pcm bytes, is_end, future)
+        self._stop = False
+        self.stats = {'batches': 0, 'utterances': 0, 'steps': 0, 'chunks': 0}
+        self._thread = threading.Thread(target=self._run, name='masr-engine-worker', daemon=True)
+        self._thread.start()
+
+    # ---- client side --------------------------------------------------------------------------------------------------
+    def recognize(self, audio):
+        """one utterance (path / wav bytes / ndarray) -> Future of {'text', 'score'}; batched with its neighbours"""
+        fut = Future()
+        with self._cv:
+            self._offline.append((time.monotonic(), audio, fut))
+            self._cv.notify()
+        return fut
+
+    def call(self, fn, *args, **kwargs):
+        """run ``fn(*args, **kwargs)`` on the worker thread (anything else that touches the engine)"""
+        fut = Future()
+        with self._cv:
+            self._calls.append((fn, args, kwargs, fut))
+            self._cv.notify()
+        return fut
+
+    def recognize_long(self, audio, **kwargs):
+        return self.call(self.predictor.predict_long, audio, **kwargs)
+
+    def stream_open(self):
+        return self.call(self.pool.open)
+
+    def stream_close(self, handle):
+        return self.call(self.pool.close, handle)
+
+    def stream_feed(self, handle, pcm_bytes, is_end=False):
+        """queue one chunk of a session -> Future of {'text', 'score'} or None (not enough audio for a window yet)"""
+        fut = Future()
+        with self._cv:
+            self._feeds.append((handle, pcm_bytes, bool(is_end), fut))
+            self._cv.notify()
+        return fut
+
+    def shutdown(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify()
+        self._thread.join()
+
+    # ---- worker side --------------------------------------------------------------------------------------------------
+    def _take(self):
+        """block until there is something to do; returns (calls, offline batch, feeds)"""
+        with self._cv:
+            while True:
+                if self._stop:
+                    return None
+                now = time.monotonic()
+                batch_ready = self._offline and (len(self._offline) >= self.max_batch or
+                                                 now - self._offline[0][0] >= self.max_wait)
+                if self._calls or self._feeds or batch_ready:
+                    calls, self._calls = self._calls, []
+                    feeds, self._feeds = self._feeds, []
+                    batch = []
+                    if batch_ready:
+                        batch, self._offline = self._offline[:self.max_batch], self._offline[self.max_batch:]
+                    return calls, batch, feeds
+                timeout = None
+                if self._offline:
+                    timeout = max(0.0, self.max_wait - (now - self._offline[0][0]))
+                self._cv.wait(timeout)
+
+    def _run(self):
+        while True:
+            work = self._take()
+            if work is None:
+                return
+            calls, batch, feeds = work
+            for fn, args, kwargs, fut in calls:
+                self._resolve(fut, fn, *args, **kwargs)
+            if feeds:
+                self._step_streams(feeds)
+            if batch:
+                self._run_batch(batch)
+
+    @staticmethod
+    def _resolve(fut, fn, *args, **kwargs):
+        if not fut.set_running_or_notify_cancel():
+            return
+        try:
+            fut.set_result(fn(*args, **kwargs))
+        except BaseException as e:          # the client gets the exception, the worker lives on
+            fut.set_exception(e)
+
+    def _run_batch(self, batch):
+        live = [(a, f) for _, a, f in batch if f.set_running_or_notify_cancel()]
+        if not live:
+            return
+        self.stats['batches'] += 1
+        self.stats['utterances'] += len(live)
+        try:
+            if len(live) == 1:
+                results = [self.predictor.predict(audio_data=live[0][0])]
+            else:
+                results = self.predictor.predict_batch([a for a, _ in live])
+            for (_, fut), res in zip(live, results):
+                fut.set_result(res)
+        except BaseException:
+            # one unreadable upload must not fail its neighbours: fall back to one call per request
+            for audio, fut in live:
+                try:
+                    fut.set_result(self.predictor.predict(audio_data=audio))
+                except BaseException as e:
+                    fut.set_exception(e)
+
+    def _step_streams(self, feeds):
+        # a session may have queued several chunks since the last tick: they are stepped in arrival order, one chunk per
+        # session per step, so that every chunk gets the partial result predict_stream would have returned for it
+        while feeds:
+            now, later, seen = [], [], set()
+            for item in feeds:
+                (later if item[0] in seen else now).append(item)
+                seen.add(item[0])
+            live = []
+            for handle, data, is_end, fut in now:
+                if not fut.set_running_or_notify_cancel():
+                    continue
+                try:
+                    self.pool.feed(handle, data, is_end=is_end)
+                    live.append((handle, fut))
+                except BaseException as e:
+                    fut.set_exception(e)
+            if live:
+                self.stats['steps'] += 1
+                self.stats['chunks'] += len(live)
+                try:
+                    out = self.pool.step()
+                    for handle, fut in live:
+                        fut.set_result(out.get(handle))
+                except BaseException as e:
+                    for _, fut in live:
+                        fut.set_exception(e)
+            feeds = later
+
+
+def _multipart_file(content_type, body, field='audio'):
+    """the bytes of multipart form field ``field`` (python-multipart is not a dependency); raw bodies pass through"""
+    if not content_type or 'multipart/form-data' not in content_type:
+        return body
+    msg = BytesParser(policy=HTTP).parsebytes(b'Content-Type: ' + content_type.encode() + b'\r\n\r\n' + body)
+    for part in msg.iter_parts():
+        if part.get_param('name', header='content-disposition') == field:
+            return part.get_payload(decode=True)
+    raise ValueError(f'multipart field {field!r} missing')
+
+
+def create_app(predictor, max_batch=32, max_wait_ms=10.0, max_frames_out=0, pool=None):
+    """FastAPI application speaking the reference server's protocol on top of an EngineWorker.  ``app.state.worker`` is the
+    worker (``.stats`` counts batches / utterances / steps / chunks).  ``pool``: a StreamPool to use for the websocket
+    sessions (default: one is built for a streaming ctc_greedy predictor)."""
+    from fastapi import FastAPI, Request, WebSocket
+    from starlette.websockets import WebSocketDisconnect
+
+    cfg = predictor.configs
+    if pool is None and cfg.streaming and cfg.decoder == 'ctc_greedy':
+        from masr_amd.serving import StreamPool
+        pool = StreamPool(predictor, max_frames_out=max_frames_out)
+    worker = EngineWorker(predictor, pool, max_batch=max_batch, max_wait_ms=max_wait_ms)
+    app = FastAPI(title='MASR')
+    app.state.worker = worker
+
+    async def _upload(request):
+        return _multipart_file(request.headers.get('content-type'), await request.body())
+
+    @app.post('/recognition')
+    async def recognition(request: Request):
+        try:
+            res = await asyncio.wrap_future(worker.recognize(await _upload(request)))
+            return {'code': 0, 'msg': 'success', 'result': res['text'], 'score': round(res['score'], 3)}
+        except Exception:
+            return {'error': 1, 'msg': 'audio read fail!'}
+
+    @app.post('/recognition_long_audio')
+    async def recognition_long_audio(request: Request):
+        try:
+            res = await asyncio.wrap_future(worker.recognize_long(await _upload(request)))
+            return {'code': 0, 'msg': 'success', 'result': res['text'], 'score': res['score']}
+        except Exception:
+            return {'error': 1, 'msg': 'audio read fail!'}
+
+    @app.websocket('/')
+    async def websocket_endpoint(websocket: WebSocket):
+        await websocket.accept()
+        if pool is None:
+            await websocket.send_json({'code': 1, 'msg': 'recognition fail, no resource!'})
+            await websocket.close()
+            return
+        handle = await asyncio.wrap_future(worker.stream_open())
+        text = ''
+        try:
+            while True:
+                data = await websocket.receive_bytes()
+                if len(data) == 0:
+                    continue
+                is_end = data[-3:] == b'end'
+                if is_end:
+                    data = data[:-3]
+                try:
+                    res = await asyncio.wrap_future(worker.stream_feed(handle, data, is_end))
+                    if res is not None:
+                        text = res['text']
+                    await websocket.send_json({'code': 0, 'result': text})
+                except WebSocketDisconnect:
+                    raise
+                except Exception:
+                    await websocket.send_json({'code': 2, 'msg': 'recognition fail!'})
+                if is_end:
+                    await websocket.close()
+                    break
+        except WebSocketDisconnect:
+            pass
+        finally:
+            await asyncio.wrap_future(worker.stream_close(handle))
+
+    @app.on_event('shutdown')
+    def _shutdown():
+        worker.shutdown()
+
+    return app

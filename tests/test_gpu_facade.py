@@ -248,6 +248,85 @@ def test_evaluate_manifest_matches_per_utterance_cer(predictor, tmp_path):
     assert r2[0]['text'] == predictor.predict(audio_data=paths[3])['text']
 
 
+def test_predict_long_batches_vad_segments(predictor):
+    """predict_long = VAD segments -> batched recognition -> texts joined like predict.py:222-233"""
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    long_pcm = np.concatenate([pcm, np.zeros(8000, np.int16), pcm[::-1], np.zeros(4000, np.int16), pcm[:70000]])
+
+    class FixedVAD:                      # the reference VADPredictor's interface (vad_predictor.py:105-168)
+        def get_speech_timestamps(self, audio, sampling_rate):
+            assert audio.dtype == np.float32 and sampling_rate == 16000
+            n = len(pcm)
+            return [{'start': 0, 'end': n}, {'start': n + 8000, 'end': 2 * n + 8000},
+                    {'start': 2 * n + 12000, 'end': 2 * n + 12000 + 70000}]
+
+    seg = [long_pcm[0:len(pcm)], long_pcm[len(pcm) + 8000:2 * len(pcm) + 8000], long_pcm[2 * len(pcm) + 12000:]]
+    single = [predictor.predict(audio_data=x.copy()) for x in seg]
+    want_text = '，'.join(r['text'] for r in single if r['text'] != '')
+    want_score = round(sum(r['score'] for r in single) / 3, 2)
+    exact = predictor.predict_long(long_pcm.copy(), vad_predictor=FixedVAD(), batch_size=1)
+    assert exact == {'text': want_text, 'score': want_score}
+    batched = predictor.predict_long(long_pcm.copy(), vad_predictor=FixedVAD(), batch_size=8)
+    assert _close(want_text, batched['text']) <= 0.05 and abs(batched['score'] - want_score) < 0.2
+    # built-in energy VAD: silence-separated speech-like bursts come back as separate, recognisable segments
+    from masr_amd.infer_utils.vad_predictor import EnergyVAD
+    res = predictor.predict_long(long_pcm.copy(), vad_predictor=EnergyVAD(), batch_size=8)
+    assert isinstance(res['text'], str) and res['score'] >= 0
+
+
+def test_server_front_end_batches_requests_and_streams(predictor):
+    """the reference server's protocol (infer_server.py) on the batching EngineWorker"""
+    import io
+    import threading
+    import warnings
+    import wave
+    warnings.simplefilter('ignore')
+    from starlette.testclient import TestClient
+    from masr_amd.server import create_app
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+
+    def wav_bytes(x):
+        b = io.BytesIO()
+        with wave.open(b, 'wb') as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(x.astype('<i2').tobytes())
+        return b.getvalue()
+
+    clips = [pcm[:64000], pcm[30000:94000], pcm[60000:124000], pcm[10000:74000]]       # equal lengths: batch == single
+    want = [predictor.predict(audio_data=c.copy()) for c in clips]
+    stream_want = []
+    predictor.reset_stream()
+    chunks = [pcm[i:i + 16000] for i in range(0, len(pcm), 16000)]
+    for i, ch in enumerate(chunks):
+        r = predictor.predict_stream(audio_data=ch.astype('<i2').tobytes(), is_end=i == len(chunks) - 1)
+        stream_want.append(r['text'] if r is not None else (stream_want[-1] if stream_want else ''))
+    predictor.reset_stream()
+
+    app = create_app(predictor, max_batch=8, max_wait_ms=300.0, max_frames_out=400)
+    with TestClient(app) as c:
+        got = [None] * len(clips)
+
+        def post(i):
+            got[i] = c.post('/recognition', content=wav_bytes(clips[i])).json()
+
+        th = [threading.Thread(target=post, args=(i,)) for i in range(len(clips))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for g, w in zip(got, want):
+            assert g['code'] == 0 and _close(w['text'], g['result']) <= 0.05 and abs(g['score'] - w['score']) < 0.2
+        stats = app.state.worker.stats
+        assert stats['utterances'] == 4 and stats['batches'] < 4                          # requests shared device calls
+        assert c.post('/recognition', content=b'not a wav').json() == {'error': 1, 'msg': 'audio read fail!'}
+        # two websocket sessions at once, each the reference's predict_stream protocol
+        with c.websocket_connect('/') as ws1, c.websocket_connect('/') as ws2:
+            for i, ch in enumerate(chunks):
+                data = ch.astype('<i2').tobytes() + (b'end' if i == len(chunks) - 1 else b'')
+                ws1.send_bytes(data)
+                ws2.send_bytes(data)
+                r1, r2 = ws1.receive_json(), ws2.receive_json()
+                assert r1 == r2 == {'code': 0, 'result': stream_want[i]}
+
+
 def test_squeezeformer_predict_stream_facade(tmp_path):
     """squeezeformer.yml as shipped (streaming: True) through MASRPredictor.predict_stream (engine-level parity of the chunk
     path: test_gpu_parity.test_squeezeformer_stream_chunks_against_reference_fixture)"""

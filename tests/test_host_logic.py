@@ -1,0 +1,138 @@
+"""CPU: host-side logic that needs neither the GPU nor the reference (VAD stand-in, request batcher)."""
+import numpy as np
+
+
+def test_energy_vad_segments():
+    """built-in stand-in for the reference's Silero VAD: same get_speech_timestamps interface (vad_predictor.py:105-168)"""
+    from masr_amd.infer_utils.vad_predictor import EnergyVAD
+    rng = np.random.default_rng(0)
+    x = rng.normal(0, 0.001, 16000 * 12).astype(np.float32)
+    for a, b in ((1.0, 3.2), (4.0, 4.1), (5.0, 9.5)):            # the 0.1 s blip is below min_speech_duration_ms
+        x[int(a * 16000):int(b * 16000)] += rng.normal(0, 0.1, int(b * 16000) - int(a * 16000)).astype(np.float32)
+    st = EnergyVAD().get_speech_timestamps(x, 16000)
+    assert len(st) == 2
+    for s, (a, b) in zip(st, ((1.0, 3.2), (5.0, 9.5))):
+        assert abs(s['start'] / 16000 - a) < 0.1 and abs(s['end'] / 16000 - b) < 0.1
+    assert EnergyVAD().get_speech_timestamps(np.zeros(0, np.float32), 16000) == []
+    capped = EnergyVAD(max_speech_duration_s=2.0).get_speech_timestamps(x, 16000)
+    assert all(s['end'] - s['start'] <= 32000 for s in capped) and len(capped) > 2
+
+
+# ---- serving front-end (masr_amd/server.py) with stand-ins for the predictor and the stream pool ---------------------------
+class _Cfg:
+    streaming = False
+    decoder = 'ctc_greedy'
+
+
+class _FakePredictor:
+    """answers with the byte length of the request so that routing mistakes are visible"""
+    configs = _Cfg()
+
+    def __init__(self):
+        self.batches = []
+
+    def predict(self, audio_data, **kw):
+        if audio_data == b'bad':
+            raise ValueError('unreadable')
+        self.batches.append(1)
+        return {'text': f'n{len(audio_data)}', 'score': 50.0}
+
+    def predict_batch(self, audio_list, **kw):
+        if any(a == b'bad' for a in audio_list):
+            raise ValueError('unreadable')
+        self.batches.append(len(audio_list))
+        return [{'text': f'n{len(a)}', 'score': 50.0} for a in audio_list]
+
+    def predict_long(self, audio_data, **kw):
+        return {'text': f'long{len(audio_data)}', 'score': 12.34}
+
+
+class _FakePool:
+    """StreamPool interface: the text of a session is the number of bytes it has been fed so far"""
+
+    def __init__(self):
+        self.sessions, self.fed, self.steps, self.closed = {}, {}, [], []
+
+    def open(self):
+        h = len(self.sessions)
+        self.sessions[h] = 0
+        return h
+
+    def close(self, h):
+        self.closed.append(h)
+
+    def feed(self, h, data, is_end=False, **kw):
+        assert h not in self.fed, 'one chunk per session per step'
+        self.sessions[h] += len(data)
+        self.fed[h] = is_end
+
+    def step(self):
+        fed, self.fed = self.fed, {}
+        self.steps.append(sorted(fed))
+        return {h: ({'text': f'b{self.sessions[h]}', 'score': 1.0} if self.sessions[h] >= 4 else None) for h in fed}
+
+
+def test_engine_worker_batches_and_routes():
+    from masr_amd.server import EngineWorker
+    p = _FakePredictor()
+    w = EngineWorker(p, None, max_batch=4, max_wait_ms=200.0)
+    futs = [w.recognize(b'x' * (i + 1)) for i in range(10)]
+    assert [f.result(timeout=10)['text'] for f in futs] == [f'n{i + 1}' for i in range(10)]
+    assert sum(p.batches) == 10 and max(p.batches) <= 4 and len(p.batches) <= 4       # 4 + 4 + (2 after the wait)
+    # a bad request fails alone
+    futs = [w.recognize(b) for b in (b'aa', b'bad', b'cccc')]
+    assert futs[0].result(timeout=10)['text'] == 'n2' and futs[2].result(timeout=10)['text'] == 'n4'
+    import pytest
+    with pytest.raises(ValueError):
+        futs[1].result(timeout=10)
+    assert w.recognize_long(b'123456').result(timeout=10) == {'text': 'long6', 'score': 12.34}
+    w.shutdown()
+
+
+def test_engine_worker_steps_streams_together():
+    from masr_amd.server import EngineWorker
+    pool = _FakePool()
+    w = EngineWorker(_FakePredictor(), pool, max_wait_ms=1.0)
+    a, b = w.stream_open().result(timeout=10), w.stream_open().result(timeout=10)
+    gate = w.call(__import__('time').sleep, 0.2)          # keep the worker busy while the chunks queue up
+    f = [w.stream_feed(a, b'12'), w.stream_feed(b, b'1234'), w.stream_feed(a, b'345', is_end=True)]
+    gate.result(timeout=10)
+    assert f[0].result(timeout=10) is None                 # 2 bytes: "not enough audio yet" (predict_stream returns None)
+    assert f[1].result(timeout=10)['text'] == 'b4'
+    assert f[2].result(timeout=10)['text'] == 'b5'
+    assert pool.steps == [[a, b], [a]]                      # both sessions in one step; the second chunk of `a` in the next
+    w.stream_close(a).result(timeout=10)
+    assert pool.closed == [a]
+    w.shutdown()
+
+
+def test_server_app_protocol():
+    """the reference server's routes and JSON shapes (infer_server.py:48-71,74-95,103-141)"""
+    import warnings
+    warnings.simplefilter('ignore')
+    from starlette.testclient import TestClient
+    from masr_amd.server import create_app
+    p, pool = _FakePredictor(), _FakePool()
+    app = create_app(p, max_batch=8, max_wait_ms=1.0, pool=pool)
+    with TestClient(app) as c:
+        body = (b'--XX\r\nContent-Disposition: form-data; name="audio"; filename="a.wav"\r\nContent-Type: audio/wav\r\n\r\n'
+                b'RIFFdata\r\n--XX--\r\n')
+        r = c.post('/recognition', content=body, headers={'content-type': 'multipart/form-data; boundary=XX'})
+        assert r.json() == {'code': 0, 'msg': 'success', 'result': 'n8', 'score': 50.0}
+        r = c.post('/recognition', content=b'bad')
+        assert r.json() == {'error': 1, 'msg': 'audio read fail!'}
+        r = c.post('/recognition_long_audio', content=b'123456')
+        assert r.json() == {'code': 0, 'msg': 'success', 'result': 'long6', 'score': 12.34}
+        with c.websocket_connect('/') as ws:
+            ws.send_bytes(b'12')
+            assert ws.receive_json() == {'code': 0, 'result': ''}
+            ws.send_bytes(b'3456')
+            assert ws.receive_json() == {'code': 0, 'result': 'b6'}
+            ws.send_bytes(b'78end')
+            assert ws.receive_json() == {'code': 0, 'result': 'b8'}
+        assert pool.closed == [0]
+    # a non-streaming model has no websocket sessions
+    app2 = create_app(_FakePredictor(), max_wait_ms=1.0)
+    with TestClient(app2) as c:
+        with c.websocket_connect('/') as ws:
+            assert ws.receive_json() == {'code': 1, 'msg': 'recognition fail, no resource!'}
