@@ -74,6 +74,19 @@ int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_for
                      int32_t B, int32_t n_max, int32_t use_db_normalization, float target_db, float* feats_dev,
                      int32_t* n_frames_dev, int16_t* norm_pcm_dev, float* gain_dev, void* stream);
 
+/* MFCC front-end.  Replaces AudioFeaturizer._compute_mfcc (masr/data_utils/featurizer/audio_featurizer.py:98-117:
+ * torchaudio.compliance.kaldi.mfcc(num_mel_bins=n_mels=80, num_ceps=n_mfcc, frame 25/10 ms, dither 0)) behind the same
+ * AudioSegment handling as masr_fbank_batch (featurize(), :36-62).  mfcc_dev [B, T, n_ceps] f32, T = 1 + (n_max-400)/160. */
+int masr_mfcc_batch(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev, int32_t B,
+                    int32_t n_max, int32_t use_db_normalization, float target_db, int32_t n_ceps, float* mfcc_dev,
+                    int32_t* n_frames_dev, float* gain_dev, void* stream);
+/* Linear log power spectrogram.  Replaces AudioFeaturizer._compute_linear (audio_featurizer.py:73-95; float64 arithmetic,
+ * 20 ms Hann frames every 10 ms, 161 bins) on the float32 samples of the segment (:51-53).
+ * feats_dev [B, T, 161] f32, T = (n_max-320)/160 + 1; n_frames_dev [B] = frames per utterance. */
+int masr_linear_batch(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev, int32_t B,
+                      int32_t n_max, int32_t use_db_normalization, float target_db, float* feats_dev, int32_t* n_frames_dev,
+                      float* gain_dev, void* stream);
+
 /* Full-context encoder.  Replaces ConformerEncoder.forward called from
  * ConformerModel.get_encoder_out (masr/model_utils/conformer/model.py:152-167, encoder.py:305-346).
  *   feats_dev [B, T, n_mels] f32 (zero padded), feat_lens_dev [B] int32 (frames)

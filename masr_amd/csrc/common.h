@@ -212,5 +212,11 @@ void launch_fbank(const void* pcm, int sample_format /*0 int16, 1 float32*/, con
                   int use_db, float target_db, const float* window, const float* melw, const int* mel_lo,
                   const int* mel_hi, const float* tw256, const float* tw512, float* feats, int T_max,
                   float* gain_scratch, int16_t* norm_out, hipStream_t s);
+void launch_mfcc(const float* fbank, long rows, int n_ceps, const float* dct /*[80][n_ceps]*/, const float* lifter, float* out,
+                 hipStream_t s);
+void launch_linear_spec(const void* pcm, int sample_format, const int* nsamp, int B, int n_max, int use_db, const float* gain,
+                        const double* win /*[320]*/, const double* tw /*[320][2]*/, double scale, float* feats /*[B][T_max][161]*/,
+                        int T_max, hipStream_t s);
+void launch_linear_frame_counts(const int* nsamp, int B, int* nfr, hipStream_t s);
 
 }  // namespace masr

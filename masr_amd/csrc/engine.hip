@@ -129,6 +129,12 @@ struct masr_engine {
     // fbank tables
     float *window = nullptr, *melw = nullptr, *tw256 = nullptr, *tw512 = nullptr;
     int *mel_lo = nullptr, *mel_hi = nullptr;
+    // mfcc / linear tables (built on first use)
+    float *dct = nullptr, *lifter = nullptr;
+    int dct_ceps = 0;
+    double *lin_win = nullptr, *lin_tw = nullptr;
+    double lin_scale = 0.0;
+    DevBuf fb_scratch;
     // workspace
     DevBuf x1, x2, x, ln, hid, qkv, att, lnpad, glu, dwo, logits, feats, enc, idx, maxp, attseq, gain, nframes, lens, xsave,
         xred;
@@ -284,7 +290,8 @@ int masr_create(const masr_config* cfg, masr_engine** out) {
     if (!cfg || !out) return fail("null argument");
     if (cfg->model_kind < 0 || cfg->model_kind > 3)
         return fail("model_kind must be 0 (conformer), 1 (squeezeformer, non-streaming), 2 (efficient_conformer) or 3 (deepspeech2)");
-    if (cfg->n_mels != 80) return fail("n_mels must be 80");
+    // n_mels = input feature size of the model: 80 (fbank), n_mfcc (mfcc) or 161 (linear) -- audio_featurizer.py:141-154
+    if (cfg->n_mels < 7 || cfg->n_mels > 512) return fail("input feature size (n_mels) must be in [7, 512]");
     if (cfg->model_kind == 3) {
         if (cfg->d_model != 1024) return fail("deepspeech2: the LSTM step kernel is specialised for rnn_size=1024");
         if (cfg->num_blocks <= 0) return fail("deepspeech2: num_rnn_layers must be positive");
@@ -1344,6 +1351,77 @@ int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_for
     if (gain_dev && use_db_normalization)
         HIPCHK(hipMemcpyAsync(gain_dev, gain, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     if (n_frames_dev) launch_frame_counts(n_samples_dev, B, n_frames_dev, nullptr, 0, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// kaldi.mfcc(num_mel_bins=80, num_ceps=n_ceps) on top of the fbank front-end (audio_featurizer.py:98-117).  The DCT / lifter
+// tables follow torchaudio's float32 construction (functional.create_dct(norm='ortho') with column 0 = sqrt(1/80), transposed;
+// lifter 1 + 0.5 * 22 * sin(pi * i / 22)).
+int masr_mfcc_batch(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev, int32_t B,
+                    int32_t n_max, int32_t use_db_normalization, float target_db, int32_t n_ceps, float* mfcc_dev,
+                    int32_t* n_frames_dev, float* gain_dev, void* stream) {
+    if (!e) return fail("null engine");
+    if (n_ceps <= 0 || n_ceps > 80) return fail("n_ceps must be in [1, 80] (num_ceps <= num_mel_bins)");
+    hipStream_t s = (hipStream_t)stream;
+    if (e->dct_ceps != n_ceps) {
+        std::vector<float> dct((size_t)80 * n_ceps), lif(n_ceps);
+        const float step = (float)(M_PI / 80.0);
+        for (int m = 0; m < 80; ++m)
+            for (int c = 0; c < n_ceps; ++c) {
+                float v = cosf((step * ((float)m + 0.5f)) * (float)c);
+                if (c == 0) v *= (float)(1.0 / sqrt(2.0));
+                v *= (float)sqrt(2.0 / 80.0);
+                if (c == 0) v = (float)sqrt(1.0 / 80.0);
+                dct[(size_t)m * n_ceps + c] = v;
+            }
+        for (int c = 0; c < n_ceps; ++c) lif[c] = 1.0f + 11.0f * sinf(((float)M_PI * (float)c) / 22.0f);
+        HIPCHK(hipStreamSynchronize(s));
+        CHK(upload(e, dct, &e->dct));           // (a changed n_ceps leaves the old table to the engine's owned list)
+        CHK(upload(e, lif, &e->lifter));
+        e->dct_ceps = n_ceps;
+    }
+    const int T_max = n_max >= 400 ? 1 + (n_max - 400) / 160 : 0;
+    CHK(e->fb_scratch.ensure((size_t)B * std::max(T_max, 1) * 80 * sizeof(float)));
+    CHK(masr_fbank_batch(e, samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, target_db,
+                         e->fb_scratch.as<float>(), n_frames_dev, nullptr, gain_dev, stream));
+    launch_mfcc(e->fb_scratch.as<float>(), (long)B * T_max, n_ceps, e->dct, e->lifter, mfcc_dev, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// AudioFeaturizer._compute_linear (audio_featurizer.py:73-95) for a padded batch: float32 (or int16 / 2^15) samples, optional
+// dB normalisation (the same gain as the fbank path), [B, T, 161] log power spectra with T = (n_max - 320) / 160 + 1.
+int masr_linear_batch(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev, int32_t B,
+                      int32_t n_max, int32_t use_db_normalization, float target_db, float* feats_dev, int32_t* n_frames_dev,
+                      float* gain_dev, void* stream) {
+    if (!e) return fail("null engine");
+    if (sample_format != 0 && sample_format != 1) return fail("sample_format must be 0 (int16) or 1 (float32)");
+    hipStream_t s = (hipStream_t)stream;
+    if (!e->lin_win) {
+        std::vector<double> win(320), tw(640);
+        double sumsq = 0.0;
+        for (int i = 0; i < 320; ++i) {                 // np.hanning(320): 0.5 + 0.5 * cos(pi * (1 - M + 2 i) / (M - 1))
+            win[i] = 0.5 + 0.5 * cos(M_PI * (double)(1 - 320 + 2 * i) / 319.0);
+            sumsq += win[i] * win[i];
+            tw[2 * i] = cos(2.0 * M_PI * i / 320.0);
+            tw[2 * i + 1] = -sin(2.0 * M_PI * i / 320.0);
+        }
+        CHK(upload(e, win, &e->lin_win));
+        CHK(upload(e, tw, &e->lin_tw));
+        e->lin_scale = sumsq * 16000.0;
+    }
+    const int T_max = n_max >= 320 ? (n_max - 320) / 160 + 1 : 0;
+    CHK(e->gain.ensure(sizeof(float) * fbank_gain_scratch_floats(B)));
+    float* gain = e->gain.as<float>();
+    if (use_db_normalization)          // T_max = 0: only the RMS -> gain kernels of the fbank front-end run
+        launch_fbank(samples_dev, sample_format, n_samples_dev, B, n_max, 1, target_db, e->window, e->melw, e->mel_lo, e->mel_hi,
+                     e->tw256, e->tw512, nullptr, 0, gain, nullptr, s);
+    launch_linear_spec(samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, gain, e->lin_win, e->lin_tw,
+                       e->lin_scale, feats_dev, T_max, s);
+    if (gain_dev && use_db_normalization)
+        HIPCHK(hipMemcpyAsync(gain_dev, gain, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    if (n_frames_dev) launch_linear_frame_counts(n_samples_dev, B, n_frames_dev, s);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -372,6 +372,102 @@ void launch_fbank(const void* pcm, int sample_format, const int* nsamp, int B, i
                        tw512, feats, T_max, gain_scratch, norm_out, s);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// MFCC = kaldi.mfcc as called by audio_featurizer.py:98-117: the 80-bin log-mel energies above, right-multiplied by the
+// orthonormal DCT-II matrix [80, n_ceps] and scaled by the cepstral lifter (torchaudio: feature.matmul(dct) * lifter).
+// One thread per output coefficient; the fbank row is broadcast-read, the table is tiny (L1 resident).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfcc_kernel(const float* __restrict__ fb, long n_out, int n_ceps,
+                                                   const float* __restrict__ dct, const float* __restrict__ lifter,
+                                                   float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    const long r = i / n_ceps;
+    const int c = (int)(i - r * n_ceps);
+    const float* row = fb + r * NMEL;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < NMEL; ++m) acc = fmaf(row[m], dct[m * n_ceps + c], acc);
+    out[i] = acc * lifter[c];
+}
+void launch_mfcc(const float* fbank, long rows, int n_ceps, const float* dct, const float* lifter, float* out, hipStream_t s) {
+    const long n = rows * n_ceps;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fbank, n, n_ceps, dct, lifter, out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Linear log power spectrogram (audio_featurizer.py:73-95): float32 samples (after the optional dB gain), 20 ms frames
+// (320 samples) every 10 ms, symmetric Hann window, 320-point real DFT -> 161 bins, power scaled by
+// 2 / (sum(w^2) * fs) (DC and Nyquist: 1 / ...), log(. + 1e-14).  The reference computes it in float64 (numpy promotes
+// the float32 frames by the float64 window); so does this kernel: one workgroup per frame, thread k = bin k, a direct DFT
+// over the windowed frame in LDS with a 320-entry twiddle table (103 kFMA fp64 per frame -- noise next to the encoder).
+// ------------------------------------------------------------------------------------------------------------------
+static constexpr int LWIN = 320, LHOP = 160, LBIN = 161;
+
+template <class ST>
+__global__ __launch_bounds__(192) void linear_spec_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp, int n_max,
+                                                          int use_db, const float* __restrict__ gain,
+                                                          const double* __restrict__ win, const double* __restrict__ tw,
+                                                          double scale, float* __restrict__ feats, int T_max) {
+    __shared__ double xw[LWIN], tc[LWIN], ts[LWIN];
+    const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    const int n = nsamp[b];
+    const int T = n >= LWIN ? (n - LWIN) / LHOP + 1 : 0;
+    float* dst = feats + ((size_t)b * T_max + t) * LBIN;
+    if (t >= T) {                       // frames behind the utterance: zero padding
+        if (tid < LBIN) dst[tid] = 0.f;
+        return;
+    }
+    const float g = use_db ? gain[b] : 1.0f;
+    const ST* src = pcm + (size_t)b * n_max + (size_t)t * LHOP;
+    for (int i = tid; i < LWIN; i += 192) {
+        float x;
+        if (sizeof(ST) == 2) x = (float)src[i] * (1.0f / 32768.0f);      // audio.py:532-546
+        else x = (float)src[i];
+        if (use_db) x = x * g;                                             // float32 in-place gain (audio.py:256-264)
+        xw[i] = (double)x * win[i];
+        tc[i] = tw[2 * i];
+        ts[i] = tw[2 * i + 1];
+    }
+    __syncthreads();
+    const int k = tid;
+    if (k >= LBIN) return;
+    double re = 0.0, im = 0.0;
+    int idx = 0;
+    for (int j = 0; j < LWIN; ++j) {
+        const double v = xw[j];
+        re = fma(v, tc[idx], re);
+        im = fma(v, ts[idx], im);
+        idx += k;
+        if (idx >= LWIN) idx -= LWIN;
+    }
+    double p = re * re + im * im;
+    if (k == 0 || k == LBIN - 1) p = p / scale;
+    else p = p * (2.0 / scale);
+    dst[k] = (float)log(p + 1e-14);
+}
+
+void launch_linear_spec(const void* pcm, int sample_format, const int* nsamp, int B, int n_max, int use_db, const float* gain,
+                        const double* win, const double* tw, double scale, float* feats, int T_max, hipStream_t s) {
+    if (B <= 0 || T_max <= 0) return;
+    if (sample_format == 0)
+        hipLaunchKernelGGL(linear_spec_kernel<int16_t>, dim3(T_max, B), dim3(192), 0, s, (const int16_t*)pcm, nsamp, n_max, use_db,
+                           gain, win, tw, scale, feats, T_max);
+    else
+        hipLaunchKernelGGL(linear_spec_kernel<float>, dim3(T_max, B), dim3(192), 0, s, (const float*)pcm, nsamp, n_max, use_db,
+                           gain, win, tw, scale, feats, T_max);
+}
+
+__global__ void linear_frame_counts_kernel(const int* __restrict__ nsamp, int B, int* __restrict__ nfr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) nfr[b] = nsamp[b] >= LWIN ? (nsamp[b] - LWIN) / LHOP + 1 : 0;
+}
+void launch_linear_frame_counts(const int* nsamp, int B, int* nfr, hipStream_t s) {
+    hipLaunchKernelGGL(linear_frame_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, nsamp, B, nfr);
+}
+
 }  // namespace masr
 
 namespace masr {

@@ -1,6 +1,7 @@
 """AudioFeaturizer with the reference's constructor / ``featurize`` contract
-(masr/data_utils/featurizer/audio_featurizer.py:21-69), computed by the batched HIP front-end
-(masr_fbank_batch): dB normalisation, int16 truncation and Kaldi fbank all run on the GPU.
+(masr/data_utils/featurizer/audio_featurizer.py:21-69,141-154), computed by the batched HIP front-end
+(masr_fbank_batch / masr_mfcc_batch / masr_linear_batch): dB normalisation, int16 truncation and the Kaldi fbank,
+Kaldi MFCC or linear log-power spectrogram all run on the GPU.
 """
 import numpy as np
 import torch
@@ -11,10 +12,12 @@ from masr_amd import runtime
 class AudioFeaturizer(object):
     def __init__(self, feature_method='fbank', n_mels=80, n_mfcc=40, sample_rate=16000, use_dB_normalization=True,
                  target_dB=-20, train=False):
-        if feature_method != 'fbank':
-            raise Exception('没有{}预处理方法'.format(feature_method) + ' (the MI355X path implements fbank only)')
-        if n_mels != 80 or sample_rate != 16000:
-            raise Exception('the MI355X fbank kernel is built for 80 mel bins @ 16 kHz')
+        if feature_method not in ('fbank', 'mfcc', 'linear'):
+            raise Exception('没有{}预处理方法'.format(feature_method))
+        if sample_rate != 16000 or (feature_method != 'linear' and n_mels != 80):
+            raise Exception('the MI355X front-end kernels are built for 16 kHz and 80 mel bins')
+        if feature_method == 'mfcc' and not 0 < n_mfcc <= n_mels:
+            raise Exception('n_mfcc must be in [1, n_mels]')
         self._feature_method = feature_method
         self._target_sample_rate = sample_rate
         self._n_mels = n_mels
@@ -39,13 +42,14 @@ class AudioFeaturizer(object):
         eng = self._eng()
         x = audio_segment._samples
         n = x.shape[0]
-        if n < 400:
+        if n < (320 if self._feature_method == 'linear' else 400):
             if self._use_dB_normalization and n > 0:
                 self._normalize_only(eng, audio_segment)
-            return np.zeros((0, self._n_mels), np.float32)
+            return np.zeros((0, self.feature_dim), np.float32)
         xs = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None].to(eng.device)
         ns = torch.tensor([n], dtype=torch.int32, device=eng.device)
-        feats, frames, gain = eng.fbank_batch(xs, ns, self._use_dB_normalization, self._target_dB, return_gain=True)
+        feats, frames, gain = eng.features_batch(self._feature_method, xs, ns, self._use_dB_normalization, self._target_dB,
+                                                 n_mfcc=self._n_mfcc, return_gain=True)
         if self._use_dB_normalization:
             g = float(gain[0])
             if not np.isfinite(g) or 20.0 * np.log10(max(g, 1e-300)) > 300.0:
@@ -60,5 +64,10 @@ class AudioFeaturizer(object):
         seg.gain_linear(float(gain[0]))
 
     @property
+    def feature_method(self):
+        return self._feature_method
+
+    @property
     def feature_dim(self):
-        return self._n_mels
+        """audio_featurizer.py:141-154"""
+        return {'linear': 161, 'mfcc': self._n_mfcc, 'fbank': self._n_mels}[self._feature_method]

@@ -140,7 +140,7 @@ class HipEngine:
         B, n_max = samples.shape
         fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
         T = 1 + (n_max - 400) // 160 if n_max >= 400 else 0
-        feats = torch.empty(B, T, self.n_mels, dtype=torch.float32, device=self.device)
+        feats = torch.empty(B, T, 80, dtype=torch.float32, device=self.device)
         frames = torch.empty(B, dtype=torch.int32, device=self.device)
         norm = torch.empty(B, n_max, dtype=torch.int16, device=self.device) if return_norm else None
         gain = torch.ones(B, dtype=torch.float32, device=self.device) if return_gain else None
@@ -153,6 +153,42 @@ class HipEngine:
         if return_gain:
             res.append(gain)
         return tuple(res)
+
+    def mfcc_batch(self, samples, n_samples, n_mfcc=40, use_db_normalization=True, target_db=-20.0, return_gain=False):
+        """kaldi.mfcc(num_mel_bins=80, num_ceps=n_mfcc) for a padded batch -> feats [B,T,n_mfcc], frames [B] (+ gains)."""
+        B, n_max = samples.shape
+        fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
+        T = 1 + (n_max - 400) // 160 if n_max >= 400 else 0
+        feats = torch.empty(B, T, int(n_mfcc), dtype=torch.float32, device=self.device)
+        frames = torch.empty(B, dtype=torch.int32, device=self.device)
+        gain = torch.ones(B, dtype=torch.float32, device=self.device) if return_gain else None
+        check(self.lib.masr_mfcc_batch(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max, 1 if use_db_normalization else 0,
+                                       float(target_db), int(n_mfcc), _ptr(feats), _ptr(frames), _ptr(gain), _stream()))
+        return (feats, frames, gain) if return_gain else (feats, frames)
+
+    def linear_batch(self, samples, n_samples, use_db_normalization=True, target_db=-20.0, return_gain=False):
+        """linear log power spectrogram (20 ms / 10 ms, 161 bins) for a padded batch -> feats [B,T,161], frames [B]."""
+        B, n_max = samples.shape
+        fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
+        T = (n_max - 320) // 160 + 1 if n_max >= 320 else 0
+        feats = torch.empty(B, T, 161, dtype=torch.float32, device=self.device)
+        frames = torch.empty(B, dtype=torch.int32, device=self.device)
+        gain = torch.ones(B, dtype=torch.float32, device=self.device) if return_gain else None
+        check(self.lib.masr_linear_batch(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max,
+                                         1 if use_db_normalization else 0, float(target_db), _ptr(feats), _ptr(frames),
+                                         _ptr(gain), _stream()))
+        return (feats, frames, gain) if return_gain else (feats, frames)
+
+    def features_batch(self, method, samples, n_samples, use_db_normalization=True, target_db=-20.0, n_mfcc=40,
+                       return_gain=False):
+        """dispatch on the reference's ``feature_method`` (audio_featurizer.py:51-69)"""
+        if method == 'fbank':
+            return self.fbank_batch(samples, n_samples, use_db_normalization, target_db, return_gain=return_gain)
+        if method == 'mfcc':
+            return self.mfcc_batch(samples, n_samples, n_mfcc, use_db_normalization, target_db, return_gain=return_gain)
+        if method == 'linear':
+            return self.linear_batch(samples, n_samples, use_db_normalization, target_db, return_gain=return_gain)
+        raise Exception('没有{}预处理方法'.format(method))
 
     # ---- encoder ----------------------------------------------------------------------------------
     def encode_full(self, feats, lens, decoding_chunk_size=-1):

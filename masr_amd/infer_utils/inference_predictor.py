@@ -44,7 +44,9 @@ class InferencePredictor:
                             f'got use_model={use_model}')
         self.device = torch.device('cuda')
         enc_conf = dict(configs.get('encoder_conf', {})) if configs is not None else {}
-        n_mels = int(configs.get('preprocess_conf', {}).get('n_mels', 80)) if configs is not None else 80
+        # input feature size of the model = AudioFeaturizer.feature_dim (audio_featurizer.py:141-154)
+        pc = configs.get('preprocess_conf', {}) if configs is not None else {}
+        n_mels = {'linear': 161, 'mfcc': int(pc.get('n_mfcc', 40))}.get(pc.get('feature_method', 'fbank'), int(pc.get('n_mels', 80)))
         self.engine = HipEngine(state_dict, encoder_conf=enc_conf, streaming=streaming, n_mels=n_mels,
                                 use_model=use_model)
         self._sid = None

@@ -159,7 +159,8 @@ class MASRPredictor:
         xs = torch.from_numpy(buf).to(eng.device)
         ns = torch.from_numpy(n).to(eng.device)
         pc = self.configs.preprocess_conf
-        feats, frames = eng.fbank_batch(xs, ns, pc.use_dB_normalization, pc.target_dB)
+        feats, frames = eng.features_batch(pc.get('feature_method', 'fbank'), xs, ns, pc.use_dB_normalization, pc.target_dB,
+                                           n_mfcc=pc.get('n_mfcc', 40))
         enc = eng.encode_full(feats, frames, -1)
         nenc = None if decode_all_frames else (((frames - 1) // 2 - 1) // 2).clamp(min=0).to(torch.int32)
         if self.configs.decoder == 'ctc_beam_search':

@@ -36,6 +36,8 @@ class StreamPool:
             raise Exception('StreamPool needs a streaming model (Conformer family or uni-directional DeepSpeech2)')
         if cfg.decoder != 'ctc_greedy':
             raise Exception('StreamPool decodes with ctc_greedy')
+        if cfg.preprocess_conf.get('feature_method', 'fbank') != 'fbank':
+            raise Exception('StreamPool batches the fbank front-end (feature_method: fbank)')
         self.predictor = predictor
         self.engine = predictor.predictor.engine
         self.vocab = predictor._text_featurizer.vocab_list

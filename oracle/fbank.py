@@ -20,6 +20,11 @@ installed in the build container, and the reference ships no fbank vectors:
 **parity unpinned** at the reference level.  ``tests/test_oracle_fbank.py``
 cross-checks this restatement against ``transformers.audio_utils`` (an
 independent numpy Kaldi mimic).
+* ``torchaudio.compliance.kaldi.mfcc`` as called by ``audio_featurizer.py:98-117`` (``num_mel_bins=n_mels=80,
+  num_ceps=n_mfcc``; torchaudio defaults ``cepstral_lifter=22, use_energy=False``): the fbank above times torchaudio's
+  orthonormal DCT-II matrix, times the lifter.  Same status: **parity unpinned**, cross-checked against ``scipy.fft.dct``.
+* ``AudioFeaturizer._compute_linear`` (``audio_featurizer.py:73-95``, in-tree numpy): restated AND pinned -- the fixture
+  ``tests/golden/features.npz`` is the output of the reference's own function (``oracle/make_golden.py --only-features``).
 """
 import math
 
@@ -146,3 +151,66 @@ def featurize_pcm16(pcm: np.ndarray, use_db_normalization=True, target_db=-20, d
         s = db_normalize(s, target_db)
     i16 = float32_to_int16(s)
     return kaldi_fbank(i16, 80, dtype), i16
+
+
+# --------------------------------------------------------------------------
+# kaldi.mfcc (torchaudio/compliance/kaldi.py: mfcc, _get_dct_matrix, _get_lifter_coeffs; functional.create_dct)
+# --------------------------------------------------------------------------
+def dct_matrix(num_ceps=40, num_mel_bins=80):
+    """[num_mel_bins, num_ceps] float32: create_dct(n_mels, n_mels, 'ortho') with column 0 := sqrt(1/n_mels), first
+    num_ceps columns.  float32 arithmetic in torch's order (python scalars multiply float32 tensors)."""
+    n = np.arange(num_mel_bins, dtype=np.float32)
+    k = np.arange(num_mel_bins, dtype=np.float32)[:, None]
+    dct = np.cos((np.float32(math.pi / float(num_mel_bins)) * (n + np.float32(0.5))) * k).astype(np.float32)   # [k, n]
+    dct[0] *= np.float32(1.0 / math.sqrt(2.0))
+    dct *= np.float32(math.sqrt(2.0 / float(num_mel_bins)))
+    dct = dct.T.copy()                                          # [n_mels, n_mfcc] (right-multiply form)
+    dct[:, 0] = np.float32(math.sqrt(1 / float(num_mel_bins)))
+    return dct[:, :num_ceps]
+
+
+def lifter_coeffs(num_ceps=40, cepstral_lifter=22.0):
+    i = np.arange(num_ceps).astype(np.float32)
+    return (np.float32(1.0) + np.float32(0.5 * cepstral_lifter) * np.sin(np.float32(math.pi) * i / np.float32(cepstral_lifter))
+            ).astype(np.float32)
+
+
+def kaldi_mfcc(waveform, num_mel_bins=80, num_ceps=40, dtype=np.float32):
+    """waveform: int16-valued samples -> [m, num_ceps]"""
+    fb = kaldi_fbank(waveform, num_mel_bins, dtype)
+    out = fb @ dct_matrix(num_ceps, num_mel_bins).astype(dtype)
+    out = out * lifter_coeffs(num_ceps).astype(dtype)[None, :]
+    return out.astype(dtype)
+
+
+# --------------------------------------------------------------------------
+# linear log power spectrogram (audio_featurizer.py:73-95)
+# --------------------------------------------------------------------------
+def linear_spectrogram(samples, sample_rate=16000, frame_shift=10.0, frame_length=20.0, eps=1e-14):
+    """samples: float32 in [-1, 1] (AudioSegment.samples after normalize) -> float64 [T, 161]"""
+    stride = int(0.001 * sample_rate * frame_shift)
+    window = int(0.001 * sample_rate * frame_length)
+    n = len(samples)
+    if n < window:
+        return np.zeros((0, window // 2 + 1))
+    t = (n - window) // stride + 1                                            # (:76-79: the tail that fills no frame is cut)
+    frames = np.stack([samples[i * stride:i * stride + window] for i in range(t)], axis=1)      # [window, T]
+    w = np.hanning(window)[:, None]
+    spec = np.abs(np.fft.rfft(frames * w, axis=0)) ** 2
+    scale = np.sum(w ** 2) * sample_rate
+    spec[1:-1, :] *= 2.0 / scale
+    spec[(0, -1), :] /= scale
+    return np.log(spec + eps).T
+
+
+def featurize_samples(samples_f32, method='fbank', use_db_normalization=True, target_db=-20, n_mfcc=40):
+    """AudioFeaturizer.featurize (audio_featurizer.py:36-69) on float32 samples for any feature_method -> float32 [T, D]"""
+    s = np.asarray(samples_f32, np.float32)
+    if use_db_normalization:
+        s = db_normalize(s, target_db)
+    if method == 'linear':
+        return linear_spectrogram(s).astype(np.float32)
+    i16 = float32_to_int16(s)
+    if method == 'mfcc':
+        return kaldi_mfcc(i16, 80, n_mfcc)
+    return kaldi_fbank(i16, 80)

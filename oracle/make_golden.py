@@ -191,6 +191,40 @@ def deepspeech2_fixture(tmp):
     print('deepspeech2 facade:', res['bi_text'], res['bi_score'], '| stream:', res['stream_text'][-1], res['stream_score'][-1])
 
 
+def features_fixture(tmp):
+    """linear / mfcc front-ends: the reference AudioFeaturizer itself on a 2 s clip of dataset/test.wav (linear is the
+    reference's own numpy code; mfcc goes through the kaldi shim = oracle restatement), plus the reference ConformerModel with
+    input_dim 161 / 40 on those features (get_encoder_out)."""
+    from masr.data_utils.audio import AudioSegment
+    from masr.data_utils.featurizer.audio_featurizer import AudioFeaturizer
+    from masr.model_utils.conformer.model import ConformerModel
+    w = wave.open(os.path.join(REF, 'dataset', 'test.wav'))
+    pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16).copy()[24000:56000]
+    out = {'pcm': pcm}
+    cfg = yaml.safe_load(open(os.path.join(REF, 'configs', 'conformer.yml'), encoding='utf-8'))
+    for method, dim in (('linear', 161), ('mfcc', 40)):
+        seg = AudioSegment(pcm.copy(), 16000)
+        fz = AudioFeaturizer(feature_method=method, n_mels=80, n_mfcc=40, use_dB_normalization=True, target_dB=-20)
+        feat = np.asarray(fz.featurize(seg))
+        assert fz.feature_dim == dim and feat.shape[1] == dim
+        out[method] = feat.astype(np.float32)
+        sd = weights.conformer_state_dict(0, 512, n_mels=dim)
+        # CMVN statistics of the right order of magnitude for this feature type
+        sd['encoder.global_cmvn.mean'] = torch.from_numpy(feat.mean(0).astype(np.float32))
+        sd['encoder.global_cmvn.istd'] = torch.from_numpy((1.0 / (feat.std(0) + 1e-3)).astype(np.float32))
+        p = os.path.join(tmp, f'mean_istd_{method}.json')
+        json.dump({'mean': sd['encoder.global_cmvn.mean'].tolist(), 'istd': sd['encoder.global_cmvn.istd'].tolist(),
+                   'feature_method': method}, open(p, 'w'))
+        m = ConformerModel(input_dim=dim, vocab_size=512, mean_istd_path=p, streaming=True, encoder_conf=cfg['encoder_conf'],
+                           decoder_conf=cfg['decoder_conf'], **cfg['model_conf']).eval()
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.startswith('decoder.') for k in missing)
+        x = torch.from_numpy(out[method])[None]
+        out[method + '_probs'] = m.get_encoder_out(x, torch.tensor([x.shape[1]])).numpy()[0]
+        out[method + '_cmvn'] = np.stack([sd['encoder.global_cmvn.mean'].numpy(), sd['encoder.global_cmvn.istd'].numpy()])
+    np.savez_compressed(os.path.join(OUT, 'features.npz'), **out)
+
+
 def main():
     import sys
     shims.install()
@@ -227,6 +261,10 @@ def main():
                    'feature_method': 'fbank'}, open(p, 'w'))
         squeezeformer_streaming_fixture(p)
         print('squeezeformer streaming fixture written')
+        return
+    if '--only-features' in sys.argv:
+        features_fixture(tmp)
+        print('features fixture written')
         return
     if '--only-deepspeech2' in sys.argv:
         deepspeech2_fixture(tmp)

@@ -68,8 +68,11 @@ def install():
         x = waveform.detach().cpu().numpy()[0]
         return torch.from_numpy(_fb.kaldi_fbank(x, num_mel_bins, np.float32))
 
-    def _mfcc(*_a, **_k):
-        raise NotImplementedError('mfcc is not on the hot path')
+    def _mfcc(waveform, num_mel_bins=23, num_ceps=13, frame_length=25.0, frame_shift=10.0, dither=0.0,
+              sample_frequency=16000.0, **_k):
+        assert frame_length == 25 and frame_shift == 10 and dither == 0.0 and sample_frequency == 16000
+        x = waveform.numpy()[0]
+        return torch.from_numpy(_fb.kaldi_mfcc(x, num_mel_bins, num_ceps, np.float32))
 
     ta = _stub('torchaudio')
     comp = _stub('torchaudio.compliance')

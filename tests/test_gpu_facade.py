@@ -478,3 +478,29 @@ def test_stream_pool_deepspeech2(tmp_path):
                 assert _close(w_['text'], g_['text']) <= 0.02 and abs(g_['score'] - w_['score']) < 0.05
     for h in hs:
         pool.close(h)
+
+
+@pytest.mark.parametrize('method', ['linear', 'mfcc'])
+def test_facade_with_linear_and_mfcc_features(tmp_path, method):
+    """preprocess_conf.feature_method linear / mfcc through MASRPredictor (featurizer + model input size 161 / n_mfcc)"""
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.utils import synthetic
+    from oracle import conformer as oc, decoders as od
+    z = np.load(os.path.join(GOLDEN, 'features.npz'))
+    dim = {'linear': 161, 'mfcc': 40}[method]
+    vpath = os.path.join(tmp_path, 'vocabulary.txt')
+    vocab = synthetic.synthetic_vocab(512)
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in vocab:
+            f.write(f'{t}\t1\n')
+    cfg = yaml.safe_load(CONFIG.replace('VOCAB', vpath).replace('feature_method: fbank', f'feature_method: {method}'))
+    sd = synthetic.conformer_state_dict(0, 512, n_mels=dim)
+    sd['encoder.global_cmvn.mean'] = torch.from_numpy(z[method + '_cmvn'][0])
+    sd['encoder.global_cmvn.istd'] = torch.from_numpy(z[method + '_cmvn'][1])
+    p = MASRPredictor(configs=cfg, use_gpu=True, state_dict=sd)
+    assert p._audio_featurizer.feature_dim == dim
+    res = p.predict(audio_data=z['pcm'].copy())
+    score, text = od.greedy_decoder(z[method + '_probs'], vocab)          # decode of the reference model's probabilities
+    assert od.cer(text, res['text']) <= 0.1 and abs(res['score'] - score) < 0.5
+    batch = p.predict_batch([z['pcm'].copy(), z['pcm'].copy()])
+    assert od.cer(text, batch[0]['text']) <= 0.1 and batch[0]['text'] == batch[1]['text']

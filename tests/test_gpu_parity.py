@@ -721,3 +721,90 @@ def test_deepspeech2_batched_recurrence_against_oracle(ds2_engines, oracle_mods,
         with torch.no_grad():
             ref = ods.get_encoder_out(sd, x, lens).numpy()
         assert probs.shape == ref.shape and np.abs(probs - ref).max() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# feature_method linear / mfcc: masr_linear_batch / masr_mfcc_batch and the encoder with input size 161 / 40
+# ---------------------------------------------------------------------------------------------------
+def test_linear_spectrogram_against_reference_fixture(eng512, oracle_mods):
+    e, _ = eng512
+    oc, od, ofb, weights, _ = oracle_mods
+    z = g('features.npz')
+    pcm = z['pcm']
+    # int16 PCM in, dB normalisation on (the reference featurizer's path, audio_featurizer.py:36-53)
+    feats, frames = e.linear_batch(dev(pcm[None, :]), dev(np.array([len(pcm)], np.int32)), True, -20.0)
+    assert int(frames[0]) == 199 and feats.shape == (1, 199, 161)
+    # the gain is only reproducible to a few ulp of float32 (see test_fbank_testwav_...): a 1-ulp change of the samples moves
+    # the weakest bins of a frame (80 dB below its peak) by up to ~1e-3 in the log domain, the typical bin by ~1e-6
+    err = np.abs(feats[0].cpu().numpy() - z['linear'])
+    assert err.max() < 3e-3 and err.mean() < 1e-5, (err.max(), err.mean())
+    # ragged float32 batch without normalisation: exact same samples -> float64 DFT vs numpy's FFT
+    lens = [16000, 320, 319, 5000, 12345]
+    x = (weights.synthetic_pcm(len(lens), max(lens), seed=5).astype(np.float32) / 32768.0).astype(np.float32)
+    for i, l in enumerate(lens):
+        x[i, l:] = 0
+    feats, frames = e.linear_batch(dev(x), dev(np.array(lens, np.int32)), False, -20.0)
+    feats = feats.cpu().numpy()
+    for i, l in enumerate(lens):
+        ref = ofb.linear_spectrogram(x[i, :l])
+        assert int(frames[i]) == ref.shape[0]
+        if ref.shape[0]:
+            assert np.abs(feats[i, :ref.shape[0]] - ref).max() < 2e-5, (i, np.abs(feats[i, :ref.shape[0]] - ref).max())
+        assert np.all(feats[i, ref.shape[0]:] == 0.0)
+    # silence: log(0 + 1e-14)
+    feats, _ = e.linear_batch(dev(np.zeros((1, 800), np.float32)), dev(np.array([800], np.int32)), False, -20.0)
+    assert np.allclose(feats.cpu().numpy(), np.log(1e-14), atol=1e-5)
+
+
+def test_mfcc_against_oracle(eng512, oracle_mods):
+    e, _ = eng512
+    oc, od, ofb, weights, _ = oracle_mods
+    z = g('features.npz')
+    pcm = z['pcm']
+    n = dev(np.array([len(pcm)], np.int32))
+    mf, frames = e.mfcc_batch(dev(pcm[None, :]), n, 40, True, -20.0)
+    fbk, _ = e.fbank_batch(dev(pcm[None, :]), n, True, -20.0)
+    assert int(frames[0]) == 198 and mf.shape == (1, 198, 40)
+    mf, fbk = mf[0].cpu().numpy(), fbk[0].cpu().numpy().astype(np.float64)
+    # the DCT + lifter stage in isolation (float64 on the kernel's own log-mel energies)
+    want = (fbk @ ofb.dct_matrix(40, 80).astype(np.float64)) * ofb.lifter_coeffs(40).astype(np.float64)
+    assert np.abs(mf - want).max() / np.abs(want).max() < 1e-6
+    # end to end against the restated kaldi.mfcc: frames holding a +-1 LSB int16 sample differ by up to 0.1 in the log-mel
+    # domain (test_fbank_testwav_...), times the lifter (<= 12); everything else agrees to ~1e-4
+    err = np.abs(mf - z['mfcc'])
+    assert err.max() < 1.0 and np.median(err) < 1e-3, (err.max(), np.median(err))
+    # other n_ceps, ragged batch
+    lens = [8000, 400, 100]
+    x = weights.synthetic_pcm(3, 8000, seed=9)
+    for i, l in enumerate(lens):
+        x[i, l:] = 0
+    mf, frames = e.mfcc_batch(dev(x), dev(np.array(lens, np.int32)), 13, True, -20.0)
+    assert frames.cpu().tolist() == [48, 1, 0] and mf.shape == (3, 48, 13)
+    ref = ofb.featurize_samples(ofb.pcm16_to_float32(x[0]), 'mfcc', n_mfcc=13)
+    err = np.abs(mf[0].cpu().numpy() - ref)
+    assert err.max() < 1.0 and np.median(err) < 1e-3, (err.max(), np.median(err))
+    assert np.all(mf[2].cpu().numpy() == 0.0)
+
+
+@pytest.mark.parametrize('method,dim', [('linear', 161), ('mfcc', 40)])
+def test_encoder_with_linear_and_mfcc_input(oracle_mods, method, dim):
+    """the reference ConformerModel(input_dim=161 / 40) on the reference featurizer's output (fixture) vs the engine"""
+    from masr_amd.engine import HipEngine
+    oc, od, ofb, weights, _ = oracle_mods
+    z = g('features.npz')
+    sd = weights.conformer_state_dict(0, 512, n_mels=dim)
+    sd['encoder.global_cmvn.mean'] = torch.from_numpy(z[method + '_cmvn'][0])
+    sd['encoder.global_cmvn.istd'] = torch.from_numpy(z[method + '_cmvn'][1])
+    e = HipEngine(sd, vocab_size=512, n_mels=dim)
+    x = dev(z[method][None])
+    enc = e.encode_full(x, dev(np.array([x.shape[1]], np.int32)), -1)
+    probs = e.ctc_probs(enc)[0].cpu().numpy()
+    assert probs.shape == z[method + '_probs'].shape
+    assert np.abs(probs - z[method + '_probs']).max() < 1e-3
+    assert (probs.argmax(-1) == z[method + '_probs'].argmax(-1)).mean() > 0.97
+    # whole chain on the device: PCM -> features -> encoder
+    feats, frames = e.features_batch(method, dev(z['pcm'][None, :]), dev(np.array([len(z['pcm'])], np.int32)), True, -20.0,
+                                     n_mfcc=40)
+    probs2 = e.ctc_probs(e.encode_full(feats, frames, -1))[0].cpu().numpy()
+    assert np.abs(probs2 - z[method + '_probs']).max() < 2e-2
+    e.close()

@@ -204,3 +204,30 @@ def test_conformer_nonstreaming_build_fixture():
         np.testing.assert_allclose(oc.get_encoder_out(sd, feats, lens, streaming=False).numpy(), z['probs'], atol=2e-6)
         # decoding_chunk_size is ignored by the non-streaming build
         assert torch.equal(oc.encoder_full(sd, feats, lens, decoding_chunk_size=16, streaming=False), enc)
+
+
+def test_linear_and_mfcc_front_end_fixture():
+    """feature_method linear / mfcc (audio_featurizer.py:73-117): the linear restatement against the reference's own function
+    (fixture from oracle/make_golden.py --only-features), the MFCC restatement against an independent DCT (scipy), and the
+    oracle Conformer with input_dim 161 / 40 against the reference ConformerModel on those features."""
+    import scipy.fft
+    from oracle import fbank as ofb
+    z = g('features.npz')
+    s = ofb.pcm16_to_float32(z['pcm'])
+    lin = ofb.featurize_samples(s, 'linear')
+    assert lin.shape == (199, 161)
+    np.testing.assert_allclose(lin, z['linear'], atol=1e-6)
+    mf = ofb.featurize_samples(s, 'mfcc')
+    assert mf.shape == (198, 40)
+    fb64 = ofb.featurize_samples(s, 'fbank').astype(np.float64)
+    ref = scipy.fft.dct(fb64, type=2, norm='ortho', axis=1)[:, :40] * ofb.lifter_coeffs(40).astype(np.float64)
+    assert np.abs(mf - ref).max() / np.abs(ref).max() < 2e-5
+    np.testing.assert_allclose(mf, z['mfcc'], atol=1e-5)
+    for method, dim in (('linear', 161), ('mfcc', 40)):
+        sd = weights.conformer_state_dict(0, 512, n_mels=dim)
+        sd['encoder.global_cmvn.mean'] = torch.from_numpy(z[method + '_cmvn'][0])
+        sd['encoder.global_cmvn.istd'] = torch.from_numpy(z[method + '_cmvn'][1])
+        x = torch.from_numpy(z[method])[None]
+        with torch.no_grad():
+            probs = oc.get_encoder_out(sd, x, torch.tensor([x.shape[1]]))[0].numpy()
+        np.testing.assert_allclose(probs, z[method + '_probs'], atol=5e-6)
