@@ -53,7 +53,7 @@ struct GemmArgs {
 
 void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s);
 // deep-K, few-row GEMM: split K over workgroups into `partial` [nsplit][M][N], then reduce + epilogue into a.C
-void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream_t s);
+void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream_t s, int amode = A_PLAIN);
 
 // ---- elementwise / reductions ------------------------------------------------------------
 // LayerNorm over rows of width 256.  If seq_t > 0 the output row is remapped to

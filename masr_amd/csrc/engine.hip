@@ -574,7 +574,16 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
         a.M = M * F2; a.N = d; a.K = 9 * d; a.ldc = d; a.act = ACT_RELU; a.alpha = 1.f;
         a.T1 = T1; a.F1 = F1; a.T2 = Tq; a.F2 = F2; a.Cc = d;
         ProfScope ps(e, s, PROF_CONV2, 2.0 * a.M * (double)a.N * a.K);
-        launch_gemm(a, A_CONV2, EPI_STD, s);
+        const int tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+        if (tiles < 640) {
+            // streaming chunk steps: ~1 workgroup of 4 waves per CU leaves the load -> LDS -> MFMA chain of every 32-wide K slab
+            // exposed (2.5 us per slab, 72 slabs); split K so that ~4-5 workgroups per CU overlap each other's latencies
+            const int nsplit = std::min(8, std::max(2, 1280 / tiles));
+            CHK(e->ffpart.ensure((size_t)nsplit * a.M * a.N * sizeof(float)));
+            launch_gemm_splitk(a, e->ffpart.as<float>(), nsplit, s, A_CONV2);
+        } else {
+            launch_gemm(a, A_CONV2, EPI_STD, s);
+        }
     }
     {   // Conformer: (W.x + b) * sqrt(d)  (embedding.py:97);  Squeezeformer: W.(x * sqrt(d)) + b  (subsampling.py:72-75)
         GemmArgs a{};

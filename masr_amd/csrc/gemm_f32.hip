@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p, const fl
 
 void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
+    if (amode == A_CONV2 && epi == EPI_SPLITK) {      // caller set a.C = partial buffer, a.nsplit, a.ksplit
+        launch_t<64, 64, 2, 2, A_CONV2, EPI_SPLITK>(a, s);
+        return;
+    }
     if (amode == A_CONV2) {
         // few output rows (streaming chunk steps): 64x64 tiles so that the grid still covers the chip
         if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 200) launch_t<64, 64, 2, 2, A_CONV2, EPI_STD>(a, s);
@@ -253,7 +257,7 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     else launch_t<64, 64, 2, 2, A_PLAIN, EPI_STD>(a, s);
 }
 
-void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream_t s) {
+void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream_t s, int amode) {
     if (a.M <= 0 || a.N <= 0) return;
     GemmArgs b = a;
     const int kts = a.K / BK;
@@ -261,7 +265,7 @@ void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream
     b.nsplit = (kts + b.ksplit - 1) / b.ksplit;          // every range owns at least one slab
     b.C = partial;
     b.ldc = a.N;
-    launch_gemm(b, A_PLAIN, EPI_SPLITK, s);
+    launch_gemm(b, amode, EPI_SPLITK, s);
     GemmArgs r = a;
     r.nsplit = b.nsplit;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)a.M * a.N + 255) / 256)), dim3(256), 0, s, r, partial, a.C);
