@@ -237,6 +237,24 @@ def test_streaming_multi_stream_lockstep(eng512, oracle_mods):
         e.stream_close(s)
 
 
+def test_streaming_many_streams_take_the_throughput_kernels(eng512, oracle_mods):
+    """>= 128 lock-step streams (M = 2048 rows per chunk step) run on the row-block / query-tiled kernels with the separate
+    cache-append launch; up to that the latency-cut small-M kernels do the same work -- same results either way."""
+    e, sd = eng512
+    gen = torch.Generator().manual_seed(12)
+    feats = torch.randn(2, 131, 80, generator=gen) * 3 + 13
+    n = 130
+    x = dev(feats[torch.arange(n) % 2])                       # streams alternate between two inputs
+    sids = [e.stream_open(40) for _ in range(n)]
+    solo = [e.stream_open(40) for _ in range(2)]
+    for cur in (0, 64):
+        many, _, _ = e.encode_chunk(sids, x[:, cur:cur + 67].contiguous())
+        few, _, _ = e.encode_chunk(solo, dev(feats[:, cur:cur + 67]))
+        assert (many[0::2] - few[0]).abs().max() < 1e-5 and (many[1::2] - few[1]).abs().max() < 1e-5
+    for s_ in sids + solo:
+        e.stream_close(s_)
+
+
 def test_short_last_chunk(eng512, oracle_mods):
     """is_end chunks are shorter than 67 frames (predict.py:296-305)."""
     e, sd = eng512
