@@ -100,7 +100,8 @@ void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hi
 
 // ---- row-block GEMM for the K = 256 projections (rowgemm.hip) -------------------------------------
 struct AttSeq;
-enum RowGemmPro { RG_PRO_PLAIN = 0, RG_PRO_LN = 1, RG_PRO_LN_PAD = 2, RG_PRO_AFFINE = 3 };
+enum RowGemmPro { RG_PRO_PLAIN = 0, RG_PRO_LN = 1, RG_PRO_LN_PAD = 2, RG_PRO_AFFINE = 3,
+                  RG_PRO_HIST = 4, RG_PRO_DWCONV = 5 };      // small-M kernel only (rowgemm_small.hip): fused streaming conv-module fronts
 enum RowGemmEpi { RG_EPI_STORE = 0, RG_EPI_RESID = 1, RG_EPI_GLU = 2, RG_EPI_CTC = 3, RG_EPI_CHAIN = 4 };
 struct RowGemmArgs {
     const float* A;       // [rows, lda] source rows (K = 256)
@@ -125,10 +126,14 @@ struct RowGemmArgs {
     int plane_cols;       // EPI_STORE: >0 -> column c goes to plane c / plane_cols (planar q | k | v buffers)
     long plane_stride;    //            floats between planes
     int a_seq_t, a_seq_stride;   // PRO_PLAIN: >0 -> source row of (b, t) = b * a_seq_stride + t, with (b, t) = divmod(row, a_seq_t)
+    float* const* cache_rd;      // PRO_HIST: per-stream cnn cache (read half / written half of the double buffer); A = x rows,
+    float* const* cache_wr;      //           seq_t new rows + pad history rows per stream, M = n * (seq_t + pad)
+    const float* dw_w;           // PRO_DWCONV: depthwise weights [pad + 1][256] and bias [256]; A = GLU rows in the padded layout
+    const float* dw_b;           //             [n][pad + seq_t][256], lnw / lnb = the conv module's LayerNorm, M = n * seq_t
     const AttSeq* kv_seqs;       // EPI_STORE, small-M kernel: columns >= 256 (k | v of the fused QKV projection) of row (b, t) =
     int kv_tq;                   //   divmod(row, kv_tq) go to stream b's key/value cache instead of C (replaces launch_kv_append)
 };
-void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);
+bool launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);   // false: not applicable, nothing launched (HIST / DWCONV)
 bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s);   // rowgemm_small.hip; false = not applicable
 void set_rowgemm_small(int on);                                                      // diagnostics (masr_debug_set key 6)
 

@@ -622,7 +622,7 @@ int ensure_layer_ws(masr_engine* e, int nseq, int Tq) {
 //  streaming (hist == true): lnpad rows [0,pad) of every sequence already hold the cnn cache; LayerNorm writes
 //                            the new rows behind them (needed for the next cache) and the GEMM reads lnpad.
 int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, bool hist, int K = 0, int mstride = 4,
-                bool pw1_done = false, bool ln_done = false) {
+                bool pw1_done = false) {
     if (K <= 0) K = e->cfg.cnn_kernel;
     const int d = e->cfg.d_model, pad = K - 1;
     const int M = c.nseq * c.Tq, Mp = c.nseq * (c.Tq + pad);
@@ -630,7 +630,7 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
     if (pw1_done) {
         // glu buffer already filled by mhsa_out_pw1 (fused out-projection -> LayerNorm -> pointwise_conv1 -> GLU)
     } else if (hist) {
-        if (!ln_done) launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, c.Tq, pad, c.lens, s);
+        launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, c.Tq, pad, c.lens, s);
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
                 e->glu.as<float>(), d, Mp, 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
     } else {
@@ -646,6 +646,43 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
                           1e-5f, s, (hist || !e->cfg.causal) ? nullptr : w.gconst);
     rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x, d,
             1.f, c.lens, c.lens ? c.Tq : 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
+    return 0;
+}
+
+// Streaming conv module of the Conformer family (LayerNorm conv norm), two launches on the small-M kernel:
+//   [cnn cache | LayerNorm(new rows)] -> pointwise_conv1 + GLU        (+ the new cache)          (rowgemm_small PRO_HIST)
+//   causal depthwise conv + LayerNorm + SiLU -> pointwise_conv2 + residual                       (rowgemm_small PRO_DWCONV)
+// (convolution.py:98-131).  Where the small-M kernel does not apply (>= 2048 rows, frames per chunk not a multiple of 4) the
+// same steps run as separate launches: conv_hist, pointwise_conv1, dwconv_ln_silu, pointwise_conv2.
+int conv_module_stream(masr_engine* e, hipStream_t s, const LayerW& w, int n, int Tq, float* const* cache_rd,
+                       float* const* cache_wr, int K) {
+    const int d = e->cfg.d_model, pad = K - 1, M = n * Tq, Mp = n * (Tq + pad);
+    float* x = e->x.as<float>();
+    {
+        RowGemmArgs a{};
+        a.A = x; a.lda = d; a.lnw = w.ln_conv_w; a.lnb = w.ln_conv_b; a.W = w.pw1_w; a.bias = w.pw1_b;
+        a.C = e->glu.as<float>(); a.ldc = d; a.M = Mp; a.N = 2 * d; a.alpha = 1.f; a.eps = 1e-5f; a.mstride = 4;
+        a.seq_t = Tq; a.pad = pad; a.cache_rd = cache_rd; a.cache_wr = cache_wr;
+        ProfScope ps(e, s, PROF_GEMM, 2.0 * Mp * (double)(2 * d) * d);
+        if (!launch_rowgemm(a, RG_PRO_HIST, RG_EPI_GLU, s)) {
+            launch_conv_hist(x, w.ln_conv_w, w.ln_conv_b, cache_rd, cache_wr, e->lnpad.as<float>(), n, Tq, pad, 0, 1e-5f, s);
+            a.A = e->lnpad.as<float>();
+            launch_rowgemm(a, RG_PRO_PLAIN, RG_EPI_GLU, s);
+        }
+    }
+    {
+        RowGemmArgs a{};
+        a.A = e->glu.as<float>(); a.lda = d; a.lnw = w.cln_w; a.lnb = w.cln_b; a.dw_w = w.dw_w; a.dw_b = w.dw_b;
+        a.W = w.pw2_w; a.bias = w.pw2_b; a.C = x; a.ldc = d; a.R = x; a.ldr = d; a.M = M; a.N = d; a.alpha = 1.f;
+        a.eps = 1e-5f; a.mstride = 4; a.seq_t = Tq; a.pad = pad;
+        ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)d * d);
+        if (!launch_rowgemm(a, RG_PRO_DWCONV, RG_EPI_RESID, s)) {
+            launch_dwconv_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), n, Tq, K, 1e-5f, s,
+                                  nullptr);
+            a.A = e->dwo.as<float>();
+            launch_rowgemm(a, RG_PRO_PLAIN, RG_EPI_RESID, s);
+        }
+    }
     return 0;
 }
 
@@ -1839,11 +1876,8 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
         mhsa(e, s, w, M, e->attseq.as<AttSeq>() + (size_t)l * n, Tq);     // q -> qkv buffer, k|v rows -> the streams' caches
         launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, 1, s);
         mhsa_out(e, s, w, M);
-        // history rows <- cnn cache (zeros at first) | LayerNorm of the new rows | new cache = last kernel-1 rows
-        // (convolution.py:100-108), one launch
         float* const* cptr = e->cnnptrs.as<float*>() + (size_t)l * n;
-        launch_conv_hist(x, w.ln_conv_w, w.ln_conv_b, cptr, cptr + (size_t)L * n, e->lnpad.as<float>(), n, Tq, pad, 0, 1e-5f, s);
-        CHK(conv_module(e, s, w, ctx, true, 0, 4, false, true));
+        CHK(conv_module_stream(e, s, w, n, Tq, cptr, cptr + (size_t)L * n, e->cfg.cnn_kernel));
         CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x));
     }
     CHK(e->enc.ensure((size_t)M * d * sizeof(float)));

@@ -409,13 +409,17 @@ static void launch_rowgemm_big(const RowGemmArgs& a, int pro, int epi, hipStream
 static int g_small = 1;
 void set_rowgemm_small(int on) { g_small = on; }
 
-void launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0) return;
+// false: nothing was launched (the fused streaming prologues HIST / DWCONV exist in the small-M kernel only; the caller then
+// runs the unfused sequence)
+bool launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return true;
     // few row blocks (streaming chunk steps, short utterances): K-split kernel with 4x more, 4x shorter workgroups
-    if (g_small && launch_rowgemm_small(a, pro, epi, s)) return;
+    if (g_small && launch_rowgemm_small(a, pro, epi, s)) return true;
+    if (pro == RG_PRO_HIST || pro == RG_PRO_DWCONV) return false;
     launch_rowgemm_big(a, pro, epi, s);
     // the big kernel stores all QKV columns to C; the streams' cache append is then its own launch
     if (a.kv_seqs && epi == RG_EPI_STORE) launch_kv_append(a.kv_seqs, a.C, a.M / a.kv_tq, a.kv_tq, s);
+    return true;
 }
 
 }  // namespace masr

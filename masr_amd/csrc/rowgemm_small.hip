@@ -6,7 +6,14 @@
 //     -> 32 MFMAs per wave, 4x more workgroups, no LDS staging: every lane loads its own A / W fragments straight
 //        from global memory (all loads issued up front, one latency exposure), the four K-quarter partial tiles are
 //        summed through LDS in a fixed order, and each wave finishes 4 of the 16 accumulator registers.
-// Prologues: plain rows (optionally from a per-sequence padded buffer) | LayerNorm(256) | per-channel affine.
+// Prologues: plain rows (optionally from a per-sequence padded buffer) | LayerNorm(256) | per-channel affine |
+//            streaming conv module, pointwise_conv1 side (HIST): row (i, tp) of the padded layout = cnn-cache row tp of stream i
+//            or LayerNorm of the new frame tp - pad; the column-block-0 workgroups also write the new cache (replaces the
+//            conv_hist launch and the lnpad buffer) |
+//            streaming conv module, pointwise_conv2 side (DWCONV): row = SiLU(LayerNorm(causal depthwise conv of the GLU
+//            output)), computed for the 32 rows in the prologue (replaces the dwconv_ln_silu launch).
+//            The last two stage the A tile in LDS (each wave prepares 4 rows); every column block repeats that work, which
+//            is ~100 kFMA against a saved kernel launch (~7 us on the dependent chain of a chunk step).
 // Epilogues: store (fused QKV; optionally the K|V columns go straight to the streams' key/value caches, which replaces
 //            the separate append launch) | residual + alpha * (.) | GLU (value tile ct = 0, gate tile ct = 1).
 // Same arithmetic as rowgemm.hip (v_mfma_f32_32x32x2_f32, fp32 throughout); only the order of the K summation differs.
@@ -22,8 +29,11 @@ __device__ __forceinline__ float rs_wsum(float v) {
 
 template <int PRO, int EPI>
 __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
+    constexpr bool STAGED = PRO == RG_PRO_HIST || PRO == RG_PRO_DWCONV;
+    constexpr int ALD = 256 + 4;
     __shared__ __align__(16) float xch[4 * 2 * 16 * 64];     // [kq][ct][acc register][lane]
     __shared__ float stat[32 * 2];                            // LayerNorm mean / rstd of the 32 rows
+    __shared__ __align__(16) float at[STAGED ? 32 * ALD : 4]; // staged A tile (HIST / DWCONV prologues)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,12 +66,14 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);      // keep them first (the scheduler otherwise mixes them into the later loads)
+    if (!STAGED) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) a[g] = *reinterpret_cast<const f32x4*>(ap + 8 * g);
+        for (int g = 0; g < 8; ++g) a[g] = *reinterpret_cast<const f32x4*>(ap + 8 * g);
+    }
 #pragma unroll
     for (int g = 0; g < 8; ++g) b[g] = *reinterpret_cast<const f32x4*>(wp + 8 * g);
     f32x4 gw[8], gb[8];
-    if (PRO != RG_PRO_PLAIN) {
+    if (PRO == RG_PRO_LN || PRO == RG_PRO_AFFINE) {
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             gw[g] = *reinterpret_cast<const f32x4*>(p.lnw + kbase + 8 * g);
@@ -108,6 +120,96 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);      // all loads above are in flight before anything waits (hipcc otherwise sinks them
                                             // next to their use: eight exposed latencies instead of one)
+
+    // ---- staged prologues: wave w prepares rows 4w .. 4w+3 of the A tile in LDS ----------------------------------------------
+    if (PRO == RG_PRO_HIST) {
+        // padded row (i, tp), per = seq_t + pad rows per stream: tp < pad -> cnn cache row tp (already normalised when it was
+        // new), else LayerNorm(x[i * seq_t + tp - pad])  (convolution.py:98-108; the cache keeps the last pad rows)
+        const int per = p.seq_t + p.pad;
+        const f32x4 lw = *reinterpret_cast<const f32x4*>(p.lnw + lane * 4);
+        const f32x4 lb = *reinterpret_cast<const f32x4*>(p.lnb + lane * 4);
+        f32x4 v4[4];
+        int tp4[4], i4[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = min(row0 + wave * 4 + rr, p.M - 1);
+            i4[rr] = row / per;
+            tp4[rr] = row - i4[rr] * per;
+            const float* src = tp4[rr] < p.pad ? p.cache_rd[i4[rr]] + (size_t)tp4[rr] * 256
+                                               : p.A + ((size_t)i4[rr] * p.seq_t + tp4[rr] - p.pad) * 256;
+            v4[rr] = *reinterpret_cast<const f32x4*>(src + lane * 4);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = wave * 4 + rr;
+            f32x4 o = v4[rr];
+            if (tp4[rr] >= p.pad) {
+                const f32x4 v = v4[rr];
+                const float mean = rs_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                const float var = rs_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + p.eps);
+                o[0] = d0 * rstd * lw[0] + lb[0];
+                o[1] = d1 * rstd * lw[1] + lb[1];
+                o[2] = d2 * rstd * lw[2] + lb[2];
+                o[3] = d3 * rstd * lw[3] + lb[3];
+            }
+            const bool live = row0 + lr < p.M;
+            if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&at[lr * ALD + lane * 4]) = o;
+            // new cache = last pad rows of [cache | new rows] -- written to the OTHER half of the double buffer, once
+            if (live && blockIdx.x == 0 && tp4[rr] >= p.seq_t)
+                *reinterpret_cast<f32x4*>(p.cache_wr[i4[rr]] + (size_t)(tp4[rr] - p.seq_t) * 256 + lane * 4) = o;
+        }
+        __syncthreads();
+    } else if (PRO == RG_PRO_DWCONV) {
+        // row (i, t): out[c] = SiLU(LayerNorm_c(b[c] + sum_j w[j][c] * gpad[i][t + j][c])), gpad = [pad history | seq_t new] GLU
+        // rows (convolution.py:120-127).  seq_t % 4 == 0 (checked by the launcher): the 4 rows of a wave share one stream and a
+        // window of KT + 3 input rows.  Same arithmetic order as dwconv_ln_silu_kernel.
+        constexpr int KMAX = 15;
+        const int KT = p.pad + 1;
+        const int row = min(row0 + wave * 4, p.M - 4);
+        const int i = row / p.seq_t, t = row - i * p.seq_t;
+        const float* gin = p.A + ((size_t)i * (p.pad + p.seq_t) + t) * 256 + lane * 4;
+        f32x4 win[KMAX + 3], w[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX + 3; ++j)
+            if (j < KT + 3) win[j] = *reinterpret_cast<const f32x4*>(gin + (size_t)j * 256);
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if (j < KT) w[j] = *reinterpret_cast<const f32x4*>(p.dw_w + j * 256 + lane * 4);
+        const f32x4 cb = *reinterpret_cast<const f32x4*>(p.dw_b + lane * 4);
+        const f32x4 lw = *reinterpret_cast<const f32x4*>(p.lnw + lane * 4);
+        const f32x4 lb = *reinterpret_cast<const f32x4*>(p.lnb + lane * 4);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            f32x4 v = cb;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j)
+                if (j < KT) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaf(w[j][k], win[rr + j][k], v[k]);
+                }
+            const float mean = rs_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+            const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+            const float var = rs_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+            const float rstd = 1.0f / sqrtf(var + p.eps);
+            f32x4 o;
+            o[0] = d0 * rstd * lw[0] + lb[0];
+            o[1] = d1 * rstd * lw[1] + lb[1];
+            o[2] = d2 * rstd * lw[2] + lb[2];
+            o[3] = d3 * rstd * lw[3] + lb[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = o[k] / (1.0f + expf(-o[k]));
+            const int lr = row - row0 + rr;                                 // (the clamped last group re-writes valid rows)
+            if (lr >= 0) *reinterpret_cast<f32x4*>(&at[lr * ALD + lane * 4]) = o;
+        }
+        __syncthreads();
+    }
+    if (STAGED) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) a[g] = *reinterpret_cast<const f32x4*>(&at[frow * ALD + kbase + 8 * g]);
+    }
 
     // ---- prologue on the A fragments (registers) ------------------------------------------------------------------
     if (PRO == RG_PRO_LN) {
@@ -227,6 +329,11 @@ bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s)
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_RESID) launch_rs<RG_PRO_PLAIN, RG_EPI_RESID>(a, s);
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_GLU) launch_rs<RG_PRO_PLAIN, RG_EPI_GLU>(a, s);
     else if (pro == RG_PRO_AFFINE && epi == RG_EPI_GLU) launch_rs<RG_PRO_AFFINE, RG_EPI_GLU>(a, s);
+    else if (pro == RG_PRO_HIST && epi == RG_EPI_GLU) launch_rs<RG_PRO_HIST, RG_EPI_GLU>(a, s);
+    else if (pro == RG_PRO_DWCONV && epi == RG_EPI_RESID) {
+        if (a.seq_t % 4 || a.M % 4 || a.pad + 1 > 15) return false;
+        launch_rs<RG_PRO_DWCONV, RG_EPI_RESID>(a, s);
+    }
     else return false;
     return true;
 }

@@ -36,6 +36,6 @@ for small_gemm in (1, 0):
         for _ in range(6):
             lat += run()[0]
         _, g_us, g_n = run(1)
-        _, f_us, f_n = run(4)
+        _, f_us, f_n = run(2)
         print(f'streams={ns} rowgemm_small={small_gemm} attention_fewq={fewq}: chunk call p50 {np.percentile(lat, 50) * 1e3:.3f} ms  p95 '
-              f'{np.percentile(lat, 95) * 1e3:.3f} ms | gemm-class {g_us:.2f} us x {g_n}, attention {f_us:.2f} us x {f_n}')
+              f'{np.percentile(lat, 95) * 1e3:.3f} ms | gemm-class {g_us:.2f} us x {g_n}, ffn {f_us:.2f} us x {f_n}')
