@@ -25,6 +25,9 @@ class AudioSegment(object):
         self._sample_rate = sample_rate
         if self._samples.ndim >= 2:
             self._samples = np.mean(self._samples, 1)
+        # mono int16 input: the batched device front-end takes the PCM as it is (x / 2^15 happens in the kernel, the same
+        # float32 value) -- half the bytes over PCIe.  Dropped as soon as the float samples are modified.
+        self._pcm16 = samples if samples.dtype == np.int16 and samples.ndim == 1 else None
 
     # ---- constructors (audio.py:56-152) ---------------------------------------------------------
     @classmethod
@@ -81,6 +84,7 @@ class AudioSegment(object):
     def gain_linear(self, factor):
         """In-place ``samples *= factor`` in float32 (what gain_db does with 10**(gain/20))."""
         self._samples *= np.float32(factor)
+        self._pcm16 = None
 
     def resample(self, target_sample_rate, filter='kaiser_best'):
         """The reference uses resampy (absent here); polyphase resampling via scipy instead --
@@ -92,4 +96,5 @@ class AudioSegment(object):
         g = gcd(int(target_sample_rate), int(self._sample_rate))
         self._samples = resample_poly(self._samples, int(target_sample_rate) // g,
                                       int(self._sample_rate) // g).astype(np.float32)
+        self._pcm16 = None
         self._sample_rate = target_sample_rate

@@ -153,11 +153,21 @@ class MASRPredictor:
             if s.sample_rate != 16000:
                 s.resample(16000)
         n = np.array([s.num_samples for s in segs], np.int32)
-        buf = np.zeros((len(segs), int(n.max())), np.float32)
+        # padded batch in a pinned staging buffer (int16 when every utterance still is the PCM it was loaded from)
+        as_pcm = all(s._pcm16 is not None for s in segs)
+        dt = torch.int16 if as_pcm else torch.float32
+        need = len(segs) * int(n.max())
+        pool = self.__dict__.setdefault('_stage', {})
+        if dt not in pool or pool[dt].numel() < need:
+            pool[dt] = torch.zeros(need + need // 4, dtype=dt, pin_memory=True)          # reused across calls
+        stage = pool[dt][:need].view(len(segs), int(n.max()))
+        buf = stage.numpy()
+        buf[:] = 0
         for i, s in enumerate(segs):
-            buf[i, :n[i]] = s._samples
-        xs = torch.from_numpy(buf).to(eng.device)
+            buf[i, :n[i]] = s._pcm16 if as_pcm else s._samples
+        xs = stage.to(eng.device, non_blocking=True)
         ns = torch.from_numpy(n).to(eng.device)
+        torch.cuda.current_stream().synchronize()          # the staging buffer is reused by the next call
         pc = self.configs.preprocess_conf
         feats, frames = eng.features_batch(pc.get('feature_method', 'fbank'), xs, ns, pc.use_dB_normalization, pc.target_dB,
                                            n_mfcc=pc.get('n_mfcc', 40))
