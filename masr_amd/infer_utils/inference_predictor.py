@@ -14,7 +14,10 @@ from masr_amd.engine import HipEngine
 
 
 def load_state_dict(model_path):
-    """inference.pt (TorchScript) or model.pt (plain state_dict) -> {name: tensor}."""
+    """inference.pt (TorchScript), model.pt (plain state_dict) or a packed file (utils/packed.py) -> {name: tensor}."""
+    from masr_amd.utils import packed
+    if packed.is_packed(model_path):
+        return packed.load_packed(model_path)[0]
     try:
         m = torch.jit.load(model_path, map_location='cpu')
         return {k: v.detach().cpu() for k, v in m.state_dict().items()}

@@ -136,3 +136,27 @@ def test_server_app_protocol():
     with TestClient(app2) as c:
         with c.websocket_connect('/') as ws:
             assert ws.receive_json() == {'code': 1, 'msg': 'recognition fail, no resource!'}
+
+
+def test_packed_weight_artefact_round_trip(tmp_path):
+    """state_dict -> one flat float32 file -> the same tensors (decoder.* and BN counters dropped)"""
+    import os
+    import torch
+    from masr_amd.infer_utils.inference_predictor import load_state_dict
+    from masr_amd.utils import packed, synthetic
+    sd = synthetic.squeezeformer_state_dict(0, 64)
+    sd['decoder.embed.0.weight'] = torch.zeros(3, 3)                              # never read by get_encoder_out*
+    sd['encoder.encoders.0.conv_module.norm.num_batches_tracked'] = torch.tensor(7)
+    path = os.path.join(tmp_path, 'model.masr')
+    n = packed.export_packed(sd, path, meta={'use_model': 'squeezeformer'})
+    kept = {k: v for k, v in sd.items() if (k.startswith('encoder.') or k.startswith('ctc.')) and 'num_batches' not in k}
+    assert n == len(kept) and packed.is_packed(path)
+    back, meta = packed.load_packed(path)
+    assert meta == {'use_model': 'squeezeformer'} and set(back) == set(kept)
+    for k, v in kept.items():
+        assert back[k].dtype == torch.float32 and tuple(back[k].shape) == tuple(v.shape)
+        assert torch.equal(back[k], v.to(torch.float32))
+    assert set(load_state_dict(path)) == set(kept)                               # the runner's loader takes the format
+    mpath = os.path.join(tmp_path, 'model.pt')
+    torch.save(sd, mpath)
+    assert not packed.is_packed(mpath)
