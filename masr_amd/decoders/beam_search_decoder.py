@@ -86,7 +86,16 @@ class BeamSearchDecoder:
         """list of [T_i, V] -> list of texts (beam_search_decoder.py:59-73), num_processes host threads."""
         return [t for _, t in self._batch([np.asarray(p) for p in probs_split])]
 
-    def _batch(self, probs_list):
+    def _batch_collect(self, pending):
+        """results of a ``_batch(..., defer=True)`` launch (synchronises with the stream it was launched on)"""
+        _, toks, lens, scores, _keep = pending
+        toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
+        return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(len(lens))]
+
+    def _batch(self, probs_list, defer=False):
+        """``defer=True`` (device-resident probabilities, GPU search): launch pruning + search on the current torch stream and
+        return a handle for ``_batch_collect`` without synchronising -- lets the caller run the search of one sub-batch on a
+        side stream while the encoder works on the next one (the search occupies one workgroup per utterance)."""
         B = len(probs_list)
         frames = np.array([p.shape[0] for p in probs_list], np.int32)
         Ts = int(frames.max()) if B else 0
@@ -111,8 +120,12 @@ class BeamSearchDecoder:
                                                  self.beam_size, self.blank_id, C.c_void_p(toks.data_ptr()), max_len,
                                                  C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            if defer:                      # nothing has been synchronised: _batch_collect() fetches the result later
+                return ('gpu', toks, lens, scores, (stacked, idx, logp, cnt, fr))
             toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
             return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(B)]
+        if defer:
+            raise Exception('deferred batch search needs the GPU search (device-resident probabilities within its limits)')
         idx, logp, cnt, K = self._candidates(stacked.reshape(B * Ts, V))
         toks = np.zeros((B, max_len), np.int32)
         lens = np.zeros(B, np.int32)
