@@ -58,6 +58,19 @@ def greedy_decoder_chunk(probs_seq, vocabulary, last_max_prob_list=None, last_ma
         (last_max_prob_list, last_max_index_list)
 
 
+def greedy_decoder_chunk_frames(ids, max_probs, vocabulary, last_max_prob_list=None, last_max_index_list=None, blank_index=0):
+    """greedy_decoder_chunk for a chunk whose per-frame (argmax id, max prob) pairs are already known (fused CTC head):
+    same state lists, same result."""
+    if last_max_prob_list is None:
+        last_max_prob_list = []
+    if last_max_index_list is None:
+        last_max_index_list = []
+    last_max_prob_list.extend(int(i) for i in ids)
+    last_max_index_list.extend(np.float32(p) for i, p in zip(ids, max_probs) if i != blank_index)
+    return decode_history(last_max_prob_list, last_max_index_list, vocabulary, blank_index) + \
+        (last_max_prob_list, last_max_index_list)
+
+
 def decode_history(index_history, prob_history, vocabulary, blank_index=0):
     """Collapse a full index history + score a non-blank prob history on the GPU."""
     eng = runtime.aux_engine()

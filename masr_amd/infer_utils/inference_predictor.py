@@ -87,6 +87,18 @@ class InferencePredictor:
         probs, _, _ = self.engine.encode_chunk([self._sid], x)
         return probs.cpu().numpy()
 
+    def predict_chunk_frames(self, x_chunk):
+        """Greedy fast path of the two chunk methods above (an addition): the per-frame (argmax id, max probability) pairs of
+        the chunk -- all that greedy_decoder_chunk reads from the probabilities (ctc_greedy_decoder.py:73-77) -- computed by
+        the fused CTC head, so the [T, V] probabilities are neither materialised nor copied to the host."""
+        if not self.streaming:
+            raise Exception(f'当前模型不支持该方法，当前模型为：{self.use_model}，参数streaming为：{self.streaming}')
+        if self._sid is None:
+            self._sid = self.engine.stream_open(0)
+        x = torch.as_tensor(np.asarray(x_chunk), dtype=torch.float32).to(self.device).contiguous()
+        _, idx, mp = self.engine.encode_chunk([self._sid], x, want_probs=False, want_argmax=True)
+        return idx[0].cpu().numpy(), mp[0].cpu().numpy()
+
     @property
     def offset(self):
         return 0 if self._sid is None else self.engine.stream_offset(self._sid)

@@ -18,7 +18,7 @@ from masr_amd import SUPPORT_MODEL
 from masr_amd.data_utils.audio import AudioSegment
 from masr_amd.data_utils.featurizer.audio_featurizer import AudioFeaturizer
 from masr_amd.data_utils.featurizer.text_featurizer import TextFeaturizer
-from masr_amd.decoders.ctc_greedy_decoder import greedy_decoder, greedy_decoder_chunk
+from masr_amd.decoders.ctc_greedy_decoder import greedy_decoder, greedy_decoder_chunk, greedy_decoder_chunk_frames
 from masr_amd.infer_utils.inference_predictor import InferencePredictor
 from masr_amd.utils.utils import dict_to_object
 
@@ -262,6 +262,14 @@ class MASRPredictor:
         for cur in range(0, num_frames - left_frames + 1, stride):
             end = min(cur + decoding_window, num_frames)
             x_chunk = self.cached_feat[:, cur:end, :]
+            if self.configs.decoder != 'ctc_beam_search':
+                # greedy: only the per-frame (argmax, max prob) pairs leave the device (fused CTC head)
+                ids, mps = self.predictor.predict_chunk_frames(x_chunk)
+                score, text, self.greedy_last_max_prob_list, self.greedy_last_max_index_list = \
+                    greedy_decoder_chunk_frames(ids, mps, vocabulary=self._text_featurizer.vocab_list,
+                                                last_max_index_list=self.greedy_last_max_index_list,
+                                                last_max_prob_list=self.greedy_last_max_prob_list)
+                continue
             if self.configs.use_model == 'deepspeech2':
                 output_chunk_probs, output_lens = self.predictor.predict_chunk_deepspeech(x_chunk=x_chunk)
             elif 'former' in self.configs.use_model:
