@@ -46,7 +46,7 @@ sv = json.load(open(os.path.join(here, 'r01_serving.json')))
 md = f'''# Round 1 results (1 x MI355X, fp32 MFMA, synthetic data, random-init weights)
 
 Raw outputs of this session's last measurement pass (`{R}`, scratch) copied here by `profiles/make_results.py`;
-`r01_hbm_traffic.json` is the PMC pass of an earlier build of the same FFN kernel (its memory behaviour has not changed since).
+`r01_hbm_traffic.json`: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same build (`profiles/summarize_pmc.py`).
 
 ## Contract line (`python bench.py`, BASELINE configs[1])
 
