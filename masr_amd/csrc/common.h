@@ -128,6 +128,7 @@ struct RowGemmArgs {
     int a_seq_t, a_seq_stride;   // PRO_PLAIN: >0 -> source row of (b, t) = b * a_seq_stride + t, with (b, t) = divmod(row, a_seq_t)
     float* const* cache_rd;      // PRO_HIST: per-stream cnn cache (read half / written half of the double buffer); A = x rows,
     float* const* cache_wr;      //           seq_t new rows + pad history rows per stream, M = n * (seq_t + pad)
+    int hist_affine;             //           1: new rows = lnw * x + lnb (Squeezeformer, convolution.py:109-110) instead of LayerNorm
     const float* dw_w;           // PRO_DWCONV: depthwise weights [pad + 1][256] and bias [256]; A = GLU rows in the padded layout
     const float* dw_b;           //             [n][pad + seq_t][256], lnw / lnb = the conv module's LayerNorm, M = n * seq_t
     const AttSeq* kv_seqs;       // EPI_STORE, small-M kernel: columns >= 256 (k | v of the fused QKV projection) of row (b, t) =

@@ -1532,10 +1532,8 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     CHK(st.att.ensure((size_t)L * st.cap * 2 * d * sizeof(float)));
     CHK(st.cnn.ensure((size_t)L * pad * d * sizeof(float)));
     HIPCHK(hipMemset(st.cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
-    if (e->cfg.model_kind != 2) {
-        CHK(st.cnn2.ensure((size_t)L * pad * d * sizeof(float)));
-        HIPCHK(hipMemset(st.cnn2.p, 0, (size_t)L * pad * d * sizeof(float)));
-    }
+    CHK(st.cnn2.ensure((size_t)L * pad * d * sizeof(float)));
+    HIPCHK(hipMemset(st.cnn2.p, 0, (size_t)L * pad * d * sizeof(float)));
     if (e->cfg.model_kind == 2)     // planar caches of the grouped layers: rows behind the last key must read as zero
         HIPCHK(hipMemset(st.att.p, 0, (size_t)L * st.cap * 2 * d * sizeof(float)));
     st.offset = 0;
@@ -1659,9 +1657,19 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
         CHK(ffn(e, s, M, w.f1_s, w.f1_b, w.f1_w1, w.f1_b1, w.f1_w2, w.f1_b2, 1.0f, 1, w.ln2_w, w.ln2_b, x));
         // conv module: [cnn cache | ada(x)] -> pointwise_conv1 + GLU -> causal depthwise + BatchNorm + SiLU -> pointwise_conv2
         float* const* cptr = e->cnnptrs.as<float*>() + (size_t)l * n;
-        launch_conv_hist(x, w.cv_s, w.cv_b, cptr, cptr + (size_t)L * n, e->lnpad.as<float>(), n, Tq, pad, 1, 1e-5f, s);
-        rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
-                e->glu.as<float>(), d, n * (Tq + pad), 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+        {   // [cnn cache | ada_scale * x + ada_bias] -> pointwise_conv1 + GLU (+ the new cache) in one launch where the small-M
+            // kernel applies, else history / affine rows first
+            RowGemmArgs a{};
+            a.A = x; a.lda = d; a.lnw = w.cv_s; a.lnb = w.cv_b; a.W = w.pw1_w; a.bias = w.pw1_b; a.C = e->glu.as<float>();
+            a.ldc = d; a.M = n * (Tq + pad); a.N = 2 * d; a.alpha = 1.f; a.eps = 1e-5f; a.mstride = 4; a.seq_t = Tq; a.pad = pad;
+            a.cache_rd = cptr; a.cache_wr = cptr + (size_t)L * n; a.hist_affine = 1;
+            ProfScope ps(e, s, PROF_GEMM, 2.0 * a.M * (double)(2 * d) * d);
+            if (!launch_rowgemm(a, RG_PRO_HIST, RG_EPI_GLU, s)) {
+                launch_conv_hist(x, w.cv_s, w.cv_b, cptr, cptr + (size_t)L * n, e->lnpad.as<float>(), n, Tq, pad, 1, 1e-5f, s);
+                a.A = e->lnpad.as<float>();
+                launch_rowgemm(a, RG_PRO_PLAIN, RG_EPI_GLU, s);
+            }
+        }
         launch_dwconv_bn_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.bn_scale, w.bn_shift, e->dwo.as<float>(), n, Tq, K, s);
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x,
                 d, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
@@ -1704,7 +1712,7 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
     const int padmax = e->cfg.cnn_kernel - 1;
     std::vector<AttSeq> hs((size_t)n * L);
     std::vector<PlaneCopy> pcs((size_t)n * e->n_group_layers);
-    std::vector<float*> hp((size_t)n * L);
+    std::vector<float*> hp((size_t)n * L * 2);   // cnn cache bases: current (read) | next (written)
     for (int l = 0; l < L; ++l) {
         if (layer_grouped(e, l) && rate(l) != 1) return fail("grouped attention after the stride layer is not supported");
         for (int i = 0; i < n; ++i) {
@@ -1743,6 +1751,7 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
                 a.pad_ = 0;
             }
             hp[(size_t)l * n + i] = st[i]->cnn.as<float>() + (size_t)l * padmax * d;
+            hp[(size_t)(L + l) * n + i] = st[i]->cnn2.as<float>() + (size_t)l * padmax * d;     // written half of the double buffer
         }
     }
     CHK(e->cnnptrs.ensure(sizeof(float*) * hp.size() + sizeof(PlaneCopy) * pcs.size()));
@@ -1766,20 +1775,19 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
             rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->attp.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d,
                     1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, 4, 0, 0, 0, 0, 0, Tq, Tpad);
         } else {
-            mhsa(e, s, w, M);
-            launch_kv_append(seqs, e->qkv.as<float>(), n, Tq, s);
+            mhsa(e, s, w, M, seqs, Tq);                 // k | v rows go straight to the streams' caches
             launch_attention(seqs, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, rate(l), s);
             mhsa_out(e, s, w, M);
         }
         const int K = layer_kernel(e, l), pad = K - 1;
         float* const* cptr = e->cnnptrs.as<float*>() + (size_t)l * n;
-        launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 0, s);
         if (l == e->stride_idx) {
+            launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 0, s);
             // StrideConformerEncoderLayer (encoder.py:454-545): x = AvgPool(x) + conv_module_stride2([cache | LN(x)])
             launch_layernorm(x, w.ln_conv_w, w.ln_conv_b, e->lnpad.as<float>(), M, 1e-5f, Tq, pad, nullptr, s);
             rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_GLU, e->lnpad.as<float>(), d, nullptr, nullptr, w.pw1_w, w.pw1_b,
                     e->glu.as<float>(), d, n * (Tq + pad), 2 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
-            launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 1, s);
+            launch_cnn_cache_move(cptr + (size_t)L * n, e->lnpad.as<float>(), n, Tq, pad, 1, s);
             launch_dwconv_stride2_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), n, Tq, K,
                                           1e-5f, s);
             launch_avgpool2(x, e->xsave.as<float>(), n, Tq, s);
@@ -1787,9 +1795,7 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
             rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d,
                     e->xsave.as<float>(), d, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
         } else {
-            EncodeCtx ctx{n, Tq, nullptr};
-            CHK(conv_module(e, s, w, ctx, true, K));
-            launch_cnn_cache_move(cptr, e->lnpad.as<float>(), n, Tq, pad, 1, s);
+            CHK(conv_module_stream(e, s, w, n, Tq, cptr, cptr + (size_t)L * n, K));
         }
         CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x));
     }
@@ -1800,6 +1806,7 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
     for (int i = 0; i < n; ++i) {
         st[i]->offset += T0;
         st[i]->offset_r += T2;
+        std::swap(st[i]->cnn, st[i]->cnn2);
     }
     return 0;
 }

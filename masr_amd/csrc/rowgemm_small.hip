@@ -143,7 +143,10 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
         for (int rr = 0; rr < 4; ++rr) {
             const int lr = wave * 4 + rr;
             f32x4 o = v4[rr];
-            if (tp4[rr] >= p.pad) {
+            if (tp4[rr] >= p.pad && p.hist_affine) {          // Squeezeformer: adaptive scale / bias instead of the LayerNorm
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = lw[k] * o[k] + lb[k];
+            } else if (tp4[rr] >= p.pad) {
                 const f32x4 v = v4[rr];
                 const float mean = rs_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
                 const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
