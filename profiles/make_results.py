@@ -57,6 +57,7 @@ Raw outputs of this session's last measurement pass (`{R}`, scratch) copied here
 * {d['value']:.0f} audio-s/s = {d['ms_per_step']:.3f} ms per step of 320 audio-s (742 GFLOP algorithmic => {742.0 / d['ms_per_step']:.1f} TFLOP/s over the whole step, {742.0 / d['ms_per_step'] / 157.3 * 100:.0f} % of the fp32 MFMA peak)
 * dominant kernel `ffn_pc_kernel`: {rf['avg_us']:.1f} us per launch measured with HIP events inside bench.py (rocprofv3 kernel trace of the same command: {kt_avg} us, `r01_final_kernel_stats.txt`) => {rf['achieved']:.1f} TFLOP/s = {rf['frac']:.3f} of peak
 * HBM-side traffic of that kernel: 58.3 MB per launch (`r01_hbm_traffic.json`, `summarize_pmc.py`) vs 20.4 MB algorithmic: x in/out 16.3 MB + the 4.2 MB of W1/W2 fetched once by EACH of the 8 XCD L2s (8 x 4.2 = 33.6 MB, served by the 256 MB Infinity Cache after the first fetch) + LN/bias vectors. No re-read of activations; the hidden tensor never leaves the CU.
+* matrix-pipe occupancy from PMC counters (`r01_mfma_util.json`): fused FFN 0.73, conv2 0.75, CTC head 0.65, embed 0.60, QKV / out-proj+pw1 / attention 0.40-0.44, pw2 0.26
 * CPU baseline (oracle port, bit-identical to the reference modules, {cb['cores']} host cores): {cb['value']:.1f} audio-s/s on {cb['sample']}
 ''' + (f"* the multi-GPU code path (torch.distributed.run, RCCL init, all-gather of the hypotheses, barriers, max over ranks) on one rank (`MASR_BENCH_FORCE_DIST=1`): {dist['value']:.0f} audio-s/s\n" if dist else '') + '''
 ## Other BASELINE configurations (`python bench.py --workload ...`)
