@@ -32,7 +32,7 @@ def committed_traffic():
     (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if absent."""
     try:
         k = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
-        return k['masr::ffn_pc_kernel<0, 0, 0>']['hbm_bytes']
+        return k['masr::ffn_pc_kernel<0, 0, 0, 0>']['hbm_bytes']
     except Exception:
         return None
 

@@ -147,9 +147,19 @@ struct FfnPostLn {
     float* y;          // destination rows (may alias x)
     float eps;
 };
+// tail: a row-local stage appended to the full (non-split) kernel: out[M, N] = LayerNorm(x_new; lnw, lnb) . W[N, 256]^T + bias
+// (the fused QKV projection that follows the first macaron FFN).  Return value 2 = done by the kernel.
+struct FfnTail {
+    const float* lnw;
+    const float* lnb;
+    const float* W;
+    const float* bias;
+    float* out;
+    int N, ldo;
+};
 int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
-                     int nsplit, hipStream_t s, const FfnPostLn* post = nullptr);
+                     int nsplit, hipStream_t s, const FfnPostLn* post = nullptr, const FfnTail* tail = nullptr);
 
 void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
                        const FfnPostLn* post);

@@ -32,6 +32,7 @@ static int fail(const std::string& m) {
         if (_r) return _r;     \
     } while (0)
 
+static int g_no_ffn_tail = 0;     // masr_debug_set key 8: 1 = the QKV projection as its own launch after the first FFN (A/B)
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
 namespace {
@@ -101,7 +102,8 @@ struct GBeam {        // device-resident streaming CTC prefix beam search (masr_
     DevBuf pool, state;
 };
 
-enum ProfKind { PROF_NONE = 0, PROF_GEMM = 1, PROF_FFN1 = 2, PROF_CONV2 = 3, PROF_ATT = 4, PROF_FBANK = 5 };
+enum ProfKind { PROF_NONE = 0, PROF_GEMM = 1, PROF_FFN1 = 2, PROF_CONV2 = 3, PROF_ATT = 4, PROF_FBANK = 5,
+                PROF_FFN_TAIL = 6 };     // 2 = the plain fused FFN kernel; 6 = its variant with the QKV tail stage (own kernel name)
 
 }  // namespace
 
@@ -183,7 +185,7 @@ struct ProfScope {
     hipStream_t s;
     bool on;
     ProfScope(masr_engine* e_, hipStream_t s_, int kind, double flops) : e(e_), s(s_) {
-        on = e->prof_kind != 0 && (e->prof_kind == kind || (e->prof_kind == PROF_GEMM && (kind == PROF_FFN1 || kind == PROF_CONV2)));
+        on = e->prof_kind != 0 && (e->prof_kind == kind || (e->prof_kind == PROF_GEMM && (kind == PROF_FFN1 || kind == PROF_CONV2 || kind == PROF_FFN_TAIL)));
         if (!on) return;
         if (e->prof_used == e->prof_events.size()) {
             hipEvent_t a, b;
@@ -539,9 +541,11 @@ struct EncodeCtx {
 };
 
 // post_*: the LayerNorm that follows the block (y <- LayerNorm(x), y may be x); fused into the split-mode reduction of small M
+// tail / tail_done: a row-local stage to run on the finished rows inside the same kernel (fused QKV projection, ffn_pc.hip TAIL);
+// *tail_done = true when the kernel did it, otherwise the caller launches it
 int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb, const float* w1, const float* b1,
         const float* w2, const float* b2, float scale = 0.5f, int affine = 0, const float* post_w = nullptr,
-        const float* post_b = nullptr, float* post_y = nullptr) {
+        const float* post_b = nullptr, float* post_y = nullptr, const FfnTail* tail = nullptr, bool* tail_done = nullptr) {
     const int d = e->cfg.d_model, dff = e->cfg.d_ff;
     // few rows (streaming chunk steps): split d_ff across workgroups so that >= ~128 CUs work on the block
     int nsplit = 1;
@@ -551,10 +555,13 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         nsplit = std::min(dff / 128, std::max(1, 128 / rowblocks));
         CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
     }
-    ProfScope ps(e, s, PROF_FFN1, 4.0 * M * (double)dff * d);
+    const bool want_tail = tail && nsplit == 1 && !g_no_ffn_tail;
+    ProfScope ps(e, s, want_tail ? PROF_FFN_TAIL : PROF_FFN1, 4.0 * M * (double)dff * d + (want_tail ? 2.0 * M * (double)tail->N * d : 0.0));
     const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine,
-                                      nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s, post_y ? &post : nullptr);
-    if (post_y && !done) launch_layernorm(e->x.as<float>(), post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
+                                      nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s, post_y ? &post : nullptr,
+                                      want_tail ? tail : nullptr);
+    if (tail_done) *tail_done = done == 2;
+    if (post_y && done != 1) launch_layernorm(e->x.as<float>(), post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
     return 0;
 }
 
@@ -1190,8 +1197,12 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     if (!e->cfg.causal)     // symmetric conv: the (K-1)/2 pad rows on both sides of every sequence stay zero for all layers
         HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + pad) * d * sizeof(float), s));
     for (const LayerW& w : e->layers) {
-        CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
-        mhsa(e, s, w, M);
+        // first macaron FFN with the attention block's LayerNorm + fused QKV projection as its tail stage (full kernel only)
+        const FfnTail tail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, 3 * d};
+        bool qkv_done = false;
+        CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2, 0.5f, 0, nullptr, nullptr, nullptr, &tail,
+                &qkv_done));
+        if (!qkv_done) mhsa(e, s, w, M);
         {
             ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
             launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v,
@@ -1968,6 +1979,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 5) g_no_chain = value;
     else if (key == 6) set_rowgemm_small(value);
     else if (key == 7) set_attention_fewq(value);
+    else if (key == 8) g_no_ffn_tail = value;
     else if (key == 2) {            // beam search phase profile of workgroup 0: value 1 = on, 0 = print + off
         if (value) {
             if (!e->beam_prof) {

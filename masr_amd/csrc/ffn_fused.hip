@@ -324,7 +324,7 @@ void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, i
 }
 int launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
-                  hipStream_t s, int variant, const FfnPostLn* post);
+                  hipStream_t s, int variant, const FfnPostLn* post, const FfnTail* tail);
 
 static int g_ffn_variant = 0;
 void set_ffn_variant(int v) { g_ffn_variant = v; }
@@ -357,13 +357,13 @@ static void launch_ffn_t(float* x, const float* lnw, const float* lnb, const flo
 
 int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
-                     int nsplit, hipStream_t s, const FfnPostLn* post) {
+                     int nsplit, hipStream_t s, const FfnPostLn* post, const FfnTail* tail) {
     if (M <= 0) return 0;
     // production path: producer/consumer kernel (ffn_pc.hip).  masr_debug_set(1, v): 9 = this file's kernel (k-split GEMM1,
     // two barriers per chunk), 1 / 2 / 4 = its ablations, 81 = producer/consumer kernel without weight loads
     if (g_ffn_variant == 0 || g_ffn_variant == 81) {
         return launch_ffn_pc(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, affine_prologue, partial, nsplit, s,
-                             g_ffn_variant == 81 ? 1 : 0, post);
+                             g_ffn_variant == 81 ? 1 : 0, post, tail);
     }
     if (affine_prologue) {
         launch_ffn_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s);

@@ -10,6 +10,11 @@
 // wave overlaps with the matrix work of the other wave on the same SIMD, and there is ONE workgroup barrier per chunk
 // (the k-split partial-sum exchange of ffn_fused.hip is gone).  Weights stream through the same wave-private,
 // double-buffered LDS slabs with a 4-deep register prefetch rotation; no barrier on the weight path.
+// TAIL = 1 (first macaron FFN of an offline Conformer layer): the 32 finished rows do not leave the CU before the next
+// row-local stage -- they are put back into the LayerNorm tile, normalised with the attention block's LayerNorm, and all 8 waves
+// run the fused QKV projection on them ([768, 256] weights through the same wave-private slab stream, 3 output tiles per
+// wave; conformer/attention.py:53-79, encoder.py:123-131).  This replaces a separate launch whose ramp, row reload +
+// LayerNorm prologue and store tail cost about as much as its 20 us of matrix work.
 #include "common.h"
 
 namespace masr {
@@ -27,12 +32,12 @@ __device__ __forceinline__ float pc_wsum(float v) {
     return wave_sum_dpp(v);
 }
 
-template <int AFFINE, int SPLIT, int VAR>
+template <int AFFINE, int SPLIT, int VAR, int TAIL>
 __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                      const float* __restrict__ w1, const float* __restrict__ b1,
                                                      const float* __restrict__ w2, const float* __restrict__ b2, int M,
                                                      int dff, float eps, float scale, float* partial,
-                                                     int chunks_per_block) {
+                                                     int chunks_per_block, FfnTail tail) {
     extern __shared__ __align__(16) float sm[];
     float* xn = sm;                              // [32][260]   LayerNorm(x) tile (A operand of GEMM1)
     float* hs = xn + PC_BM * PC_XLD;             // [2][32][132] hidden tile (A operand of GEMM2), double-buffered
@@ -230,8 +235,94 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const float v = res[r] + scale * (acc2[n][r] + bv2);
+                    if (row0 + lr < M) x[(size_t)(row0 + lr) * PC_D + col] = v;
+                    if (TAIL) xn[lr * PC_XLD + col] = v;          // the LayerNorm tile is free: every producer passed its last read
+                }
+            }
+        }
+    }
+    if (!TAIL) return;
+
+    // ---- tail stage: out[32 rows, tail.N] = LayerNorm_tail(x_new) . Wt^T + bt, all 8 waves -----------------------------------
+    __syncthreads();
+    {
+        const f32x4 gw = *reinterpret_cast<const f32x4*>(tail.lnw + lane * 4);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(tail.lnb + lane * 4);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = wave * 4 + rr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&xn[lr * PC_XLD + lane * 4]);
+            const float mean = pc_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+            const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+            const float var = pc_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+            const float rstd = 1.0f / sqrtf(var + eps);
+            f32x4 o;
+            o[0] = d0 * rstd * gw[0] + gb[0];
+            o[1] = d1 * rstd * gw[1] + gb[1];
+            o[2] = d2 * rstd * gw[2] + gb[2];
+            o[3] = d3 * rstd * gw[3] + gb[3];
+            if (row0 + lr >= M) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&xn[lr * PC_XLD + lane * 4]) = o;
+        }
+    }
+    // weight tile t of this wave: rows t * 256 + 32 * wave .. +31 of Wt [N, 256]; slab j = k range 32j .. 32j+31
+    const int ntile = (tail.N + 255) / 256;
+    const float* tl[4];                                // N is a multiple of 256 (launcher): per-lane bases + wave-uniform tile offset
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tl[i] = tail.W + (size_t)(wave * 32 + lr8 + 8 * i) * PC_D + lc4;
+    auto tsrc = [&](int t, int j, int i) -> const float* {
+        return tl[i] + (size_t)(min(t, ntile - 1) * 256) * PC_D + j * 32;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(tsrc(0, 0, i));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+#pragma unroll
+    for (int k = 1; k <= PC_NSET; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(tsrc(0, k, i));
+    __syncthreads();                                  // normalised tile complete
+    {
+        const float* xa = xn + frow * PC_XLD + 4 * fh;
+        for (int t = 0; t < ntile; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* wp = wfrag + (j & 1) * PC_WSLAB;
+                f32x4 a[2], b[2];
+                a[0] = *reinterpret_cast<const f32x4*>(xa + j * 32);
+                b[0] = *reinterpret_cast<const f32x4*>(wp);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g + 1 < 4) {
+                        a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(xa + j * 32 + 8 * (g + 1));
+                        b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc, 0, 0, 0);
+                        const int slot = g * 4 + q, pset = (j + 1) % PC_NSET;
+                        if (slot < 8) {
+                            if ((slot & 1) == 0) *reinterpret_cast<f32x4*>(dst_of(j + 1, slot >> 1)) = pre[pset][slot >> 1];
+                        } else if ((slot & 1) == 0) {
+                            pre[pset][(slot - 8) >> 1] = *reinterpret_cast<const f32x4*>(
+                                tsrc(t + (j + 1 + PC_NSET) / 8, (j + 1 + PC_NSET) & 7, (slot - 8) >> 1));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            const int col = t * 256 + wave * 32 + frow;
+            if (col < tail.N) {
+                const float bv = tail.bias[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
                     const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    if (row < M) x[(size_t)row * PC_D + col] = res[r] + scale * (acc2[n][r] + bv2);
+                    if (row < M) tail.out[(size_t)row * tail.ldo + col] = acc[r] + bv;
                 }
             }
         }
@@ -242,13 +333,15 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
 template <int AFFINE, int VAR>
 static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                        const float* b2, int M, int dff, float eps, float scale, float* partial, int nsplit, hipStream_t s,
-                       const FfnPostLn* post) {
+                       const FfnPostLn* post, const FfnTail* tail) {
     const size_t lds = (size_t)(PC_BM * PC_XLD + 2 * PC_BM * PC_HLD + 8 * 2 * PC_WSLAB) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 0, VAR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 0, VAR, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, 0>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, 0, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, 0, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
@@ -256,25 +349,30 @@ static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float
     if (partial && nsplit > 1) {
         const int cpb = (nchunk + nsplit - 1) / nsplit;
         const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
-        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
-                           b1, w2, b2, M, dff, eps, scale, partial, cpb);
+        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, 0, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
+                           b1, w2, b2, M, dff, eps, scale, partial, cpb, FfnTail{});
         launch_ffn_reduce(x, partial, b2, M, ny, scale, s, post);
         return post && post->y ? 1 : 0;
+    } else if (tail && tail->out && tail->N % 256 == 0 && !AFFINE && VAR == 0) {
+        hipLaunchKernelGGL((ffn_pc_kernel<0, 0, 0, 1>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
+                           b2, M, dff, eps, scale, (float*)nullptr, 0, *tail);
+        return 2;                                         // tail stage done
     } else {
-        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 0, VAR>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1,
-                           w2, b2, M, dff, eps, scale, (float*)nullptr, 0);
+        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 0, VAR, 0>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1,
+                           b1, w2, b2, M, dff, eps, scale, (float*)nullptr, 0, FfnTail{});
     }
     return 0;
 }
 
-// returns 1 when the post LayerNorm was applied (split-d_ff path), 0 when the caller still has to run it
+// returns 1 when the post LayerNorm was applied (split-d_ff path), 2 when the tail stage ran (full kernel with `tail`), 0 when
+// the caller still has to run whichever it asked for
 int launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
-                  hipStream_t s, int variant, const FfnPostLn* post) {
+                  hipStream_t s, int variant, const FfnPostLn* post, const FfnTail* tail) {
     if (M <= 0) return 0;
-    if (affine_prologue) return launch_pc_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post);
-    if (variant == 1) return launch_pc_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post);
-    return launch_pc_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post);
+    if (affine_prologue) return launch_pc_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, nullptr);
+    if (variant == 1) return launch_pc_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, nullptr);
+    return launch_pc_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, tail);
 }
 
 }  // namespace masr

@@ -18,6 +18,9 @@
 //            CHAIN (offline conformer layer): attention out-projection + residual, then -- the 32 updated rows never leaving
 //            the CU -- LayerNorm + pad mask + pointwise_conv1 + GLU in the same kernel (weights [Wo; W_pw1] concatenated,
 //            one continuous slab stream): encoder.py:123-131 + convolution.py:98-119
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace masr {
@@ -125,10 +128,20 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
     };
     const int lr8 = lane >> 3, lc4 = (lane & 7) * 4;
     f32x4 pre[RG_NSET][4];
+    // Every epilogue except CTC has N a multiple of 256 (768 / 256 / 512 / 768: checked by the launcher), so all weight rows
+    // exist and the address is a per-lane base (one pointer per 8-row piece i) + a wave-uniform tile offset + a constant: the
+    // prefetch loads between the MFMAs then cost one add each instead of a clamp / multiply / 64-bit add chain.
+    const float* wl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wl[i] = p.W + (size_t)(wave * 32 + lr8 + 8 * i) * RG_K + lc4;
     auto src_of = [&](int t, int j, int i) -> const float* {
         const int tt = min(t, ntiles - 1);
-        const int r = min(wrow_of(tt) + lr8 + 8 * i, p.N - 1);         // clamp: rows >= N are masked in the epilogue
-        return p.W + (size_t)r * RG_K + j * 32 + lc4;
+        if (EPI == RG_EPI_CTC) {
+            const int r = min(wrow_of(tt) + lr8 + 8 * i, p.N - 1);     // clamp: rows >= N are masked in the epilogue
+            return p.W + (size_t)r * RG_K + j * 32 + lc4;
+        }
+        const int trow = (EPI == RG_EPI_GLU) ? (tt & 1) * 256 : (tbase + tt) * 256;     // wave-uniform
+        return wl[i] + (size_t)trow * RG_K + j * 32;
     };
     auto dst_of = [&](int buf, int i) -> float* { return wmine + buf * RG_WSLAB + (lr8 + 8 * i) * RG_WLD + lc4; };
 
@@ -387,6 +400,10 @@ static void launch_rg(const RowGemmArgs& a, hipStream_t s) {
         attr_done = true;
     }
     const int rowblocks = (a.M + RG_BM - 1) / RG_BM, ngroups = (a.N + 255) / 256;
+    if (EPI != RG_EPI_CTC && a.N % 256 != 0) {
+        fprintf(stderr, "rowgemm: N must be a multiple of 256 for this epilogue\n");
+        abort();
+    }
     if (can_split && ngroups > 1 && rowblocks < 64)
         hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI, can_split ? 1 : 0>), dim3(rowblocks, ngroups), dim3(512), lds, s, a);
     else

@@ -40,7 +40,7 @@ for w in ('efficient_b32', 'squeezeformer_b64_beam', 'stream16', 'deepspeech2_b1
     rows.append(f"| `{w}` | {x['value']:.0f} | {x['ms_per_step']:.2f} | {note} |")
 dist = last_json(R + 'bench_dist1.json') if os.path.exists(R + 'bench_dist1.json') else None
 rf, cb = d['roofline'], d['cpu_baseline']
-kt = [l for l in open(os.path.join(here, 'r01_final_kernel_stats.txt')) if 'ffn_pc_kernel<0, 0, 0>' in l][0].split()
+kt = [l for l in open(os.path.join(here, 'r01_final_kernel_stats.txt')) if 'ffn_pc_kernel<0, 0, 0, 0>' in l][0].split()
 kt_avg = [t for t in kt if t.replace('.', '', 1).isdigit()][2]
 sv = json.load(open(os.path.join(here, 'r01_serving.json')))
 md = f'''# Round 1 results (1 x MI355X, fp32 MFMA, synthetic data, random-init weights)
