@@ -57,7 +57,7 @@ Raw outputs of this session's last measurement pass (`{R}`, scratch) copied here
 * {d['value']:.0f} audio-s/s = {d['ms_per_step']:.3f} ms per step of 320 audio-s (742 GFLOP algorithmic => {742.0 / d['ms_per_step']:.1f} TFLOP/s over the whole step, {742.0 / d['ms_per_step'] / 157.3 * 100:.0f} % of the fp32 MFMA peak)
 * dominant kernel `ffn_pc_kernel`: {rf['avg_us']:.1f} us per launch measured with HIP events inside bench.py (rocprofv3 kernel trace of the same command: {kt_avg} us, `r01_final_kernel_stats.txt`) => {rf['achieved']:.1f} TFLOP/s = {rf['frac']:.3f} of peak
 * HBM-side traffic of that kernel: 58.3 MB per launch (`r01_hbm_traffic.json`, `summarize_pmc.py`) vs 20.4 MB algorithmic: x in/out 16.3 MB + the 4.2 MB of W1/W2 fetched once by EACH of the 8 XCD L2s (8 x 4.2 = 33.6 MB, served by the 256 MB Infinity Cache after the first fetch) + LN/bias vectors. No re-read of activations; the hidden tensor never leaves the CU.
-* matrix-pipe occupancy from PMC counters (`r01_mfma_util.json`): fused FFN 0.73, conv2 0.75, CTC head 0.65, embed 0.60, QKV / out-proj+pw1 / attention 0.40-0.44, pw2 0.26
+* matrix-pipe occupancy from PMC counters (`r01_mfma_util.json`): fused FFN 0.72 (0.71 with the QKV tail stage), conv2 0.75, CTC head 0.64, embed 0.60, out-proj+pw1 / attention 0.40-0.44, pw2 0.25
 * CPU baseline (oracle port, bit-identical to the reference modules, {cb['cores']} host cores): {cb['value']:.1f} audio-s/s on {cb['sample']}
 ''' + (f"* the multi-GPU code path (torch.distributed.run, RCCL init, all-gather of the hypotheses, barriers, max over ranks) on one rank (`MASR_BENCH_FORCE_DIST=1`): {dist['value']:.0f} audio-s/s\n" if dist else '') + '''
 ## Other BASELINE configurations (`python bench.py --workload ...`)
@@ -70,7 +70,7 @@ Streaming kernel table (16 lock-step streams): `r01_stream16_kernel_stats.txt`.
 
 ## Progress within round 1 (ms per batch-32 step)
 
-10.19 (first correct path) -> 9.8 (fused FFN v1) -> 8.76 (row-block GEMMs) -> 8.50 (fused CTC head, parallel rms / collapse) -> 8.29 (batched residual loads) -> 8.12 (no GEMM rows for the conv history) -> 7.79 (producer/consumer FFN) -> 7.56 (pinned prefetch schedule in the row-block GEMMs, wave-pair attention) -> 7.53 (out-projection + pointwise_conv1 in one kernel) -> 7.44 (parallel rms tail sum) -> 7.37 (DPP wave sums in the LayerNorm prologues).
+10.19 (first correct path) -> 9.8 (fused FFN v1) -> 8.76 (row-block GEMMs) -> 8.50 (fused CTC head, parallel rms / collapse) -> 8.29 (batched residual loads) -> 8.12 (no GEMM rows for the conv history) -> 7.79 (producer/consumer FFN) -> 7.56 (pinned prefetch schedule in the row-block GEMMs, wave-pair attention) -> 7.53 (out-projection + pointwise_conv1 in one kernel) -> 7.44 (parallel rms tail sum) -> 7.37 (DPP wave sums in the LayerNorm prologues) -> 7.26 (QKV projection as the tail stage of the first FFN kernel).
 
 ## Streaming chunk call (16 lock-step streams, p50 per `masr_encode_chunk` call incl. the argmax read-back)
 
