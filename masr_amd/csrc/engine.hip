@@ -988,7 +988,11 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
     for (int i = 0; i < L; ++i) {
         const LayerW& w = e->layers[i];
         int M = B * Tq;
-        CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
+        // regular layers: LayerNorm + fused QKV projection ride on the first FFN kernel (tail stage), like the Conformer
+        const FfnTail tail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, 3 * d};
+        bool qkv_done = false;
+        CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2, 0.5f, 0, nullptr, nullptr, nullptr,
+                layer_grouped(e, i) ? nullptr : &tail, &qkv_done));
         if (layer_grouped(e, i)) {
             if (Tq != T0) return fail("grouped attention after the stride layer is not supported");
             // q | k | v -> planar, time-padded buffers; attention over T/3 positions with d_k' = 192
@@ -1001,7 +1005,7 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
             rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->attp.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d,
                     1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride, 0, 0, 0, 0, 0, Tq, Tpad);
         } else {
-            mhsa(e, s, w, M);
+            if (!qkv_done) mhsa(e, s, w, M);
             {
                 ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
                 launch_attention(seq_r, B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v, 0, pstride, s);
