@@ -156,6 +156,8 @@ struct FfnTail {
     const float* bias;
     float* out;
     int N, ldo;
+    const float* pre_lnw;      // optional: x <- LayerNorm(x; pre_lnw, pre_lnb) first, written back (the previous layer's norm_final,
+    const float* pre_lnb;      // encoder.py:160-161, riding on this launch instead of its own)
 };
 int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,

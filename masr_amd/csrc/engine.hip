@@ -556,6 +556,8 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
     }
     const bool want_tail = tail && nsplit == 1 && !g_no_ffn_tail;
+    if (tail && tail->pre_lnw && !want_tail)          // the deferred LayerNorm of the previous layer, as its own launch
+        launch_layernorm(e->x.as<float>(), tail->pre_lnw, tail->pre_lnb, e->x.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
     ProfScope ps(e, s, want_tail ? PROF_FFN_TAIL : PROF_FFN1, 4.0 * M * (double)dff * d + (want_tail ? 2.0 * M * (double)tail->N * d : 0.0));
     const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine,
                                       nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s, post_y ? &post : nullptr,
@@ -989,7 +991,7 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
         const LayerW& w = e->layers[i];
         int M = B * Tq;
         // regular layers: LayerNorm + fused QKV projection ride on the first FFN kernel (tail stage), like the Conformer
-        const FfnTail tail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, 3 * d};
+        const FfnTail tail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, 3 * d, nullptr, nullptr};
         bool qkv_done = false;
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2, 0.5f, 0, nullptr, nullptr, nullptr,
                 layer_grouped(e, i) ? nullptr : &tail, &qkv_done));
@@ -1200,9 +1202,11 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), feat_lens_dev, B, Tq, 4, s);
     if (!e->cfg.causal)     // symmetric conv: the (K-1)/2 pad rows on both sides of every sequence stay zero for all layers
         HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + pad) * d * sizeof(float), s));
+    const LayerW* prev = nullptr;                 // layer whose norm_final is still pending (it rides on the next FFN launch)
     for (const LayerW& w : e->layers) {
         // first macaron FFN with the attention block's LayerNorm + fused QKV projection as its tail stage (full kernel only)
-        const FfnTail tail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, 3 * d};
+        const FfnTail tail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, 3 * d,
+                           prev ? prev->ln_fin_w : nullptr, prev ? prev->ln_fin_b : nullptr};
         bool qkv_done = false;
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2, 0.5f, 0, nullptr, nullptr, nullptr, &tail,
                 &qkv_done));
@@ -1220,8 +1224,9 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
             CHK(conv_module(e, s, w, ctx, false, 0, 4, true));
         }
         CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
-        launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        prev = &w;                                 // norm_final deferred to the next layer's first FFN launch
     }
+    launch_layernorm(x, prev->ln_fin_w, prev->ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
     launch_layernorm(x, e->after_w, e->after_b, enc_out_dev, M, 1e-5f, 0, 0, nullptr, s);
     HIPCHK(hipGetLastError());
     return 0;

@@ -60,6 +60,28 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
             const int row = min(row0 + wave * 4 + rr, M - 1);
             v4[rr] = *reinterpret_cast<const f32x4*>(x + (size_t)row * PC_D + lane * 4);
         }
+        if (TAIL && tail.pre_lnw) {
+            // the previous layer's closing LayerNorm on my rows, written back as the new residual stream (read again by the
+            // epilogue of this workgroup only, after workgroup barriers)
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(tail.pre_lnw + lane * 4);
+            const f32x4 pb = *reinterpret_cast<const f32x4*>(tail.pre_lnb + lane * 4);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const f32x4 v = v4[rr];
+                const float mean = pc_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                const float var = pc_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + eps);
+                f32x4 o;
+                o[0] = d0 * rstd * pw[0] + pb[0];
+                o[1] = d1 * rstd * pw[1] + pb[1];
+                o[2] = d2 * rstd * pw[2] + pb[2];
+                o[3] = d3 * rstd * pw[3] + pb[3];
+                v4[rr] = o;
+                const int row = row0 + wave * 4 + rr;
+                if (row < M) *reinterpret_cast<f32x4*>(x + (size_t)row * PC_D + lane * 4) = o;
+            }
+        }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int lr = wave * 4 + rr;
