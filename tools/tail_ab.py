@@ -1,4 +1,5 @@
-"""Diagnostic: batch-32 step with and without the QKV tail stage of the first FFN kernel (masr_debug_set key 8)."""
+"""Diagnostic: batch-32 step with and without the QKV tail stage + deferred norm_final on the first FFN kernel
+(masr_debug_set key 8)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,6 +20,6 @@ for rep in range(2):
             r = e.transcribe_batch(pcm, n)
         torch.cuda.synchronize()
         outs[off] = r
-        print(f'tail stage {"off" if off else "on "}: {(time.perf_counter() - t0) * 100:.3f} ms per step')
+        print(f'FFN tail stage {("on ", "off")[off]}: {(time.perf_counter() - t0) * 100:.3f} ms per step')
 same = all(torch.equal(a, b) for a, b in zip(outs[0][:2], outs[1][:2]))
 print('token ids identical:', same, ' max score diff:', float((outs[0][2] - outs[1][2]).abs().max()))
