@@ -70,7 +70,7 @@ Streaming kernel table (16 lock-step streams): `r01_stream16_kernel_stats.txt`.
 
 ## Progress within round 1 (ms per batch-32 step)
 
-10.19 (first correct path) -> 9.8 (fused FFN v1) -> 8.76 (row-block GEMMs) -> 8.50 (fused CTC head, parallel rms / collapse) -> 8.29 (batched residual loads) -> 8.12 (no GEMM rows for the conv history) -> 7.79 (producer/consumer FFN) -> 7.56 (pinned prefetch schedule in the row-block GEMMs, wave-pair attention) -> 7.53 (out-projection + pointwise_conv1 in one kernel) -> 7.44 (parallel rms tail sum) -> 7.37 (DPP wave sums in the LayerNorm prologues) -> 7.26 (QKV projection as the tail stage of the first FFN kernel).
+10.19 (first correct path) -> 9.8 (fused FFN v1) -> 8.76 (row-block GEMMs) -> 8.50 (fused CTC head, parallel rms / collapse) -> 8.29 (batched residual loads) -> 8.12 (no GEMM rows for the conv history) -> 7.79 (producer/consumer FFN) -> 7.56 (pinned prefetch schedule in the row-block GEMMs, wave-pair attention) -> 7.53 (out-projection + pointwise_conv1 in one kernel) -> 7.44 (parallel rms tail sum) -> 7.37 (DPP wave sums in the LayerNorm prologues) -> 7.26 (QKV projection as the tail stage of the first FFN kernel) -> 7.16 (the layer's closing LayerNorm on the next layer's first FFN launch).
 
 ## Streaming chunk call (16 lock-step streams, p50 per `masr_encode_chunk` call incl. the argmax read-back)
 
