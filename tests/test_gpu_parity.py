@@ -826,3 +826,24 @@ def test_encoder_with_linear_and_mfcc_input(oracle_mods, method, dim):
     probs2 = e.ctc_probs(e.encode_full(feats, frames, -1))[0].cpu().numpy()
     assert np.abs(probs2 - z[method + '_probs']).max() < 2e-2
     e.close()
+
+
+def test_ffn_tail_stage_matches_separate_launches(eng512):
+    """offline Conformer layers: QKV projection + deferred norm_final inside the first FFN launch (ffn_pc TAIL) vs the separate
+    rowgemm / layernorm launches -- same arithmetic, so the encoder output must be bit-identical; ragged batch whose last
+    32-row block is partial (9 x 250 = 2250 rows)."""
+    e, _ = eng512
+    gen = torch.Generator().manual_seed(21)
+    feats = torch.randn(9, 1003, 80, generator=gen) * 3 + 13
+    lens = torch.tensor([1003, 990, 700, 1003, 512, 333, 1003, 801, 67], dtype=torch.int32)
+    feats = feats * (torch.arange(1003)[None, :, None] < lens[:, None, None])
+    x, n = dev(feats), dev(lens)
+    fused = e.encode_full(x, n, -1).clone()
+    e.lib.masr_debug_set(e.h, 8, 1)
+    try:
+        plain = e.encode_full(x, n, -1).clone()
+    finally:
+        e.lib.masr_debug_set(e.h, 8, 0)
+    assert fused.shape == (9, 250, 256)
+    assert torch.equal(fused, plain)
+    assert torch.isfinite(fused).all()
