@@ -89,7 +89,11 @@ class MASRPredictor:
         raise Exception(f'不支持该数据类型，当前数据类型为：{type(audio_data)}')
 
     def predict(self, audio_data, use_pun=False, is_itn=False, sample_rate=16000):
-        """predict.py:167-192: one utterance -> {'text', 'score'}."""
+        """predict.py:167-192: one utterance -> {'text', 'score'}.  With ``decoder: ctc_greedy`` the utterance takes the batched
+        device path as a batch of one (features, encoder, fused CTC head and best-path collapse without the numpy round trips
+        between the reference's stages: features -> host -> device, probabilities [T', V] -> host -> device)."""
+        if self.configs.decoder != 'ctc_beam_search' and not is_itn:
+            return self.predict_batch([audio_data], sample_rate=sample_rate)[0]
         audio_segment = self._load_audio(audio_data=audio_data, sample_rate=sample_rate)
         audio_feature = self._audio_featurizer.featurize(audio_segment)
         input_data = np.array(audio_feature).astype(np.float32)[np.newaxis, :]
