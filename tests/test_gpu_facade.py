@@ -302,7 +302,7 @@ def test_server_front_end_batches_requests_and_streams(predictor):
         stream_want.append(r['text'] if r is not None else (stream_want[-1] if stream_want else ''))
     predictor.reset_stream()
 
-    app = create_app(predictor, max_batch=8, max_wait_ms=300.0, max_frames_out=400)
+    app = create_app(predictor, max_batch=8, max_wait_ms=1500.0, max_frames_out=400)
     with TestClient(app) as c:
         got = [None] * len(clips)
 
