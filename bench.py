@@ -1,14 +1,29 @@
-"""bench.py -- audio-seconds/sec of the offline hot path (BASELINE config 2) on N MI355X GPUs.
+"""bench.py -- audio-seconds/sec of the offline hot path (BASELINE configs[1]) on N MI355X GPUs.
 
-A "step" is one pass of PCM -> fbank -> Conformer encoder -> CTC greedy over one batch of
-32 x 10 s synthetic 16 kHz utterances per GPU, inputs resident in HBM (weak scaling: every rank
-owns its own batch; for N > 1 the hypotheses are all-gathered over RCCL inside the step).
-Prints ONE JSON line on rank 0 (contract in the task statement; extra keys: roofline, cpu_baseline).
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of PCM -> fbank -> Conformer encoder -> CTC greedy -> hypotheses as TEXT ON THE HOST over one batch of
+32 x 10 s synthetic 16 kHz utterances per GPU (weak scaling: every rank owns its own batch; for N > 1 the hypotheses are
+all-gathered over RCCL inside the step -- the path's only exchange).  The int16 PCM is resident in HBM when the timed region
+starts; the token ids come back through a pinned buffer and step k's text is built while step k+1 runs on the GPU.
+
+``--gpus N`` with N > 1 launches the N ranks itself (``python -m torch.distributed.run``, one process per GPU) unless it is
+already running under such a launcher (WORLD_SIZE set, as the driver does); a WORLD_SIZE that disagrees with ``--gpus`` is an
+error.  Rank 0 prints ONE JSON line (contract in the task statement) with these additions:
+  roofline      the fused FFN kernel: algorithmic FLOPs / HIP-event time of its launches inside the timed region
+  timing        the same step measured two more ways: ``device_only`` (no D2H, no text: round 1's number) and
+                ``host_to_host`` (pinned host PCM -> H2D -> ... -> text, SURVEY 8(d)'s "PCM-on-host to hypotheses-on-host")
+  cpu_baseline  the reference's CPU path on this node's host cores, bounded sample (N = 1 only)
+  extra         BASELINE configs[2,3,4] timed on the same engine build (short runs; ``--no-extra`` skips them)
 """
 import argparse
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -21,20 +36,68 @@ BATCH = 32
 N_SAMPLES = 160000          # 10 s @ 16 kHz
 VOCAB = 4233
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GFLOP_PER_STEP = 742.0        # 23.18 GFLOP per 10 s utterance x 32
 
 
 def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
+# ---- launch ------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_under_torchrun(n, argv):
+    """--gpus N outside a launcher: start the N ranks ourselves (one process per GPU) and relay rank 0's JSON line"""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    log('launching ' + ' '.join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
+
+
+def make_engine(kind, device, vocab=VOCAB):
+    """the HIP engine of one rank; MASR_BENCH_ENGINE_FACTORY=module:callable swaps in a stand-in (CPU tests of the
+    launch / shard / gather / timing code -- the JSON line then says so in ``data``)"""
+    hook = os.environ.get('MASR_BENCH_ENGINE_FACTORY')
+    if hook:
+        mod, fn = hook.split(':')
+        return getattr(importlib.import_module(mod), fn)(kind, device, vocab)
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    if kind == 'conformer':
+        return HipEngine(synthetic.conformer_state_dict(0, vocab), vocab_size=vocab, device=device)
+    if kind == 'efficient_conformer':
+        return HipEngine(synthetic.efficient_conformer_state_dict(0, vocab), vocab_size=vocab, streaming=True,
+                         use_model='efficient_conformer', device=device)
+    if kind == 'squeezeformer':
+        return HipEngine(synthetic.squeezeformer_state_dict(0, vocab), vocab_size=vocab, streaming=False,
+                         use_model='squeezeformer', device=device)
+    raise SystemExit(f'unknown engine kind {kind}')
+
+
+def data_tag():
+    return 'synthetic' if not os.environ.get('MASR_BENCH_ENGINE_FACTORY') else 'synthetic, STAND-IN ENGINE (test hook, not a measurement)'
+
+
+# ---- evidence helpers ------------------------------------------------------------------------------------------------------
 def committed_traffic():
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this build
-    (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); None if absent."""
-    try:
-        k = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
-        return k['masr::ffn_pc_kernel<0, 0, 0, 0>']['hbm_bytes']
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this build
+    (profiles/rNN_hbm_traffic.json: FETCH_SIZE with the gfx950 correction + WRITE_SIZE); (bytes, file) or (None, None)."""
+    for name in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+        try:
+            k = json.load(open(os.path.join(ROOT, 'profiles', name)))['kernels']
+            for key, v in k.items():
+                if 'ffn_pc_kernel<0, 0, 0, 0>' in key:
+                    return v['hbm_bytes'], name
+        except Exception:
+            continue
+    return None, None
 
 
 def host_cores():
@@ -49,249 +112,378 @@ def host_cores():
     return min(n, 64)
 
 
-def cpu_baseline(sample_utts=4, reps=2):
-    """The CPU oracle (restatement of the reference's PyTorch CPU path, pinned bit-identical to the
-    reference modules) timed on this host: featurize + get_encoder_out + greedy on a bounded sample."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(budget_s=24.0):
+    """MASR's own CPU predict path on this node's host cores, on a bounded sample of the contract workload.  Two legs
+    (SURVEY 8(d)): (i) the batched ``get_encoder_out`` path (trainer.py:632) on 4 x 10 s, (ii) the per-utterance
+    ``MASRPredictor.predict`` loop (featurize + encoder + greedy, B = 1 calls, predict.py:167-192) -- ``value`` is leg (ii),
+    the way MASR users run it.  kind = "reference" when /root/reference is importable (the unmodified reference modules via
+    oracle/shims), else "port" (oracle/, pinned bit-identical to those modules).  >= 5 timed repetitions per leg, median."""
     from masr_amd.utils import synthetic
-    from oracle import conformer as oc, decoders as od, fbank as ofb
+    from oracle import conformer as oc, decoders as od, fbank as ofb, shims
     cores = host_cores()
     torch.set_num_threads(cores)
-    log(f'cpu_baseline: {cores} threads')
     sd = synthetic.conformer_state_dict(0, VOCAB)
     vocab = synthetic.synthetic_vocab(VOCAB)
-    pcm = synthetic.synthetic_pcm(sample_utts, N_SAMPLES, seed=1234)
-    times = []
-    for r in range(reps + 1):
-        t0 = time.perf_counter()
-        feats = np.stack([ofb.featurize_pcm16(pcm[i])[0] for i in range(sample_utts)])
+    pcm = synthetic.synthetic_pcm(4, N_SAMPLES, seed=1234)
+    kind = 'port'
+    encode = lambda f, l: oc.get_encoder_out(sd, f, l)
+    if shims.reference_available():
+        try:
+            from oracle import make_golden
+            shims.install()
+            model = make_golden.build_reference_conformer(sd, VOCAB, tempfile.mkdtemp(prefix='masr_ref_'))[0]
+            encode = lambda f, l: model.get_encoder_out(f, l)      # the reference's ConformerModel with these weights
+            kind = 'reference'
+        except Exception as exc:                                        # noqa: BLE001
+            log(f'cpu_baseline: reference modules not usable here ({exc}); timing the port')
+    log(f'cpu_baseline: {kind}, {cores} threads, {cpu_model()}')
+
+    def leg_batched():
+        feats = np.stack([ofb.featurize_pcm16(pcm[i])[0] for i in range(4)])
         with torch.no_grad():
-            probs = oc.get_encoder_out(sd, torch.from_numpy(feats), torch.full((sample_utts,), feats.shape[1])).numpy()
+            probs = encode(torch.from_numpy(feats), torch.full((4,), feats.shape[1])).numpy()
         od.greedy_decoder_batch(list(probs), vocab)
-        dt = time.perf_counter() - t0
-        log(f'cpu_baseline rep {r}: {dt:.2f} s for {sample_utts} x 10 s')
-        if r > 0:
-            times.append(dt)
-        if dt > 60 and r >= 1:
-            break
-    med = float(np.median(times))
-    return {'value': sample_utts * 10.0 / med, 'unit': 'audio-seconds/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{sample_utts} x 10 s utterances (batched get_encoder_out path, trainer.py:632), '
-                      f'median of {reps}, torch threads={cores}'}
+        return 40.0
+
+    def leg_predict_loop():
+        for i in range(2):
+            feat = ofb.featurize_pcm16(pcm[i])[0][None]
+            with torch.no_grad():
+                probs = encode(torch.from_numpy(feat), torch.tensor([feat.shape[1]])).numpy()[0]
+            od.greedy_decoder(probs, vocab)
+        return 20.0
+
+    out = {}
+    for name, leg in (('batched', leg_batched), ('predict_loop', leg_predict_loop)):
+        leg()                                                           # warm-up
+        times, t_leg = [], time.perf_counter()
+        while len(times) < 5 or (time.perf_counter() - t_leg < budget_s / 2 and len(times) < 9):
+            t0 = time.perf_counter()
+            audio = leg()
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_leg > budget_s and len(times) >= 5:
+                break
+        out[name] = {'value': round(audio / float(np.median(times)), 2), 'reps': len(times),
+                     'median_s': round(float(np.median(times)), 3)}
+        log(f'cpu_baseline {name}: {out[name]}')
+    return {'value': out['predict_loop']['value'], 'unit': 'audio-seconds/sec', 'cores': cores, 'kind': kind,
+            'cpu_model': cpu_model(),
+            'sample': f'leg (ii) per-utterance predict loop: 2 x 10 s utterances, B = 1 calls (featurize + get_encoder_out + '
+                      f'greedy), median of {out["predict_loop"]["reps"]} reps, torch threads = {cores}',
+            'batched': {'value': out['batched']['value'], 'reps': out['batched']['reps'],
+                        'sample': 'leg (i) batched get_encoder_out path (trainer.py:632): 4 x 10 s in one padded batch'}}
 
 
-def other_workload(args, device):
-    """Secondary workloads (parity-test configurations of BASELINE.json timed for DESIGN.md; NOT the contract line)."""
-    import ctypes as C
-    from masr_amd.engine import HipEngine
+# ---- the contract workload ----------------------------------------------------------------------------------------------
+class ContractStep:
+    """one rank's step of configs[1]; ``mode``: 'full' (HBM-resident PCM -> text on host, pipelined), 'device' (-> token ids
+    on the device, nothing synchronised), 'host' (pinned host PCM -> H2D -> ... -> text on host)"""
+
+    def __init__(self, eng, rank, world, vocab):
+        from masr_amd import parallel
+        from masr_amd.utils import synthetic
+        self.parallel, self.eng, self.rank, self.world = parallel, eng, rank, world
+        self.dev = eng.device
+        self.vocab = np.array(vocab, dtype=object)
+        pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234 + rank))
+        pin = self.dev.type == 'cuda'
+        self.pcm_host = pcm.pin_memory() if pin else pcm
+        self.pcm = pcm.to(self.dev)
+        self.n = torch.full((BATCH,), N_SAMPLES, dtype=torch.int32, device=self.dev)
+        self.Tp = eng.out_frames(1 + (N_SAMPLES - 400) // 160)
+        self.out = (torch.empty(BATCH, self.Tp, dtype=torch.int32, device=self.dev),
+                    torch.empty(BATCH, dtype=torch.int32, device=self.dev),
+                    torch.empty(BATCH, dtype=torch.float32, device=self.dev))
+        rows = world * BATCH
+        mk = lambda *shape, dt: torch.empty(*shape, dtype=dt, pin_memory=pin)
+        self.host = [(mk(rows, self.Tp, dt=torch.int32), mk(rows, dt=torch.int32), mk(rows, dt=torch.float32)) for _ in range(2)]
+        self.events = [torch.cuda.Event() if pin else None for _ in range(2)]
+        self.pending = None
+        self.texts = None
+        self.n_texts = 0
+
+    def _finish(self, slot):
+        """hypotheses of a finished step as text on the host (rank 0: of all ranks' utterances; others: their own shard)"""
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+        tok, nt, _ = self.host[slot]
+        lo, hi = (0, self.world * BATCH) if self.rank == 0 else (self.rank * BATCH, (self.rank + 1) * BATCH)
+        self.texts = self.parallel.tokens_to_text(tok[lo:hi].numpy(), nt[lo:hi].numpy(), self.vocab)
+        self.n_texts += len(self.texts)
+
+    def flush(self):
+        if self.pending is not None:
+            self._finish(self.pending)
+            self.pending = None
+
+    def step(self, i, mode='full'):
+        pcm = self.pcm
+        if mode == 'host':
+            pcm = self.pcm_host.to(self.dev, non_blocking=True)         # 10.2 MB over PCIe, same stream as the kernels
+        self.eng.transcribe_batch(pcm, self.n, out=self.out)
+        tok, nt, sc = self.parallel.gather_hypotheses(*self.out)       # RCCL all-gather of [32, T'+2] int32 per rank (N > 1)
+        if mode == 'device':
+            return
+        slot = i & 1
+        for dst, src in zip(self.host[slot], (tok, nt, sc)):
+            dst.copy_(src, non_blocking=True)
+        if self.events[slot] is not None:
+            self.events[slot].record()
+        self.flush()                                                    # text of the previous step, under this step's kernels
+        self.pending = slot
+
+
+def run_contract(args, rank, world, local):
+    from masr_amd import parallel
     from masr_amd.utils import synthetic
+    eng = make_engine('conformer', local)
+    cs = ContractStep(eng, rank, world, synthetic.synthetic_vocab(VOCAB))
+    log(f'rank {rank}/{world}: engine ready on device {local}, warmup {args.warmup}')
+
+    def prof_on():
+        eng.profile_select(args.profile_kind)
+        eng.profile_read(reset=True)
+
+    dt = parallel.timed_region(lambda i: cs.step(i, 'full'), args.steps, args.warmup, after_warmup=prof_on, flush=cs.flush)
+    prof_ms, prof_n, prof_flops = eng.profile_read(reset=True)
+    eng.profile_select(0)
+    n_texts, sample_text = cs.n_texts, (cs.texts[0] if cs.texts else '')
+    log(f'rank {rank}: timed region done: {dt * 1e3 / args.steps:.3f} ms/step')
+    dt_dev = parallel.timed_region(lambda i: cs.step(i, 'device'), args.steps, 1)
+    dt_host = parallel.timed_region(lambda i: cs.step(i, 'host'), args.steps, 1, flush=cs.flush)
+    res = None
+    if rank == 0:
+        audio_step = world * BATCH * (N_SAMPLES / 16000.0)
+        roofline = None
+        if prof_n > 0 and prof_ms > 0:
+            achieved = prof_flops / (prof_ms * 1e-3) / 1e12
+            traffic, tfile = committed_traffic()
+            roofline = {'bound': 'mfma', 'kernel': 'ffn_pc_kernel (LN + [B*T\',256]x[256,2048] + SiLU + x[2048,256] + residual)',
+                        'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                        'traffic_note': f'HBM bytes per launch from the committed PMC passes (profiles/{tfile}); algorithmic bytes '
+                                        'per launch = 20.4 MB (x in/out + W1 + W2); measured = x in/out 16.3 MB + the 4.2 MB of '
+                                        'weights fetched once by each of the 8 XCD L2s (Infinity Cache hits after the first)',
+                        'launches': int(prof_n), 'avg_us': round(prof_ms * 1e3 / prof_n, 2),
+                        'flops_per_launch': prof_flops / prof_n}
+        per = lambda t: {'value': round(audio_step * args.steps / t, 1), 'ms_per_step': round(t * 1e3 / args.steps, 3)}
+        res = {'metric': 'audio-seconds/sec (RTF^-1), conformer_streaming_fbank b32x10s, PCM->fbank->encoder->ctc_greedy->text',
+               'value': per(dt)['value'], 'unit': 'audio-seconds/sec', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': per(dt)['ms_per_step'], 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': data_tag(),
+               'config': {'workload': 'configs[1]: conformer.yml streaming fbank, batch=32 synthetic 16 kHz 10 s '
+                                      'utterances per GPU, ctc_greedy, random-init weights V=4233',
+                          'global_batch': world * BATCH, 'audio_seconds_per_step': audio_step,
+                          'parallelism': f'dp{world}', 'world_size_observed': parallel.world_info()[1],
+                          'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else 'none',
+                          'algorithmic_gflop_per_step_per_gpu': GFLOP_PER_STEP,
+                          'timed_region': 'int16 PCM resident in HBM -> token ids -> (all-gather) -> D2H -> text on host; '
+                                          f'{n_texts} transcripts built inside it, e.g. {sample_text[:12]!r}'},
+               'roofline': roofline,
+               'timing': {'device_only': dict(per(dt_dev), note='PCM in HBM -> token ids in HBM, nothing synchronised per step'),
+                          'host_to_host': dict(per(dt_host), note='pinned host int16 PCM -> H2D -> ... -> D2H -> text on host')}}
+    return eng, res
+
+
+# ---- secondary workloads (BASELINE configs[2,3,4]) ----------------------------------------------------------------------
+def facade(use_model, decoder, device, streaming=True, vocab=VOCAB, beam_conf=None):
+    """a MASRPredictor on synthetic weights (the drop-in surface; StreamPool / predict_batch hang off it)"""
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.utils import synthetic
+    d = tempfile.mkdtemp(prefix='masr_bench_')
+    vpath = os.path.join(d, 'vocabulary.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in synthetic.synthetic_vocab(vocab):
+            f.write(f'{t}\t1\n')
+    sd = {'conformer': synthetic.conformer_state_dict, 'efficient_conformer': synthetic.efficient_conformer_state_dict,
+          'squeezeformer': synthetic.squeezeformer_state_dict}[use_model](0, vocab)
+    cfg = {'encoder_conf': {}, 'preprocess_conf': {'feature_method': 'fbank', 'n_mels': 80, 'n_mfcc': 40, 'sample_rate': 16000,
+                                                   'use_dB_normalization': True, 'target_dB': -20},
+           'dataset_conf': {'dataset_vocab': vpath}, 'use_model': use_model, 'streaming': streaming, 'decoder': decoder,
+           'metrics_type': 'cer'}
+    if beam_conf:
+        cfg['ctc_beam_search_decoder_conf'] = beam_conf
     torch.cuda.set_device(device)
-    rng = np.random.default_rng(1234)
-    if args.workload == 'efficient_b32':
-        eng = HipEngine(synthetic.efficient_conformer_state_dict(0, VOCAB), vocab_size=VOCAB, streaming=True,
-                        use_model='efficient_conformer', device=device)
-        pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234)).cuda()
-        n = torch.full((BATCH,), N_SAMPLES, dtype=torch.int32, device='cuda')
-        step = lambda: eng.transcribe_batch(pcm, n)
-        audio = BATCH * 10.0
-        desc = 'configs[3] shard: efficient_conformer.yml, 32 x 10 s per GPU, ctc_greedy'
-    elif args.workload == 'squeezeformer_b64_beam':
-        from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
-        eng = HipEngine(synthetic.squeezeformer_state_dict(0, VOCAB), vocab_size=VOCAB, streaming=False,
-                        use_model='squeezeformer', device=device)
-        lens = rng.integers(32000, 320001, 64).astype(np.int32)
-        order = np.argsort(-lens)                       # longest first (one padded batch; sort limits nothing here)
-        lens = lens[order]
-        pcm_h = synthetic.synthetic_pcm(64, int(lens.max()), seed=1234)
-        for i, l in enumerate(lens):
-            pcm_h[i, l:] = 0
-        # length buckets (SURVEY 8d: padded-to-max computes 2.55 TFLOP for 1.43 TFLOP of audio): the batch is sorted by length
-        # and cut into sub-batches (2 of 32 by default), each padded to ITS longest utterance; all of them resident in HBM before the step
-        nb = int(os.environ.get('MASR_BENCH_BUCKETS', '2'))
-        parts = []
-        for b0 in range(0, 64, 64 // nb):
-            b1 = b0 + 64 // nb
-            fr = 1 + (lens[b0:b1].astype(np.int64) - 400) // 160                    # feature frames, encoder frames (host side:
-            parts.append((torch.from_numpy(np.ascontiguousarray(pcm_h[b0:b1, :int(lens[b0])])).cuda(),   # no sync in the step)
-                          torch.from_numpy(lens[b0:b1]).cuda(), (((fr - 1) // 2 - 1) // 2).clip(min=0).tolist()))
-        dec = BeamSearchDecoder(alpha=0, beta=0, beam_size=300, cutoff_prob=0.99, cutoff_top_n=40,
-                                vocab_list=synthetic.synthetic_vocab(VOCAB), num_processes=min(host_cores(), 32))
+    return MASRPredictor(configs=cfg, use_gpu=True, state_dict=sd)
 
-        side = torch.cuda.Stream()
 
-        def step():
-            # longest bucket first; the prefix search of a bucket (one workgroup per utterance, ~21 us per frame with these flat
-            # synthetic posteriors) runs on a side stream under the encoder of the next, shorter one
-            main = torch.cuda.current_stream()
-            pend, seqs = [], []
-            for k, (pcm_b, n_b, nenc) in enumerate(parts):
-                feats, frames = eng.fbank_batch(pcm_b, n_b)
-                enc = eng.encode_full(feats, frames, -1)
-                probs = eng.ctc_probs(enc)
-                seqs += [probs[i, :nenc[i]] for i in range(probs.shape[0])]
-                if nb <= 2 or k % 2 == 1:
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        pend.append((dec._batch(seqs, defer=True), seqs))
-                    seqs = []
-            out = []
-            for p_, _ in pend:
-                out += dec._batch_collect(p_)
-            main.wait_stream(side)
-            return out
-        audio = float(lens.sum()) / 16000.0
-        desc = f'configs[2]: squeezeformer.yml non-streaming, 64 utterances 2-20 s ({audio:.1f} audio-s) in {nb} length buckets ' \
-               f'of {64 // nb}, ctc_beam_search (LM-free, beam 300, cutoff_top_n 40; pruning and prefix search on the GPU, on a ' \
-               f'side stream under the next buckets\' encoder)'
-    elif args.workload == 'stream16':
-        eng = HipEngine(synthetic.conformer_state_dict(0, VOCAB), vocab_size=VOCAB, device=device)
-        ns = 16
-        pcm = torch.from_numpy(synthetic.synthetic_pcm(ns, N_SAMPLES, seed=1234)).cuda()
-        n = torch.full((ns,), N_SAMPLES, dtype=torch.int32, device='cuda')
-        feats, _ = eng.fbank_batch(pcm, n)                       # [16, 998, 80]
-        sids = [eng.stream_open(300) for _ in range(ns)]
-        lat = []
+def extra_efficient_b256(args, rank, world, local):
+    """configs[3]: efficient_conformer.yml streaming fbank, 256 x 10 s utterances sharded DP over the ranks (256 / N per GPU in
+    device passes of 32), RCCL all-gather of the hypotheses; strong scaling by construction of the config"""
+    from masr_amd import parallel
+    eng = make_engine('efficient_conformer', local)
+    from masr_amd.utils import synthetic
+    total = 256
+    lo, hi = parallel.shard_range(total, rank, world)
+    passes = [(torch.from_numpy(synthetic.synthetic_pcm(min(BATCH, hi - b0), N_SAMPLES, seed=77 + b0)).to(eng.device),
+               torch.full((min(BATCH, hi - b0),), N_SAMPLES, dtype=torch.int32, device=eng.device)) for b0 in range(lo, hi, BATCH)]
+    per = -(-total // world)
+    Tp = eng.out_frames(1 + (N_SAMPLES - 400) // 160)
+    tok = torch.full((per, Tp), -1, dtype=torch.int32, device=eng.device)
+    nt = torch.zeros(per, dtype=torch.int32, device=eng.device)
+    sc = torch.zeros(per, dtype=torch.float32, device=eng.device)
+    vocab = np.array(synthetic.synthetic_vocab(VOCAB), dtype=object)
+    texts = []
 
-        def step():
-            for sid in sids:
-                eng.stream_reset(sid)
-            for cur in range(0, feats.shape[1] - 67 + 1, 64):     # 15 chunk steps of 0.64 s each, 16 streams in lock-step
-                t0 = time.perf_counter()
-                _, idx, mp = eng.encode_chunk(sids, feats[:, cur:cur + 67].contiguous(), want_probs=False, want_argmax=True)
-                idx.cpu()
+    def step(i):
+        k = 0
+        for pcm, n in passes:
+            b = pcm.shape[0]
+            eng.transcribe_batch(pcm, n, out=(tok[k:k + b], nt[k:k + b], sc[k:k + b]))
+            k += b
+        t, c, _ = parallel.gather_hypotheses(tok, nt, sc)
+        if rank == 0:
+            texts[:] = parallel.tokens_to_text(t.cpu().numpy(), c.cpu().numpy(), vocab)
+    steps = max(2, args.steps // 4)
+    dt = parallel.timed_region(step, steps, 1)
+    eng.close()
+    return {'workload': f'configs[3]: efficient_conformer.yml streaming fbank, 256 x 10 s utterances sharded over {world} GPU(s) '
+                        f'({hi - lo} on rank 0, device passes of 32), ctc_greedy, all-gather of hypotheses, text on host',
+            'value': round(total * 10.0 * steps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world, 'steps': steps,
+            'ms_per_step': round(dt * 1e3 / steps, 3), 'scaling': 'strong', 'transcripts': len(texts)}
+
+
+def extra_stream128(args, rank, world, local):
+    """configs[4]: conformer.yml streaming, 128 concurrent synthetic streams (128 / N sticky per GPU) fed 0.5 s (8000-sample)
+    int16 PCM chunks in lock-step through the REAL stream framing (StreamPool.feed / step: ragged fbank of the pending
+    samples, 67-frame windows, greedy history collapse); per-call latency p50 / p95 and aggregate audio-s/s"""
+    from masr_amd import parallel
+    from masr_amd.serving import StreamPool
+    from masr_amd.utils import synthetic
+    pred = facade('conformer', 'ctc_greedy', local)
+    pool = parallel.ShardedStreamPool(StreamPool(pred, max_frames_out=320))
+    n_streams, chunk, n_chunks = 128, 8000, 20
+    gids = [pool.open() for _ in range(n_streams)]
+    mine = pool.local_ids()
+    pcm = synthetic.synthetic_pcm(len(mine), chunk * n_chunks, seed=4321 + rank)
+    lat = []
+
+    def utterance(record):
+        for g in mine:
+            pool.reset(g)
+        for c in range(n_chunks):
+            t0 = time.perf_counter()
+            for j, g in enumerate(mine):
+                pool.feed(g, pcm[j, c * chunk:(c + 1) * chunk].tobytes(), is_end=(c == n_chunks - 1))
+            pool.step()
+            if record:
                 lat.append(time.perf_counter() - t0)
-        audio = ns * 15 * 0.64
-        desc = 'configs[4] shard: conformer.yml streaming, 16 concurrent streams per GPU in lock-step, 67-frame windows / 64 stride'
-    elif args.workload in ('deepspeech2_b1', 'deepspeech2_b32'):
-        # configs[0] is CPU plumbing in BASELINE.json; timed here on the GPU for DESIGN.md (bi-directional, one 8.39 s
-        # utterance the length of dataset/test.wav) and at batch 32 x 10 s
-        B = 1 if args.workload == 'deepspeech2_b1' else BATCH
-        ns = 134240 if B == 1 else N_SAMPLES
-        eng = HipEngine(synthetic.deepspeech2_state_dict(0, VOCAB, bidirectional=True), vocab_size=VOCAB, streaming=False,
-                        encoder_conf={'num_rnn_layers': 5, 'rnn_size': 1024}, use_model='deepspeech2', device=device)
-        pcm = torch.from_numpy(synthetic.synthetic_pcm(B, ns, seed=1234)).cuda()
-        n = torch.full((B,), ns, dtype=torch.int32, device='cuda')
-        step = lambda: eng.transcribe_batch(pcm, n)
-        audio = B * ns / 16000.0
-        desc = f'configs[0] on the GPU: deepspeech2.yml non-streaming (5 x bi-LSTM-1024), batch {B} x {ns / 16000:.2f} s, ctc_greedy'
-    else:
-        raise SystemExit(f'unknown workload {args.workload}')
-    for _ in range(args.warmup):
-        step()
+
+    utterance(False)
+    dt = parallel.timed_region(lambda i: utterance(True), 2, 0)
+    lat_all = parallel.gather_floats(lat)
+    pred.predictor.engine.close()
+    return {'workload': f'configs[4]: conformer.yml streaming chunk = 0.5 s online, 128 concurrent synthetic streams over {world} '
+                        f'GPU(s) ({len(mine)} per GPU, sticky), real predict_stream framing, ctc_greedy partials every call',
+            'value': round(n_streams * n_chunks * 0.5 * 2 / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world,
+            'call_latency_ms': {'p50': round(float(np.percentile(lat_all, 50)) * 1e3, 3),
+                                'p95': round(float(np.percentile(lat_all, 95)) * 1e3, 3), 'calls': len(lat_all),
+                                'note': 'one call = feed + step of all streams of a GPU for one 0.5 s chunk (python framing included)'}}
+
+
+def extra_squeezeformer_beam(args, rank, world, local, lm=True):
+    """configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances of 2-20 s (seed 1234) padded per length bucket,
+    ctc_beam_search (beam 300, cutoff_top_n 40, alpha 2.2 / beta 4.3 with a synthetic character n-gram LM when ``lm``)"""
+    from masr_amd.utils import synthetic
+    rng = np.random.default_rng(1234)
+    lens = np.sort(rng.integers(32000, 320001, 64).astype(np.int32))[::-1].copy()
+    pcm_h = synthetic.synthetic_pcm(64, int(lens.max()), seed=1234)
+    audio = [pcm_h[i, :lens[i]] for i in range(64)]
+    conf = {'alpha': 2.2 if lm else 0, 'beta': 4.3 if lm else 0, 'beam_size': 300, 'cutoff_prob': 0.99, 'cutoff_top_n': 40,
+            'num_processes': 10}
+    if lm:
+        from masr_amd.decoders.lm_scorer import write_synthetic_arpa
+        d = tempfile.mkdtemp(prefix='masr_lm_')
+        conf['language_model_path'] = write_synthetic_arpa(os.path.join(d, 'lm.arpa'), synthetic.synthetic_vocab(VOCAB), seed=5)
+    pred = facade('squeezeformer', 'ctc_beam_search', local, streaming=False, beam_conf=conf)
+    steps = 2
+    pred.predict_batch(audio, batch_size=32)
     torch.cuda.synchronize()
-    if args.workload == 'stream16':
-        lat.clear()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for _ in range(steps):
+        res = pred.predict_batch(audio, batch_size=32)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    res = {'workload': desc, 'value': round(audio * args.steps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1,
-           'steps': args.steps, 'ms_per_step': round(dt * 1e3 / args.steps, 3), 'dtype': 'f32', 'data': 'synthetic'}
-    if args.workload == 'stream16':
-        res['chunk_call_latency_ms'] = {'p50': round(float(np.percentile(lat, 50)) * 1e3, 3),
-                                        'p95': round(float(np.percentile(lat, 95)) * 1e3, 3), 'calls': len(lat)}
-    eng.close()
-    return res
+    total = float(lens.sum()) / 16000.0
+    pred.predictor.engine.close()
+    return {'workload': f'configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s), two '
+                        f'length buckets of 32, ctc_beam_search beam 300 / top-n 40, '
+                        + ('alpha 2.2 beta 4.3 with a synthetic 3-gram character LM scored on the GPU' if lm else 'LM-free'),
+            'value': round(total * steps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps,
+            'ms_per_step': round(dt * 1e3 / steps, 3), 'transcripts': len(res)}
+
+
+def run_extras(args, rank, world, local):
+    out = {}
+    jobs = [('efficient_b256', extra_efficient_b256), ('stream128', extra_stream128)]
+    if world == 1:
+        jobs.append(('squeezeformer_b64_beam', extra_squeezeformer_beam))
+    for name, fn in jobs:
+        try:
+            t0 = time.perf_counter()
+            out[name] = fn(args, rank, world, local)
+            log(f'rank {rank}: extra {name} done in {time.perf_counter() - t0:.1f} s')
+        except Exception as exc:                                        # noqa: BLE001  (the contract line must still print)
+            out[name] = {'error': f'{type(exc).__name__}: {exc}'}
+            log(f'rank {rank}: extra {name} FAILED: {exc}')
+            if world > 1:
+                raise            # a rank that dropped out of a collective cannot continue: fail the job loudly
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true')
     ap.add_argument('--workload', default='conformer_b32',
-                    help='conformer_b32 (BASELINE configs[1], the contract line) | squeezeformer_b64_beam (configs[2]) | '
-                         'efficient_b32 (configs[3] per-GPU shard) | stream16 (configs[4] per-GPU shard) | deepspeech2_b1 | deepspeech2_b32')
+                    help='conformer_b32 (BASELINE configs[1], the contract line, default) | efficient_b256 | stream128 | '
+                         'squeezeformer_b64_beam | squeezeformer_b64_beam_nolm  (one secondary workload only, own JSON line)')
     ap.add_argument('--profile-kind', type=int, default=2, help='kernel class timed with HIP events (2 = fused FFN)')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    import torch.distributed as dist
-    # MASR_BENCH_FORCE_DIST=1: take the RCCL path (init, all-gather, barriers, max over ranks) even with one rank --
-    # lets a 1-GPU box exercise the code the multi-GPU launch runs
-    force_dist = os.environ.get('MASR_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ
-    if world > 1 or force_dist:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    env_world = int(os.environ.get('WORLD_SIZE', '0'))
+    if env_world == 0 and args.gpus > 1:
+        sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
+    if env_world and env_world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks')
+    from masr_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))   # RCCL
-    n_gpus = world if world > 1 else 1
-    use_dist = world > 1 or force_dist
 
-    from masr_amd.engine import HipEngine, subsampled_len
-    from masr_amd.utils import synthetic
     if args.workload != 'conformer_b32':
+        fn = {'efficient_b256': extra_efficient_b256, 'stream128': extra_stream128,
+              'squeezeformer_b64_beam': extra_squeezeformer_beam,
+              'squeezeformer_b64_beam_nolm': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, lm=False)}[args.workload]
+        res = fn(args, rank, world, local)
         if rank == 0:
-            print(json.dumps(other_workload(args, local)), flush=True)
-        return
-    sd = synthetic.conformer_state_dict(0, VOCAB)
-    eng = HipEngine(sd, vocab_size=VOCAB, device=local)
-    pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234 + rank)).cuda()
-    n = torch.full((BATCH,), N_SAMPLES, dtype=torch.int32, device='cuda')
-    Tp = subsampled_len(1 + (N_SAMPLES - 400) // 160)
-    out = (torch.empty(BATCH, Tp, dtype=torch.int32, device='cuda'), torch.empty(BATCH, dtype=torch.int32, device='cuda'),
-           torch.empty(BATCH, dtype=torch.float32, device='cuda'))
-    gathered = torch.empty(world * BATCH, Tp, dtype=torch.int32, device='cuda') if use_dist else None
-
-    def step():
-        eng.transcribe_batch(pcm, n, out=out)
-        if use_dist:   # the only exchange step: hypotheses (token ids, -1 padded), ~32 KB per rank
-            dist.all_gather_into_tensor(gathered, out[0])
-
-    log(f'rank {rank}: engine ready, warmup {args.warmup}')
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    eng.profile_select(args.profile_kind)
-    eng.profile_read(reset=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    log(f'rank {rank}: timed region done: {dt * 1e3 / args.steps:.2f} ms/step')
-    prof_ms, prof_n, prof_flops = eng.profile_read(reset=True)
-    eng.profile_select(0)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if rank == 0:
-        audio_s = n_gpus * BATCH * (N_SAMPLES / 16000.0) * args.steps
-        roofline = None
-        if prof_n > 0 and prof_ms > 0:
-            achieved = prof_flops / (prof_ms * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'ffn_pc_kernel (LN + [B*T\',256]x[256,2048] + SiLU + x[2048,256] + residual)',
-                        'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': committed_traffic(),
-                        'traffic_note': 'HBM bytes per launch from committed PMC passes (profiles/r01_hbm_traffic.json); '
-                                        'algorithmic bytes per launch = 20.4 MB (x in/out + W1 + W2); measured = x in/out 16.3 MB + the 4.2 MB of weights '
-                                        'fetched once by each of the 8 XCD L2s (Infinity Cache hits after the first)',
-                        'launches': int(prof_n), 'avg_us': round(prof_ms * 1e3 / prof_n, 2),
-                        'flops_per_launch': prof_flops / prof_n}
-        res = {'metric': 'audio-seconds/sec (RTF^-1), conformer_streaming_fbank b32x10s, PCM->fbank->encoder->ctc_greedy',
-               'value': round(audio_s / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': n_gpus, 'steps': args.steps,
-               'warmup': args.warmup, 'ms_per_step': round(dt * 1e3 / args.steps, 3), 'higher_is_better': True,
-               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'configs[1]: conformer.yml streaming fbank, batch=32 synthetic 16 kHz 10 s '
-                                      'utterances per GPU, ctc_greedy, random-init weights V=4233',
-                          'global_batch': n_gpus * BATCH, 'audio_seconds_per_step': n_gpus * BATCH * 10.0,
-                          'parallelism': f'dp{n_gpus}', 'algorithmic_gflop_per_step_per_gpu': 742.0},
-               'roofline': roofline}
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(res), flush=True)
-    eng.close()
-    if use_dist:
-        dist.destroy_process_group()
+            print(json.dumps(dict(res, dtype='f32', data=data_tag()), ensure_ascii=False), flush=True)
+    else:
+        eng, res = run_contract(args, rank, world, local)
+        eng.close()
+        extra = None if args.no_extra else run_extras(args, rank, world, local)
+        if rank == 0:
+            if extra is not None:
+                res['extra'] = extra
+            if world == 1 and not args.no_cpu_baseline:
+                res['cpu_baseline'] = cpu_baseline()
+            print(json.dumps(res, ensure_ascii=False), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -69,10 +69,20 @@ int masr_finalize(masr_engine* e, void* stream);
  *   n_frames_dev [B] int32 (out, may be NULL)
  *   norm_pcm_dev [B, n_max] int16 (out, may be NULL): the normalised int16 samples (audio.py:549-574)
  *   gain_dev     [B] f32 (out, may be NULL): linear gain 10^(gain_dB/20) applied by normalize()
- *                (audio.py:256-264) -- lets the host mirror the reference's in-place mutation */
+ *                (audio.py:256-264) -- lets the host mirror the reference's in-place mutation
+ *   use_db_normalization  0 = off; 1 = gains computed on the device (every scalar step of rms_db / normalize / gain_db evaluated
+ *                in double and rounded once to float32); 2 = gains SUPPLIED in gain_dev (in): the caller evaluated
+ *                audio.py:287-304,519-529 with its own numpy on the mean square returned by masr_mean_square -- numpy's float32
+ *                log10 / power are not correctly rounded and differ between hosts, so this is the mode that reproduces the
+ *                reference's int16 samples bit for bit on the host it runs on.  Same meaning in masr_mfcc_batch / masr_linear_batch. */
 int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev,
                      int32_t B, int32_t n_max, int32_t use_db_normalization, float target_db, float* feats_dev,
                      int32_t* n_frames_dev, int16_t* norm_pcm_dev, float* gain_dev, void* stream);
+
+/* mean_square_dev[b] = float32 np.mean(samples ** 2) of utterance b in numpy's own summation order (8192-element buffered
+ * pairwise sums) -- the quantity AudioSegment.rms_db starts from (masr/data_utils/audio.py:519-529), bit-identical to numpy. */
+int masr_mean_square(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev, int32_t B,
+                     int32_t n_max, float* mean_square_dev, void* stream);
 
 /* MFCC front-end.  Replaces AudioFeaturizer._compute_mfcc (masr/data_utils/featurizer/audio_featurizer.py:98-117:
  * torchaudio.compliance.kaldi.mfcc(num_mel_bins=n_mels=80, num_ceps=n_mfcc, frame 25/10 ms, dither 0)) behind the same

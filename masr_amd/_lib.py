@@ -52,6 +52,7 @@ SIGNATURES = {
     'masr_gbeam_advance': [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P],
     'masr_gbeam_reset': [_P, _I],
     'masr_gbeam_close': [_P, _I],
+    'masr_mean_square': [_P, _P, _I, _P, _I, _I, _P, _P],
     'masr_mfcc_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     'masr_linear_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     'masr_transcribe_batch': [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],

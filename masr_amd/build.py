@@ -1,12 +1,21 @@
-"""Build libmasr_hip.so for gfx950 with hipcc (in-tree, no JIT cache)."""
+"""Build libmasr_hip.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+Every source is compiled to its own object (re-compiled only when it, a shared header or the public header is newer), the
+objects are compiled in parallel, and the link step runs when any object changed."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, 'csrc')
 LIB_DIR = os.path.join(ROOT, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmasr_hip.so')
-SOURCES = ['gemm_f32.hip', 'ffn_fused.hip', 'ffn_pc.hip', 'rowgemm.hip', 'rowgemm_small.hip', 'elementwise.hip', 'attention.hip', 'lstm.hip', 'beam_gpu.hip', 'fbank.hip', 'engine.hip', 'beam_search.cpp']
+SOURCES = ['gemm_f32.hip', 'ffn_reduce.hip', 'ffn_pc.hip', 'rowgemm.hip', 'rowgemm_small.hip', 'elementwise.hip',
+           'attention.hip', 'convchain.hip', 'lstm.hip', 'beam_gpu.hip', 'lm_scorer.cpp', 'fbank.hip', 'engine.hip',
+           'beam_search.cpp']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'lm_scorer.h'),
+           os.path.join(os.path.dirname(ROOT), 'include', 'masr_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value']
 
 
 def _hipcc():
@@ -16,13 +25,28 @@ def _hipcc():
     return 'hipcc'
 
 
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _obj(src):
+    return os.path.join(LIB_DIR, os.path.splitext(src)[0] + '.o')
+
+
+def _stale(src):
+    obj = _obj(src)
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, src)] + [h for h in HEADERS if os.path.exists(h)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(os.path.dirname(ROOT), 'include', 'masr_hip.h'))
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return any(_stale(s) or os.path.getmtime(_obj(s)) > t for s in _sources())
 
 
 def build(force=False, verbose=False):
@@ -30,21 +54,23 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + '.o')
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-c',
-               os.path.join(CSRC, src), '-o', obj]
+    todo = [s for s in _sources() if force or _stale(s)]
+
+    def compile_one(src):
+        cmd = [_hipcc()] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', _obj(src)]
         if verbose:
-            print(' '.join(cmd))
+            print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', LIB_PATH] + objs
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, os.cpu_count() or 1))) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', LIB_PATH] + [_obj(s) for s in _sources()]
     if verbose:
-        print(' '.join(cmd))
+        print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIB_PATH
 
 
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force='--force' in sys.argv, verbose=True))

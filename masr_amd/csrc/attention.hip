@@ -525,12 +525,8 @@ void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int head
     if (nseq <= 0 || max_nq <= 0 || group != 3) return;
     constexpr int DKG = 192, NW = 2;
     const size_t lds = (size_t)(3 * 32 * (DKG + 4) + 2 * DKG) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_grouped_kernel<DKG, NW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(attention_grouped_kernel<DKG, NW>), lds, attr);
     hipLaunchKernelGGL((attention_grouped_kernel<DKG, NW>), dim3((max_nq + 32 * NW - 1) / (32 * NW), heads, nseq),
                        dim3(64 * NW), lds, s, seqs, heads * DKG, ptab, t_true, bias_u, bias_v, 1.0f / sqrtf((float)DKG));
 }

@@ -468,11 +468,8 @@ size_t beam_gpu_lds_bytes(int beam, int K) {
 template <int NPT>
 static void launch_beam_t(const BeamGpuArgs& a, int B, size_t lds, hipStream_t s) {
     auto k = beam_search_kernel<NPT>;
-    static size_t attr = 0;
-    if (lds > attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, attr);
     hipLaunchKernelGGL(k, dim3(B), dim3(BS_THREADS), lds, s, a);
 }
 

@@ -9,6 +9,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace masr {
 
+// Opt-in to more than 64 KB of dynamic LDS for a kernel, checked and per device: `st` is the call site's table of the sizes
+// already granted on each device ordinal (one process may drive several GPUs).  A failing hipFuncSetAttribute is not silent: it is
+// recorded with note_launch_error() and the C ABI entry point that issued the launch returns it (engine.hip, LAUNCHCHK).
+struct LdsAttr {
+    size_t granted[32] = {};
+};
+void ensure_dynamic_lds(const void* fn, size_t bytes, LdsAttr& st);
+void note_launch_error(const char* what, hipError_t e);
+
 #ifdef __HIPCC__
 // Sum over the 64 lanes of a wave, result in every lane.  DPP row shifts / row broadcasts (a scan whose last lane holds the
 // total) + one readlane: ~10 VALU instructions.  __shfl_xor lowers to ds_bpermute_b32, i.e. six dependent LDS round trips
@@ -226,10 +235,13 @@ void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* l
 
 // ---- features ------------------------------------------------------------------------------
 size_t fbank_gain_scratch_floats(int B);   // size of gain_scratch ([B] gains + partial sums)
+// use_db: 0 = no dB normalisation, 1 = gains computed on the device, 2 = gains supplied in gain_scratch[0 .. B)
 void launch_fbank(const void* pcm, int sample_format /*0 int16, 1 float32*/, const int* nsamp, int B, int n_max,
                   int use_db, float target_db, const float* window, const float* melw, const int* mel_lo,
                   const int* mel_hi, const float* tw256, const float* tw512, float* feats, int T_max,
                   float* gain_scratch, int16_t* norm_out, hipStream_t s);
+void launch_mean_square(const void* pcm, int sample_format, const int* nsamp, int B, int n_max, float* gain_scratch,
+                        float* ms_out, hipStream_t s);
 void launch_mfcc(const float* fbank, long rows, int n_ceps, const float* dct /*[80][n_ceps]*/, const float* lifter, float* out,
                  hipStream_t s);
 void launch_linear_spec(const void* pcm, int sample_format, const int* nsamp, int B, int n_max, int use_db, const float* gain,

@@ -32,6 +32,39 @@ static int fail(const std::string& m) {
         if (_r) return _r;     \
     } while (0)
 
+// errors noted by the kernel launchers (a refused dynamic-LDS opt-in, ...) since the last check on this thread
+static thread_local std::string g_launch_err;
+namespace masr {
+void note_launch_error(const char* what, hipError_t e) {
+    if (g_launch_err.empty()) g_launch_err = std::string(what) + ": " + hipGetErrorString(e);
+}
+void ensure_dynamic_lds(const void* fn, size_t bytes, LdsAttr& st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (bytes <= st.granted[dev]) return;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        note_launch_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
+        return;
+    }
+    st.granted[dev] = bytes;
+}
+}  // namespace masr
+// after a group of launches: a launcher-side error first, then the runtime's sticky launch error
+#define LAUNCHCHK()                                     \
+    do {                                                \
+        if (!g_launch_err.empty()) {                    \
+            std::string _m = g_launch_err;              \
+            g_launch_err.clear();                       \
+            (void)hipGetLastError();                    \
+            return fail(_m);                            \
+        }                                               \
+        HIPCHK(hipGetLastError());                      \
+    } while (0)
+// every entry point that touches the device first makes the engine's GPU current on the calling thread (an engine on
+// device != 0 may be driven from a worker thread whose current device is still 0)
+#define ENTER(e) HIPCHK(hipSetDevice((e)->cfg.device_id))
+
 static int g_no_ffn_tail = 0;     // masr_debug_set key 8: 1 = the QKV projection as its own launch after the first FFN (A/B)
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
@@ -956,7 +989,7 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
         CHK(ffn(e, s, M, w.f2_s, w.f2_b, w.f2_w1, w.f2_b1, w.f2_w2, w.f2_b2, 1.0f, 1));
         launch_layernorm(x, w.ln4_w, w.ln4_b, i == L - 1 ? enc_out : x, M, 1e-5f, 0, 0, nullptr, s);
     }
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1034,7 +1067,7 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
         launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
     }
     launch_layernorm(x, e->after_w, e->after_b, enc_out, B * Tq, 1e-5f, 0, 0, nullptr, s);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1169,7 +1202,7 @@ static int ds2_forward(masr_engine* e, hipStream_t s, const float* feats, const 
         launch_layernorm_generic(e->rnn_out.as<float>(), w.ln_w, w.ln_b, out, M, D, 1e-5f, s);
         in = out;
     }
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     if (Tq_out) *Tq_out = Tq;
     return 0;
 }
@@ -1179,6 +1212,7 @@ extern "C" {
 int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat_lens_dev, int32_t B, int32_t T,
                      int32_t decoding_chunk_size, float* enc_out_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
+    ENTER(e);
     if (B <= 0) return fail("empty batch");
     hipStream_t s = (hipStream_t)stream;
     if (e->cfg.model_kind == 3) return ds2_forward(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev, nullptr, nullptr);
@@ -1228,7 +1262,7 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     }
     launch_layernorm(x, prev->ln_fin_w, prev->ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
     launch_layernorm(x, e->after_w, e->after_b, enc_out_dev, M, 1e-5f, 0, 0, nullptr, s);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1242,13 +1276,14 @@ static int ctc_head(masr_engine* e, const float* enc_dev, int M, float* probs_de
     }
     gemm(e, s, enc_dev, d, e->ctc_w, e->ctc_b, logits, V, M, V, d, ACT_NONE, 1.f, nullptr, 0);
     launch_softmax_argmax(logits, M, V, V, write_probs, argmax_dev, maxprob_dev, s);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
 int masr_ctc_probs(masr_engine* e, const float* enc_dev, int32_t M, float* probs_dev, int32_t* argmax_dev,
                    float* maxprob_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
+    ENTER(e);
     if (!probs_dev) return fail("probs_dev is null");
     if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
     return ctc_head(e, enc_dev, M, probs_dev, 1, argmax_dev, maxprob_dev, (hipStream_t)stream);
@@ -1257,12 +1292,13 @@ int masr_ctc_probs(masr_engine* e, const float* enc_dev, int32_t M, float* probs
 int masr_ctc_greedy_frames(masr_engine* e, const float* enc_dev, int32_t M, int32_t* argmax_dev, float* maxprob_dev,
                            void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
+    ENTER(e);
     if (e->cfg.model_kind == 3)      // K = 1024 / 2048 rows: generic GEMM + softmax statistics (logits stay in a workspace)
         return ctc_head(e, enc_dev, M, nullptr, 0, argmax_dev, maxprob_dev, (hipStream_t)stream);
     // fused: logits GEMM + online softmax statistics + argmax, nothing but (idx, prob) leaves the chip
     rowgemm(e, (hipStream_t)stream, RG_PRO_PLAIN, RG_EPI_CTC, enc_dev, e->cfg.d_model, nullptr, nullptr, e->ctc_w,
             e->ctc_b, nullptr, 0, M, e->cfg.vocab_size, nullptr, 0, 1.f, nullptr, 0, 0, 0, argmax_dev, maxprob_dev);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1270,28 +1306,31 @@ int masr_ctc_collapse(masr_engine* e, const int32_t* argmax_dev, const float* ma
                       int32_t B, int32_t Tp, int32_t blank, int32_t* tokens_dev, int32_t* n_tokens_dev,
                       float* score_dev, void* stream) {
     if (!e) return fail("null engine");
+    ENTER(e);
     launch_ctc_collapse(argmax_dev, maxprob_dev, n_frames_dev, B, Tp, blank, tokens_dev, n_tokens_dev, score_dev,
                         (hipStream_t)stream);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
 int masr_argmax_rows(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t* argmax_dev,
                      float* maxprob_dev, void* stream) {
     if (!e) return fail("null engine");
+    ENTER(e);
     if (V > 8192) return fail("V > 8192 not supported");
     launch_argmax_rows(probs_dev, M, V, argmax_dev, maxprob_dev, (hipStream_t)stream);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
 int masr_ctc_topk(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t top_n, float cutoff_prob,
                   int32_t* idx_dev, float* logp_dev, int32_t* count_dev, void* stream) {
     if (!e) return fail("null engine");
+    ENTER(e);
     if (V > 8192) return fail("V > 8192 not supported");
     if (top_n <= 0) return fail("top_n must be positive");
     launch_topk_prune(probs_dev, M, V, top_n, cutoff_prob, idx_dev, logp_dev, count_dev, (hipStream_t)stream);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1299,6 +1338,7 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
                          const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size, int32_t blank,
                          int32_t* tokens_dev, int32_t max_len, int32_t* len_dev, float* score_dev, void* stream) {
     if (!e) return fail("null engine");
+    ENTER(e);
     if (B <= 0 || T_stride <= 0) return fail("empty batch");
     if (e->cfg.vocab_size > 8192 && e->finalized) return fail("vocab_size > 8192 not supported");
     BeamGpuArgs a{};
@@ -1319,7 +1359,7 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
     a.prof = e->beam_prof;
     a.tokens = tokens_dev; a.len = len_dev; a.score = score_dev;
     if (launch_beam_search(a, B, (hipStream_t)stream)) return fail("beam search launch rejected the sizes");
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1335,6 +1375,7 @@ static void gbeam_args(GBeam& g, BeamGpuArgs& a) {
 
 int masr_gbeam_open(masr_engine* e, int32_t beam_size, int32_t blank, int32_t max_frames, int32_t* handle) {
     if (!e || !handle) return fail("null argument");
+    ENTER(e);
     if (beam_size < 1 || beam_size > 512) return fail("beam_size must be in [1, 512]");
     if (max_frames <= 0) max_frames = 5000;
     int id = -1;
@@ -1373,6 +1414,7 @@ int masr_gbeam_reset(masr_engine* e, int32_t handle) {
 int masr_gbeam_close(masr_engine* e, int32_t handle) {
     GBeam* g;
     CHK(gbeam_of(e, handle, &g));
+    ENTER(e);
     HIPCHK(hipDeviceSynchronize());
     g->pool.release();
     g->state.release();
@@ -1385,6 +1427,7 @@ int masr_gbeam_advance(masr_engine* e, int32_t handle, const int32_t* idx_dev, c
                        int32_t* len_dev, float* score_dev, void* stream) {
     GBeam* g;
     CHK(gbeam_of(e, handle, &g));
+    ENTER(e);
     if (T < 0 || K > 64 || beam_gpu_lds_bytes(g->beam, K) > 160 * 1024) return fail("unsupported chunk / cutoff_top_n");
     BeamGpuArgs a{};
     a.cidx = idx_dev; a.clp = logp_dev; a.ccount = count_dev; a.frames = nullptr;
@@ -1395,7 +1438,7 @@ int masr_gbeam_advance(masr_engine* e, int32_t handle, const int32_t* idx_dev, c
     a.tokens = tokens_dev; a.len = len_dev; a.score = score_dev;
     // (the kernel stops allocating trie nodes at the pool capacity; max_frames bounds the utterance length)
     if (launch_beam_search(a, 1, (hipStream_t)stream)) return fail("beam search launch rejected the sizes");
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     g->started = true;
     return 0;
 }
@@ -1404,20 +1447,37 @@ int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_for
                      int32_t B, int32_t n_max, int32_t use_db_normalization, float target_db, float* feats_dev,
                      int32_t* n_frames_dev, int16_t* norm_pcm_dev, float* gain_dev, void* stream) {
     if (!e) return fail("null engine");
+    ENTER(e);
     if (sample_format != 0 && sample_format != 1) return fail("sample_format must be 0 (int16) or 1 (float32)");
     hipStream_t s = (hipStream_t)stream;
     const int T_max = n_max >= 400 ? 1 + (n_max - 400) / 160 : 0;
     CHK(e->gain.ensure(sizeof(float) * fbank_gain_scratch_floats(B)));
     float* gain = e->gain.as<float>();
+    if (use_db_normalization == 2) {      // gains evaluated by the caller (masr_mean_square + the host's numpy, audio.py:287-304)
+        if (!gain_dev) return fail("use_db_normalization = 2 needs the gains in gain_dev");
+        HIPCHK(hipMemcpyAsync(gain, gain_dev, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    }
     {
         ProfScope ps(e, s, PROF_FBANK, 0.0);
         launch_fbank(samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, target_db, e->window,
                      e->melw, e->mel_lo, e->mel_hi, e->tw256, e->tw512, feats_dev, T_max, gain, norm_pcm_dev, s);
     }
-    if (gain_dev && use_db_normalization)
+    if (gain_dev && use_db_normalization == 1)
         HIPCHK(hipMemcpyAsync(gain_dev, gain, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     if (n_frames_dev) launch_frame_counts(n_samples_dev, B, n_frames_dev, nullptr, 0, s);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
+    return 0;
+}
+
+int masr_mean_square(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev, int32_t B,
+                     int32_t n_max, float* mean_square_dev, void* stream) {
+    if (!e || !mean_square_dev) return fail("null argument");
+    ENTER(e);
+    if (sample_format != 0 && sample_format != 1) return fail("sample_format must be 0 (int16) or 1 (float32)");
+    CHK(e->gain.ensure(sizeof(float) * fbank_gain_scratch_floats(B)));
+    launch_mean_square(samples_dev, sample_format, n_samples_dev, B, n_max, e->gain.as<float>(), mean_square_dev,
+                       (hipStream_t)stream);
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1428,6 +1488,7 @@ int masr_mfcc_batch(masr_engine* e, const void* samples_dev, int32_t sample_form
                     int32_t n_max, int32_t use_db_normalization, float target_db, int32_t n_ceps, float* mfcc_dev,
                     int32_t* n_frames_dev, float* gain_dev, void* stream) {
     if (!e) return fail("null engine");
+    ENTER(e);
     if (n_ceps <= 0 || n_ceps > 80) return fail("n_ceps must be in [1, 80] (num_ceps <= num_mel_bins)");
     hipStream_t s = (hipStream_t)stream;
     if (e->dct_ceps != n_ceps) {
@@ -1452,7 +1513,7 @@ int masr_mfcc_batch(masr_engine* e, const void* samples_dev, int32_t sample_form
     CHK(masr_fbank_batch(e, samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, target_db,
                          e->fb_scratch.as<float>(), n_frames_dev, nullptr, gain_dev, stream));
     launch_mfcc(e->fb_scratch.as<float>(), (long)B * T_max, n_ceps, e->dct, e->lifter, mfcc_dev, s);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1462,6 +1523,7 @@ int masr_linear_batch(masr_engine* e, const void* samples_dev, int32_t sample_fo
                       int32_t n_max, int32_t use_db_normalization, float target_db, float* feats_dev, int32_t* n_frames_dev,
                       float* gain_dev, void* stream) {
     if (!e) return fail("null engine");
+    ENTER(e);
     if (sample_format != 0 && sample_format != 1) return fail("sample_format must be 0 (int16) or 1 (float32)");
     hipStream_t s = (hipStream_t)stream;
     if (!e->lin_win) {
@@ -1480,15 +1542,18 @@ int masr_linear_batch(masr_engine* e, const void* samples_dev, int32_t sample_fo
     const int T_max = n_max >= 320 ? (n_max - 320) / 160 + 1 : 0;
     CHK(e->gain.ensure(sizeof(float) * fbank_gain_scratch_floats(B)));
     float* gain = e->gain.as<float>();
-    if (use_db_normalization)          // T_max = 0: only the RMS -> gain kernels of the fbank front-end run
+    if (use_db_normalization == 2) {
+        if (!gain_dev) return fail("use_db_normalization = 2 needs the gains in gain_dev");
+        HIPCHK(hipMemcpyAsync(gain, gain_dev, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    } else if (use_db_normalization)          // T_max = 0: only the RMS -> gain kernels of the fbank front-end run
         launch_fbank(samples_dev, sample_format, n_samples_dev, B, n_max, 1, target_db, e->window, e->melw, e->mel_lo, e->mel_hi,
                      e->tw256, e->tw512, nullptr, 0, gain, nullptr, s);
     launch_linear_spec(samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, gain, e->lin_win, e->lin_tw,
                        e->lin_scale, feats_dev, T_max, s);
-    if (gain_dev && use_db_normalization)
+    if (gain_dev && use_db_normalization == 1)
         HIPCHK(hipMemcpyAsync(gain_dev, gain, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     if (n_frames_dev) launch_linear_frame_counts(n_samples_dev, B, n_frames_dev, s);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1496,6 +1561,7 @@ int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t*
                           int32_t n_max, int32_t use_db_normalization, float target_db, int32_t decode_all_frames,
                           int32_t* tokens_dev, int32_t* n_tokens_dev, float* score_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
+    ENTER(e);
     if (n_max < 400) return fail("n_max < 400 samples: no frame");
     hipStream_t s = (hipStream_t)stream;
     const int d = enc_dim(e), F = e->cfg.n_mels;
@@ -1524,6 +1590,7 @@ int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t*
 
 int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id) {
     if (!e || !e->finalized) return fail("engine not finalized");
+    ENTER(e);
     if (e->cfg.model_kind == 3) {
         if (!e->cfg.causal) return fail("deepspeech2: streaming needs the uni-directional model");
     } else if (!e->cfg.causal) {
@@ -1573,6 +1640,7 @@ static int stream_of(masr_engine* e, int id, Stream** out) {
 int masr_stream_reset(masr_engine* e, int32_t stream_id) {
     Stream* st;
     CHK(stream_of(e, stream_id, &st));
+    ENTER(e);
     const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(st->cnn.p, 0, (e->cfg.model_kind == 3 ? (size_t)L * 2 * d : (size_t)L * pad * d) * sizeof(float)));
@@ -1585,6 +1653,7 @@ int masr_stream_reset(masr_engine* e, int32_t stream_id) {
 int masr_stream_close(masr_engine* e, int32_t stream_id) {
     Stream* st;
     CHK(stream_of(e, stream_id, &st));
+    ENTER(e);
     HIPCHK(hipDeviceSynchronize());
     st->att.release();
     st->cnn.release();
@@ -1836,6 +1905,7 @@ extern "C" {
 int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, const float* feats_dev, int32_t Tc,
                       float* probs_dev, int32_t* argmax_dev, float* maxprob_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
+    ENTER(e);
     if (n <= 0) return fail("no streams");
     hipStream_t s = (hipStream_t)stream;
     const int d = e->cfg.d_model, H = e->cfg.heads, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
@@ -1921,6 +1991,7 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
 int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, float* cnn_dev, void* stream) {
     Stream* st;
     CHK(stream_of(e, stream_id, &st));
+    ENTER(e);
     hipStream_t s = (hipStream_t)stream;
     const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1, H = e->cfg.heads;
     if (e->cfg.model_kind == 3) {       // att_dev <- h [L][rnn_size], cnn_dev <- c [L][rnn_size]
@@ -1959,7 +2030,7 @@ int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, 
     } else if (cnn_dev) {
         launch_export_cnn(st->cnn.as<float>(), cnn_dev, L, pad, d, s);
     }
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -1968,17 +2039,19 @@ int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, 
 int masr_op_layernorm(masr_engine* e, const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev,
                       int32_t M, float eps, void* stream) {
     if (!e) return fail("null engine");
+    ENTER(e);
     launch_layernorm(x_dev, w_dev, b_dev, y_dev, M, eps, 0, 0, nullptr, (hipStream_t)stream);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
 int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
                  float* c_dev, int32_t M, int32_t N, int32_t K, int32_t act, float alpha, void* stream) {
     if (!e) return fail("null engine");
+    ENTER(e);
     if (K % 32) return fail("K must be a multiple of 32");
     gemm(e, (hipStream_t)stream, a_dev, K, w_dev, bias_dev, c_dev, N, M, N, K, act, alpha, res_dev, N);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK();
     return 0;
 }
 
@@ -2017,6 +2090,7 @@ int masr_profile_select(masr_engine* e, int32_t kind) {
 
 int masr_profile_read(masr_engine* e, double* total_ms, int64_t* launches, double* flops, int32_t reset) {
     if (!e) return fail("null engine");
+    ENTER(e);
     double tot = 0.0;
     for (size_t i = 0; i < e->prof_used; ++i) {
         HIPCHK(hipEventSynchronize(e->prof_events[i].second));

@@ -179,8 +179,11 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__
 }
 
 // pass 2: sequential float32 accumulation of the chunk sums (numpy's buffered reduction) + the gain
+// ms_out (optional): the float32 mean square itself == np.mean(samples ** 2) of audio.py:524, bit for bit -- lets the host
+// evaluate the reference's scalar numpy expressions (log10 / power in float32, not correctly rounded and machine dependent)
+// on its own numpy and hand the gain back (use_db == 2)
 __global__ void rms_final_kernel(const int* __restrict__ nsamp, int B, float target_db,
-                                 const float* __restrict__ chunk_sum, float* __restrict__ gain) {
+                                 const float* __restrict__ chunk_sum, float* __restrict__ gain, float* __restrict__ ms_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int n = min(nsamp[b], NP_BUF * MAX_CHUNKS);
@@ -190,6 +193,7 @@ __global__ void rms_final_kernel(const int* __restrict__ nsamp, int B, float tar
     for (int c = 0; c < nc; ++c) tot = __fadd_rn(tot, cs[c]);
     if (tail > 0) tot = __fadd_rn(tot, cs[MAX_CHUNKS]);
     float ms = n > 0 ? __fdiv_rn(tot, (float)n) : 0.f;
+    if (ms_out) ms_out[b] = ms;
     if (ms == 0.f || !(ms == ms)) ms = 1.f;
     // float32 scalar arithmetic of rms_db / normalize / gain_db (numpy >= 2 promotion): each
     // step is evaluated in double and rounded once to float32
@@ -344,13 +348,13 @@ static void launch_fbank_t(const ST* pcm, const int* nsamp, int B, int n_max, in
                            const float* window, const float* melw, const int* mel_lo, const int* mel_hi,
                            const float* tw256, const float* tw512, float* feats, int T_max, float* gain_scratch,
                            int16_t* norm_out, hipStream_t s) {
-    if (use_db) {
+    if (use_db == 1) {       // (use_db == 2: the caller has already put its own gains into gain_scratch[0 .. B))
         // gain_scratch: [B] gains followed by [B][MAX_CHUNKS + 1] chunk sums
         float* chunk_sum = gain_scratch + B;
         const int nblk = (std::min(n_max / NP_BUF, MAX_CHUNKS) + 3) / 4 + 1;
         hipLaunchKernelGGL(rms_partial_kernel<ST>, dim3(nblk, B), dim3(256), 0, s, pcm, nsamp, n_max, chunk_sum);
         hipLaunchKernelGGL(rms_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, nsamp, B, target_db, chunk_sum,
-                           gain_scratch);
+                           gain_scratch, (float*)nullptr);
     }
     if (norm_out)
         hipLaunchKernelGGL(norm_int16_kernel<ST>, dim3((n_max + 255) / 256, B), dim3(256), 0, s, pcm, nsamp, n_max,
@@ -358,6 +362,19 @@ static void launch_fbank_t(const ST* pcm, const int* nsamp, int B, int n_max, in
     if (T_max > 0)
         hipLaunchKernelGGL(fbank_kernel<ST>, dim3((T_max + 3) / 4, B), dim3(256), 0, s, pcm, nsamp, n_max, use_db,
                            gain_scratch, window, melw, mel_lo, mel_hi, tw256, tw512, feats, T_max);
+}
+
+// ms_out[b] = float32 np.mean(samples ** 2) of utterance b (numpy's summation order); gain_scratch as in launch_fbank
+void launch_mean_square(const void* pcm, int sample_format, const int* nsamp, int B, int n_max, float* gain_scratch,
+                        float* ms_out, hipStream_t s) {
+    if (B <= 0) return;
+    float* chunk_sum = gain_scratch + B;
+    const int nblk = (std::min(n_max / NP_BUF, MAX_CHUNKS) + 3) / 4 + 1;
+    if (sample_format == 0)
+        hipLaunchKernelGGL(rms_partial_kernel<int16_t>, dim3(nblk, B), dim3(256), 0, s, (const int16_t*)pcm, nsamp, n_max, chunk_sum);
+    else
+        hipLaunchKernelGGL(rms_partial_kernel<float>, dim3(nblk, B), dim3(256), 0, s, (const float*)pcm, nsamp, n_max, chunk_sum);
+    hipLaunchKernelGGL(rms_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, nsamp, B, -20.f, chunk_sum, gain_scratch, ms_out);
 }
 
 void launch_fbank(const void* pcm, int sample_format, const int* nsamp, int B, int n_max, int use_db, float target_db,

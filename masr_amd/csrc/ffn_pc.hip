@@ -357,16 +357,10 @@ static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float
                        const float* b2, int M, int dff, float eps, float scale, float* partial, int nsplit, hipStream_t s,
                        const FfnPostLn* post, const FfnTail* tail) {
     const size_t lds = (size_t)(PC_BM * PC_XLD + 2 * PC_BM * PC_HLD + 8 * 2 * PC_WSLAB) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 0, VAR, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, 0, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, 0, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static LdsAttr attr_full, attr_split, attr_tail;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 0, VAR, 0>), lds, attr_full);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, 0, 0>), lds, attr_split);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, 0, 1>), lds, attr_tail);
     const int nchunk = dff / PC_CH;
     if (partial && nsplit > 1) {
         const int cpb = (nchunk + nsplit - 1) / nsplit;

@@ -209,11 +209,8 @@ static void launch_t(const GemmArgs& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDP * sizeof(float);
     auto k = gemm_f32_kernel<BM, BN, WM, WN, AMODE, EPI>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, attr);
     hipLaunchKernelGGL(k, dim3(nbm * nbn, EPI == EPI_SPLITK ? a.nsplit : 1), dim3(256), lds, s, a);
 }
 

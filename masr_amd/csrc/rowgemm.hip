@@ -390,15 +390,9 @@ template <int PRO, int EPI>
 static void launch_rg(const RowGemmArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(RG_BM * RG_ALD + 8 * 2 * RG_WSLAB + (EPI == RG_EPI_CHAIN ? RG_BM * RG_ALD : 8 * RG_BM * 3)) * sizeof(float);
     constexpr bool can_split = EPI == RG_EPI_STORE || EPI == RG_EPI_RESID;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_kernel<PRO, EPI, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (can_split)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm_kernel<PRO, EPI, can_split ? 1 : 0>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static LdsAttr attr0, attr1;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(rowgemm_kernel<PRO, EPI, 0>), lds, attr0);
+    if (can_split) ensure_dynamic_lds(reinterpret_cast<const void*>(rowgemm_kernel<PRO, EPI, can_split ? 1 : 0>), lds, attr1);
     const int rowblocks = (a.M + RG_BM - 1) / RG_BM, ngroups = (a.N + 255) / 256;
     if (EPI != RG_EPI_CTC && a.N % 256 != 0) {
         fprintf(stderr, "rowgemm: N must be a multiple of 256 for this epilogue\n");

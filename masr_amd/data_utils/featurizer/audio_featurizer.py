@@ -48,20 +48,19 @@ class AudioFeaturizer(object):
             return np.zeros((0, self.feature_dim), np.float32)
         xs = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None].to(eng.device)
         ns = torch.tensor([n], dtype=torch.int32, device=eng.device)
-        feats, frames, gain = eng.features_batch(self._feature_method, xs, ns, self._use_dB_normalization, self._target_dB,
-                                                 n_mfcc=self._n_mfcc, return_gain=True)
+        # the gain is evaluated with the reference's own numpy expressions on this host (engine.reference_gains; raises beyond
+        # max_gain_db like AudioSegment.normalize), the samples are scaled by it on the device
+        gain = eng.host_gains(xs, ns, self._target_dB) if self._use_dB_normalization else None
+        feats, frames = eng.features_batch(self._feature_method, xs, ns, self._use_dB_normalization, self._target_dB,
+                                           n_mfcc=self._n_mfcc, gain_in=gain)
         if self._use_dB_normalization:
-            g = float(gain[0])
-            if not np.isfinite(g) or 20.0 * np.log10(max(g, 1e-300)) > 300.0:
-                raise ValueError(f"无法将段规范化到{self._target_dB}dB，音频增益已经超过max_gain_db (300dB)")
-            audio_segment.gain_linear(g)          # the reference normalises in place (audio.py:304)
+            audio_segment.gain_linear(float(gain[0]))          # the reference normalises in place (audio.py:304)
         return feats[0].cpu().numpy()
 
     def _normalize_only(self, eng, seg):
         xs = torch.from_numpy(np.ascontiguousarray(seg._samples, dtype=np.float32))[None].to(eng.device)
         ns = torch.tensor([xs.shape[1]], dtype=torch.int32, device=eng.device)
-        _, _, gain = eng.fbank_batch(xs, ns, True, self._target_dB, return_gain=True)
-        seg.gain_linear(float(gain[0]))
+        seg.gain_linear(float(eng.host_gains(xs, ns, self._target_dB)[0]))
 
     @property
     def feature_method(self):

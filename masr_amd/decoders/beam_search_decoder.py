@@ -31,6 +31,7 @@ class BeamSearchDecoder:
         self.use_gpu_search = True       # False: prefix search on host threads (masr_beam_search_batch)
         self._gstream = None             # device-resident streaming search (masr_gbeam_*), opened on first use
         self._gout = None
+        self.last_tokens = []            # token ids of the last decode_chunk result
         if alpha or beta:
             logger.warning('masr_amd BeamSearchDecoder: the external language-model scorer is not implemented; '
                            'decoding with the acoustic CTC scores only (alpha = beta = 0)')
@@ -40,11 +41,30 @@ class BeamSearchDecoder:
             raise _lib.MasrError('masr_beam_create failed')
         self._stream = h
 
+    def fork(self):
+        """a decoder with the same configuration (and the same language model tables) but its own streaming search state --
+        one per concurrent ``predict_stream`` session (serving.StreamPool)"""
+        other = object.__new__(BeamSearchDecoder)
+        other.__dict__.update(self.__dict__)
+        other._gstream, other._gout, other.last_tokens = None, None, []
+        h = C.c_void_p()
+        if self._lib.masr_beam_create(self.beam_size, self.blank_id, C.byref(h)) != 0:
+            raise _lib.MasrError('masr_beam_create failed')
+        other._stream = h
+        return other
+
+    def close(self):
+        """release the streaming search state (host trie + device-resident beam)"""
+        if getattr(self, '_gstream', None) is not None:
+            check(self._lib.masr_gbeam_close(runtime.aux_engine().h, self._gstream))
+            self._gstream = None
+        if getattr(self, '_stream', None):
+            self._lib.masr_beam_destroy(self._stream)
+            self._stream = None
+
     def __del__(self):
         try:
-            if getattr(self, '_stream', None):
-                self._lib.masr_beam_destroy(self._stream)
-                self._stream = None
+            self.close()
         except Exception:
             pass
 
@@ -92,7 +112,7 @@ class BeamSearchDecoder:
         toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
         return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(len(lens))]
 
-    def _batch(self, probs_list, defer=False):
+    def _batch(self, probs_list, defer=False, want_tokens=False):
         """``defer=True`` (device-resident probabilities, GPU search): launch pruning + search on the current torch stream and
         return a handle for ``_batch_collect`` without synchronising -- lets the caller run the search of one sub-batch on a
         side stream while the encoder works on the next one (the search occupies one workgroup per utterance)."""
@@ -123,6 +143,8 @@ class BeamSearchDecoder:
             if defer:                      # nothing has been synchronised: _batch_collect() fetches the result later
                 return ('gpu', toks, lens, scores, (stacked, idx, logp, cnt, fr))
             toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
+            if want_tokens:          # (token ids, score): what a multi-GPU caller gathers instead of text
+                return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(B)]
             return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(B)]
         if defer:
             raise Exception('deferred batch search needs the GPU search (device-resident probabilities within its limits)')
@@ -137,12 +159,15 @@ class BeamSearchDecoder:
                                               scores.ctypes.data_as(C.c_void_p))
         if rc != 0:
             raise _lib.MasrError('masr_beam_search_batch failed')
+        if want_tokens:
+            return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(B)]
         return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(B)]
 
     def decode_chunk(self, probs, logits_lens):
         """streaming: feed a chunk probs [1, T, V]; returns (score, text) of the best prefix so far
         (beam_search_decoder.py:75-91)."""
-        p = np.asarray(probs)[0][:int(np.asarray(logits_lens).reshape(-1)[0])]
+        n_valid = int(np.asarray(logits_lens).reshape(-1)[0])
+        p = probs[0][:n_valid] if torch.is_tensor(probs) else np.asarray(probs)[0][:n_valid]     # device tensors stay there
         if self.use_gpu_search and self.gpu_search_supported(1, p.shape[1]):
             return self._decode_chunk_gpu(p)
         idx, logp, cnt, K = self._candidates(p)
@@ -152,6 +177,7 @@ class BeamSearchDecoder:
         toks = np.zeros(4096, np.int32)
         n, sc = C.c_int32(), C.c_float()
         self._lib.masr_beam_result(self._stream, toks.ctypes.data_as(C.c_void_p), 4096, C.byref(n), C.byref(sc))
+        self.last_tokens = toks[:n.value].tolist()
         return float(sc.value), self._text(toks[:n.value])
 
     def _decode_chunk_gpu(self, p):
@@ -174,7 +200,8 @@ class BeamSearchDecoder:
                                            C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         n = int(lens.item())
-        return float(scores.item()), self._text(toks[0, :n].cpu().numpy())
+        self.last_tokens = toks[0, :n].cpu().numpy().tolist()
+        return float(scores.item()), self._text(self.last_tokens)
 
     def reset_decoder(self):
         """beam_search_decoder.py:93-96."""

@@ -32,6 +32,49 @@ def subsampled_len(t):
     return ((t - 1) // 2 - 1) // 2
 
 
+def reference_gains(mean_square, target_db, max_gain_db=300.0):
+    """float32 mean squares [B] -> linear gains [B] with the reference's own scalar expressions, verbatim in numpy on this host:
+    ``rms_db = 10 * np.log10(mean_square)`` (audio.py:524-529), ``gain = target_db - rms_db`` and the max_gain_db check
+    (:300-304), ``samples *= 10. ** (gain / 20.)`` (:256-264)."""
+    out = np.empty(len(mean_square), np.float32)
+    for i, ms in enumerate(np.asarray(mean_square, np.float32)):
+        if ms == 0 or ms != ms:
+            ms = 1
+        rms_db = 10 * np.log10(ms)
+        gain = target_db - rms_db
+        if gain > max_gain_db:
+            raise ValueError(f"无法将段规范化到{target_db}dB，音频增益{gain}增益已经超过max_gain_db ({max_gain_db}dB)")
+        out[i] = 10. ** (min(max_gain_db, gain) / 20.)
+    return out
+
+
+def _validate_encoder_conf(use_model, enc, state_dict):
+    """The kernels implement exactly the module variants the shipped YAMLs select; anything else must fail here instead of
+    loading cleanly into the wrong arithmetic (e.g. ``cnn_module_norm: batch_norm`` has LayerNorm-shaped ``norm.weight``)."""
+    def want(key, allowed, default):
+        v = enc.get(key, default)
+        if v not in allowed:
+            raise _lib.MasrError(f'{use_model}: encoder_conf.{key}={v!r} is not implemented (supported: {allowed})')
+    if use_model in ('conformer', 'efficient_conformer'):
+        want('cnn_module_norm', ('layer_norm',), 'layer_norm')
+        want('activation_type', ('swish',), 'swish')
+        want('normalize_before', (True,), True)
+        want('use_cnn_module', (True,), True)
+        want('macaron_style', (True,), True)
+        want('input_layer', ('conv2d',), 'conv2d')
+        want('pos_enc_layer_type', ('rel_pos',), 'rel_pos')
+        if state_dict is not None and any(k.endswith('conv_module.norm.running_mean') for k in state_dict):
+            raise _lib.MasrError(f'{use_model}: the checkpoint holds BatchNorm statistics (conv_module.norm.running_mean): '
+                                 f'cnn_module_norm=batch_norm is not implemented on this path')
+    elif use_model == 'squeezeformer':
+        want('cnn_norm_type', ('batch_norm',), 'batch_norm')
+        want('activation_type', ('swish',), 'swish')
+        want('normalize_before', (False,), False)
+        want('pos_enc_layer_type', ('rel_pos',), 'rel_pos')
+        want('adaptive_scale', (True,), True)
+        want('dw_stride', (False,), False)
+
+
 class HipEngine:
     """One engine per GPU rank.  ``state_dict`` uses the reference key names
     (``encoder.*`` / ``ctc.*``; extra keys are ignored); ``state_dict=None`` gives a weight-less
@@ -48,6 +91,7 @@ class HipEngine:
             vocab_size = int(state_dict[ctc_key].shape[0]) if state_dict is not None else 1
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
+        _validate_encoder_conf(use_model, enc, state_dict)
         if use_model == 'conformer':
             cfg = MasrConfig(model_kind=0, d_model=int(enc.get('output_size', 256)),
                              heads=int(enc.get('attention_heads', 4)), d_ff=int(enc.get('linear_units', 2048)),
@@ -74,7 +118,9 @@ class HipEngine:
             stride_idx = eff.get('stride_layer_idx', [3])
             stride_idx = stride_idx if isinstance(stride_idx, (list, tuple)) else [stride_idx]
             groups = list(eff.get('group_layer_idx', [0, 1, 2, 3]))
-            if len(stride_idx) != 1 or list(eff.get('stride', [2])) not in ([2], 2) or groups != list(range(len(groups))):
+            stride = eff.get('stride', [2])
+            stride = list(stride) if isinstance(stride, (list, tuple)) else [stride]
+            if len(stride_idx) != 1 or stride != [2] or groups != list(range(len(groups))):
                 raise _lib.MasrError('efficient_conformer: only one stride-2 layer and leading grouped layers are supported')
             cfg = MasrConfig(model_kind=2, d_model=int(enc.get('output_size', 256)),
                              heads=int(enc.get('attention_heads', 4)), d_ff=int(enc.get('linear_units', 2048)),
@@ -133,19 +179,43 @@ class HipEngine:
             pass
 
     # ---- features -------------------------------------------------------------------------------
+    def mean_square(self, samples, n_samples):
+        """float32 ``np.mean(samples ** 2)`` per utterance in numpy's summation order (audio.py:524) -> [B] f32 (device)"""
+        B, n_max = samples.shape
+        fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
+        ms = torch.empty(B, dtype=torch.float32, device=self.device)
+        check(self.lib.masr_mean_square(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max, _ptr(ms), _stream()))
+        return ms
+
+    def host_gains(self, samples, n_samples, target_db, max_gain_db=300.0):
+        """The reference's normalisation gain evaluated where the reference evaluates it: the mean square comes from the
+        device (bit-identical to numpy's), the scalar float32 expressions of ``rms_db`` / ``normalize`` / ``gain_db``
+        (audio.py:256-264,287-304,519-529) run on THIS host's numpy, whose float32 log10 / power are not correctly rounded
+        and differ between machines.  Returns linear gains [B] f32 (device); raises like ``normalize`` beyond max_gain_db."""
+        return torch.from_numpy(reference_gains(self.mean_square(samples, n_samples).cpu().numpy(), target_db,
+                                                max_gain_db)).to(self.device)
+
+    def _db_mode(self, use_db_normalization, gain_in, B, return_gain):
+        """-> (mode for the C ABI, gain tensor): 0 off / 1 device gains (returned in the tensor when asked) / 2 supplied gains"""
+        if use_db_normalization and gain_in is not None:
+            return 2, gain_in.to(device=self.device, dtype=torch.float32).contiguous().clone()
+        gain = torch.ones(B, dtype=torch.float32, device=self.device) if return_gain else None
+        return (1 if use_db_normalization else 0), gain
+
     def fbank_batch(self, samples, n_samples, use_db_normalization=True, target_db=-20.0, return_norm=False,
-                    return_gain=False):
+                    return_gain=False, gain_in=None):
         """samples int16 PCM or float32 [B, n_max] (device), n_samples int32 [B] (device)
-        -> feats [B,T,80], frames [B] (+ normalised int16 samples, + linear gains)."""
+        -> feats [B,T,80], frames [B] (+ normalised int16 samples, + linear gains).  ``gain_in`` [B]: linear gains supplied
+        by the caller (``host_gains``) instead of the device's own evaluation."""
         B, n_max = samples.shape
         fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
         T = 1 + (n_max - 400) // 160 if n_max >= 400 else 0
         feats = torch.empty(B, T, 80, dtype=torch.float32, device=self.device)
         frames = torch.empty(B, dtype=torch.int32, device=self.device)
         norm = torch.empty(B, n_max, dtype=torch.int16, device=self.device) if return_norm else None
-        gain = torch.ones(B, dtype=torch.float32, device=self.device) if return_gain else None
+        mode, gain = self._db_mode(use_db_normalization, gain_in, B, return_gain)
         check(self.lib.masr_fbank_batch(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max,
-                                        1 if use_db_normalization else 0, float(target_db), _ptr(feats), _ptr(frames),
+                                        mode, float(target_db), _ptr(feats), _ptr(frames),
                                         _ptr(norm), _ptr(gain), _stream()))
         res = [feats, frames]
         if return_norm:
@@ -154,40 +224,44 @@ class HipEngine:
             res.append(gain)
         return tuple(res)
 
-    def mfcc_batch(self, samples, n_samples, n_mfcc=40, use_db_normalization=True, target_db=-20.0, return_gain=False):
+    def mfcc_batch(self, samples, n_samples, n_mfcc=40, use_db_normalization=True, target_db=-20.0, return_gain=False,
+                   gain_in=None):
         """kaldi.mfcc(num_mel_bins=80, num_ceps=n_mfcc) for a padded batch -> feats [B,T,n_mfcc], frames [B] (+ gains)."""
         B, n_max = samples.shape
         fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
         T = 1 + (n_max - 400) // 160 if n_max >= 400 else 0
         feats = torch.empty(B, T, int(n_mfcc), dtype=torch.float32, device=self.device)
         frames = torch.empty(B, dtype=torch.int32, device=self.device)
-        gain = torch.ones(B, dtype=torch.float32, device=self.device) if return_gain else None
-        check(self.lib.masr_mfcc_batch(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max, 1 if use_db_normalization else 0,
+        mode, gain = self._db_mode(use_db_normalization, gain_in, B, return_gain)
+        check(self.lib.masr_mfcc_batch(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max, mode,
                                        float(target_db), int(n_mfcc), _ptr(feats), _ptr(frames), _ptr(gain), _stream()))
         return (feats, frames, gain) if return_gain else (feats, frames)
 
-    def linear_batch(self, samples, n_samples, use_db_normalization=True, target_db=-20.0, return_gain=False):
+    def linear_batch(self, samples, n_samples, use_db_normalization=True, target_db=-20.0, return_gain=False, gain_in=None):
         """linear log power spectrogram (20 ms / 10 ms, 161 bins) for a padded batch -> feats [B,T,161], frames [B]."""
         B, n_max = samples.shape
         fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
         T = (n_max - 320) // 160 + 1 if n_max >= 320 else 0
         feats = torch.empty(B, T, 161, dtype=torch.float32, device=self.device)
         frames = torch.empty(B, dtype=torch.int32, device=self.device)
-        gain = torch.ones(B, dtype=torch.float32, device=self.device) if return_gain else None
+        mode, gain = self._db_mode(use_db_normalization, gain_in, B, return_gain)
         check(self.lib.masr_linear_batch(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max,
-                                         1 if use_db_normalization else 0, float(target_db), _ptr(feats), _ptr(frames),
+                                         mode, float(target_db), _ptr(feats), _ptr(frames),
                                          _ptr(gain), _stream()))
         return (feats, frames, gain) if return_gain else (feats, frames)
 
     def features_batch(self, method, samples, n_samples, use_db_normalization=True, target_db=-20.0, n_mfcc=40,
-                       return_gain=False):
+                       return_gain=False, gain_in=None):
         """dispatch on the reference's ``feature_method`` (audio_featurizer.py:51-69)"""
         if method == 'fbank':
-            return self.fbank_batch(samples, n_samples, use_db_normalization, target_db, return_gain=return_gain)
+            return self.fbank_batch(samples, n_samples, use_db_normalization, target_db, return_gain=return_gain,
+                                    gain_in=gain_in)
         if method == 'mfcc':
-            return self.mfcc_batch(samples, n_samples, n_mfcc, use_db_normalization, target_db, return_gain=return_gain)
+            return self.mfcc_batch(samples, n_samples, n_mfcc, use_db_normalization, target_db, return_gain=return_gain,
+                                   gain_in=gain_in)
         if method == 'linear':
-            return self.linear_batch(samples, n_samples, use_db_normalization, target_db, return_gain=return_gain)
+            return self.linear_batch(samples, n_samples, use_db_normalization, target_db, return_gain=return_gain,
+                                     gain_in=gain_in)
         raise Exception('没有{}预处理方法'.format(method))
 
     # ---- encoder ----------------------------------------------------------------------------------
@@ -204,6 +278,13 @@ class HipEngine:
         """encoder output frames for T feature frames (the Efficient Conformer halves the rate once more)."""
         Tp = subsampled_len(T)
         return (Tp + 1) // 2 if getattr(self, 'use_model', 'conformer') == 'efficient_conformer' else Tp
+
+    def enc_frames(self, feat_frames):
+        """valid encoder frames per utterance for its feature frames (tensor or array; mirrors launch_frame_counts in
+        elementwise.hip: Conv2dSubsampling4, once more halved with ceil by the Efficient Conformer's stride layer)."""
+        n4 = ((feat_frames - 1) // 2 - 1) // 2
+        n4 = n4.clamp(min=0) if torch.is_tensor(n4) else np.maximum(n4, 0)
+        return (n4 + 1) // 2 if self.use_model == 'efficient_conformer' else n4
 
     def ctc_probs(self, enc, want_argmax=False):
         M = enc.numel() // self.enc_dim

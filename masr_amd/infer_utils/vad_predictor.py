@@ -70,8 +70,9 @@ class EnergyVAD(object):
             lo = 0 if k == 0 else (regions[k - 1][1] + s) // 2
             hi = total if k == len(regions) - 1 else (e + regions[k + 1][0]) // 2
             s, e = max(lo, s - pad), min(hi, e + pad)
-            while e - s > max_len:                            # the encoder's positional table is finite: cap the segment length
-                out.append({'start': int(s), 'end': int(s + max_len)})
-                s += max_len
-            out.append({'start': int(s), 'end': int(e)})
+            # the encoder's positional table is finite: cap the segment length -- cut an over-long region into equal pieces
+            # (never a full-length piece plus a remainder too short to recognise)
+            pieces = max(1, -(-(e - s) // max_len))
+            edges = [s + (e - s) * k // pieces for k in range(pieces + 1)]
+            out.extend({'start': int(a), 'end': int(b)} for a, b in zip(edges, edges[1:]))
         return out

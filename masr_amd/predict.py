@@ -1,11 +1,17 @@
 """MASRPredictor -- the reference facade (masr/predict.py) on the MI355X engine.
 
-Same constructor and ``predict`` / ``predict_stream`` / ``reset_stream`` contract
-(predict.py:20-26,167-171,237-244,346); the three hot components are the HIP-backed mirrors:
-AudioFeaturizer (fbank), InferencePredictor (Conformer encoder + CTC head) and the greedy
-decoders.  ``predict_batch`` is an addition: the whole PCM -> text path for a padded batch in one
-device call (no host round trip of probabilities).
+Same constructor and ``predict`` / ``predict_long`` / ``predict_stream`` / ``reset_stream`` contract
+(predict.py:20-26,167-171,195-199,237-244,346); everything between the audio and the text runs in libmasr_hip.so.
+How the calls map onto the engine:
+
+  * ``predict`` is ``predict_batch`` with a batch of one: padded PCM -> features -> encoder -> CTC decode in one device
+    pass, no numpy round trips between the reference's stages;
+  * ``predict_stream`` is a ``serving.StreamPool`` with a single session (the pool is the one implementation of the
+    reference's stream framing; a server opens more sessions on the same pool);
+  * ``predict_batch`` / ``evaluate`` shard their utterances over the ranks of an initialised ``torch.distributed`` process
+    group (one process per GPU, ``parallel.py``) and all-gather the hypotheses.
 """
+import json
 import logging
 import os
 from io import BufferedReader
@@ -14,11 +20,11 @@ import numpy as np
 import torch
 import yaml
 
-from masr_amd import SUPPORT_MODEL
+from masr_amd import SUPPORT_MODEL, parallel
 from masr_amd.data_utils.audio import AudioSegment
 from masr_amd.data_utils.featurizer.audio_featurizer import AudioFeaturizer
 from masr_amd.data_utils.featurizer.text_featurizer import TextFeaturizer
-from masr_amd.decoders.ctc_greedy_decoder import greedy_decoder, greedy_decoder_chunk, greedy_decoder_chunk_frames
+from masr_amd.decoders.ctc_greedy_decoder import greedy_decoder
 from masr_amd.infer_utils.inference_predictor import InferencePredictor
 from masr_amd.utils.utils import dict_to_object
 
@@ -42,15 +48,13 @@ class MASRPredictor:
         self.use_gpu = use_gpu
         self._text_featurizer = TextFeaturizer(vocab_filepath=self.configs.dataset_conf.dataset_vocab)
         self._audio_featurizer = AudioFeaturizer(**self.configs.preprocess_conf)
-        # streaming decode state (predict.py:69-73)
-        self.remained_wav = None
-        self.cached_feat = None
-        self.greedy_last_max_prob_list = None
-        self.greedy_last_max_index_list = None
         self.beam_search_decoder = None
         self.vad_predictor = None
+        self._pool = None             # predict_stream: a StreamPool with one session, opened on first use
+        self._session = None
+        self._stage = {}              # pinned host staging buffers of predict_batch, per sample type
         if self.configs.decoder == 'ctc_beam_search':
-            # predict.py:96-109; here the search is masr_amd's own (GPU pruning + host prefix search, LM-free)
+            # predict.py:96-109; the search is masr_amd's own (vocabulary pruning, prefix search and LM scoring on the GPU)
             from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
             self.beam_search_decoder = BeamSearchDecoder(vocab_list=self._text_featurizer.vocab_list,
                                                          **self.configs.ctc_beam_search_decoder_conf)
@@ -65,42 +69,40 @@ class MASRPredictor:
         self.predict(audio_data=warmup_audio, is_itn=False)
         self.reset_stream()
 
+    # ---- helpers ----------------------------------------------------------------------------------------------------------
     def decode(self, output_data, use_pun, is_itn):
-        """predict.py:118-144."""
+        """predict.py:118-144: probabilities [T', V] of one utterance -> (score, text)."""
         if self.configs.decoder == 'ctc_beam_search':
             score, text = self.beam_search_decoder.decode_beam_search_offline(probs_split=output_data)
         else:
             score, text = greedy_decoder(probs_seq=output_data, vocabulary=self._text_featurizer.vocab_list)
-        if is_itn:
-            raise Exception('inverse text normalisation (WeTextProcessing) is outside the hot path')
+        self._no_itn(is_itn)
         return score, text
 
     @staticmethod
+    def _no_itn(is_itn):
+        if is_itn:
+            raise Exception('inverse text normalisation (WeTextProcessing) is outside the hot path')
+
+    @staticmethod
     def _load_audio(audio_data, sample_rate=16000):
-        """predict.py:146-164."""
-        if isinstance(audio_data, str):
-            return AudioSegment.from_file(audio_data)
-        elif isinstance(audio_data, BufferedReader):
-            return AudioSegment.from_file(audio_data)
-        elif isinstance(audio_data, np.ndarray):
-            return AudioSegment.from_ndarray(audio_data, sample_rate)
-        elif isinstance(audio_data, bytes):
-            return AudioSegment.from_bytes(audio_data)
+        """predict.py:146-164: path / binary file object / ndarray / wav bytes -> AudioSegment."""
+        loaders = ((str, AudioSegment.from_file), (BufferedReader, AudioSegment.from_file),
+                   (np.ndarray, lambda a: AudioSegment.from_ndarray(a, sample_rate)), (bytes, AudioSegment.from_bytes))
+        for kind, load in loaders:
+            if isinstance(audio_data, kind):
+                return load(audio_data)
         raise Exception(f'不支持该数据类型，当前数据类型为：{type(audio_data)}')
 
+    def _text(self, ids):
+        vocab = self._text_featurizer.vocab_list
+        return ''.join(vocab[j] for j in ids).replace('<space>', ' ')
+
+    # ---- offline ------------------------------------------------------------------------------------------------------------
     def predict(self, audio_data, use_pun=False, is_itn=False, sample_rate=16000):
-        """predict.py:167-192: one utterance -> {'text', 'score'}.  With ``decoder: ctc_greedy`` the utterance takes the batched
-        device path as a batch of one (features, encoder, fused CTC head and best-path collapse without the numpy round trips
-        between the reference's stages: features -> host -> device, probabilities [T', V] -> host -> device)."""
-        if self.configs.decoder != 'ctc_beam_search' and not is_itn:
-            return self.predict_batch([audio_data], sample_rate=sample_rate)[0]
-        audio_segment = self._load_audio(audio_data=audio_data, sample_rate=sample_rate)
-        audio_feature = self._audio_featurizer.featurize(audio_segment)
-        input_data = np.array(audio_feature).astype(np.float32)[np.newaxis, :]
-        audio_len = np.array([input_data.shape[1]]).astype(np.int64)
-        output_data = self.predictor.predict(input_data, audio_len)[0]
-        score, text = self.decode(output_data=output_data, use_pun=use_pun, is_itn=is_itn)
-        return {'text': text, 'score': score}
+        """predict.py:167-192: one utterance -> {'text', 'score'} (a batch of one on the device path)."""
+        self._no_itn(is_itn)
+        return self._predict_local([self._load_audio(audio_data, sample_rate)])[0]
 
     def init_vad(self, vad_predictor=None):
         """predict.py:110-115.  ``vad_predictor``: any object with the reference VADPredictor's ``get_speech_timestamps``;
@@ -114,11 +116,12 @@ class MASRPredictor:
     def predict_long(self, audio_data, use_pun=False, is_itn=False, sample_rate=16000, vad_predictor=None, batch_size=32):
         """predict.py:195-234: long audio -> VAD segments -> text.  The reference recognises the segments one after the
         other (``self.predict`` per segment, :220); here they go through ``predict_batch`` in length-sorted batches of
-        ``batch_size`` (one device call per batch); texts are joined in time order exactly like the reference (:222-227,233).
+        ``batch_size`` (one device pass per batch); texts are joined in time order exactly like the reference (:222-227,233).
         A padded batch follows the reference's own batch > 1 semantics (its pad mask keeps one padding-contaminated key per
         shorter utterance, trainer.py:632); ``batch_size=1`` is the reference's per-segment ``predict`` to the bit."""
         if use_pun:
             raise Exception('punctuation (PaddleNLP) is outside the hot path and not provided')
+        self._no_itn(is_itn)
         self.init_vad(vad_predictor)
         audio_segment = self._load_audio(audio_data=audio_data, sample_rate=sample_rate)
         if audio_segment.sample_rate != self.configs.preprocess_conf.sample_rate:
@@ -130,15 +133,11 @@ class MASRPredictor:
         results = [None] * len(pieces)
         for lo in range(0, len(order), batch_size):
             idx = order[lo:lo + batch_size]
-            if len(idx) == 1:
-                results[idx[0]] = self.predict(audio_data=pieces[idx[0]], sample_rate=audio_segment.sample_rate)
-                continue
-            for i, res in zip(idx, self.predict_batch([pieces[i] for i in idx], sample_rate=audio_segment.sample_rate)):
+            for i, res in zip(idx, self._predict_local([AudioSegment.from_ndarray(pieces[i], audio_segment.sample_rate)
+                                                        for i in idx])):
                 results[i] = res
         texts, scores = '', []
         for res in results:
-            if is_itn:
-                raise Exception('inverse text normalisation (WeTextProcessing) is outside the hot path')
             if res['text'] != '':
                 texts = texts + '，' + res['text']
             scores.append(res['score'])
@@ -147,24 +146,16 @@ class MASRPredictor:
             texts = texts[1:]
         return {'text': texts, 'score': round(sum(scores) / len(scores), 2) if scores else 0}
 
-    def predict_batch(self, audio_list, sample_rate=16000, decode_all_frames=False):
-        """Batched offline path on the device: padded int16/float PCM -> fbank -> encoder -> greedy
-        in ONE library call.  Returns [{'text','score'}].  ``decode_all_frames=True`` reproduces
-        the reference's batch evaluation quirk of decoding padded frames (trainer.py:340)."""
+    def _stage_batch(self, segs, n):
+        """padded batch in a reused pinned staging buffer -> device (int16 when every utterance still is the PCM it was
+        loaded from: half the bytes over PCIe, x / 2^15 happens in the kernel)"""
         eng = self.predictor.engine
-        segs = [self._load_audio(a, sample_rate) for a in audio_list]
-        for s in segs:
-            if s.sample_rate != 16000:
-                s.resample(16000)
-        n = np.array([s.num_samples for s in segs], np.int32)
-        # padded batch in a pinned staging buffer (int16 when every utterance still is the PCM it was loaded from)
         as_pcm = all(s._pcm16 is not None for s in segs)
         dt = torch.int16 if as_pcm else torch.float32
         need = len(segs) * int(n.max())
-        pool = self.__dict__.setdefault('_stage', {})
-        if dt not in pool or pool[dt].numel() < need:
-            pool[dt] = torch.zeros(need + need // 4, dtype=dt, pin_memory=True)          # reused across calls
-        stage = pool[dt][:need].view(len(segs), int(n.max()))
+        if dt not in self._stage or self._stage[dt].numel() < need:
+            self._stage[dt] = torch.zeros(need + need // 4, dtype=dt, pin_memory=True)
+        stage = self._stage[dt][:need].view(len(segs), int(n.max()))
         buf = stage.numpy()
         buf[:] = 0
         for i, s in enumerate(segs):
@@ -172,26 +163,91 @@ class MASRPredictor:
         xs = stage.to(eng.device, non_blocking=True)
         ns = torch.from_numpy(n).to(eng.device)
         torch.cuda.current_stream().synchronize()          # the staging buffer is reused by the next call
+        return xs, ns
+
+    def _predict_local(self, segs, decode_all_frames=False, as_tokens=False):
+        """AudioSegments -> [{'text','score'}] on THIS rank's engine.  Utterances too short for one feature frame decode to
+        the empty transcript (the reference's encoder cannot take them either); a silent utterance raises like
+        ``AudioSegment.normalize`` (audio.py:300-303)."""
+        eng = self.predictor.engine
         pc = self.configs.preprocess_conf
-        feats, frames = eng.features_batch(pc.get('feature_method', 'fbank'), xs, ns, pc.use_dB_normalization, pc.target_dB,
-                                           n_mfcc=pc.get('n_mfcc', 40))
+        rate = int(pc.get('sample_rate', 16000))
+        method = pc.get('feature_method', 'fbank')
+        min_samples = 320 if method == 'linear' else 400
+        for s in segs:
+            if s.sample_rate != rate:
+                s.resample(rate)
+        out = [None] * len(segs)
+        # 7 feature frames is the least Conv2dSubsampling4 accepts (subsampling.py:65-112)
+        ok = [i for i, s in enumerate(segs) if s.num_samples >= min_samples + 6 * 160]
+        for i in range(len(segs)):
+            if i not in ok:
+                out[i] = ([], 0) if as_tokens else {'text': '', 'score': 0}
+        if not ok:
+            return out
+        live = [segs[i] for i in ok]
+        n = np.array([s.num_samples for s in live], np.int32)
+        xs, ns = self._stage_batch(live, n)
+        gain = eng.host_gains(xs, ns, pc.target_dB) if pc.use_dB_normalization else None
+        feats, frames = eng.features_batch(method, xs, ns, pc.use_dB_normalization, pc.target_dB, n_mfcc=pc.get('n_mfcc', 40),
+                                           gain_in=gain)
         enc = eng.encode_full(feats, frames, -1)
-        nenc = None if decode_all_frames else (((frames - 1) // 2 - 1) // 2).clamp(min=0).to(torch.int32)
+        nenc = None if decode_all_frames else eng.enc_frames(frames).to(torch.int32)
         if self.configs.decoder == 'ctc_beam_search':
-            # probabilities stay on the GPU for the vocabulary pruning; the prefix search runs on host threads
+            # probabilities stay on the GPU: vocabulary pruning, prefix search and LM scoring run there
             probs = eng.ctc_probs(enc)
-            n_host = [probs.shape[1]] * len(segs) if nenc is None else nenc.cpu().tolist()
-            res = self.beam_search_decoder._batch([probs[i, :n_host[i]] for i in range(len(segs))])
-            return [{'text': t, 'score': sc} for sc, t in res]
+            n_host = [probs.shape[1]] * len(live) if nenc is None else nenc.cpu().tolist()
+            res = self.beam_search_decoder._batch([probs[i, :n_host[i]] for i in range(len(live))], want_tokens=as_tokens)
+            for i, r in zip(ok, res):
+                out[i] = r if as_tokens else {'text': r[1], 'score': r[0]}
+            return out
         idx, mp = eng.ctc_greedy_frames(enc)
         tok, ntok, score = eng.ctc_collapse(idx, mp, nenc)
         tok, ntok, score = tok.cpu().numpy(), ntok.cpu().numpy(), score.cpu().numpy()
-        vocab = self._text_featurizer.vocab_list
-        out = []
-        for i in range(len(segs)):
-            text = ''.join(vocab[j] for j in tok[i, :ntok[i]]).replace('<space>', ' ')
-            out.append({'text': text, 'score': float(score[i]) * 100.0 if ntok[i] > 0 or score[i] > 0 else 0})
+        for j, i in enumerate(ok):
+            sc = float(score[j]) * 100.0 if ntok[j] > 0 or score[j] > 0 else 0
+            ids = tok[j, :ntok[j]]
+            out[i] = (ids.tolist(), sc) if as_tokens else {'text': self._text(ids), 'score': sc}
         return out
+
+    def predict_batch(self, audio_list, sample_rate=16000, decode_all_frames=False, batch_size=0, distributed=None):
+        """Batched offline path (an addition; the reference's only batched consumer is MASRTrainer.evaluate,
+        trainer.py:592-651): a list of utterances -> [{'text','score'}] in input order.
+
+        ``decode_all_frames=True`` reproduces the reference's batch evaluation quirk of decoding padded frames
+        (trainer.py:340).  ``batch_size`` > 0 cuts the (length-sorted) work into device passes of that many utterances.
+        With an initialised ``torch.distributed`` group (``distributed=None``: automatically when world > 1) the utterances
+        are dealt out length-balanced over the ranks -- every rank must call with the same list -- each rank decodes its
+        shard on its own GPU and ONE all-gather of the token ids returns all hypotheses to every rank."""
+        segs = [self._load_audio(a, sample_rate) for a in audio_list]
+        rank, world = parallel.world_info()
+        if distributed is None:
+            distributed = world > 1
+        if not distributed or world == 1:
+            return self._run_sorted(segs, list(range(len(segs))), decode_all_frames, batch_size, as_tokens=False)
+        shards = parallel.length_balanced_shards([s.num_samples for s in segs], world)
+        mine = shards[rank]
+        local = self._run_sorted(segs, mine, decode_all_frames, batch_size, as_tokens=True, keep_order_of=mine)
+        tmax = max([len(t) for t, _ in local], default=0)
+        tok = torch.full((len(mine), max(tmax, 1)), -1, dtype=torch.int32)
+        nt = torch.zeros(len(mine), dtype=torch.int32)
+        sc = torch.zeros(len(mine), dtype=torch.float32)
+        for j, (t, s) in enumerate(local):
+            tok[j, :len(t)] = torch.tensor(t, dtype=torch.int32)
+            nt[j], sc[j] = len(t), s
+        tok, nt, sc = parallel.gather_sharded_results(tok, nt, sc, shards, len(segs))
+        return [{'text': self._text(tok[i, :nt[i]]), 'score': float(sc[i])} for i in range(len(segs))]
+
+    def _run_sorted(self, segs, which, decode_all_frames, batch_size, as_tokens, keep_order_of=None):
+        """decode ``segs[i] for i in which`` in length-sorted device passes; results in the order of ``which``"""
+        order = sorted(which, key=lambda i: -segs[i].num_samples) if batch_size else list(which)
+        step = batch_size if batch_size else max(len(order), 1)
+        got = {}
+        for lo in range(0, len(order), step):
+            idx = order[lo:lo + step]
+            for i, r in zip(idx, self._predict_local([segs[i] for i in idx], decode_all_frames, as_tokens)):
+                got[i] = r
+        return [got[i] for i in which]
 
     def evaluate(self, manifest, batch_size=32, display_result=False, decode_all_frames=False):
         """Batched offline evaluation on the engine (the reference's batch > 1 consumer: MASRTrainer.evaluate,
@@ -199,8 +255,8 @@ class MASRPredictor:
         and ``text``, data_utils/reader.py:32-40,55), utterances are sorted by duration, padded per batch and decoded with
         the configured decoder; returns (loss, error_rate) like the reference with loss = -1 (no CTC loss on this path) and
         error_rate = mean CER or WER over utterances (configs.metrics_type).  ``decode_all_frames=True`` reproduces the
-        reference's decoding of the padded frames (trainer.py:340-344)."""
-        import json
+        reference's decoding of the padded frames (trainer.py:340-344).  Under an initialised process group every rank reads
+        the manifest, decodes its length-balanced shard and all ranks return the same error rate."""
         from masr_amd.utils.metrics import cer, wer
         items = []
         with open(manifest, 'r', encoding='utf-8') as f:
@@ -211,97 +267,35 @@ class MASRPredictor:
                     items.append((d['audio_filepath'], d['text'], float(d.get('duration', 0.0))))
         items.sort(key=lambda it: it[2])
         metric = wer if self.configs.metrics_type == 'wer' else cer
+        results = self.predict_batch([it[0] for it in items], decode_all_frames=decode_all_frames, batch_size=batch_size)
         errors = []
-        for lo in range(0, len(items), batch_size):
-            chunk = items[lo:lo + batch_size]
-            results = self.predict_batch([it[0] for it in chunk], decode_all_frames=decode_all_frames)
-            for (path, label, _), res in zip(chunk, results):
-                err = metric(res['text'], label)
-                errors.append(err)
-                if display_result:
-                    logger.info(f'预测结果为：{res["text"]}')
-                    logger.info(f'实际标签为：{label}')
-                    logger.info(f'这条数据的{self.configs.metrics_type}：{round(err, 6)}，'
-                                f'当前{self.configs.metrics_type}：{round(sum(errors) / len(errors), 6)}')
+        for (path, label, _), res in zip(items, results):
+            err = metric(res['text'], label)
+            errors.append(err)
+            if display_result:
+                logger.info(f'预测结果为：{res["text"]}')
+                logger.info(f'实际标签为：{label}')
+                logger.info(f'这条数据的{self.configs.metrics_type}：{round(err, 6)}，'
+                            f'当前{self.configs.metrics_type}：{round(sum(errors) / len(errors), 6)}')
         return -1, (float(sum(errors) / len(errors)) if errors else -1)
 
+    # ---- streaming ------------------------------------------------------------------------------------------------------------
     def predict_stream(self, audio_data, is_end=False, use_pun=False, is_itn=False, channels=1, samp_width=2,
                        sample_rate=16000):
-        """predict.py:237-343: feed raw PCM bytes / ndarray chunks, get the transcript so far."""
+        """predict.py:237-343: feed raw PCM bytes / ndarray chunks, get the transcript so far ({'text','score'}), or None
+        while fewer frames than one decoding window have arrived.  One session of a ``StreamPool``."""
         if not self.configs.streaming:
             raise Exception(f"不支持改该模型流式识别，当前模型：{self.configs.use_model}，参数streaming为：{self.configs.streaming}")
-        if isinstance(audio_data, np.ndarray):
-            audio_data = AudioSegment.from_ndarray(audio_data, sample_rate)
-        elif isinstance(audio_data, bytes):
-            audio_data = AudioSegment.from_pcm_bytes(audio_data, channels=channels, samp_width=samp_width,
-                                                     sample_rate=sample_rate)
-        else:
-            raise Exception(f'不支持该数据类型，当前数据类型为：{type(audio_data)}')
-        if self.remained_wav is None:
-            self.remained_wav = audio_data
-        else:
-            self.remained_wav = AudioSegment(np.concatenate([self.remained_wav.samples, audio_data.samples]),
-                                             audio_data.sample_rate)
-        # featurize everything not yet turned into frames; NB this re-normalises the carried-over
-        # samples in place on every call, exactly like the reference (predict.py:274, audio.py:304)
-        x_chunk = self._audio_featurizer.featurize(self.remained_wav)
-        x_chunk = np.array(x_chunk).astype(np.float32)[np.newaxis, :]
-        if self.cached_feat is None:
-            self.cached_feat = x_chunk
-        else:
-            self.cached_feat = np.concatenate([self.cached_feat, x_chunk], axis=1)
-        self.remained_wav._samples = self.remained_wav.samples[160 * x_chunk.shape[1]:]
-
-        decoding_chunk_size, context, subsampling = 16, 7, 4
-        cached_feature_num = context - subsampling                           # 3 frames of overlap
-        decoding_window = (decoding_chunk_size - 1) * subsampling + context  # 67
-        stride = subsampling * decoding_chunk_size                           # 64
-        num_frames = self.cached_feat.shape[1]
-        if num_frames < decoding_window and not is_end:
-            return None
-        if num_frames < context:
-            return None
-        left_frames = context if is_end else decoding_window
-        score, text, end = None, None, None
-        for cur in range(0, num_frames - left_frames + 1, stride):
-            end = min(cur + decoding_window, num_frames)
-            x_chunk = self.cached_feat[:, cur:end, :]
-            if self.configs.decoder != 'ctc_beam_search':
-                # greedy: only the per-frame (argmax, max prob) pairs leave the device (fused CTC head)
-                ids, mps = self.predictor.predict_chunk_frames(x_chunk)
-                score, text, self.greedy_last_max_prob_list, self.greedy_last_max_index_list = \
-                    greedy_decoder_chunk_frames(ids, mps, vocabulary=self._text_featurizer.vocab_list,
-                                                last_max_index_list=self.greedy_last_max_index_list,
-                                                last_max_prob_list=self.greedy_last_max_prob_list)
-                continue
-            if self.configs.use_model == 'deepspeech2':
-                output_chunk_probs, output_lens = self.predictor.predict_chunk_deepspeech(x_chunk=x_chunk)
-            elif 'former' in self.configs.use_model:
-                num_decoding_left_chunks = -1
-                required_cache_size = decoding_chunk_size * num_decoding_left_chunks
-                output_chunk_probs = self.predictor.predict_chunk_conformer(x_chunk=x_chunk,
-                                                                            required_cache_size=required_cache_size)
-                output_lens = np.array([output_chunk_probs.shape[1]])
-            else:
-                raise Exception(f'当前模型不支持该方法，当前模型为：{self.configs.use_model}')
-            if self.configs.decoder == 'ctc_beam_search':
-                score, text = self.beam_search_decoder.decode_chunk(probs=output_chunk_probs, logits_lens=output_lens)
-            else:
-                score, text, self.greedy_last_max_prob_list, self.greedy_last_max_index_list = \
-                    greedy_decoder_chunk(probs_seq=output_chunk_probs[0], vocabulary=self._text_featurizer.vocab_list,
-                                         last_max_index_list=self.greedy_last_max_index_list,
-                                         last_max_prob_list=self.greedy_last_max_prob_list)
-        self.cached_feat = self.cached_feat[:, end - cached_feature_num:, :]
-        if is_itn:
-            raise Exception('inverse text normalisation (WeTextProcessing) is outside the hot path')
-        return {'text': text, 'score': score}
+        self._no_itn(is_itn)
+        if self._pool is None:
+            from masr_amd.serving import StreamPool
+            self._pool = StreamPool(self)
+            self._session = self._pool.open()
+        self._pool.feed(self._session, audio_data, is_end, channels=channels, samp_width=samp_width, sample_rate=sample_rate)
+        return self._pool.step()[self._session]
 
     def reset_stream(self):
-        """predict.py:346-353."""
+        """predict.py:346-353: forget the stream (caches, pending audio and frames, decoder history)."""
         self.predictor.reset_stream()
-        self.remained_wav = None
-        self.cached_feat = None
-        self.greedy_last_max_prob_list = None
-        self.greedy_last_max_index_list = None
-        if self.configs.decoder == 'ctc_beam_search' and getattr(self, 'beam_search_decoder', None) is not None:
-            self.beam_search_decoder.reset_decoder()
+        if self._pool is not None:
+            self._pool.reset(self._session)

@@ -6,7 +6,8 @@ is a single ``np.memmap`` (the engine copies every tensor to the device as it is
     file = b'MASRPACK' | u32 version | u32 header bytes | header JSON (utf-8) | padding to 64 B | float32 data
     header = {"tensors": {name: {"shape": [...], "offset": first float index}}, "meta": {...}}
 
-Only what ``get_encoder_out`` / ``get_encoder_out_chunk`` touch is kept (``encoder.*`` and ``ctc.*``; the attention
+Only what ``get_encoder_out`` / ``get_encoder_out_chunk`` touch is kept (``encoder.*``, ``ctc.*`` and DeepSpeech2's
+``decoder.ctc_lo.*``; the attention
 decoder of the reference model is never run on this path, conformer/model.py:152-190); BatchNorm / adaptive-scale folding
 stays where it is done for every source format, at engine load.
 """
@@ -21,7 +22,9 @@ VERSION = 1
 
 
 def _keep(name):
-    return (name.startswith('encoder.') or name.startswith('ctc.')) and not name.endswith('num_batches_tracked')
+    # encoder.* and the CTC head: ctc.ctc_lo.* (Conformer family) / decoder.ctc_lo.* (DeepSpeech2, deepspeech2/model.py:36)
+    return (name.startswith('encoder.') or name.startswith('ctc.') or name.startswith('decoder.ctc_lo.')) \
+        and not name.endswith('num_batches_tracked')
 
 
 def export_packed(state_dict, path, meta=None):
