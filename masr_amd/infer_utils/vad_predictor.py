@@ -1,15 +1,23 @@
 """Voice-activity segmentation for ``MASRPredictor.predict_long``.
 
-The reference cuts long audio with Silero VAD, a third-party ONNX model run through onnxruntime
-(masr/infer_utils/vad_predictor.py:13-175, predict.py:195-234).  Neither the model nor onnxruntime belongs to the MI355X hot
-path, so ``predict_long`` takes ANY object with the reference's interface
+The reference cuts long audio with Silero VAD: a small third-party ONNX network (``silero_vad.onnx``, run through onnxruntime)
+that maps a 512-sample window + LSTM state to a speech probability, followed by a hysteresis / minimum-duration / padding
+state machine in plain Python (masr/infer_utils/vad_predictor.py:13-175, predict.py:195-234).  What belongs to this repo:
 
-    get_speech_timestamps(audio: np.float32[N], sampling_rate: int) -> [{'start': int, 'end': int}, ...]   (sample indices)
+* ``VADPredictor`` -- the reference class's interface and its segmentation logic (``get_speech_timestamps`` :106-175,
+  ``stream_vad`` :177-216, ``reset_states`` :73-81, the chunk validation :53-71), written out here and pinned against the
+  reference class on scripted probability sequences (tests/test_vad_cpu.py).  The network itself is a pluggable ``session``
+  with onnxruntime's ``run(None, {'input', 'h', 'c', 'sr'}) -> (prob, h, c)`` signature: the ONNX file is third-party weights
+  that are neither in the reference repository nor in this image, so without a session (or onnxruntime + a model path) the
+  class refuses to construct -- it never guesses probabilities.
+* ``EnergyVAD`` -- the built-in stand-in used by ``predict_long`` when no VAD is supplied: short-time energy against an
+  adaptive noise floor with hysteresis, minimum speech / silence durations and padding (the same knobs as the reference class,
+  :19-35).  It is NOT Silero and will not cut at the same samples.
 
--- the reference's own ``VADPredictor`` can be passed unchanged where onnxruntime is installed.  ``EnergyVAD`` below is the
-built-in stand-in: short-time energy against an adaptive noise floor with hysteresis, minimum speech / silence durations and
-padding (the same knobs as the reference class, :19-35).  It is NOT Silero and will not cut at the same samples.
+``predict_long`` takes ANY object with ``get_speech_timestamps(audio: np.float32[N], sampling_rate) -> [{'start', 'end'}]``.
 """
+import os
+
 import numpy as np
 
 
@@ -76,3 +84,146 @@ class EnergyVAD(object):
             edges = [s + (e - s) * k // pieces for k in range(pieces + 1)]
             out.extend({'start': int(a), 'end': int(b)} for a, b in zip(edges, edges[1:]))
         return out
+
+
+class VADPredictor(object):
+    """masr/infer_utils/vad_predictor.py:11-216 with a pluggable network ``session`` (see the module docstring)."""
+
+    def __init__(self, path=None, threshold: float = 0.5, min_speech_duration_ms: int = 250, min_silence_duration_ms: int = 100,
+                 window_size_samples: int = 512, speech_pad_ms: int = 30, session=None):
+        if session is None:
+            try:
+                import onnxruntime
+            except ImportError as exc:
+                raise Exception('VADPredictor needs the Silero network: pass session=<object with onnxruntime\'s run()> or '
+                                'install onnxruntime and give the path of silero_vad.onnx') from exc
+            if path is None or not os.path.exists(path):
+                raise Exception(f'Silero VAD model not found: {path}')
+            session = onnxruntime.InferenceSession(path)
+            session.intra_op_num_threads = 1
+            session.inter_op_num_threads = 1
+        self.session = session
+        self.threshold = threshold
+        self.min_speech_duration_ms = min_speech_duration_ms
+        self.min_silence_duration_ms = min_silence_duration_ms
+        self.window_size_samples = window_size_samples
+        self.speech_pad_ms = speech_pad_ms
+        self.sample_rates = [8000, 16000]
+        self.reset_states()
+
+    # ---- network call (:53-104) -------------------------------------------------------------------------------------------
+    def reset_states(self, batch_size=1):
+        self._h = np.zeros((2, batch_size, 64), np.float32)
+        self._c = np.zeros((2, batch_size, 64), np.float32)
+        self._last_sr = 0
+        self._last_batch_size = 0
+        self.triggered = False
+        self.temp_end = 0
+        self.current_sample = 0
+
+    def _validate_input(self, x, sr):
+        x = np.asarray(x)
+        if x.ndim == 1:
+            x = x[np.newaxis, :]
+        if x.ndim > 2:
+            raise ValueError(f'Too many dimensions for input audio chunk {x.ndim}')
+        if sr != 16000 and sr % 16000 == 0:
+            x = x[::sr // 16000]           # (the reference strides the FIRST axis here, :61-64 -- kept as it is)
+            sr = 16000
+        if sr not in self.sample_rates:
+            raise ValueError(f'Supported sampling rates: {self.sample_rates} (or multiply of 16000)')
+        if sr / x.shape[1] > 31.25:
+            raise ValueError('Input audio chunk is too short')
+        return x, sr
+
+    def __call__(self, x, sr):
+        x, sr = self._validate_input(x, sr)
+        batch = x.shape[0]
+        if not self._last_batch_size or (self._last_sr and self._last_sr != sr) or self._last_batch_size != batch:
+            self.reset_states(batch)
+        out, self._h, self._c = self.session.run(None, {'input': x, 'h': self._h, 'c': self._c,
+                                                        'sr': np.array(sr, dtype=np.int64)})
+        self._last_sr, self._last_batch_size = sr, batch
+        return out
+
+    # ---- offline segmentation (:106-175) ------------------------------------------------------------------------------------
+    def speech_probabilities(self, audio, sampling_rate):
+        w = self.window_size_samples
+        probs = []
+        for start in range(0, len(audio), w):
+            chunk = audio[start:start + w]
+            if len(chunk) < w:
+                chunk = np.pad(chunk, (0, int(w - len(chunk))))
+            probs.append(self(chunk, sampling_rate).item())
+        return probs
+
+    def get_speech_timestamps(self, audio, sampling_rate):
+        """audio np.float32 [N] -> [{'start': sample, 'end': sample}]: a window opens a segment at >= threshold; the segment
+        closes at the first window below (threshold - 0.15) that is followed by min_silence of such windows without another
+        >= threshold window in between; segments not longer than min_speech are dropped; then padding, shared gaps halved."""
+        self.reset_states()
+        total = len(audio)
+        w = self.window_size_samples
+        min_speech = sampling_rate * self.min_speech_duration_ms / 1000
+        min_silence = sampling_rate * self.min_silence_duration_ms / 1000
+        pad = sampling_rate * self.speech_pad_ms / 1000
+        low = self.threshold - 0.15
+        segments, start, quiet_at = [], None, 0
+        for i, p in enumerate(self.speech_probabilities(audio, sampling_rate)):
+            pos = w * i
+            if p >= self.threshold:
+                quiet_at = 0
+                if start is None:
+                    start = pos
+                continue
+            if start is None or p >= low:
+                continue
+            if not quiet_at:
+                quiet_at = pos
+            if pos - quiet_at >= min_silence:
+                if quiet_at - start > min_speech:
+                    segments.append({'start': start, 'end': quiet_at})
+                start, quiet_at = None, 0
+        if start is not None and total - start > min_speech:
+            segments.append({'start': start, 'end': total})
+        for k, seg in enumerate(segments):
+            if k == 0:
+                seg['start'] = int(max(0, seg['start'] - pad))
+            if k == len(segments) - 1:
+                seg['end'] = int(min(total, seg['end'] + pad))
+                continue
+            nxt = segments[k + 1]
+            gap = nxt['start'] - seg['end']
+            if gap < 2 * pad:
+                seg['end'] += int(gap // 2)
+                nxt['start'] = int(max(0, nxt['start'] - gap // 2))
+            else:
+                seg['end'] = int(min(total, seg['end'] + pad))
+                nxt['start'] = int(max(0, nxt['start'] - pad))
+        return segments
+
+    # ---- streaming (:177-216) ---------------------------------------------------------------------------------------------------
+    def stream_vad(self, x, sampling_rate, return_seconds=False):
+        """one window at a time -> {'start': t} when speech begins, {'end': t} when it has ended, else None"""
+        if len(x) < self.window_size_samples:
+            return None
+        x = np.asarray(x)
+        min_silence = sampling_rate * self.min_silence_duration_ms / 1000
+        pad = sampling_rate * self.speech_pad_ms / 1000
+        self.current_sample += x.shape[-1]
+        p = self(x, sampling_rate).item()
+        stamp = lambda t: round(t / sampling_rate, 1) if return_seconds else int(t)
+        if p >= self.threshold:
+            self.temp_end = 0
+            if not self.triggered:
+                self.triggered = True
+                return {'start': stamp(self.current_sample - pad)}
+            return None
+        if p < self.threshold - 0.15 and self.triggered:
+            if not self.temp_end:
+                self.temp_end = self.current_sample
+            if self.current_sample - self.temp_end >= min_silence:
+                end = self.temp_end + pad
+                self.temp_end, self.triggered = 0, False
+                return {'end': stamp(end)}
+        return None

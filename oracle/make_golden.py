@@ -48,6 +48,59 @@ def build_reference_conformer(sd, vocab_size, tmp):
     return m.eval(), cfg, p
 
 
+def reference_gain(pcm):
+    """what AudioSegment.normalize(-20) multiplied the samples of ``pcm`` by ON THIS HOST (audio.py:287-304: float32 log10 /
+    power of this numpy build) and the mean square it started from"""
+    from masr.data_utils.audio import AudioSegment
+    seg = AudioSegment.from_ndarray(pcm, 16000)
+    before = seg.samples.copy()
+    ms = np.mean(before ** 2)
+    gain = np.float32(10.) ** (np.float32(-20 - 10 * np.log10(ms)) / np.float32(20.))
+    seg.normalize(target_db=-20)
+    assert np.array_equal(before * gain, seg.samples)
+    return {'gain': np.float32(gain), 'mean_square': np.float32(ms)}
+
+
+def record_facade(pred, pcm, step=8000):
+    """predict(pcm) and every predict_stream partial of a reference MASRPredictor, fed ``step``-sample chunks"""
+    off = pred.predict(audio_data=pcm.copy())
+    texts, scores, valid = [], [], []
+    for s in range(0, len(pcm), step):
+        r = pred.predict_stream(audio_data=pcm[s:s + step].tobytes(), is_end=(s + step >= len(pcm)))
+        valid.append(r is not None and r['text'] is not None)
+        texts.append('' if not valid[-1] else r['text'])
+        scores.append(0.0 if not valid[-1] else float(r['score']))
+    pred.reset_stream()
+    return {'offline_text': np.array(off['text']), 'offline_score': np.array(off['score'], np.float64),
+            'stream_text': np.array(texts), 'stream_score': np.array(scores, np.float64), 'stream_valid': np.array(valid)}
+
+
+def nonorm_fixture(tmp):
+    """predictor_nonorm.npz: the reference facade with ``use_dB_normalization: False`` (conformer.yml otherwise) on
+    dataset/test.wav -- no machine-dependent float32 log10 / power anywhere on the path, so every partial transcript of this
+    fixture must be reproduced EXACTLY on any host."""
+    from masr.predict import MASRPredictor
+    w = wave.open(os.path.join(REF, 'dataset', 'test.wav'))
+    pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16).copy()
+    sd = weights.conformer_state_dict(0, 4233)
+    m, cfg, mean_istd = build_reference_conformer(sd, 4233, tmp)
+    vpath = os.path.join(tmp, 'vocabulary_nn.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in weights.synthetic_vocab(4233):
+            f.write(f'{t}\t1\n')
+    mdir = os.path.join(tmp, 'models', 'conformer_nonorm')
+    os.makedirs(mdir, exist_ok=True)
+    torch.jit.save(m.export(), os.path.join(mdir, 'inference.pt'))
+    cfg['dataset_conf']['dataset_vocab'] = vpath
+    cfg['dataset_conf']['mean_istd_path'] = mean_istd
+    cfg['decoder'] = 'ctc_greedy'
+    cfg['preprocess_conf']['use_dB_normalization'] = False
+    pred = MASRPredictor(configs=cfg, model_path=os.path.join(mdir, 'inference.pt'), use_gpu=False)
+    rec = record_facade(pred, pcm)
+    np.savez_compressed(os.path.join(OUT, 'predictor_nonorm.npz'), **rec)
+    print('nonorm facade:', rec['offline_text'], rec['offline_score'], rec['stream_text'][-1])
+
+
 def golden_inputs():
     g = torch.Generator().manual_seed(1)
     feats = torch.randn(3, 331, 80, generator=g) * 3 + 13
@@ -262,6 +315,13 @@ def main():
         squeezeformer_streaming_fixture(p)
         print('squeezeformer streaming fixture written')
         return
+    if '--only-nonorm' in sys.argv:
+        nonorm_fixture(tmp)
+        z = dict(np.load(os.path.join(OUT, 'testwav.npz')))
+        z.update(reference_gain(z['pcm']))
+        np.savez_compressed(os.path.join(OUT, 'testwav.npz'), **z)
+        print('nonorm + testwav gain fixtures written', z['gain'], z['mean_square'])
+        return
     if '--only-features' in sys.argv:
         features_fixture(tmp)
         print('features fixture written')
@@ -281,7 +341,8 @@ def main():
     feat = AudioFeaturizer(feature_method='fbank', n_mels=80, sample_rate=16000, use_dB_normalization=True,
                            target_dB=-20).featurize(seg)
     i16 = seg.to('int16')
-    np.savez_compressed(os.path.join(OUT, 'testwav.npz'), pcm=pcm, norm_i16=i16, fbank=feat.astype(np.float32))
+    np.savez_compressed(os.path.join(OUT, 'testwav.npz'), pcm=pcm, norm_i16=i16, fbank=feat.astype(np.float32),
+                        **reference_gain(pcm))
 
     # ---- conformer V=512 ----------------------------------------------------
     feats, lens = golden_inputs()

@@ -1,0 +1,87 @@
+"""CPU: the on-disk formats either side of the path and the host-side gain arithmetic.
+
+* ``inference.pt``: the REAL reference models (via oracle/shims) exported with ``model.export()`` + ``torch.jit.save`` exactly
+  like ``MASRTrainer.export`` (trainer.py:653-697) must come back from ``load_state_dict`` key for key, value for value;
+* packed artefact: DeepSpeech2 keeps its ``decoder.ctc_lo.*`` head; the bf16 blob widens back to the rounded weights;
+* ``engine.reference_gains`` == what ``AudioSegment.normalize`` multiplies by on this host (bit-exact, random utterances).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shims, weights
+
+needs_ref = pytest.mark.skipif(not shims.reference_available(), reason='reference checkout not present')
+
+
+@needs_ref
+@pytest.mark.parametrize('family', ['conformer', 'deepspeech2'])
+def test_torchscript_export_round_trips_key_for_key(tmp_path, family):
+    from masr_amd.infer_utils.inference_predictor import load_state_dict
+    from oracle import make_golden
+    shims.install()
+    if family == 'conformer':
+        sd = weights.conformer_state_dict(0, 64)
+        model = make_golden.build_reference_conformer(sd, 64, str(tmp_path))[0]
+        head = 'ctc.ctc_lo.weight'
+    else:
+        sd = weights.deepspeech2_state_dict(0, 64, bidirectional=False)
+        model = make_golden.build_reference_deepspeech2(sd, 64, True, str(tmp_path))
+        model = model[0] if isinstance(model, tuple) else model
+        head = 'decoder.ctc_lo.weight'
+    path = os.path.join(tmp_path, 'inference.pt')
+    torch.jit.save(model.export(), path)                       # trainer.py:684-689
+    back = load_state_dict(path)
+    want = model.state_dict()
+    assert set(back) == set(want) and head in back            # TorchScript keeps every parameter and buffer under its name
+    for k, v in want.items():
+        assert tuple(back[k].shape) == tuple(v.shape) and torch.equal(back[k].to(v.dtype), v), k
+    for k, v in sd.items():                                    # and those are the tensors the engine is keyed by
+        if k in back:
+            assert torch.equal(back[k].float(), torch.as_tensor(v).float()), k
+    # model.pt (plain state_dict, trainer.py:308) takes the other branch of the loader
+    mpath = os.path.join(tmp_path, 'model.pt')
+    torch.save(model.state_dict(), mpath)
+    assert set(load_state_dict(mpath)) == set(want)
+
+
+def test_packed_deepspeech2_keeps_its_head_and_bf16_blob(tmp_path):
+    from masr_amd.infer_utils.inference_predictor import load_state_dict
+    from masr_amd.utils import packed, synthetic
+    sd = synthetic.deepspeech2_state_dict(0, 50, rnn_size=64, num_rnn_layers=2, bidirectional=True)
+    p32, p16 = os.path.join(tmp_path, 'ds2.masr'), os.path.join(tmp_path, 'ds2_bf16.masr')
+    n = packed.export_packed(sd, p32)
+    assert n == len(sd) and {'decoder.ctc_lo.weight', 'decoder.ctc_lo.bias'} <= set(load_state_dict(p32))
+    for k, v in load_state_dict(p32).items():
+        assert torch.equal(v, torch.as_tensor(sd[k]).float())
+    assert packed.export_packed(sd, p16, dtype='bf16') == n
+    assert os.path.getsize(p16) < 0.55 * os.path.getsize(p32) + 4096
+    back, _ = packed.load_packed(p16)
+    for k, v in back.items():
+        want = torch.as_tensor(sd[k]).float().to(torch.bfloat16).float()
+        assert v.dtype == torch.float32 and torch.equal(v, want), k
+    with pytest.raises(ValueError):
+        packed.export_packed(sd, p16, dtype='fp8')
+
+
+@needs_ref
+def test_reference_gains_equal_audio_segment_normalize():
+    from masr_amd.engine import reference_gains
+    shims.install()
+    from masr.data_utils.audio import AudioSegment
+    rng = np.random.default_rng(11)
+    for k in range(200):
+        n = int(rng.integers(400, 40000))
+        x = (rng.normal(0, 10 ** rng.uniform(-4, -0.3), n)).astype(np.float32)
+        seg = AudioSegment.from_ndarray(x.copy(), 16000)
+        ms = np.mean(seg.samples ** 2)
+        target = int(rng.integers(-30, -9)) if k % 2 else float(rng.uniform(-30, -10))
+        seg.normalize(target_db=target)
+        g = reference_gains(np.array([ms], np.float32), target)
+        assert g.dtype == np.float32 and np.array_equal(x * g[0], seg.samples), (k, g)
+    with pytest.raises(ValueError):                              # silence: gain above max_gain_db (audio.py:300-303)
+        reference_gains(np.array([1e-38], np.float32), -20, max_gain_db=300.0)
+    assert reference_gains(np.array([0.0], np.float32), -20)[0] == np.float32(10.) ** (np.float32(-20) / np.float32(20.))

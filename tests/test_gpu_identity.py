@@ -1,0 +1,178 @@
+"""GPU: transcript identity at the facade level (north_star: "greedy transcript bit-identical ... CER equal to reference on
+dataset/test.wav").  The fixtures were recorded from the REAL reference facade (oracle/make_golden.py, MASRPredictor(use_gpu=
+False) on the TorchScript export of the synthetic model):
+
+  predictor.npz         conformer.yml as shipped (use_dB_normalization: True): predict + every predict_stream partial
+  predictor_nonorm.npz  the same with use_dB_normalization: False
+  testwav.npz           test.wav's PCM, the reference's normalised int16 samples, the float32 gain it applied (on the host
+                        that generated the fixture) and the mean square it started from
+
+The only machine-dependent arithmetic on the path is the normalisation gain (numpy's float32 log10 / power are not correctly
+rounded and differ between hosts, engine.reference_gains).  Three isolations:
+  (a) normalisation OFF (predictor_nonorm.npz): every transcript must be IDENTICAL, scores to 1e-3 -- unconditionally;
+  (b) the reference's own normalised samples fed with normalisation off: the offline transcript of predictor.npz, identical;
+  (c) normalisation ON with the fixture's gain supplied: int16 samples bit-exact, transcript identical; with this host's own
+      numpy gain: identical whenever this numpy reproduces the fixture's gain (reported either way, CER printed).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+CONFIG = """
+encoder_conf: {output_size: 256, attention_heads: 4, linear_units: 2048, num_blocks: 12, input_layer: conv2d,
+  normalize_before: True, cnn_module_kernel: 15, use_cnn_module: True, activation_type: swish, pos_enc_layer_type: rel_pos}
+preprocess_conf: {feature_method: fbank, n_mels: 80, n_mfcc: 40, sample_rate: 16000, use_dB_normalization: NORM, target_dB: -20}
+dataset_conf: {dataset_vocab: VOCAB}
+use_model: conformer
+streaming: True
+decoder: ctc_greedy
+metrics_type: cer
+"""
+
+
+def _predictor(d, norm):
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.utils import synthetic
+    vpath = os.path.join(d, 'vocabulary.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in synthetic.synthetic_vocab(4233):
+            f.write(f'{t}\t1\n')
+    cfg = yaml.safe_load(CONFIG.replace('VOCAB', vpath).replace('NORM', str(norm)))
+    return MASRPredictor(configs=cfg, use_gpu=True, state_dict=synthetic.conformer_state_dict(0, 4233))
+
+
+@pytest.fixture(scope='module')
+def pred_nonorm(tmp_path_factory):
+    p = _predictor(str(tmp_path_factory.mktemp('nonorm')), False)
+    yield p
+    p.predictor.engine.close()
+
+
+@pytest.fixture(scope='module')
+def pred_norm(tmp_path_factory):
+    p = _predictor(str(tmp_path_factory.mktemp('norm')), True)
+    yield p
+    p.predictor.engine.close()
+
+
+def _cer(a, b):
+    from oracle import decoders as od
+    return od.cer(a, b)
+
+
+def _stream(pred, pcm, z, exact):
+    pred.reset_stream()
+    worst, k = 0.0, 0
+    for s in range(0, len(pcm), 8000):
+        r = pred.predict_stream(audio_data=pcm[s:s + 8000].tobytes(), is_end=(s + 8000 >= len(pcm)))
+        valid = r is not None and r['text'] is not None
+        assert valid == bool(z['stream_valid'][k]), f'call {k}: validity differs'
+        if valid:
+            ref = str(z['stream_text'][k])
+            worst = max(worst, _cer(ref, r['text']))
+            if exact:
+                assert r['text'] == ref, (k, r['text'], ref)
+                assert abs(r['score'] - float(z['stream_score'][k])) < 1e-3, (k, r['score'], float(z['stream_score'][k]))
+        k += 1
+    pred.reset_stream()
+    return worst
+
+
+def test_a_normalisation_off_every_transcript_identical(pred_nonorm):
+    z = np.load(os.path.join(GOLDEN, 'predictor_nonorm.npz'))
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    res = pred_nonorm.predict(audio_data=pcm.copy())
+    assert res['text'] == str(z['offline_text']), (res['text'], str(z['offline_text']))
+    assert abs(res['score'] - float(z['offline_score'])) < 1e-3, (res['score'], float(z['offline_score']))
+    assert _stream(pred_nonorm, pcm, z, exact=True) == 0.0
+    # the same through the batched path and the one-call C entry point
+    assert pred_nonorm.predict_batch([pcm.copy()])[0]['text'] == str(z['offline_text'])
+    eng = pred_nonorm.predictor.engine
+    tok, ntok, score = eng.transcribe_batch(torch.from_numpy(pcm[None]).cuda(), torch.tensor([len(pcm)], dtype=torch.int32).cuda(),
+                                            use_db_normalization=False)
+    text = pred_nonorm._text(tok[0, :int(ntok[0])].cpu().numpy())
+    assert text == str(z['offline_text']) and abs(float(score[0]) * 100.0 - float(z['offline_score'])) < 1e-3
+
+
+def test_b_reference_normalised_samples_give_the_reference_transcript(pred_nonorm):
+    """predictor.npz was recorded WITH normalisation; its int16 samples are in testwav.npz.  Fed with normalisation off they
+    are exactly what the reference's featurizer saw, so the offline transcript must be the fixture's."""
+    z = np.load(os.path.join(GOLDEN, 'predictor.npz'))
+    norm_i16 = np.load(os.path.join(GOLDEN, 'testwav.npz'))['norm_i16']
+    res = pred_nonorm.predict(audio_data=norm_i16.copy())
+    assert res['text'] == str(z['offline_text']), (res['text'], str(z['offline_text']))
+    assert abs(res['score'] - float(z['offline_score'])) < 1e-3
+
+
+def test_c_normalisation_on_with_the_reference_gain(pred_norm):
+    from masr_amd.engine import reference_gains
+    tw = np.load(os.path.join(GOLDEN, 'testwav.npz'))
+    z = np.load(os.path.join(GOLDEN, 'predictor.npz'))
+    pcm = tw['pcm']
+    eng = pred_norm.predictor.engine
+    xs = torch.from_numpy(pcm[None]).cuda()
+    ns = torch.tensor([len(pcm)], dtype=torch.int32).cuda()
+    # the device's mean square IS numpy's (buffered pairwise summation replicated)
+    ms = eng.mean_square(xs, ns).cpu().numpy()
+    assert ms[0] == tw['mean_square'], (ms[0], tw['mean_square'])
+    # the fixture's gain supplied: the normalised int16 samples are the reference's, bit for bit
+    feats, frames, norm = eng.fbank_batch(xs, ns, True, -20, return_norm=True, gain_in=torch.tensor([tw['gain']]))
+    assert np.array_equal(norm[0].cpu().numpy(), tw['norm_i16'])
+    # this host's numpy on the same mean square (what predict() does)
+    mine = reference_gains(ms, -20)[0]
+    same_host_arithmetic = mine == tw['gain']
+    res = pred_norm.predict(audio_data=pcm.copy())
+    cer_off = _cer(str(z['offline_text']), res['text'])
+    cer_stream = _stream(pred_norm, pcm, z, exact=same_host_arithmetic)
+    print(f"normalisation on: numpy gain here {mine!r} vs fixture {tw['gain']!r} ({'same' if same_host_arithmetic else 'DIFFERENT'} "
+          f"float32 log10 / power); offline CER {cer_off}, worst streaming-partial CER {cer_stream}")
+    if same_host_arithmetic:
+        assert res['text'] == str(z['offline_text']) and abs(res['score'] - float(z['offline_score'])) < 1e-3
+    else:                       # +-1 LSB on a fraction of the int16 samples: transcripts may move by single characters
+        assert cer_off <= 0.05 and cer_stream <= 0.1
+
+
+def test_ragged_efficient_conformer_batch_equals_per_utterance(tmp_path):
+    """the valid-frame count of the Efficient Conformer is ceil(T'/2) (stride layer): a ragged predict_batch must not decode
+    padding frames of the shorter utterances.  Checked against per-utterance decoding of the SAME padded batch rows."""
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.utils import synthetic
+    from oracle import efficient_conformer as oe, decoders as od, fbank as ofb
+    V = 300
+    vocab = synthetic.synthetic_vocab(V)
+    vpath = os.path.join(tmp_path, 'vocabulary.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in vocab:
+            f.write(f'{t}\t1\n')
+    cfg = {'encoder_conf': {}, 'preprocess_conf': {'feature_method': 'fbank', 'n_mels': 80, 'n_mfcc': 40, 'sample_rate': 16000,
+                                                   'use_dB_normalization': False, 'target_dB': -20},
+           'dataset_conf': {'dataset_vocab': vpath}, 'use_model': 'efficient_conformer', 'streaming': True,
+           'decoder': 'ctc_greedy', 'metrics_type': 'cer'}
+    sd = synthetic.efficient_conformer_state_dict(0, V)
+    p = MASRPredictor(configs=cfg, use_gpu=True, state_dict=sd)
+    lens = [40000, 17000, 29123, 9000]
+    pcm = synthetic.synthetic_pcm(len(lens), max(lens), seed=8)
+    got = p.predict_batch([pcm[i, :l] for i, l in enumerate(lens)])
+    # oracle on the same zero-padded batch (reference batch semantics), each utterance decoded over ITS frames
+    T = ofb.num_frames(max(lens))
+    feats = np.zeros((len(lens), T, 80), np.float32)
+    frames = []
+    for i, l in enumerate(lens):
+        f, _ = ofb.featurize_pcm16(pcm[i, :l], use_db_normalization=False)
+        feats[i, :f.shape[0]] = f
+        frames.append(f.shape[0])
+    with torch.no_grad():
+        probs = oe.get_encoder_out(sd, torch.from_numpy(feats), torch.tensor(frames)).numpy()
+    for i, fr in enumerate(frames):
+        n_enc = (((fr - 1) // 2 - 1) // 2 + 1) // 2
+        s_ref, t_ref = od.greedy_decoder(probs[i, :n_enc], vocab)
+        assert _cer(t_ref, got[i]['text']) <= 0.05, (i, got[i]['text'], t_ref)
+        assert abs(got[i]['score'] - s_ref) < 0.1
+        assert len(got[i]['text']) <= n_enc               # nothing decoded from the padding behind the utterance
+    p.predictor.engine.close()

@@ -1,0 +1,164 @@
+"""GPU: size-regime parity.  The fixtures of test_gpu_parity.py are T = 331 frames (T' <= 82), B = 3; the kernels change
+regime with size -- attention key-tile loops, positional-table offsets, the FFN / GEMM split heuristics, >= 64 row blocks,
+more workgroups than CUs.  Here the HIP path is compared with the CPU oracle (pinned bit-identical to the reference modules,
+tests/test_oracle_golden.py) at BASELINE.json's own sizes:
+
+  * one 20 s utterance (T = 1998 -> T' = 498 keys; Squeezeformer 249 after its time reduction) -- configs[2]'s longest;
+  * a ragged batch of 32 utterances up to 10 s (T = 998 -> T' = 248, M = 7936 rows) -- configs[1] / [3];
+  * chunk steps with a long history (offset ~ 1000 encoder frames) for one stream and for >= 128 lock-step streams -- configs[4].
+
+Bar: encoder output / probabilities <= 1e-3 (fp32), as north_star states.  The achieved error is printed (-s) and asserted.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def _inputs(B, T, seed, ragged):
+    gen = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, T, 80, generator=gen) * 3 + 13
+    lens = torch.full((B,), T, dtype=torch.int64)
+    if ragged and B > 1:
+        lens[1:] = torch.randint(T // 3, T + 1, (B - 1,), generator=gen)
+        lens[B // 2] = T - 1
+    feats = feats * (torch.arange(T)[None, :, None] < lens[:, None, None])      # collate_fn zero padding
+    return feats, lens
+
+
+def _families():
+    """(name, engine factory, oracle encoder) for the four model families as their YAMLs ship them"""
+    from masr_amd.engine import HipEngine
+    from oracle import conformer as oc, efficient_conformer as oe, squeezeformer as osq, weights
+    V = 512
+    return {
+        'conformer': (lambda: (HipEngine(sd := weights.conformer_state_dict(0, V), vocab_size=V), sd),
+                      lambda sd, f, l: oc.encoder_full(sd, f, l, -1)),
+        'squeezeformer': (lambda: (HipEngine(sd := weights.squeezeformer_state_dict(0, V), vocab_size=V, streaming=False,
+                                             use_model='squeezeformer'), sd),
+                          lambda sd, f, l: osq.encoder_full(sd, f, l)),
+        'squeezeformer_streaming': (lambda: (HipEngine(sd := weights.squeezeformer_state_dict(0, V, streaming=True), vocab_size=V,
+                                                       streaming=True, use_model='squeezeformer'), sd),
+                                    lambda sd, f, l: osq.encoder_full(sd, f, l, causal=True)),
+        'efficient_conformer': (lambda: (HipEngine(sd := weights.efficient_conformer_state_dict(0, V), vocab_size=V, streaming=True,
+                                                   use_model='efficient_conformer'), sd),
+                                lambda sd, f, l: oe.encoder_full(sd, f, l)),
+    }
+
+
+@pytest.fixture(scope='module', params=['conformer', 'squeezeformer', 'squeezeformer_streaming', 'efficient_conformer'])
+def family(request):
+    make, oracle = _families()[request.param]
+    eng, sd = make()
+    yield request.param, eng, sd, oracle
+    eng.close()
+
+
+def _compare(name, what, enc, ref, lens_enc=None):
+    assert tuple(enc.shape) == tuple(ref.shape), (enc.shape, ref.shape)
+    d = (enc - ref).abs()
+    if lens_enc is not None:                       # rows behind an utterance's own frames are padding-defined garbage in both
+        keep = torch.arange(enc.shape[1])[None, :] < lens_enc[:, None]
+        d = d * keep[:, :, None]
+    err = d.max().item()
+    print(f'{name} {what}: max |enc - oracle| = {err:.3e} over {tuple(enc.shape)}')
+    assert err < 1e-3, f'{name} {what}: {err}'
+
+
+def test_long_utterance_20s_against_oracle(family):
+    name, eng, sd, oracle = family
+    feats, lens = _inputs(1, 1998, seed=20, ragged=False)
+    with torch.no_grad():
+        ref = oracle(sd, feats, lens)
+    enc = eng.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
+    _compare(name, '1 x 20 s', enc, ref)
+
+
+def test_batch32_10s_against_oracle(family):
+    name, eng, sd, oracle = family
+    feats, lens = _inputs(32, 998, seed=32, ragged=True)
+    with torch.no_grad():
+        ref = oracle(sd, feats, lens)
+    enc = eng.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
+    _compare(name, '32 x <= 10 s (ragged)', enc, ref, eng.enc_frames(lens))
+    # and the whole device path at that size: CTC head + collapse agree with the oracle's argmax path where the oracle's
+    # top-2 margin is above the numerical noise
+    probs = torch.softmax(torch.nn.functional.linear(ref, sd['ctc.ctc_lo.weight'], sd['ctc.ctc_lo.bias']), dim=-1)
+    idx, mp = eng.ctc_greedy_frames(dev(enc))
+    top2 = probs.topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 2e-3
+    keep = torch.arange(enc.shape[1])[None, :] < eng.enc_frames(lens)[:, None]
+    agree = (idx.cpu() == probs.argmax(-1))[safe & keep]
+    print(f'{name}: {int((safe & keep).sum())} decided frames of {int(keep.sum())}, argmax agreement {agree.float().mean():.6f}')
+    assert agree.all()
+
+
+def test_deepspeech2_sizes_against_oracle():
+    """bi-directional DeepSpeech2: one 20 s utterance (498 LSTM steps on the per-unit kernel) and 32 ragged utterances of up
+    to 3 s (the MFMA recurrence for 5..32 sequences)"""
+    from masr_amd.engine import HipEngine
+    from oracle import deepspeech2 as ods, weights
+    sd = weights.deepspeech2_state_dict(0, 300, bidirectional=True)
+    eng = HipEngine(sd, encoder_conf={'num_rnn_layers': 5, 'rnn_size': 1024}, streaming=False, use_model='deepspeech2')
+    try:
+        for B, T, what in ((1, 1998, '1 x 20 s'), (32, 298, '32 x <= 3 s (ragged)')):
+            feats, lens = _inputs(B, T, seed=B, ragged=True)
+            with torch.no_grad():
+                ref = ods.get_encoder_out(sd, feats, lens)
+            probs = eng.ctc_probs(eng.encode_full(dev(feats), dev(lens, torch.int32))).cpu()[:, :ref.shape[1]]
+            n_enc = ((lens - 1) // 2 - 1) // 2
+            keep = torch.arange(ref.shape[1])[None, :] < n_enc[:, None]
+            err = ((probs - ref).abs() * keep[:, :, None]).max().item()
+            print(f'deepspeech2 {what}: max |probs - oracle| = {err:.3e}')
+            assert err < 1e-3
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize('n_streams', [1, 130])
+def test_chunk_steps_with_long_history_against_oracle(n_streams):
+    """62 chunk steps of 16 encoder frames: the last ones attend over ~1000 cached keys (positional table offsets ~ 1000,
+    many key tiles, cache appends far into the stream's buffer).  130 lock-step streams take the throughput kernels, a single
+    stream the latency-cut ones; streams alternate between two inputs and every checked stream must match ITS oracle run."""
+    from masr_amd.engine import HipEngine
+    from oracle import conformer as oc, weights
+    V = 512
+    sd = weights.conformer_state_dict(0, V)
+    eng = HipEngine(sd, vocab_size=V)
+    steps, win, stride = 62, 67, 64
+    T = stride * (steps - 1) + win
+    gen = torch.Generator().manual_seed(5)
+    feats = torch.randn(2, T, 80, generator=gen) * 3 + 13
+    check_from = steps - 3
+    ref = []
+    with torch.no_grad():
+        for u in range(2 if n_streams > 1 else 1):
+            att, cnn, off, tail = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0), 0, []
+            for k in range(steps):
+                p, att, cnn = oc.get_encoder_out_chunk(sd, feats[u:u + 1, k * stride:k * stride + win], off, -1, att, cnn)
+                off += p.shape[1]
+                if k >= check_from:
+                    tail.append(p[0])
+            ref.append(torch.stack(tail))
+    assert off == 16 * steps
+    try:
+        sids = [eng.stream_open(16 * steps + 16) for _ in range(n_streams)]
+        x = dev(feats[torch.arange(n_streams) % 2])
+        worst = 0.0
+        for k in range(steps):
+            probs, _, _ = eng.encode_chunk(sids, x[:, k * stride:k * stride + win].contiguous())
+            if k >= check_from:
+                for s in sorted({0, min(1, n_streams - 1), n_streams - 1}):
+                    worst = max(worst, (probs[s].cpu() - ref[s % 2][k - check_from]).abs().max().item())
+        print(f'{n_streams} stream(s), offset {eng.stream_offset(sids[0])}: max |probs - oracle| over the last 3 chunk steps = {worst:.3e}')
+        assert eng.stream_offset(sids[0]) == 16 * steps and worst < 1e-3
+    finally:
+        eng.close()
