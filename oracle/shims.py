@@ -10,6 +10,7 @@ numpy restatement in ``oracle/fbank.py`` (torchaudio is not installed).
 ``oracle/make_golden.py`` (fixture generation) and by CPU tests that are
 skipped when the reference is absent.
 """
+import importlib.machinery
 import os
 import sys
 import types
@@ -24,6 +25,7 @@ def reference_available() -> bool:
 
 def _stub(name, **attrs):
     m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)     # importlib.util.find_spec(name) must keep working on a stub
     m.__dict__.update(attrs)
     sys.modules[name] = m
     return m
