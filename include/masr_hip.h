@@ -125,6 +125,22 @@ int masr_ctc_collapse(masr_engine* e, const int32_t* argmax_dev, const float* ma
 int masr_argmax_rows(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t* argmax_dev,
                      float* maxprob_dev, void* stream);
 
+/* External n-gram language model scorer of the beam search.  Replaces the `Scorer` of paddlespeech_ctcdecoders (scorer.cpp on
+ * KenLM; constructed in masr/decoders/beam_search_decoder.py:29-35, swig_wrapper.py:4-18; parameters alpha / beta of
+ * configs/conformer.yml:74-88).  Character-based ARPA models up to order 5; `vocab_utf8` = the model's vocabulary tokens (the
+ * LM words are matched to them by string; <s> / </s> get ids V / V + 1; n-grams with words the model cannot emit are dropped).
+ * KenLM binaries are not parsed (returns non-zero, masr_lm_last_error()).  The table is uploaded to a GPU on first use there.
+ *   masr_lm_cond_log_prob      ln P(ids[n-1] | ids[..n-2]) as Scorer::get_log_cond_prob scores the <s>-padded n-gram
+ *                              (OOV_SCORE = -1000 as soon as one word is unknown to the LM)
+ *   masr_lm_sentence_log_prob  Scorer::get_sent_log_prob: sum over the words and </s> */
+typedef struct masr_lm masr_lm;
+int masr_lm_load_arpa(const char* path, const char* const* vocab_utf8, int32_t V, masr_lm** out);
+void masr_lm_destroy(masr_lm* lm);
+const char* masr_lm_last_error(void);
+int masr_lm_info(const masr_lm* lm, int32_t* max_order, int64_t* n_ngrams, int32_t* char_based, int64_t* skipped);
+int masr_lm_cond_log_prob(const masr_lm* lm, const int32_t* ids, int32_t n, float* out);
+int masr_lm_sentence_log_prob(const masr_lm* lm, const int32_t* ids, int32_t n, float* out);
+
 /* CTC prefix beam search.  Replaces BeamSearchDecoder.* -> paddlespeech_ctcdecoders
  * (masr/decoders/beam_search_decoder.py:45-96, swig_wrapper.py:35-121; third-party, un-vendored: parity
  * unpinned, external LM scorer not implemented = the alpha 0 path).
@@ -143,10 +159,18 @@ int masr_beam_reset(masr_beam* h);
 int masr_beam_advance(masr_beam* h, const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
                       int32_t T, int32_t K);
 int masr_beam_result(masr_beam* h, int32_t* tokens_host, int32_t max_len, int32_t* len, float* score);
+/* binds the external scorer (or NULL) and restarts the search: a prefix extended by a character adds
+ * alpha * ln P_LM(character | last words of the prefix) + beta to its score (ctc_beam_search_decoder.cpp); the reported score is
+ * the decoder's approx_ctc (scorer share removed again).  The *_lm variants of the batch searches take the same three values. */
+int masr_beam_set_lm(masr_beam* h, const masr_lm* lm, float alpha, float beta);
 int masr_beam_search_batch(const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
                            const int32_t* frames_host, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
                            int32_t blank, int32_t num_threads, int32_t* tokens_host, int32_t max_len, int32_t* len_host,
                            float* score_host);
+int masr_beam_search_batch_lm(const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
+                              const int32_t* frames_host, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
+                              int32_t blank, int32_t num_threads, const masr_lm* lm, float alpha, float beta,
+                              int32_t* tokens_host, int32_t max_len, int32_t* len_host, float* score_host);
 
 /* CTC prefix beam search of a whole batch ON THE GPU (one workgroup per utterance; live prefixes, candidate scores and
  * the top-`beam_size` selection live in LDS, trie nodes of survivors in HBM).  Same inputs as masr_beam_search_batch but
@@ -158,6 +182,12 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
                          const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
                          int32_t blank, int32_t* tokens_dev, int32_t max_len, int32_t* len_dev, float* score_dev,
                          void* stream);
+/* the same with the external scorer applied inside the kernel (LM table, known-word map in HBM; every live prefix carries its
+ * packed last words, matched context length and backoff weights in LDS) */
+int masr_beam_search_gpu_lm(masr_engine* e, const int32_t* idx_dev, const float* logp_dev, const int32_t* count_dev,
+                            const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
+                            int32_t blank, masr_lm* lm, float alpha, float beta, int32_t* tokens_dev, int32_t max_len,
+                            int32_t* len_dev, float* score_dev, void* stream);
 
 /* Streaming variant: a device-resident search per stream.  masr_gbeam_advance consumes the pruned candidates of the next T
  * frames (device arrays from masr_ctc_topk) and returns the best prefix so far (tokens/len/score device arrays); the
@@ -170,6 +200,8 @@ int masr_gbeam_advance(masr_engine* e, int32_t handle, const int32_t* idx_dev, c
                        int32_t* len_dev, float* score_dev, void* stream);
 int masr_gbeam_reset(masr_engine* e, int32_t handle);
 int masr_gbeam_close(masr_engine* e, int32_t handle);
+/* external scorer of a streaming search (between utterances only: after open or reset) */
+int masr_gbeam_set_lm(masr_engine* e, int32_t handle, masr_lm* lm, float alpha, float beta);
 
 /* One call for the whole offline hot path (MASRPredictor.predict semantics, masr/predict.py:167-192,
  * batched like MASRTrainer.evaluate, trainer.py:632): PCM -> fbank -> encoder -> CTC greedy.

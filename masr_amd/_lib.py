@@ -52,6 +52,16 @@ SIGNATURES = {
     'masr_gbeam_advance': [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P],
     'masr_gbeam_reset': [_P, _I],
     'masr_gbeam_close': [_P, _I],
+    'masr_gbeam_set_lm': [_P, _I, _P, _F, _F],
+    'masr_beam_set_lm': [_P, _P, _F, _F],
+    'masr_beam_search_batch_lm': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _F, _P, _I, _P, _P],
+    'masr_beam_search_gpu_lm': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _F, _F, _P, _I, _P, _P, _P],
+    'masr_lm_load_arpa': [C.c_char_p, C.POINTER(C.c_char_p), _I, C.POINTER(_P)],
+    'masr_lm_destroy': [_P],
+    'masr_lm_last_error': [],
+    'masr_lm_info': [_P, C.POINTER(_I), C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_int64)],
+    'masr_lm_cond_log_prob': [_P, C.POINTER(_I), _I, C.POINTER(_F)],
+    'masr_lm_sentence_log_prob': [_P, C.POINTER(_I), _I, C.POINTER(_F)],
     'masr_mean_square': [_P, _P, _I, _P, _I, _I, _P, _P],
     'masr_mfcc_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     'masr_linear_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _P],
@@ -68,7 +78,8 @@ SIGNATURES = {
     'masr_profile_select': [_P, _I],
     'masr_profile_read': [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _I],
 }
-_RESTYPE = {'masr_last_error': C.c_char_p, 'masr_destroy': None, 'masr_beam_destroy': None}
+_RESTYPE = {'masr_last_error': C.c_char_p, 'masr_destroy': None, 'masr_beam_destroy': None, 'masr_lm_destroy': None,
+            'masr_lm_last_error': C.c_char_p}
 
 
 def lib():

@@ -43,6 +43,9 @@ __device__ __forceinline__ unsigned okey(float f) {       // larger float -> lar
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ __forceinline__ float ikey(unsigned k) {       // inverse of okey
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
 
 // identity of the prefix string: hash chain over its characters (64 bits; never 0)
 __device__ __forceinline__ unsigned long long str_hash(unsigned long long parent, int ch) {
@@ -149,7 +152,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     float* ext = rep + beam;                                            // [beam] parent-extension term of nb_cur
     int* head = reinterpret_cast<int*>(ext + beam);                      // [beam] first live child
     int* next = head + beam;                                             // [beam] next live child of the same parent
-    int* c_idx = next + beam;                                            // [BS_KMAX]
+    unsigned long long* lv_ctx = reinterpret_cast<unsigned long long*>(next + beam + (beam & 1));   // [2][beam] packed LM context
+    float* lv_bo = reinterpret_cast<float*>(lv_ctx + 2 * beam);          // [2][beam][4] backoffs of the context's suffixes
+    int* lv_m = reinterpret_cast<int*>(lv_bo + 8 * beam);                // [2][beam] m | oov << 8
+    int* c_idx = lv_m + 2 * beam;                                        // [BS_KMAX]
     float* c_lp = reinterpret_cast<float*>(c_idx + BS_KMAX);             // [BS_KMAX]
     int* hist = reinterpret_cast<int*>(c_lp + BS_KMAX);                  // [7][256]: one per radix pass of a step
     int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
@@ -158,9 +164,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 
     int* pool_parent = a.pool_parent + (size_t)u * a.pool_cap;
     int* pool_ch = a.pool_ch + (size_t)u * a.pool_cap;
-    int* st_i = a.state_i + (size_t)u * (2 + 2 * beam);
-    float* st_f = a.state_f + (size_t)u * (3 * beam);
-    unsigned long long* st_h = a.state_h + (size_t)u * (2 * beam);
+    int* st_i = a.state_i + (size_t)u * (2 + 3 * beam);
+    float* st_f = a.state_f + (size_t)u * (7 * beam);
+    unsigned long long* st_h = a.state_h + (size_t)u * (3 * beam);
+    const bool use_lm = a.use_lm != 0;
 
     int n, pool_count, cur = 0;
     if (a.init) {
@@ -171,6 +178,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             pool_ch[0] = -1;
             lv_node[0] = 0; lv_ch[0] = -1; lv_hid[0] = 0x1234567887654321ull; lv_phid[0] = 0ull;
             lv_b[0] = 0.f; lv_nb[0] = -INFINITY; lv_sc[0] = 0.f;
+            if (use_lm) {
+                const LmState s0 = lm_state_of(a.lm, lm_root_ctx(a.lm));
+                lv_ctx[0] = s0.ctx; lv_m[0] = s0.m | (s0.oov << 8);
+                for (int j = 0; j < 4; ++j) lv_bo[j] = s0.bo[j];
+            }
         }
     } else {
         n = st_i[0];
@@ -179,6 +191,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             lv_node[i] = st_i[2 + i]; lv_ch[i] = st_i[2 + beam + i];
             lv_hid[i] = st_h[i]; lv_phid[i] = st_h[beam + i];
             lv_b[i] = st_f[i]; lv_nb[i] = st_f[beam + i]; lv_sc[i] = st_f[2 * beam + i];
+            if (use_lm) {
+                lv_ctx[i] = st_h[2 * beam + i]; lv_m[i] = st_i[2 + 2 * beam + i];
+                for (int j = 0; j < 4; ++j) lv_bo[4 * i + j] = st_f[(3 + j) * beam + i];
+            }
         }
     }
     const unsigned NEG = okey(-INFINITY);
@@ -246,6 +262,14 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         if (my_p < n) {
             const float sc = lv_sc[o + my_p], pb = lv_b[o + my_p], pnb = lv_nb[o + my_p];
             const int ch = lv_ch[o + my_p], hd = head[my_p];
+            LmState sp;
+            if (use_lm) {
+                sp.ctx = lv_ctx[o + my_p];
+                const int mo = lv_m[o + my_p];
+                sp.m = mo & 255; sp.oov = mo >> 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sp.bo[j] = lv_bo[4 * (o + my_p) + j];
+            }
             for (int k = my_g; k < cnt; k += G) {
                 const int c = c_idx[k];
                 const float lp = c_lp[k];
@@ -257,6 +281,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                     } else {
                         val = lp + sc;
                     }
+                    // the external scorer: every way into the prefix p + c carries the same alpha * ln P_LM + beta
+                    if (use_lm && val > -INFINITY) val += a.alpha * lm_cond(a.lm, sp, c) + a.beta;
                     for (int j = hd; j >= 0; j = next[j])
                         if (lv_ch[o + j] == c) {                    // the child (p, c) is a live prefix: merge into it
                             ext[j] = val;
@@ -388,6 +414,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             lv_b[o2 + my_slot] = bcur[tid];
             lv_nb[o2 + my_slot] = my_nb;
             lv_sc[o2 + my_slot] = my_sc;
+            if (use_lm) {
+                lv_ctx[o2 + my_slot] = lv_ctx[o + tid]; lv_m[o2 + my_slot] = lv_m[o + tid];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lv_bo[4 * (o2 + my_slot) + j] = lv_bo[4 * (o + tid) + j];
+            }
         }
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
@@ -400,7 +431,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                     const int e = slist[tid + i * BS_THREADS];
                     const int p = e / cnt, k = e - p * cnt;
                     const int c = c_idx[k];
-                    const float add = c == lv_ch[o + p] ? c_lp[k] + lv_b[o + p] : c_lp[k] + lv_sc[o + p];
+                    const float add = ikey(kk);           // the entry's own score (acoustic term + scorer term), as ranked
                     if (node < a.pool_cap) {
                         pool_parent[node] = lv_node[o + p];
                         pool_ch[node] = c;
@@ -412,6 +443,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                     lv_b[o2 + slot] = -INFINITY;
                     lv_nb[o2 + slot] = add;
                     lv_sc[o2 + slot] = add;
+                    if (use_lm) {                         // the new prefix's scorer state: its words, matched suffixes, backoffs
+                        const LmState sn = lm_state_of(a.lm, lm_push(lv_ctx[o + p], c));
+                        lv_ctx[o2 + slot] = sn.ctx; lv_m[o2 + slot] = sn.m | (sn.oov << 8);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) lv_bo[4 * (o2 + slot) + j] = sn.bo[j];
+                    }
                 }
             }
         }
@@ -431,6 +468,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         st_i[2 + i] = lv_node[o + i]; st_i[2 + beam + i] = lv_ch[o + i];
         st_h[i] = lv_hid[o + i]; st_h[beam + i] = lv_phid[o + i];
         st_f[i] = lv_b[o + i]; st_f[beam + i] = lv_nb[o + i]; st_f[2 * beam + i] = lv_sc[o + i];
+        if (use_lm) {
+            st_h[2 * beam + i] = lv_ctx[o + i]; st_i[2 + 2 * beam + i] = lv_m[o + i];
+            for (int j = 0; j < 4; ++j) st_f[(3 + j) * beam + i] = lv_bo[4 * (o + i) + j];
+        }
     }
     if (wave == 0) {
         float bs = -INFINITY;
@@ -453,16 +494,28 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             int node = lv_node[o + bi], L = 0;
             for (int x = node; x > 0 && x < a.pool_cap; x = pool_parent[x]) ++L;
             a.len[u] = L;
-            a.score[u] = bs;
             int pos = L - 1;
             for (int x = node; x > 0 && x < a.pool_cap; x = pool_parent[x], --pos)
                 if (pos < a.max_len) a.tokens[(size_t)u * a.max_len + pos] = pool_ch[x];
+            if (use_lm && L <= a.max_len) {
+                // approx_ctc of the reference decoder: the scorer's share is taken out again -- score - |prefix| * beta
+                // - alpha * ln P_LM(sentence), where the sentence probability also counts </s> (Scorer::get_sent_log_prob)
+                unsigned long long ctx = lm_root_ctx(a.lm);
+                float sent = L == 0 ? lm_cond(a.lm, lm_state_of(a.lm, ctx), a.lm.bos) : 0.f;
+                for (int i = 0; i <= L; ++i) {
+                    const int w = i < L ? a.tokens[(size_t)u * a.max_len + i] : a.lm.eos;
+                    sent += lm_cond(a.lm, lm_state_of(a.lm, ctx), w);
+                    ctx = lm_push(ctx, w);
+                }
+                bs = bs - (float)L * a.beta - a.alpha * sent;
+            }
+            a.score[u] = bs;
         }
     }
 }
 
 size_t beam_gpu_lds_bytes(int beam, int K) {
-    return (size_t)beam * K * 6 + (size_t)26 * beam * 4 + BS_HASH * 12 + 2 * BS_KMAX * 4 + 7 * 256 * 4 + (6 + 32) * BS_WAVES * 4 + 8 * 4 + 128;
+    return (size_t)beam * K * 6 + (size_t)(26 + 14) * beam * 4 + 8 + BS_HASH * 12 + 2 * BS_KMAX * 4 + 7 * 256 * 4 + (6 + 32) * BS_WAVES * 4 + 8 * 4 + 128;
 }
 
 template <int NPT>

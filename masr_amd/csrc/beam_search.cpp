@@ -18,6 +18,13 @@
 #include <vector>
 
 #include "../../include/masr_hip.h"
+#include "lm_scorer.h"
+
+namespace masr {
+LmView lm_host_view(const masr_lm* lm);       // lm_scorer.cpp
+}
+using masr::LmState;
+using masr::LmView;
 
 namespace {
 
@@ -35,6 +42,7 @@ struct Node {
     int ch = -1;          // character of this node (-1 = root)
     int parent = -1;
     bool exists = true;
+    LmState lm{};         // external scorer state of this prefix (its last words; lm_scorer.h)
     std::vector<std::pair<int, int>> kids;   // (character, node index)
 };
 
@@ -42,12 +50,24 @@ struct Beam {
     std::vector<Node> pool;
     std::vector<int> prefixes;               // node indices, first min(size, beam) are live candidates
     int beam_size = 300, blank = 0;
+    // external scorer (ctc_beam_search_decoder.cpp: a new prefix p + c adds alpha * ln P_LM(c | p) + beta); lm == nullptr: off
+    const masr_lm* lm = nullptr;
+    LmView view{};
+    float alpha = 0.f, beta = 0.f;
+
+    void set_lm(const masr_lm* m, float a, float b) {
+        lm = m;
+        alpha = a;
+        beta = b;
+        if (lm) view = masr::lm_host_view(lm);
+    }
 
     void reset() {
         pool.clear();
         pool.emplace_back();
         pool[0].score = 0.f;
         pool[0].b_prev = 0.f;
+        if (lm) pool[0].lm = masr::lm_state_of(view, masr::lm_root_ctx(view));
         prefixes.assign(1, 0);
     }
 
@@ -64,6 +84,7 @@ struct Beam {
         Node k;
         k.ch = c;
         k.parent = n;
+        if (lm) k.lm = masr::lm_state_of(view, masr::lm_push(pool[n].lm.ctx, c));
         pool.push_back(k);
         const int id = (int)pool.size() - 1;
         pool[n].kids.emplace_back(c, id);
@@ -117,10 +138,11 @@ struct Beam {
                 if (c == pool[p].ch) pool[p].nb_cur = log_sum_exp(pool[p].nb_cur, lp + pool[p].nb_prev);
                 const int pc = pool[p].ch;
                 const float pscore = pool[p].score, pb = pool[p].b_prev;
-                const int q = child(p, c);          // may reallocate the pool: no references held across it
                 float add = NEG_INF;
                 if (c == pc && pb > NEG_INF) add = lp + pb;
                 else if (c != pc) add = lp + pscore;
+                if (lm && add > NEG_INF) add += alpha * masr::lm_cond(view, pool[p].lm, c) + beta;
+                const int q = child(p, c);          // may reallocate the pool: no references held across it
                 pool[q].nb_cur = log_sum_exp(pool[q].nb_cur, add);
             }
         }
@@ -147,6 +169,19 @@ struct Beam {
         }
         const int len = std::min((int)rev.size(), max_len);
         for (int i = 0; i < len; ++i) tokens[i] = rev[rev.size() - 1 - i];
+        if (lm) {
+            // approx_ctc: the scorer's share is taken out of the reported score again -- |prefix| * beta and
+            // alpha * ln P_LM(sentence), the sentence probability counting </s> too (Scorer::get_sent_log_prob)
+            const int L = (int)rev.size();
+            unsigned long long ctx = masr::lm_root_ctx(view);
+            float sent = L == 0 ? masr::lm_cond(view, masr::lm_state_of(view, ctx), view.bos) : 0.f;
+            for (int i = 0; i <= L; ++i) {
+                const int w = i < L ? rev[L - 1 - i] : view.eos;
+                sent += masr::lm_cond(view, masr::lm_state_of(view, ctx), w);
+                ctx = masr::lm_push(ctx, w);
+            }
+            *score = *score - (float)L * beta - alpha * sent;
+        }
         return (int)rev.size();
     }
 };
@@ -171,6 +206,13 @@ int masr_beam_create(int32_t beam_size, int32_t blank, masr_beam** out) {
 
 void masr_beam_destroy(masr_beam* h) { delete h; }
 
+int masr_beam_set_lm(masr_beam* h, const masr_lm* lm, float alpha, float beta) {
+    if (!h) return 1;
+    h->b.set_lm(lm, alpha, beta);
+    h->b.reset();
+    return 0;
+}
+
 int masr_beam_reset(masr_beam* h) {
     if (!h) return 1;
     h->b.reset();
@@ -194,6 +236,14 @@ int masr_beam_search_batch(const int32_t* idx_host, const float* logp_host, cons
                            const int32_t* frames_host, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
                            int32_t blank, int32_t num_threads, int32_t* tokens_host, int32_t max_len, int32_t* len_host,
                            float* score_host) {
+    return masr_beam_search_batch_lm(idx_host, logp_host, count_host, frames_host, B, T_stride, K, beam_size, blank, num_threads,
+                                     nullptr, 0.f, 0.f, tokens_host, max_len, len_host, score_host);
+}
+
+int masr_beam_search_batch_lm(const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
+                              const int32_t* frames_host, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
+                              int32_t blank, int32_t num_threads, const masr_lm* lm, float alpha, float beta,
+                              int32_t* tokens_host, int32_t max_len, int32_t* len_host, float* score_host) {
     if (B <= 0) return 0;
     if (num_threads <= 0) num_threads = 1;
     num_threads = std::min(num_threads, B);
@@ -201,6 +251,7 @@ int masr_beam_search_batch(const int32_t* idx_host, const float* logp_host, cons
         Beam bm;
         bm.beam_size = beam_size;
         bm.blank = blank;
+        bm.set_lm(lm, alpha, beta);
         for (int b = tid; b < B; b += num_threads) {
             bm.reset();
             const size_t base = (size_t)b * T_stride;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lm_scorer.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -186,15 +188,26 @@ struct BeamGpuArgs {
     int* pool_parent;      // [B][pool_cap]
     int* pool_ch;          // [B][pool_cap]
     int pool_cap;
-    int* state_i;          // [B][2 + 2 * beam]: n_live, pool_count, node[], ch[]                (persistent streams)
-    unsigned long long* state_h;   // [B][2 * beam]: string identity of the prefix and of its parent
-    float* state_f;        // [B][3 * beam]:     b[], nb[], score[]
+    int* state_i;          // [B][2 + 3 * beam]: n_live, pool_count, node[], ch[], lm m|oov[]     (persistent streams)
+    unsigned long long* state_h;   // [B][3 * beam]: string identity of the prefix and of its parent, packed LM context
+    float* state_f;        // [B][7 * beam]:     b[], nb[], score[], LM backoffs [4][]
     int init;              // 1: start from the empty prefix; 0: continue from state_*
     int* tokens;           // [B][max_len]
     int* len;              // [B]
     float* score;          // [B]
     long long* prof;       // optional [8] cycle counters of workgroup 0 (phase breakdown), or nullptr
+    // external scorer (lm_scorer.h): a new prefix p + c adds alpha * ln P_LM(c | last words of p) + beta to its score
+    int use_lm;
+    LmView lm;             // table / known in the memory of the launch device
+    float alpha, beta;
 };
+// per-utterance search state in HBM: [3 * beam] u64 | [2 + 3 * beam] int | [7 * beam] float
+inline size_t beam_state_bytes(int beam) { return (size_t)3 * beam * 8 + (size_t)(2 + 3 * beam) * 4 + (size_t)7 * beam * 4 + 8; }
+inline void beam_state_carve(void* base, int B, int beam, unsigned long long** h, int** i, float** f) {
+    *h = reinterpret_cast<unsigned long long*>(base);                       // [B][3 * beam]
+    *i = reinterpret_cast<int*>(*h + (size_t)B * 3 * beam);                 // [B][2 + 3 * beam]
+    *f = reinterpret_cast<float*>(*i + (size_t)B * (2 + 3 * (size_t)beam)); // [B][7 * beam]
+}
 size_t beam_gpu_lds_bytes(int beam, int K);
 int launch_beam_search(const BeamGpuArgs& a, int B, hipStream_t s);   // 1: sizes not supported
 

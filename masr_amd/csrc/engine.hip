@@ -13,6 +13,10 @@
 #include "common.h"
 
 using namespace masr;
+namespace masr {
+int lm_device_view(masr_lm* lm, LmView* out);      // lm_scorer.cpp: the LM table in the memory of the current device
+}
+extern "C" const char* masr_lm_last_error(void);
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) {
@@ -133,6 +137,8 @@ struct GBeam {        // device-resident streaming CTC prefix beam search (masr_
     bool open = false, started = false;
     int beam = 0, blank = 0, cap = 0;
     DevBuf pool, state;
+    masr_lm* lm = nullptr;       // external scorer bound with masr_gbeam_set_lm (not owned)
+    float alpha = 0.f, beta = 0.f;
 };
 
 enum ProfKind { PROF_NONE = 0, PROF_GEMM = 1, PROF_FFN1 = 2, PROF_CONV2 = 3, PROF_ATT = 4, PROF_FBANK = 5,
@@ -1334,9 +1340,27 @@ int masr_ctc_topk(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, 
     return 0;
 }
 
+static int bind_lm(BeamGpuArgs& a, masr_lm* lm, float alpha, float beta) {
+    a.use_lm = 0;
+    a.alpha = alpha;
+    a.beta = beta;
+    if (!lm) return 0;
+    if (lm_device_view(lm, &a.lm)) return fail(masr_lm_last_error());
+    a.use_lm = 1;
+    return 0;
+}
+
 int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* logp_dev, const int32_t* count_dev,
                          const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size, int32_t blank,
                          int32_t* tokens_dev, int32_t max_len, int32_t* len_dev, float* score_dev, void* stream) {
+    return masr_beam_search_gpu_lm(e, idx_dev, logp_dev, count_dev, frames_dev, B, T_stride, K, beam_size, blank, nullptr, 0.f,
+                                   0.f, tokens_dev, max_len, len_dev, score_dev, stream);
+}
+
+int masr_beam_search_gpu_lm(masr_engine* e, const int32_t* idx_dev, const float* logp_dev, const int32_t* count_dev,
+                            const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size, int32_t blank,
+                            masr_lm* lm, float alpha, float beta, int32_t* tokens_dev, int32_t max_len, int32_t* len_dev,
+                            float* score_dev, void* stream) {
     if (!e) return fail("null engine");
     ENTER(e);
     if (B <= 0 || T_stride <= 0) return fail("empty batch");
@@ -1349,12 +1373,11 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
         return fail("beam search on the GPU needs cutoff_top_n <= 64, beam_size <= 512 and beam_size*cutoff_top_n*4 B + tables "
                     "within 160 KB of LDS; use masr_beam_search_batch (host threads) beyond that");
     CHK(e->beam_pool.ensure((size_t)B * a.pool_cap * 2 * sizeof(int)));
-    CHK(e->beam_state.ensure((size_t)B * (4 + 9 * (size_t)beam_size) * sizeof(int)));
+    CHK(e->beam_state.ensure((size_t)B * beam_state_bytes(beam_size)));
     a.pool_parent = e->beam_pool.as<int>();
     a.pool_ch = a.pool_parent + (size_t)B * a.pool_cap;
-    a.state_h = e->beam_state.as<unsigned long long>();                    // [B][2*beam] u64, then ints, then floats
-    a.state_i = reinterpret_cast<int*>(a.state_h + (size_t)B * 2 * beam_size);
-    a.state_f = reinterpret_cast<float*>(a.state_i + (size_t)B * (2 + 2 * (size_t)beam_size));
+    beam_state_carve(e->beam_state.p, B, beam_size, &a.state_h, &a.state_i, &a.state_f);
+    CHK(bind_lm(a, lm, alpha, beta));
     a.init = 1;
     a.prof = e->beam_prof;
     a.tokens = tokens_dev; a.len = len_dev; a.score = score_dev;
@@ -1368,9 +1391,7 @@ static void gbeam_args(GBeam& g, BeamGpuArgs& a) {
     a.pool_cap = g.cap;
     a.pool_parent = g.pool.as<int>();
     a.pool_ch = a.pool_parent + g.cap;
-    a.state_h = g.state.as<unsigned long long>();
-    a.state_i = reinterpret_cast<int*>(a.state_h + 2 * (size_t)g.beam);
-    a.state_f = reinterpret_cast<float*>(a.state_i + 2 + 2 * (size_t)g.beam);
+    beam_state_carve(g.state.p, 1, g.beam, &a.state_h, &a.state_i, &a.state_f);
 }
 
 int masr_gbeam_open(masr_engine* e, int32_t beam_size, int32_t blank, int32_t max_frames, int32_t* handle) {
@@ -1390,7 +1411,9 @@ int masr_gbeam_open(masr_engine* e, int32_t beam_size, int32_t blank, int32_t ma
     g.blank = blank;
     g.cap = max_frames * beam_size + 1;
     CHK(g.pool.ensure((size_t)g.cap * 2 * sizeof(int)));
-    CHK(g.state.ensure((4 + 9 * (size_t)beam_size) * sizeof(int)));
+    CHK(g.state.ensure(beam_state_bytes(beam_size)));
+    g.lm = nullptr;
+    g.alpha = g.beta = 0.f;
     g.open = true;
     g.started = false;
     *handle = id;
@@ -1401,6 +1424,16 @@ static int gbeam_of(masr_engine* e, int id, GBeam** out) {
     if (!e) return fail("null engine");
     if (id < 0 || id >= (int)e->gbeams.size() || !e->gbeams[id].open) return fail("bad beam handle");
     *out = &e->gbeams[id];
+    return 0;
+}
+
+int masr_gbeam_set_lm(masr_engine* e, int32_t handle, masr_lm* lm, float alpha, float beta) {
+    GBeam* g;
+    CHK(gbeam_of(e, handle, &g));
+    if (g->started) return fail("the language model of a stream can only change between utterances (after masr_gbeam_reset)");
+    g->lm = lm;
+    g->alpha = alpha;
+    g->beta = beta;
     return 0;
 }
 
@@ -1433,6 +1466,7 @@ int masr_gbeam_advance(masr_engine* e, int32_t handle, const int32_t* idx_dev, c
     a.cidx = idx_dev; a.clp = logp_dev; a.ccount = count_dev; a.frames = nullptr;
     a.T_stride = T; a.K = K; a.beam = g->beam; a.blank = g->blank; a.max_len = max_len;
     gbeam_args(*g, a);
+    CHK(bind_lm(a, g->lm, g->alpha, g->beta));
     a.init = g->started ? 0 : 1;
     a.prof = nullptr;
     a.tokens = tokens_dev; a.len = len_dev; a.score = score_dev;

@@ -1,0 +1,124 @@
+// External n-gram language model scorer of the CTC beam search (reference: the `Scorer` of the third-party
+// paddlespeech_ctcdecoders that masr/decoders/beam_search_decoder.py:29-42 and swig_wrapper.py:4-18 construct; scorer.cpp of
+// DeepSpeech2 / PaddleSpeech ctc_decoders on top of KenLM -- un-vendored, absent here: parity UNPINNED, the published algorithm
+// is restated).  Character-based models only (every LM word is one vocabulary token, as the reference's Mandarin LMs are).
+//
+// Layout shared by the host search (beam_search.cpp) and the GPU kernel (beam_gpu.hip): ONE open-addressing hash table of all
+// n-grams of all orders.  Key = 64-bit hash chain over (order, w_1 .. w_n) with w = vocabulary token id (+ <s>, </s> behind
+// them); value = (ln P, ln backoff).  16-byte entries, linear probing, load <= 0.5, key 0 = empty slot.  A lookup is one
+// 16-byte load per probe.  In HBM the table of a pruned 5-gram Mandarin LM (~10^8 n-grams) is ~4 GB -- resident next to the
+// 138 MB of encoder weights; nothing is paged.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LM_HD __host__ __device__ __forceinline__
+#else
+#define LM_HD inline
+#endif
+
+namespace masr {
+
+struct LmEntry {
+    unsigned long long key;   // 0 = empty
+    float prob;               // ln P(w_n | w_1 .. w_{n-1}) as stored in the ARPA file (log10 there)
+    float backoff;            // ln backoff weight of this n-gram as a context (0 when the file has none)
+};
+
+struct LmView {
+    const LmEntry* table;
+    unsigned long long mask;          // slots - 1 (power of two)
+    const unsigned char* known;       // [n_words]: 1 = the token is an LM word (unigram present and not <unk>)
+    int max_order;                    // <= 5 (contexts are packed 4 x 16 bits)
+    int n_words;                      // vocabulary size + 2
+    int bos, eos;                     // ids of <s> and </s> (= vocabulary size, vocabulary size + 1)
+};
+
+static constexpr float LM_OOV_SCORE = -1000.0f;   // scorer.h OOV_SCORE: returned as it is (not converted from log10)
+
+LM_HD unsigned long long lm_mix(unsigned long long h, unsigned long long w) {
+    unsigned long long z = (h ^ (w + 1)) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
+    z ^= z >> 29;
+    return z;
+}
+// key of the n-gram made of the `len` most recent context words (packed 16 bits each, most recent in the low bits) followed by
+// `w` (w < 0: the context n-gram itself, `len` words)
+LM_HD unsigned long long lm_key(unsigned long long ctx, int len, int w) {
+    unsigned long long h = 0x5851F42D4C957F2Dull + (unsigned long long)(len + (w >= 0 ? 1 : 0));
+    for (int j = len - 1; j >= 0; --j) h = lm_mix(h, (ctx >> (16 * j)) & 0xFFFFull);
+    if (w >= 0) h = lm_mix(h, (unsigned long long)w);
+    return h ? h : 1ull;
+}
+LM_HD bool lm_find(const LmView& lm, unsigned long long key, float* prob, float* backoff) {
+    unsigned long long h = key & lm.mask;
+    while (true) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint4 raw = *reinterpret_cast<const uint4*>(lm.table + h);          // one 16-byte load per probe
+        const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
+        const float p = __uint_as_float(raw.z), b = __uint_as_float(raw.w);
+#else
+        const LmEntry e = lm.table[h];
+        const unsigned long long k = e.key;
+        const float p = e.prob, b = e.backoff;
+#endif
+        if (k == key) {
+            *prob = p;
+            *backoff = b;
+            return true;
+        }
+        if (k == 0ull) return false;
+        h = (h + 1) & lm.mask;
+    }
+}
+
+// What a live prefix carries for scoring its extensions: its last max_order - 1 words (<s>-padded, scorer.cpp make_ngram),
+// the longest suffix of them that exists as an n-gram in the model (`m` words; ARPA models are prefix-closed, so no longer
+// n-gram can match any extension), the backoff weights of those suffixes, and whether one of the words is unknown to the LM.
+struct LmState {
+    unsigned long long ctx;   // 4 x 16 bits, most recent word in the low bits
+    float bo[4];              // bo[j] = ln backoff of the (j + 1)-word suffix, j < m
+    int m;                    // 0 .. max_order - 1
+    int oov;                  // 1: an unknown word among the last max_order - 1 words -> every extension scores OOV
+};
+
+LM_HD LmState lm_state_of(const LmView& lm, unsigned long long ctx) {
+    LmState s;
+    s.ctx = ctx;
+    s.m = 0;
+    s.oov = 0;
+    const int k = lm.max_order - 1;
+    for (int j = 0; j < 4; ++j) s.bo[j] = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int w = (int)((ctx >> (16 * j)) & 0xFFFFull);
+        if (w >= lm.n_words || !lm.known[w]) s.oov = 1;
+    }
+    for (int len = 1; len <= k; ++len) {
+        float p, b;
+        if (!lm_find(lm, lm_key(ctx, len, -1), &p, &b)) break;
+        s.bo[len - 1] = b;
+        s.m = len;
+    }
+    return s;
+}
+LM_HD unsigned long long lm_root_ctx(const LmView& lm) {      // the empty prefix: <s> <s> <s> <s>
+    const unsigned long long b = (unsigned long long)lm.bos;
+    return b | (b << 16) | (b << 32) | (b << 48);
+}
+LM_HD unsigned long long lm_push(unsigned long long ctx, int w) { return (ctx << 16) | (unsigned long long)(w & 0xFFFF); }
+
+// ln P(w | the state's words): Scorer::get_log_cond_prob on make_ngram(prefix + w) -- KenLM BaseScore from the null context
+// == the ARPA backoff recursion: the longest (suffix, w) n-gram in the model, plus the backoff weights of the longer suffixes
+LM_HD float lm_cond(const LmView& lm, const LmState& s, int w) {
+    if (s.oov || w >= lm.n_words || !lm.known[w]) return LM_OOV_SCORE;
+    float acc = 0.f;
+    for (int len = s.m; len >= 0; --len) {
+        float p, b;
+        if (lm_find(lm, lm_key(s.ctx, len, w), &p, &b)) return acc + p;
+        if (len > 0) acc += s.bo[len - 1];
+    }
+    return LM_OOV_SCORE;       // (a known word always has its unigram)
+}
+
+}  // namespace masr

@@ -1,11 +1,16 @@
 """BeamSearchDecoder with the reference's constructor / method contract
 (masr/decoders/beam_search_decoder.py:9-96).  The reference hands the search to the third-party SWIG
 module ``paddlespeech_ctcdecoders`` (+ a KenLM language model); here the per-frame vocabulary pruning runs
-on the GPU (masr_ctc_topk) and so does the LM-free CTC prefix beam search of whole utterances
-(masr_beam_search_gpu: one workgroup per utterance) and of streams (masr_gbeam_*: the live prefixes stay on the device
+on the GPU (masr_ctc_topk) and so does the CTC prefix beam search of whole utterances
+(masr_beam_search_gpu_lm: one workgroup per utterance) and of streams (masr_gbeam_*: the live prefixes stay on the device
 between decode_chunk calls); sizes beyond the kernel's limits use the host-thread search inside libmasr_hip.so
-(masr_beam_*).  The external LM scorer (alpha / beta) is NOT implemented: a missing
-language model file is not an error, scores are the log probability of the best prefix (alpha = 0 path)."""
+(masr_beam_*).
+
+External scorer (alpha, beta): ``language_model_path`` is read as a character-based ARPA n-gram model (decoders/lm_scorer.py;
+KenLM's binary .klm format is not parsed -> an error that says so) and applied inside the search, on the GPU table or the
+host table: a prefix extended by a character adds alpha * ln P_LM + beta; the returned score is the decoder's approx_ctc.
+When the file does not exist (the reference would download 2.8 GB, beam_search_decoder.py:19-28 -- there is no network
+here) the decoder logs a warning and searches with the acoustic scores only (alpha = beta = 0)."""
 import ctypes as C
 import logging
 
@@ -32,14 +37,35 @@ class BeamSearchDecoder:
         self._gstream = None             # device-resident streaming search (masr_gbeam_*), opened on first use
         self._gout = None
         self.last_tokens = []            # token ids of the last decode_chunk result
-        if alpha or beta:
-            logger.warning('masr_amd BeamSearchDecoder: the external language-model scorer is not implemented; '
-                           'decoding with the acoustic CTC scores only (alpha = beta = 0)')
         self._lib = _lib.lib()
+        self._ext_scorer = None
+        if alpha or beta:
+            import os
+            if language_model_path and os.path.exists(language_model_path):
+                from masr_amd.decoders.lm_scorer import LanguageModel
+                self._ext_scorer = LanguageModel(language_model_path, vocab_list)
+                logger.info(f'language model: model path = {language_model_path}, is_character_based = '
+                            f'{self._ext_scorer.is_character_based}, max_order = {self._ext_scorer.get_max_order()}, '
+                            f'dict_size = {self._ext_scorer.get_dict_size()}')
+            else:
+                logger.warning(f'masr_amd BeamSearchDecoder: language model {language_model_path} not found (nothing can be '
+                               f'downloaded here); decoding with the acoustic CTC scores only (alpha = beta = 0)')
+                self.alpha = self.beta = 0
         h = C.c_void_p()
         if self._lib.masr_beam_create(self.beam_size, self.blank_id, C.byref(h)) != 0:
             raise _lib.MasrError('masr_beam_create failed')
         self._stream = h
+        self._bind_host_lm()
+
+    def _lm_args(self):
+        """(lm handle or NULL, alpha, beta) for the *_lm entry points"""
+        if self._ext_scorer is None:
+            return C.c_void_p(0), C.c_float(0.0), C.c_float(0.0)
+        return self._ext_scorer.h, C.c_float(float(self.alpha)), C.c_float(float(self.beta))
+
+    def _bind_host_lm(self):
+        if self._ext_scorer is not None:
+            self._lib.masr_beam_set_lm(self._stream, *self._lm_args())
 
     def fork(self):
         """a decoder with the same configuration (and the same language model tables) but its own streaming search state --
@@ -51,6 +77,7 @@ class BeamSearchDecoder:
         if self._lib.masr_beam_create(self.beam_size, self.blank_id, C.byref(h)) != 0:
             raise _lib.MasrError('masr_beam_create failed')
         other._stream = h
+        other._bind_host_lm()
         return other
 
     def close(self):
@@ -135,11 +162,12 @@ class BeamSearchDecoder:
             toks = torch.zeros(B, max_len, dtype=torch.int32, device=eng.device)
             lens = torch.zeros(B, dtype=torch.int32, device=eng.device)
             scores = torch.zeros(B, dtype=torch.float32, device=eng.device)
-            check(self._lib.masr_beam_search_gpu(eng.h, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
-                                                 C.c_void_p(cnt.data_ptr()), C.c_void_p(fr.data_ptr()), B, Ts, K,
-                                                 self.beam_size, self.blank_id, C.c_void_p(toks.data_ptr()), max_len,
-                                                 C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
-                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            check(self._lib.masr_beam_search_gpu_lm(eng.h, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                                    C.c_void_p(cnt.data_ptr()), C.c_void_p(fr.data_ptr()), B, Ts, K,
+                                                    self.beam_size, self.blank_id, *self._lm_args(),
+                                                    C.c_void_p(toks.data_ptr()), max_len,
+                                                    C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             if defer:                      # nothing has been synchronised: _batch_collect() fetches the result later
                 return ('gpu', toks, lens, scores, (stacked, idx, logp, cnt, fr))
             toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
@@ -152,11 +180,11 @@ class BeamSearchDecoder:
         toks = np.zeros((B, max_len), np.int32)
         lens = np.zeros(B, np.int32)
         scores = np.zeros(B, np.float32)
-        rc = self._lib.masr_beam_search_batch(idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
-                                              cnt.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.c_void_p), B, Ts, K,
-                                              self.beam_size, self.blank_id, self.num_processes,
-                                              toks.ctypes.data_as(C.c_void_p), max_len, lens.ctypes.data_as(C.c_void_p),
-                                              scores.ctypes.data_as(C.c_void_p))
+        rc = self._lib.masr_beam_search_batch_lm(idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
+                                                 cnt.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.c_void_p), B, Ts, K,
+                                                 self.beam_size, self.blank_id, self.num_processes, *self._lm_args(),
+                                                 toks.ctypes.data_as(C.c_void_p), max_len, lens.ctypes.data_as(C.c_void_p),
+                                                 scores.ctypes.data_as(C.c_void_p))
         if rc != 0:
             raise _lib.MasrError('masr_beam_search_batch failed')
         if want_tokens:
@@ -187,6 +215,8 @@ class BeamSearchDecoder:
             h = C.c_int32()
             check(self._lib.masr_gbeam_open(eng.h, self.beam_size, self.blank_id, 5000, C.byref(h)))
             self._gstream = h.value
+            if self._ext_scorer is not None:
+                check(self._lib.masr_gbeam_set_lm(eng.h, self._gstream, *self._lm_args()))
         T = p.shape[0]
         idx, logp, cnt, K = self._candidates(p, to_host=False)
         max_len = 5000

@@ -239,8 +239,9 @@ class MASRPredictor:
         return [{'text': self._text(tok[i, :nt[i]]), 'score': float(sc[i])} for i in range(len(segs))]
 
     def _run_sorted(self, segs, which, decode_all_frames, batch_size, as_tokens, keep_order_of=None):
-        """decode ``segs[i] for i in which`` in length-sorted device passes; results in the order of ``which``"""
-        order = sorted(which, key=lambda i: -segs[i].num_samples) if batch_size else list(which)
+        """decode ``segs[i] for i in which`` in length-sorted device passes (shortest first, ties in input order -- the batches
+        ``evaluate`` forms from a duration-sorted manifest); results in the order of ``which``"""
+        order = sorted(which, key=lambda i: segs[i].num_samples) if batch_size else list(which)
         step = batch_size if batch_size else max(len(order), 1)
         got = {}
         for lo in range(0, len(order), step):

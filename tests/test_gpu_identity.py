@@ -122,7 +122,7 @@ def test_c_normalisation_on_with_the_reference_gain(pred_norm):
     ms = eng.mean_square(xs, ns).cpu().numpy()
     assert ms[0] == tw['mean_square'], (ms[0], tw['mean_square'])
     # the fixture's gain supplied: the normalised int16 samples are the reference's, bit for bit
-    feats, frames, norm = eng.fbank_batch(xs, ns, True, -20, return_norm=True, gain_in=torch.tensor([tw['gain']]))
+    feats, frames, norm = eng.fbank_batch(xs, ns, True, -20, return_norm=True, gain_in=torch.tensor([float(tw['gain'])]))
     assert np.array_equal(norm[0].cpu().numpy(), tw['norm_i16'])
     # this host's numpy on the same mean square (what predict() does)
     mine = reference_gains(ms, -20)[0]
