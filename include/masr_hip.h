@@ -218,6 +218,10 @@ int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t*
 int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id);
 int masr_stream_reset(masr_engine* e, int32_t stream_id);
 int masr_stream_close(masr_engine* e, int32_t stream_id);
+/* required_cache_size of forward_chunk for one stream (conformer/encoder.py:397-410): < 0 (default) every cached key stays
+ * visible -- what MASRPredictor.predict_stream passes (predict.py:312-313); >= 0 a chunk attends over at most that many cached
+ * keys (Conformer only).  masr_stream_export_cache then returns the last min(required_cache_size, offset) rows. */
+int masr_stream_set_history(masr_engine* e, int32_t stream_id, int32_t required_cache_size);
 int masr_stream_offset(masr_engine* e, int32_t stream_id, int32_t* offset);
 int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, const float* feats_dev, int32_t Tc,
                       float* probs_dev, int32_t* argmax_dev, float* maxprob_dev, void* stream);

@@ -127,6 +127,7 @@ struct Stream {
     int offset = 0;
     int offset_r = 0;   // frames emitted at the reduced rate (Squeezeformer blocks between time reduction and recovery)
     int cap = 0;
+    int history = -1;   // required_cache_size of forward_chunk: < 0 keep every key, >= 0 attend over at most that many cached keys
     DevBuf att;  // [L][cap][2*d]  (k | v per row)
     DevBuf cnn;  // [L][kernel-1][d]   (DeepSpeech2: LSTM state [L][2 (h, c)][rnn_size])
     DevBuf cnn2; // Conformer / Squeezeformer: second half of the double-buffered cnn cache (a chunk step reads `cnn`, writes
@@ -1659,6 +1660,7 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
         HIPCHK(hipMemset(st.att.p, 0, (size_t)L * st.cap * 2 * d * sizeof(float)));
     st.offset = 0;
     st.offset_r = 0;
+    st.history = -1;
     st.open = true;
     *stream_id = id;
     return 0;
@@ -1693,6 +1695,16 @@ int masr_stream_close(masr_engine* e, int32_t stream_id) {
     st->cnn.release();
     st->cnn2.release();
     st->open = false;
+    return 0;
+}
+
+int masr_stream_set_history(masr_engine* e, int32_t stream_id, int32_t required_cache_size) {
+    Stream* st;
+    CHK(stream_of(e, stream_id, &st));
+    if (required_cache_size >= 0 && e->cfg.model_kind != 0)
+        return fail("a bounded attention history (required_cache_size >= 0) is implemented for the Conformer; the Squeezeformer / "
+                    "Efficient-Conformer streams keep all history (required_cache_size < 0, what predict_stream passes)");
+    st->history = required_cache_size;
     return 0;
 }
 
@@ -1978,14 +1990,19 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
         for (int i = 0; i < n; ++i) {
             AttSeq& a = hs[(size_t)l * n + i];
             float* cache = st[i]->att.as<float>() + (size_t)l * st[i]->cap * 2 * d;
+            // keys the chunk attends over: the last cache_t1 cached rows + its own (encoder.py:390-395,397-410: the reference
+            // trims its cache tensor to required_cache_size after every step; here the rows stay where they were appended and
+            // the window moves).  The positional index of the first key is offset - cache_t1.
+            const int cache_t1 = st[i]->history < 0 ? st[i]->offset : std::min(st[i]->offset, st[i]->history);
+            const int first = st[i]->offset - cache_t1;
             a.q = e->qkv.as<float>() + (size_t)i * Tq * 3 * d;
-            a.k = cache;
-            a.v = cache + d;
+            a.k = cache + (size_t)first * 2 * d;
+            a.v = a.k + d;
             a.out = e->att.as<float>() + (size_t)i * Tq * d;
             a.nq = Tq;
-            a.nk = st[i]->offset + Tq;
+            a.nk = cache_t1 + Tq;          // (the new rows are appended at k + (nk - nq) rows = cache row `offset`)
             a.klen = a.nk;
-            a.pos0 = 0;          // offset - cache_t1 == 0 with keep-all history (encoder.py:395)
+            a.pos0 = first;
             a.q_abs0 = st[i]->offset;
             a.pad_ = 0;
         }
@@ -2052,8 +2069,10 @@ int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, 
             for (int l = 0; l < L; ++l)
                 launch_export_att(st->att.as<float>() + (size_t)l * st->cap * 2 * d, att_dev + (size_t)l * st->offset * 2 * d, 1, H,
                                   st->cap, st->offset, d / H, s, (l >= e->reduce_idx && l < e->recover_idx) ? 2 : 1);
-        } else {
-            launch_export_att(st->att.as<float>(), att_dev, L, H, st->cap, st->offset, d / H, s);
+        } else {       // the last min(history, offset) rows: what the reference's trimmed cache tensor holds
+            const int t = st->history < 0 ? st->offset : std::min(st->offset, st->history);
+            if (t > 0)
+                launch_export_att(st->att.as<float>() + (size_t)(st->offset - t) * 2 * d, att_dev, L, H, st->cap, t, d / H, s);
         }
     }
     if (cnn_dev && e->cfg.model_kind == 2) {       // each layer's own K-1 rows, left-padded with zeros to cnn_module_kernel - 1

@@ -118,7 +118,8 @@ class BeamSearchDecoder:
     def gpu_search_supported(self, T, V):
         """limits of masr_beam_search_gpu (include/masr_hip.h): LDS-resident entry table and 32-bit trie keys."""
         K = min(self.cutoff_top_n, V)
-        return K <= 64 and 2 <= self.beam_size <= 512 and self.beam_size * K * 6 + 80 * self.beam_size + 2048 <= 160 * 1024
+        # beam_gpu_lds_bytes (beam_gpu.hip): extension keys + survivor list, 40 words of live-prefix state, fixed tables
+        return K <= 64 and 2 <= self.beam_size <= 512 and self.beam_size * K * 6 + 160 * self.beam_size + 22568 <= 160 * 1024
 
     def _text(self, toks):
         return ''.join(self.vocab_list[t] for t in toks).replace('<space>', ' ')

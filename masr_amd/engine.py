@@ -345,6 +345,11 @@ class HipEngine:
     def stream_close(self, sid):
         check(self.lib.masr_stream_close(self.h, sid))
 
+    def stream_set_history(self, sid, required_cache_size):
+        """forward_chunk's required_cache_size for this stream: < 0 keep all cached keys, >= 0 at most that many (Conformer)"""
+        check(self.lib.masr_stream_set_history(self.h, sid, int(required_cache_size)))
+        self.__dict__.setdefault('_history', {})[sid] = int(required_cache_size)
+
     def stream_offset(self, sid):
         off = C.c_int32()
         check(self.lib.masr_stream_offset(self.h, sid, C.byref(off)))
@@ -368,6 +373,9 @@ class HipEngine:
             check(self.lib.masr_stream_export_cache(self.h, sid, _ptr(h), _ptr(c), _stream()))
             return h, c
         t = self.stream_offset(sid)
+        hist = self.__dict__.get('_history', {}).get(sid, -1)
+        if hist >= 0:
+            t = min(t, hist)
         dk = self.d_model // self.heads
         att = torch.zeros(self.num_blocks, self.heads, t, 2 * dk, dtype=torch.float32, device=self.device)
         cnn = torch.zeros(self.num_blocks, 1, self.d_model, self.cnn_kernel - 1, dtype=torch.float32, device=self.device)

@@ -53,6 +53,7 @@ class InferencePredictor:
         self.engine = HipEngine(state_dict, encoder_conf=enc_conf, streaming=streaming, n_mels=n_mels,
                                 use_model=use_model)
         self._sid = None
+        self._history = -1
 
     # offline (inference_predictor.py:52-64): probs = softmax(ctc_lo(encoder(speech)))
     def predict(self, speech, speech_lengths):
@@ -79,10 +80,12 @@ class InferencePredictor:
     def predict_chunk_conformer(self, x_chunk, required_cache_size):
         if not ('former' in self.use_model and self.streaming):
             raise Exception(f'当前模型不支持该方法，当前模型为：{self.use_model}，参数streaming为：{self.streaming}')
-        if required_cache_size >= 0:
-            raise Exception('only required_cache_size < 0 (keep all history, predict.py:312-313) is implemented')
         if self._sid is None:
             self._sid = self.engine.stream_open(0)
+        required_cache_size = int(np.asarray(required_cache_size).reshape(-1)[0])
+        if required_cache_size != self._history:          # (>= 0: bounded attention history, conformer/encoder.py:397-410)
+            self.engine.stream_set_history(self._sid, required_cache_size)
+            self._history = required_cache_size
         x = torch.as_tensor(np.asarray(x_chunk), dtype=torch.float32).to(self.device).contiguous()
         probs, _, _ = self.engine.encode_chunk([self._sid], x)
         return probs.cpu().numpy()

@@ -162,3 +162,51 @@ def test_chunk_steps_with_long_history_against_oracle(n_streams):
         assert eng.stream_offset(sids[0]) == 16 * steps and worst < 1e-3
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('required', [0, 16, 40])
+def test_bounded_attention_history_against_oracle(required):
+    """forward_chunk with required_cache_size >= 0 (conformer/encoder.py:397-410; the oracle's handling of it is pinned against
+    the live reference in tests/test_oracle_golden.py): probabilities of every chunk step and the exported cache"""
+    from masr_amd.engine import HipEngine
+    from oracle import conformer as oc, weights
+    V = 512
+    sd = weights.conformer_state_dict(0, V)
+    eng = HipEngine(sd, vocab_size=V)
+    gen = torch.Generator().manual_seed(6)
+    feats = torch.randn(2, 64 * 5 + 67, 80, generator=gen) * 3 + 13
+    try:
+        sids = [eng.stream_open(200), eng.stream_open(200)]
+        eng.stream_set_history(sids[0], required)               # stream 1 keeps all history: lock-step streams may differ
+        att0, cnn0 = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0)
+        att1, cnn1 = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0)
+        off = 0
+        for cur in range(0, feats.shape[1] - 67 + 1, 64):
+            with torch.no_grad():
+                p0, att0, cnn0 = oc.get_encoder_out_chunk(sd, feats[:1, cur:cur + 67], off, required, att0, cnn0)
+                p1, att1, cnn1 = oc.get_encoder_out_chunk(sd, feats[1:, cur:cur + 67], off, -1, att1, cnn1)
+            off += p0.shape[1]
+            probs, _, _ = eng.encode_chunk(sids, dev(feats[:, cur:cur + 67]))
+            assert (probs[0].cpu() - p0[0]).abs().max() < 1e-3 and (probs[1].cpu() - p1[0]).abs().max() < 1e-3
+        att, cnn = eng.stream_export_cache(sids[0])
+        assert tuple(att.shape) == tuple(att0.shape) and att0.shape[2] == min(required, off)
+        if att0.numel():
+            assert (att.cpu() - att0).abs().max() < 1e-3
+        assert (cnn.cpu() - cnn0).abs().max() < 1e-3
+        # the facade-level runner takes the reference's argument (inference_predictor.py:80-94)
+    finally:
+        eng.close()
+
+
+def test_bounded_history_is_rejected_where_it_is_not_built():
+    from masr_amd._lib import MasrError
+    from masr_amd.engine import HipEngine
+    from oracle import weights
+    eng = HipEngine(weights.efficient_conformer_state_dict(0, 64), vocab_size=64, streaming=True, use_model='efficient_conformer')
+    try:
+        sid = eng.stream_open(100)
+        with pytest.raises(MasrError, match='required_cache_size'):
+            eng.stream_set_history(sid, 16)
+        eng.stream_set_history(sid, -1)
+    finally:
+        eng.close()

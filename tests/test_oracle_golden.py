@@ -146,6 +146,22 @@ def test_oracle_against_live_reference():
     lens = torch.tensor([150, 99])
     with torch.no_grad():
         assert (m.get_encoder_out(x, lens) - oc.get_encoder_out(sd, x, lens)).abs().max() < 1e-6
+        # bounded attention history (required_cache_size >= 0, conformer/encoder.py:397-410): the kept cache and the positional
+        # offset of its first key must follow the reference step by step
+        for req in (0, 16, 24, 40):
+            ra, rc = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0)
+            oa, oc_ = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0)
+            off = 0
+            for cur in range(0, 150 - 67 + 1 + 64, 64):
+                ch = x[:1, cur:cur + 67]
+                if ch.shape[1] < 7:
+                    break
+                pr, ra, rc = m.get_encoder_out_chunk(ch, torch.tensor([off]), torch.tensor([req]), ra, rc)
+                po, oa, oc_ = oc.get_encoder_out_chunk(sd, ch, off, req, oa, oc_)
+                off += pr.shape[1]
+                assert (pr - po).abs().max() < 1e-6 and ra.shape == oa.shape
+                assert ra.numel() == 0 or (ra - oa).abs().max() < 1e-6
+            assert ra.shape[2] == min(req, off)
 
 
 def test_deepspeech2_fixture():
