@@ -170,9 +170,26 @@ struct FfnTail {
     const float* pre_lnw;      // optional: x <- LayerNorm(x; pre_lnw, pre_lnb) first, written back (the previous layer's norm_final,
     const float* pre_lnb;      // encoder.py:160-161, riding on this launch instead of its own)
 };
+// head: the rest of the conv module in front of the block, on the workgroup's own 32 rows, before the block's LayerNorm:
+//   x <- x + mask(pointwise_conv2(SiLU(LayerNorm(depthwise_conv(glu)))))       (convolution.py:120-131, encoder.py:137-148)
+// the depthwise conv reads the GLU rows of the padded layout [nseq][pad + seq_t][256] (ktaps - 1 = pad history rows in front,
+// gconst: constant history rows that are not materialised).  Return value bit 2 (4) = done by the kernel.
+struct FfnHead {
+    const float* glu;          // nullptr: no head stage
+    const float* dw_w;         // [ktaps][256]
+    const float* dw_b;
+    const float* lnw;          // the conv module's LayerNorm
+    const float* lnb;
+    const float* gconst;       // [256] or nullptr
+    const float* W;            // pointwise_conv2 [256, 256]
+    const float* bias;
+    const int* lens;           // feature lengths for the pad mask, or nullptr
+    int seq_t, ktaps, mstride;
+};
 int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
-                     int nsplit, hipStream_t s, const FfnPostLn* post = nullptr, const FfnTail* tail = nullptr);
+                     int nsplit, hipStream_t s, const FfnPostLn* post = nullptr, const FfnTail* tail = nullptr,
+                     const FfnHead* head = nullptr);
 
 void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
                        const FfnPostLn* post);

@@ -70,6 +70,7 @@ void ensure_dynamic_lds(const void* fn, size_t bytes, LdsAttr& st) {
 #define ENTER(e) HIPCHK(hipSetDevice((e)->cfg.device_id))
 
 static int g_no_ffn_tail = 0;     // masr_debug_set key 8: 1 = the QKV projection as its own launch after the first FFN (A/B)
+static int g_no_ffn_head = 0;     // masr_debug_set key 9: 1 = depthwise conv and pointwise_conv2 as their own launches before the second FFN (A/B)
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
 namespace {
@@ -143,7 +144,7 @@ struct GBeam {        // device-resident streaming CTC prefix beam search (masr_
 };
 
 enum ProfKind { PROF_NONE = 0, PROF_GEMM = 1, PROF_FFN1 = 2, PROF_CONV2 = 3, PROF_ATT = 4, PROF_FBANK = 5,
-                PROF_FFN_TAIL = 6 };     // 2 = the plain fused FFN kernel; 6 = its variant with the QKV tail stage (own kernel name)
+                PROF_FFN_TAIL = 6, PROF_FFN_HEAD = 7 };     // 2 = the plain fused FFN kernel; 6 = its variant with the QKV tail stage, 7 = with the conv-module head stage (own kernel names)
 
 }  // namespace
 
@@ -225,7 +226,7 @@ struct ProfScope {
     hipStream_t s;
     bool on;
     ProfScope(masr_engine* e_, hipStream_t s_, int kind, double flops) : e(e_), s(s_) {
-        on = e->prof_kind != 0 && (e->prof_kind == kind || (e->prof_kind == PROF_GEMM && (kind == PROF_FFN1 || kind == PROF_CONV2 || kind == PROF_FFN_TAIL)));
+        on = e->prof_kind != 0 && (e->prof_kind == kind || (e->prof_kind == PROF_GEMM && (kind == PROF_FFN1 || kind == PROF_CONV2 || kind == PROF_FFN_TAIL || kind == PROF_FFN_HEAD)));
         if (!on) return;
         if (e->prof_used == e->prof_events.size()) {
             hipEvent_t a, b;
@@ -585,7 +586,8 @@ struct EncodeCtx {
 // *tail_done = true when the kernel did it, otherwise the caller launches it
 int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb, const float* w1, const float* b1,
         const float* w2, const float* b2, float scale = 0.5f, int affine = 0, const float* post_w = nullptr,
-        const float* post_b = nullptr, float* post_y = nullptr, const FfnTail* tail = nullptr, bool* tail_done = nullptr) {
+        const float* post_b = nullptr, float* post_y = nullptr, const FfnTail* tail = nullptr, bool* tail_done = nullptr,
+        const FfnHead* head = nullptr, bool* head_done = nullptr) {
     const int d = e->cfg.d_model, dff = e->cfg.d_ff;
     // few rows (streaming chunk steps): split d_ff across workgroups so that >= ~128 CUs work on the block
     int nsplit = 1;
@@ -596,12 +598,26 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
     }
     const bool want_tail = tail && nsplit == 1 && !g_no_ffn_tail;
+    const bool want_head = head && head->glu && nsplit == 1 && !want_tail && !g_no_ffn_head && !affine &&
+                           (head->ktaps == 15 || head->ktaps == 7);
+    if (head_done) *head_done = want_head;
+    if (head && head->glu && !want_head) {
+        // the rest of the conv module as its own two launches: depthwise conv + LayerNorm + SiLU, pointwise_conv2 + mask + residual
+        CHK(e->dwo.ensure((size_t)M * d * sizeof(float)));
+        launch_dwconv_ln_silu(head->glu, head->dw_w, head->dw_b, head->lnw, head->lnb, e->dwo.as<float>(), M / head->seq_t,
+                              head->seq_t, head->ktaps, 1e-5f, s, head->gconst);
+        float* x = e->x.as<float>();
+        rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, head->W, head->bias, x, d, M, d, x, d,
+                1.f, head->lens, head->lens ? head->seq_t : 0, 0, 0, nullptr, nullptr, PROF_GEMM, head->mstride);
+    }
     if (tail && tail->pre_lnw && !want_tail)          // the deferred LayerNorm of the previous layer, as its own launch
         launch_layernorm(e->x.as<float>(), tail->pre_lnw, tail->pre_lnb, e->x.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
-    ProfScope ps(e, s, want_tail ? PROF_FFN_TAIL : PROF_FFN1, 4.0 * M * (double)dff * d + (want_tail ? 2.0 * M * (double)tail->N * d : 0.0));
+    ProfScope ps(e, s, want_tail ? PROF_FFN_TAIL : want_head ? PROF_FFN_HEAD : PROF_FFN1,
+                 4.0 * M * (double)dff * d + (want_tail ? 2.0 * M * (double)tail->N * d : 0.0) + (want_head ? 2.0 * M * (double)d * d : 0.0));
     const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine,
                                       nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s, post_y ? &post : nullptr,
-                                      want_tail ? tail : nullptr);
+                                      want_tail ? tail : nullptr, want_head ? head : nullptr);
+    if (want_head && done != 4) return fail("ffn(): head stage was not launched");
     if (tail_done) *tail_done = done == 2;
     if (post_y && done != 1) launch_layernorm(e->x.as<float>(), post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
     return 0;
@@ -1260,11 +1276,16 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
         if (g_no_chain) {
             mhsa_out(e, s, w, M);
             CHK(conv_module(e, s, w, ctx, false));
+            CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
         } else {
+            // out-projection + residual + LayerNorm + pointwise_conv1 + GLU in one kernel; the rest of the conv module
+            // (depthwise conv, LayerNorm, SiLU, pointwise_conv2, residual) is the head stage of the second FFN kernel
             mhsa_out_pw1(e, s, w, ctx);
-            CHK(conv_module(e, s, w, ctx, false, 0, 4, true));
+            const FfnHead head{e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->cfg.causal ? w.gconst : nullptr,
+                               w.pw2_w, w.pw2_b, feat_lens_dev, Tq, e->cfg.cnn_kernel, 4};
+            CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, &head));
         }
-        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
         prev = &w;                                 // norm_final deferred to the next layer's first FFN launch
     }
     launch_layernorm(x, prev->ln_fin_w, prev->ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
@@ -2115,6 +2136,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 6) set_rowgemm_small(value);
     else if (key == 7) set_attention_fewq(value);
     else if (key == 8) g_no_ffn_tail = value;
+    else if (key == 9) g_no_ffn_head = value;
     else if (key == 2) {            // beam search phase profile of workgroup 0: value 1 = on, 0 = print + off
         if (value) {
             if (!e->beam_prof) {

@@ -32,12 +32,16 @@ __device__ __forceinline__ float pc_wsum(float v) {
     return wave_sum_dpp(v);
 }
 
-template <int AFFINE, int SPLIT, int VAR, int TAIL>
+// HEADK > 0 (second FFN of an offline Conformer layer): the conv module's depthwise conv (HEADK taps) + LayerNorm + SiLU +
+// pointwise_conv2 + residual run first, on the same 32 rows (FfnHead, common.h): the depthwise conv reads its HEADK - 1 earlier
+// GLU rows from the padded buffer the previous kernel wrote, everything behind it is row-local.  Replaces two launches
+// (dwconv_ln_silu_kernel, rowgemm PRO_PLAIN / EPI_RESID) with the same arithmetic in the same order (bit-identical).
+template <int AFFINE, int SPLIT, int VAR, int TAIL, int HEADK>
 __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                      const float* __restrict__ w1, const float* __restrict__ b1,
                                                      const float* __restrict__ w2, const float* __restrict__ b2, int M,
                                                      int dff, float eps, float scale, float* partial,
-                                                     int chunks_per_block, FfnTail tail) {
+                                                     int chunks_per_block, FfnTail tail, FfnHead head) {
     extern __shared__ __align__(16) float sm[];
     float* xn = sm;                              // [32][260]   LayerNorm(x) tile (A operand of GEMM1)
     float* hs = xn + PC_BM * PC_XLD;             // [2][32][132] hidden tile (A operand of GEMM2), double-buffered
@@ -49,6 +53,137 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     const int row0 = blockIdx.x * PC_BM;
     const int frow = lane & 31, fh = lane >> 5;
     float* wmine = wpv + wave * 2 * PC_WSLAB;
+    const int lr8 = lane >> 3, lc4 = (lane & 7) * 4;
+    f32x4 pre[PC_NSET][4];
+    auto dst_of = [&](int s, int i) -> float* { return wmine + (s & 1) * PC_WSLAB + (lr8 + 8 * i) * PC_WLD + lc4; };
+    const float* wfrag = wmine + frow * PC_WLD + 4 * fh;
+
+    if (HEADK > 0) {
+        // ---- head 1: depthwise conv of my 32 rows -> xn tile.  Thread = (channel c, 16-row half); the window slides down the
+        // rows like dwconv_ln_silu_kernel's and is reloaded where a new sequence starts (rows are (b, t) = divmod(row, seq_t)).
+        {
+            constexpr int KT = HEADK > 0 ? HEADK : 1, pad = KT - 1;      // (KT: no zero-length arrays in the HEADK = 0 kernels)
+            const int c = tid & 255, half = tid >> 8;
+            float w[KT], win[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) w[j] = head.dw_w[j * 256 + c];
+            const float bv = head.dw_b[c];
+            const float gc = head.gconst ? head.gconst[c] : 0.f;
+            const bool has_gc = head.gconst != nullptr;
+#pragma unroll
+            for (int j = 0; j < KT; ++j) win[j] = 0.f;
+#pragma unroll 1
+            for (int rr = 0; rr < 16; ++rr) {
+                const int lr = half * 16 + rr;
+                const int row = min(row0 + lr, M - 1);
+                const int b = row / head.seq_t, t = row - b * head.seq_t;
+                const float* gin = head.glu + ((size_t)b * (pad + head.seq_t) + t) * 256 + c;     // padded rows t .. t + pad
+                if (rr == 0 || t == 0 || row0 + lr >= M) {
+#pragma unroll
+                    for (int j = 0; j < pad; ++j) win[j + 1] = (has_gc && t + j < pad) ? gc : gin[(size_t)j * 256];
+                }
+#pragma unroll
+                for (int j = 0; j < pad; ++j) win[j] = win[j + 1];
+                win[pad] = gin[(size_t)pad * 256];
+                float acc = bv;                       // out[t] = b + sum_j w[j] * gpad[t + j]
+#pragma unroll
+                for (int j = 0; j < KT; ++j) acc = fmaf(w[j], win[j], acc);
+                xn[lr * PC_XLD + c] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- head 2: LayerNorm + SiLU per row (wave w: rows 4w .. 4w+3), in place: the A tile of pointwise_conv2 ------------
+        {
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(head.lnw + lane * 4);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(head.lnb + lane * 4);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int lr = wave * 4 + rr;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&xn[lr * PC_XLD + lane * 4]);
+                const float mean = pc_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                const float var = pc_wsum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + eps);
+                f32x4 o;
+                o[0] = d0 * rstd * ww[0] + bb[0];
+                o[1] = d1 * rstd * ww[1] + bb[1];
+                o[2] = d2 * rstd * ww[2] + bb[2];
+                o[3] = d3 * rstd * ww[3] + bb[3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = o[i] / (1.0f + expf(-o[i]));
+                *reinterpret_cast<f32x4*>(&xn[lr * PC_XLD + lane * 4]) = o;
+            }
+        }
+        // ---- head 3: pointwise_conv2 on all 8 waves (wave w: output channels 32w .. 32w+31, K = 256 in 8 slabs through the
+        // wave-private slab pipeline), + bias, pad mask, residual -> x (global) and, raw, back into the xn tile ----------------
+        const float* hl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hl[i] = head.W + (size_t)(wave * 32 + lr8 + 8 * i) * PC_D + lc4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(hl[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+#pragma unroll
+        for (int k = 1; k <= PC_NSET; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(hl[i] + k * 32);
+        __syncthreads();                                  // A tile complete
+        {
+            const float* xa = xn + frow * PC_XLD + 4 * fh;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* wp = wfrag + (j & 1) * PC_WSLAB;
+                f32x4 a[2], b[2];
+                a[0] = *reinterpret_cast<const f32x4*>(xa + j * 32);
+                b[0] = *reinterpret_cast<const f32x4*>(wp);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g + 1 < 4) {
+                        a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(xa + j * 32 + 8 * (g + 1));
+                        b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc, 0, 0, 0);
+                        const int slot = g * 4 + q, pset = (j + 1) % PC_NSET;
+                        if (slot < 8) {
+                            if ((slot & 1) == 0 && j + 1 < 8) *reinterpret_cast<f32x4*>(dst_of(j + 1, slot >> 1)) = pre[pset][slot >> 1];
+                        } else if ((slot & 1) == 0 && j + 1 + PC_NSET < 8) {
+                            pre[pset][(slot - 8) >> 1] = *reinterpret_cast<const f32x4*>(hl[(slot - 8) >> 1] + (j + 1 + PC_NSET) * 32);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            const int col = wave * 32 + frow;
+            const float bv = head.bias[col];
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, M - 1);
+                res[r] = x[(size_t)row * PC_D + col];
+            }
+            __syncthreads();                              // every wave has read its A fragments: the tile may be overwritten
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int row = row0 + lr;
+                float v = acc[r] + bv;
+                if (head.lens) {
+                    const int rc = min(row, M - 1);
+                    const int b = rc / head.seq_t, tt = rc - b * head.seq_t;
+                    if (head.mstride * tt >= head.lens[b]) v = 0.f;
+                }
+                v = res[r] + v;
+                if (row < M) x[(size_t)row * PC_D + col] = v;
+                xn[lr * PC_XLD + col] = v;
+            }
+        }
+        __syncthreads();                                  // the updated rows are in the xn tile (and on their way to x)
+    }
 
     // ---- LayerNorm prologue: wave w normalises rows 4w..4w+3 ----------------------------------------
     {
@@ -58,7 +193,8 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = min(row0 + wave * 4 + rr, M - 1);
-            v4[rr] = *reinterpret_cast<const f32x4*>(x + (size_t)row * PC_D + lane * 4);
+            v4[rr] = HEADK > 0 ? *reinterpret_cast<const f32x4*>(&xn[(wave * 4 + rr) * PC_XLD + lane * 4])
+                               : *reinterpret_cast<const f32x4*>(x + (size_t)row * PC_D + lane * 4);
         }
         if (TAIL && tail.pre_lnw) {
             // the previous layer's closing LayerNorm on my rows, written back as the new residual stream (read again by the
@@ -113,8 +249,6 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     const int chunk_lo = SPLIT ? blockIdx.y * chunks_per_block : 0;
     const int chunk_hi = SPLIT ? min(chunk_lo + chunks_per_block, dff / PC_CH) : dff / PC_CH;
     const int nchunk = chunk_hi - chunk_lo;
-    const int lr8 = lane >> 3, lc4 = (lane & 7) * 4;
-    f32x4 pre[PC_NSET][4];
     // branch-free addressing: role-dependent strides are wave-uniform scalars
     const float* wbase = role == 0 ? w1 + (size_t)(idx * 32) * PC_D : w2 + (size_t)(idx * 64) * dff;
     const size_t rs = role == 0 ? (size_t)PC_D : (size_t)dff;            // row stride of my weight matrix
@@ -124,7 +258,6 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
         const size_t joff = role == 0 ? (size_t)(j * 32) : (size_t)((j & 1) * 32) * dff + (size_t)((j >> 1) * 32);
         return wlane + (size_t)(8 * i) * rs + (size_t)chunk * cs + joff;
     };
-    auto dst_of = [&](int s, int i) -> float* { return wmine + (s & 1) * PC_WSLAB + (lr8 + 8 * i) * PC_WLD + lc4; };
     const int nlast = chunk_hi - 1;
     // side work in the MFMA issue slots of slab (c, j): store slab s+1 (set (j+1)%NSET) to LDS, refill that set with slab
     // s+1+NSET (chunk index clamped past the end: re-fetches land in buffers nobody reads any more)
@@ -148,7 +281,6 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
         for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, k, i));
     __syncthreads();                                 // xn tile complete
 
-    const float* wfrag = wmine + frow * PC_WLD + 4 * fh;
     // Phases p = 0 .. nchunk+1, one workgroup barrier at the end of each:
     //   producer: MFMAs of chunk p (p < nchunk) with the bias + SiLU + LDS store of chunk p-1 spread over the free issue
     //             slots between them (the raw sums of chunk p-1 wait in accp) -> hs[(p-1) & 1]
@@ -352,43 +484,56 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
 }
 
 
+template <int HEADK>
+static void launch_head_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                          const float* b2, int M, int dff, float eps, float scale, hipStream_t s, const FfnHead& head, size_t lds) {
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, 0, 0, HEADK>), lds, attr);
+    hipLaunchKernelGGL((ffn_pc_kernel<0, 0, 0, 0, HEADK>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
+                       b2, M, dff, eps, scale, (float*)nullptr, 0, FfnTail{}, head);
+}
+
 template <int AFFINE, int VAR>
 static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                        const float* b2, int M, int dff, float eps, float scale, float* partial, int nsplit, hipStream_t s,
-                       const FfnPostLn* post, const FfnTail* tail) {
+                       const FfnPostLn* post, const FfnTail* tail, const FfnHead* head) {
     const size_t lds = (size_t)(PC_BM * PC_XLD + 2 * PC_BM * PC_HLD + 8 * 2 * PC_WSLAB) * sizeof(float);
     static LdsAttr attr_full, attr_split, attr_tail;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 0, VAR, 0>), lds, attr_full);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, 0, 0>), lds, attr_split);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, 0, 1>), lds, attr_tail);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 0, VAR, 0, 0>), lds, attr_full);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, 0, 0, 0>), lds, attr_split);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, 0, 1, 0>), lds, attr_tail);
     const int nchunk = dff / PC_CH;
     if (partial && nsplit > 1) {
         const int cpb = (nchunk + nsplit - 1) / nsplit;
         const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
-        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, 0, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
-                           b1, w2, b2, M, dff, eps, scale, partial, cpb, FfnTail{});
+        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, 0, 0, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
+                           b1, w2, b2, M, dff, eps, scale, partial, cpb, FfnTail{}, FfnHead{});
         launch_ffn_reduce(x, partial, b2, M, ny, scale, s, post);
         return post && post->y ? 1 : 0;
+    } else if (head && head->glu && (head->ktaps == 15 || head->ktaps == 7) && !AFFINE && VAR == 0 && !(tail && tail->out)) {
+        if (head->ktaps == 15) launch_head_t<15>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s, *head, lds);
+        else launch_head_t<7>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s, *head, lds);
+        return 4;                                         // head stage done
     } else if (tail && tail->out && tail->N % 256 == 0 && !AFFINE && VAR == 0) {
-        hipLaunchKernelGGL((ffn_pc_kernel<0, 0, 0, 1>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
-                           b2, M, dff, eps, scale, (float*)nullptr, 0, *tail);
+        hipLaunchKernelGGL((ffn_pc_kernel<0, 0, 0, 1, 0>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
+                           b2, M, dff, eps, scale, (float*)nullptr, 0, *tail, FfnHead{});
         return 2;                                         // tail stage done
     } else {
-        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 0, VAR, 0>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1,
-                           b1, w2, b2, M, dff, eps, scale, (float*)nullptr, 0, FfnTail{});
+        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 0, VAR, 0, 0>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1,
+                           b1, w2, b2, M, dff, eps, scale, (float*)nullptr, 0, FfnTail{}, FfnHead{});
     }
     return 0;
 }
 
-// returns 1 when the post LayerNorm was applied (split-d_ff path), 2 when the tail stage ran (full kernel with `tail`), 0 when
-// the caller still has to run whichever it asked for
+// returns 1 when the post LayerNorm was applied (split-d_ff path), 2 when the tail stage ran (full kernel with `tail`), 4 when
+// the head stage ran (full kernel with `head`), 0 when the caller still has to run whichever it asked for
 int launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
-                  hipStream_t s, int variant, const FfnPostLn* post, const FfnTail* tail) {
+                  hipStream_t s, int variant, const FfnPostLn* post, const FfnTail* tail, const FfnHead* head) {
     if (M <= 0) return 0;
-    if (affine_prologue) return launch_pc_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, nullptr);
-    if (variant == 1) return launch_pc_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, nullptr);
-    return launch_pc_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, tail);
+    if (affine_prologue) return launch_pc_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, nullptr, nullptr);
+    if (variant == 1) return launch_pc_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, nullptr, nullptr);
+    return launch_pc_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, tail, head);
 }
 
 }  // namespace masr

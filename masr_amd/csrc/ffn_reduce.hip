@@ -79,17 +79,17 @@ void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, i
 }
 int launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
-                  hipStream_t s, int variant, const FfnPostLn* post, const FfnTail* tail);
+                  hipStream_t s, int variant, const FfnPostLn* post, const FfnTail* tail, const FfnHead* head);
 
 static int g_ffn_variant = 0;
 void set_ffn_variant(int v) { g_ffn_variant = v; }   // masr_debug_set(1, v): 81 = the kernel without weight loads (MFMA-only floor)
 
 int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
-                     int nsplit, hipStream_t s, const FfnPostLn* post, const FfnTail* tail) {
+                     int nsplit, hipStream_t s, const FfnPostLn* post, const FfnTail* tail, const FfnHead* head) {
     if (M <= 0) return 0;
     return launch_ffn_pc(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, affine_prologue, partial, nsplit, s,
-                         g_ffn_variant == 81 ? 1 : 0, post, tail);
+                         g_ffn_variant == 81 ? 1 : 0, post, tail, head);
 }
 
 }  // namespace masr

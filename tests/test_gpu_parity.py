@@ -847,3 +847,35 @@ def test_ffn_tail_stage_matches_separate_launches(eng512):
     assert fused.shape == (9, 250, 256)
     assert torch.equal(fused, plain)
     assert torch.isfinite(fused).all()
+
+
+@pytest.mark.parametrize('streaming', [True, False])
+def test_ffn_head_stage_matches_separate_launches(oracle_mods, streaming):
+    """offline Conformer layers: depthwise conv + LayerNorm + SiLU + pointwise_conv2 + residual as the HEAD stage of the second
+    FFN launch (ffn_pc HEADK) vs dwconv_ln_silu_kernel + the row-block GEMM -- same arithmetic in the same order, so the encoder
+    output must be bit-identical.  Ragged batch (pad masks), sequence boundaries inside 32-row blocks (T' = 250), a partial last
+    block; the causal build (constant history rows) and the streaming: False build (symmetric zero padding)."""
+    from masr_amd.engine import HipEngine
+    weights = oracle_mods[3]
+    sd = weights.conformer_state_dict(0, 512)
+    e = HipEngine(sd, vocab_size=512, streaming=streaming)
+    try:
+        gen = torch.Generator().manual_seed(22)
+        feats = torch.randn(9, 1003, 80, generator=gen) * 3 + 13
+        lens = torch.tensor([1003, 990, 700, 1003, 512, 333, 1003, 801, 67], dtype=torch.int32)
+        feats = feats * (torch.arange(1003)[None, :, None] < lens[:, None, None])
+        x, n = dev(feats), dev(lens)
+        fused = e.encode_full(x, n, -1).clone()
+        e.lib.masr_debug_set(e.h, 9, 1)
+        try:
+            plain = e.encode_full(x, n, -1).clone()
+        finally:
+            e.lib.masr_debug_set(e.h, 9, 0)
+        assert fused.shape == (9, 250, 256) and torch.isfinite(fused).all()
+        assert torch.equal(fused, plain), (fused - plain).abs().max().item()
+        oc = oracle_mods[0]
+        with torch.no_grad():
+            ref = oc.encoder_full(sd, feats[:3], lens[:3].long(), -1, streaming=streaming)
+        assert (fused[:3].cpu() - ref).abs().max() < 1e-3
+    finally:
+        e.close()
