@@ -86,14 +86,25 @@ def data_tag():
 
 
 # ---- evidence helpers ------------------------------------------------------------------------------------------------------
-def committed_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this build
-    (profiles/rNN_hbm_traffic.json: FETCH_SIZE with the gfx950 correction + WRITE_SIZE); (bytes, file) or (None, None)."""
+# kernels timed with HIP events inside the engine (masr_profile_*): (profile kind, rocprof kernel-name fragment, description)
+ROOFLINE_KERNELS = [
+    (6, 'ffn_pc_kernel<0, 0, 0, 1, 0>', "ffn_pc_kernel TAIL: LN + [B*T',256]x[256,2048] + SiLU + x[2048,256] + 1/2 residual, then LN + fused "
+        "QKV projection [256,768] on the same rows (16.64 + 3.12 GFLOP per launch)"),
+    (7, 'ffn_pc_kernel<0, 0, 0, 0, 15>', 'ffn_pc_kernel HEAD: depthwise conv + LN + SiLU + pointwise_conv2 [256,256] + residual, then '
+        'LN + FFN + 1/2 residual (1.04 + 16.64 GFLOP per launch)'),
+    (3, 'gemm_f32_kernel<128, 128, 2, 2, 1, 0>', 'Conv2d(256,256,3,stride 2) of the subsampling front-end as an implicit GEMM (177.9 GFLOP)'),
+    (4, 'attention_kernel', 'rel-pos multi-head self-attention (6 * d * T\'^2 * B = 3.0 GFLOP per launch)'),
+]
+
+
+def committed_traffic(fragment):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this build (profiles/rNN_hbm_traffic.json:
+    FETCH_SIZE with the gfx950 correction + WRITE_SIZE); (bytes, file) or (None, None)."""
     for name in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
         try:
             k = json.load(open(os.path.join(ROOT, 'profiles', name)))['kernels']
             for key, v in k.items():
-                if 'ffn_pc_kernel<0, 0, 0, 0>' in key:
+                if fragment in key or (name.startswith('r01') and 'ffn_pc_kernel<0, 0, 0, 1>' in key and 'ffn_pc_kernel<0, 0, 0, 1, 0>' == fragment):
                     return v['hbm_bytes'], name
         except Exception:
             continue
@@ -261,21 +272,38 @@ def run_contract(args, rank, world, local):
     log(f'rank {rank}: timed region done: {dt * 1e3 / args.steps:.3f} ms/step')
     dt_dev = parallel.timed_region(lambda i: cs.step(i, 'device'), args.steps, 1)
     dt_host = parallel.timed_region(lambda i: cs.step(i, 'host'), args.steps, 1, flush=cs.flush)
+    others = []
+    if rank == 0:                        # the other heavy kernels, each timed the same way over a few more steps (rank-local)
+        for kind, frag, desc in ROOFLINE_KERNELS:
+            if kind == args.profile_kind:
+                continue
+            eng.profile_select(kind)
+            eng.profile_read(reset=True)
+            for i in range(3):
+                cs.step(i, 'device')
+            torch.cuda.synchronize() if torch.cuda.is_available() else None
+            ms, n, fl = eng.profile_read(reset=True)
+            if n > 0 and ms > 0:
+                ach = fl / (ms * 1e-3) / 1e12
+                others.append({'kernel': desc, 'rocprof_name': frag, 'achieved': round(ach, 2), 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                               'launches': int(n), 'avg_us': round(ms * 1e3 / n, 2), 'flops_per_launch': fl / n})
+        eng.profile_select(0)
     res = None
     if rank == 0:
         audio_step = world * BATCH * (N_SAMPLES / 16000.0)
         roofline = None
         if prof_n > 0 and prof_ms > 0:
             achieved = prof_flops / (prof_ms * 1e-3) / 1e12
-            traffic, tfile = committed_traffic()
-            roofline = {'bound': 'mfma', 'kernel': 'ffn_pc_kernel (LN + [B*T\',256]x[256,2048] + SiLU + x[2048,256] + residual)',
+            kind, frag, desc = next((k for k in ROOFLINE_KERNELS if k[0] == args.profile_kind), (args.profile_kind, '', f'profile kind {args.profile_kind}'))
+            traffic, tfile = committed_traffic(frag)
+            roofline = {'bound': 'mfma', 'kernel': desc, 'rocprof_name': frag,
                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
                         'traffic_note': f'HBM bytes per launch from the committed PMC passes (profiles/{tfile}); algorithmic bytes '
-                                        'per launch = 20.4 MB (x in/out + W1 + W2); measured = x in/out 16.3 MB + the 4.2 MB of '
-                                        'weights fetched once by each of the 8 XCD L2s (Infinity Cache hits after the first)',
+                                        'per launch = x in/out 16.3 MB + qkv out 24.4 MB + weights 5.0 MB; the weights are fetched '
+                                        'once by each of the 8 XCD L2s (Infinity Cache hits after the first)',
                         'launches': int(prof_n), 'avg_us': round(prof_ms * 1e3 / prof_n, 2),
-                        'flops_per_launch': prof_flops / prof_n}
+                        'flops_per_launch': prof_flops / prof_n, 'other_kernels': others}
         per = lambda t: {'value': round(audio_step * args.steps / t, 1), 'ms_per_step': round(t * 1e3 / args.steps, 3)}
         res = {'metric': 'audio-seconds/sec (RTF^-1), conformer_streaming_fbank b32x10s, PCM->fbank->encoder->ctc_greedy->text',
                'value': per(dt)['value'], 'unit': 'audio-seconds/sec', 'n_gpus': world, 'steps': args.steps,
@@ -451,7 +479,9 @@ def main():
     ap.add_argument('--workload', default='conformer_b32',
                     help='conformer_b32 (BASELINE configs[1], the contract line, default) | efficient_b256 | stream128 | '
                          'squeezeformer_b64_beam | squeezeformer_b64_beam_nolm  (one secondary workload only, own JSON line)')
-    ap.add_argument('--profile-kind', type=int, default=2, help='kernel class timed with HIP events (2 = fused FFN)')
+    ap.add_argument('--profile-kind', type=int, default=6,
+                    help='kernel timed with HIP events for the roofline block (6 = fused FFN + QKV tail, the heaviest kernel by total '
+                         'time; 7 = conv-module head + FFN, 3 = conv2 implicit GEMM, 4 = attention)')
     args = ap.parse_args()
 
     env_world = int(os.environ.get('WORLD_SIZE', '0'))

@@ -444,12 +444,15 @@ int masr_finalize(masr_engine* e, void* stream) {
         CHK(upload(e, w, &e->conv1_w));
         CHK(up(e, "encoder.embed.conv.0.bias", {d}, &e->conv1_b));
     }
-    {   // conv2 [co,ci,3,3] -> [co][(kh*3+kw)*d + ci]
+    {   // conv2 [co,ci,3,3] -> [co][ci / 32][kh*3+kw][ci % 32]: the implicit GEMM walks the nine window positions of one
+        // 32-channel block in consecutive K slabs, so the overlapping input columns of neighbouring positions (kw = 2 of one
+        // output, kw = 0 of the next) are re-read a slab or two later -- out of L1 / L2 instead of HBM
         CHK(get(e, "encoder.embed.conv.2.weight", {d, d, 3, 3}, &t));
         std::vector<float> w((size_t)d * 9 * d);
         for (int co = 0; co < d; ++co)
             for (int ci = 0; ci < d; ++ci)
-                for (int k = 0; k < 9; ++k) w[(size_t)co * 9 * d + k * d + ci] = t->v[((size_t)co * d + ci) * 9 + k];
+                for (int k = 0; k < 9; ++k)
+                    w[(size_t)co * 9 * d + (size_t)(ci / 32) * 9 * 32 + k * 32 + ci % 32] = t->v[((size_t)co * d + ci) * 9 + k];
         CHK(upload(e, w, &e->conv2_w));
         CHK(up(e, "encoder.embed.conv.2.bias", {d}, &e->conv2_b));
     }
@@ -803,7 +806,8 @@ static int upload_conv_frontend(masr_engine* e, const std::string& c1, const std
         std::vector<float> w((size_t)d * 9 * d);
         for (int co = 0; co < d; ++co)
             for (int ci = 0; ci < d; ++ci)
-                for (int k = 0; k < 9; ++k) w[(size_t)co * 9 * d + k * d + ci] = t->v[((size_t)co * d + ci) * 9 + k];
+                for (int k = 0; k < 9; ++k)          // [co][ci / 32][kh*3+kw][ci % 32], see masr_finalize
+                    w[(size_t)co * 9 * d + (size_t)(ci / 32) * 9 * 32 + k * 32 + ci % 32] = t->v[((size_t)co * d + ci) * 9 + k];
         CHK(upload(e, w, &e->conv2_w));
     }
     CHK(up(e, c2 + ".bias", {d}, &e->conv2_b));

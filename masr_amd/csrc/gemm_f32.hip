@@ -9,7 +9,8 @@
 // * Fragment trick: MFMA sums over k in any order, so lane half h=(lane>>5) takes the 4 consecutive
 //   k values {8g+4h .. 8g+4h+3} of each 8-wide k group with ONE 16-byte LDS read for A and for W.
 // * A operand modes: plain row-major, or implicit-GEMM gather for the 3x3/stride-2 subsampling
-//   conv over channels-last activations (reference conformer/subsampling.py:86-110).
+//   conv over channels-last activations (reference conformer/subsampling.py:86-110), K ordered
+//   [32-channel block][kh][kw][channel] so that overlapping window columns are re-read while still cached.
 // * Epilogue: bias, ReLU/SiLU, alpha, residual, row masking.  (The K = 256 projections of the layers use
 //   rowgemm.hip, the FFN ffn_pc.hip; this kernel serves conv2, the embed projection, the positional-key
 //   precompute and the full-probability CTC head.)
@@ -89,10 +90,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         if (AMODE == A_PLAIN) {
             aoff = (size_t)kt * BK;
         } else {
-            const int kseg = 3 * p.Cc;            // one kh row of the 3x3 window: (kw, c) contiguous
-            const int k0 = kt * BK;
-            const int kh = k0 / kseg;
-            aoff = (size_t)kh * p.F1 * p.Cc + (k0 - kh * kseg);
+            // K is ordered [channel block of 32][kh][kw][32 channels] (weights re-laid out at load): slab kt = window position
+            // kt % 9 of channel block kt / 9
+            const int cb = kt / 9, pos = kt - 9 * cb;
+            const int kh = pos / 3, kw = pos - 3 * kh;
+            aoff = ((size_t)kh * p.F1 + kw) * p.Cc + (size_t)cb * BK;
         }
 #pragma unroll
         for (int i = 0; i < AL; ++i)

@@ -188,7 +188,7 @@ int masr_lm_load_arpa(const char* path, const char* const* vocab_utf8, int32_t V
                        "character-based like the reference's Mandarin models");
     masr_lm* lm = new masr_lm();
     size_t slots = 16;
-    while (slots < rows.size() * 2) slots <<= 1;
+    while (slots < rows.size() * 3) slots <<= 1;          // load <= 1/3: ~1.2 probes per hit, ~1.4 per miss
     lm->table.assign(slots, LmEntry{0ull, 0.f, 0.f});
     const unsigned long long mask = slots - 1;
     for (const Raw& r : rows) {

@@ -4,9 +4,9 @@
 // is restated).  Character-based models only (every LM word is one vocabulary token, as the reference's Mandarin LMs are).
 //
 // Layout shared by the host search (beam_search.cpp) and the GPU kernel (beam_gpu.hip): ONE open-addressing hash table of all
-// n-grams of all orders.  Key = 64-bit hash chain over (order, w_1 .. w_n) with w = vocabulary token id (+ <s>, </s> behind
-// them); value = (ln P, ln backoff).  16-byte entries, linear probing, load <= 0.5, key 0 = empty slot.  A lookup is one
-// 16-byte load per probe.  In HBM the table of a pruned 5-gram Mandarin LM (~10^8 n-grams) is ~4 GB -- resident next to the
+// n-grams of all orders.  Key = 64-bit hash chain over the words from the last one backwards (+ the order) with w = vocabulary
+// token id (+ <s>, </s> behind them); value = (ln P, ln backoff).  16-byte entries, linear probing, load <= 1/3, key 0 =
+// empty slot.  A lookup is one 16-byte load per probe; the probes of one backoff recursion are issued together.  In HBM the table of a pruned 5-gram Mandarin LM (~10^8 n-grams) is ~4 GB -- resident next to the
 // 138 MB of encoder weights; nothing is paged.
 #pragma once
 #include <stdint.h>
@@ -43,26 +43,42 @@ LM_HD unsigned long long lm_mix(unsigned long long h, unsigned long long w) {
     z ^= z >> 29;
     return z;
 }
-// key of the n-gram made of the `len` most recent context words (packed 16 bits each, most recent in the low bits) followed by
-// `w` (w < 0: the context n-gram itself, `len` words)
+// Keys are hash chains that start at the LAST word of the n-gram and walk backwards: h_1 = mix(seed, w_n), h_2 = mix(h_1, w_{n-1}),
+// ... ; key of the n-gram = fin(h_n, n).  One pass over a prefix's packed words (most recent in the low bits) therefore yields the
+// keys of ALL its suffix n-grams -- what the backoff recursion looks up.
+static constexpr unsigned long long LM_SEED = 0x5851F42D4C957F2Dull;
+LM_HD unsigned long long lm_fin(unsigned long long h, int n) {
+    const unsigned long long k = h ^ ((unsigned long long)n * 0xA24BAED4963EE407ull);
+    return k ? k : 1ull;
+}
+// key of the n-gram (the `len` most recent words of ctx, then w)
 LM_HD unsigned long long lm_key(unsigned long long ctx, int len, int w) {
-    unsigned long long h = 0x5851F42D4C957F2Dull + (unsigned long long)(len + (w >= 0 ? 1 : 0));
-    for (int j = len - 1; j >= 0; --j) h = lm_mix(h, (ctx >> (16 * j)) & 0xFFFFull);
-    if (w >= 0) h = lm_mix(h, (unsigned long long)w);
-    return h ? h : 1ull;
+    unsigned long long h = lm_mix(LM_SEED, (unsigned long long)w);
+    for (int j = 0; j < len; ++j) h = lm_mix(h, (ctx >> (16 * j)) & 0xFFFFull);
+    return lm_fin(h, len + 1);
+}
+// key of the n-gram made of the `len` most recent words of ctx themselves (len >= 1)
+LM_HD unsigned long long lm_key_ctx(unsigned long long ctx, int len) { return lm_key(ctx >> 16, len - 1, (int)(ctx & 0xFFFFull)); }
+
+LM_HD void lm_load_entry(const LmView& lm, unsigned long long slot, unsigned long long* k, float* p, float* b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 raw = *reinterpret_cast<const uint4*>(lm.table + slot);          // one 16-byte load per probe
+    *k = ((unsigned long long)raw.y << 32) | raw.x;
+    *p = __uint_as_float(raw.z);
+    *b = __uint_as_float(raw.w);
+#else
+    const LmEntry e = lm.table[slot];
+    *k = e.key;
+    *p = e.prob;
+    *b = e.backoff;
+#endif
 }
 LM_HD bool lm_find(const LmView& lm, unsigned long long key, float* prob, float* backoff) {
     unsigned long long h = key & lm.mask;
     while (true) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const uint4 raw = *reinterpret_cast<const uint4*>(lm.table + h);          // one 16-byte load per probe
-        const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
-        const float p = __uint_as_float(raw.z), b = __uint_as_float(raw.w);
-#else
-        const LmEntry e = lm.table[h];
-        const unsigned long long k = e.key;
-        const float p = e.prob, b = e.backoff;
-#endif
+        unsigned long long k;
+        float p, b;
+        lm_load_entry(lm, h, &k, &p, &b);
         if (k == key) {
             *prob = p;
             *backoff = b;
@@ -96,7 +112,7 @@ LM_HD LmState lm_state_of(const LmView& lm, unsigned long long ctx) {
     }
     for (int len = 1; len <= k; ++len) {
         float p, b;
-        if (!lm_find(lm, lm_key(ctx, len, -1), &p, &b)) break;
+        if (!lm_find(lm, lm_key_ctx(ctx, len), &p, &b)) break;
         s.bo[len - 1] = b;
         s.m = len;
     }
@@ -112,10 +128,27 @@ LM_HD unsigned long long lm_push(unsigned long long ctx, int w) { return (ctx <<
 // == the ARPA backoff recursion: the longest (suffix, w) n-gram in the model, plus the backoff weights of the longer suffixes
 LM_HD float lm_cond(const LmView& lm, const LmState& s, int w) {
     if (s.oov || w >= lm.n_words || !lm.known[w]) return LM_OOV_SCORE;
+    // keys of (suffix of length len, w) for len = 0 .. m in one pass; their first probes are independent loads, all in flight
+    // before the first is looked at (one memory round trip instead of m + 1); linear probing continues only on a collision
+    unsigned long long key[5], k0[5];
+    float p0[5], b0[5];
+    unsigned long long h = lm_mix(LM_SEED, (unsigned long long)w);
+#pragma unroll
+    for (int len = 0; len < 5; ++len) {
+        key[len] = lm_fin(h, len + 1);
+        h = lm_mix(h, (s.ctx >> (16 * len)) & 0xFFFFull);
+    }
+#pragma unroll
+    for (int len = 0; len < 5; ++len)
+        if (len <= s.m) lm_load_entry(lm, key[len] & lm.mask, &k0[len], &p0[len], &b0[len]);
     float acc = 0.f;
-    for (int len = s.m; len >= 0; --len) {
-        float p, b;
-        if (lm_find(lm, lm_key(s.ctx, len, w), &p, &b)) return acc + p;
+#pragma unroll
+    for (int len = 4; len >= 0; --len) {
+        if (len > s.m) continue;
+        bool hit = k0[len] == key[len];
+        float p = p0[len], b;
+        if (!hit && k0[len] != 0ull) hit = lm_find(lm, key[len], &p, &b);      // occupied by another n-gram: walk on
+        if (hit) return acc + p;
         if (len > 0) acc += s.bo[len - 1];
     }
     return LM_OOV_SCORE;       // (a known word always has its unigram)

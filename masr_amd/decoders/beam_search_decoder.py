@@ -134,10 +134,13 @@ class BeamSearchDecoder:
         """list of [T_i, V] -> list of texts (beam_search_decoder.py:59-73), num_processes host threads."""
         return [t for _, t in self._batch([np.asarray(p) for p in probs_split])]
 
-    def _batch_collect(self, pending):
+    def _batch_collect(self, pending, want_tokens=False):
         """results of a ``_batch(..., defer=True)`` launch (synchronises with the stream it was launched on)"""
-        _, toks, lens, scores, _keep = pending
+        _, toks, lens, scores, _keep, ev = pending
+        ev.synchronize()
         toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
+        if want_tokens:
+            return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(len(lens))]
         return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(len(lens))]
 
     def _batch(self, probs_list, defer=False, want_tokens=False):
@@ -170,7 +173,9 @@ class BeamSearchDecoder:
                                                     C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             if defer:                      # nothing has been synchronised: _batch_collect() fetches the result later
-                return ('gpu', toks, lens, scores, (stacked, idx, logp, cnt, fr))
+                ev = torch.cuda.Event()
+                ev.record()
+                return ('gpu', toks, lens, scores, (stacked, idx, logp, cnt, fr, probs_list), ev)
             toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
             if want_tokens:          # (token ids, score): what a multi-GPU caller gathers instead of text
                 return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(B)]

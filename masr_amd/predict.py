@@ -165,10 +165,12 @@ class MASRPredictor:
         torch.cuda.current_stream().synchronize()          # the staging buffer is reused by the next call
         return xs, ns
 
-    def _predict_local(self, segs, decode_all_frames=False, as_tokens=False):
+    def _predict_local(self, segs, decode_all_frames=False, as_tokens=False, defer=False):
         """AudioSegments -> [{'text','score'}] on THIS rank's engine.  Utterances too short for one feature frame decode to
         the empty transcript (the reference's encoder cannot take them either); a silent utterance raises like
-        ``AudioSegment.normalize`` (audio.py:300-303)."""
+        ``AudioSegment.normalize`` (audio.py:300-303).  ``defer=True`` (beam search on the GPU): the prefix search is launched
+        on a side stream and a zero-argument function that returns the results is handed back -- the caller runs the next
+        device pass (features + encoder on the main stream) underneath it."""
         eng = self.predictor.engine
         pc = self.configs.preprocess_conf
         rate = int(pc.get('sample_rate', 16000))
@@ -184,7 +186,7 @@ class MASRPredictor:
             if i not in ok:
                 out[i] = ([], 0) if as_tokens else {'text': '', 'score': 0}
         if not ok:
-            return out
+            return (lambda: out) if defer else out
         live = [segs[i] for i in ok]
         n = np.array([s.num_samples for s in live], np.int32)
         xs, ns = self._stage_batch(live, n)
@@ -197,10 +199,23 @@ class MASRPredictor:
             # probabilities stay on the GPU: vocabulary pruning, prefix search and LM scoring run there
             probs = eng.ctc_probs(enc)
             n_host = [probs.shape[1]] * len(live) if nenc is None else nenc.cpu().tolist()
-            res = self.beam_search_decoder._batch([probs[i, :n_host[i]] for i in range(len(live))], want_tokens=as_tokens)
-            for i, r in zip(ok, res):
-                out[i] = r if as_tokens else {'text': r[1], 'score': r[0]}
-            return out
+            seqs = [probs[i, :n_host[i]] for i in range(len(live))]
+            dec = self.beam_search_decoder
+
+            def fill(res):
+                for i, r in zip(ok, res):
+                    out[i] = r if as_tokens else {'text': r[1], 'score': r[0]}
+                return out
+            if defer and dec.use_gpu_search and dec.gpu_search_supported(probs.shape[1], probs.shape[2]):
+                main = torch.cuda.current_stream()
+                if getattr(self, '_side', None) is None:
+                    self._side = torch.cuda.Stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    pending = dec._batch(seqs, defer=True)
+                return lambda: fill(dec._batch_collect(pending, want_tokens=as_tokens))
+            res = fill(dec._batch(seqs, want_tokens=as_tokens))
+            return (lambda: res) if defer else res
         idx, mp = eng.ctc_greedy_frames(enc)
         tok, ntok, score = eng.ctc_collapse(idx, mp, nenc)
         tok, ntok, score = tok.cpu().numpy(), ntok.cpu().numpy(), score.cpu().numpy()
@@ -208,7 +223,7 @@ class MASRPredictor:
             sc = float(score[j]) * 100.0 if ntok[j] > 0 or score[j] > 0 else 0
             ids = tok[j, :ntok[j]]
             out[i] = (ids.tolist(), sc) if as_tokens else {'text': self._text(ids), 'score': sc}
-        return out
+        return (lambda: out) if defer else out
 
     def predict_batch(self, audio_list, sample_rate=16000, decode_all_frames=False, batch_size=0, distributed=None):
         """Batched offline path (an addition; the reference's only batched consumer is MASRTrainer.evaluate,
@@ -243,11 +258,16 @@ class MASRPredictor:
         ``evaluate`` forms from a duration-sorted manifest); results in the order of ``which``"""
         order = sorted(which, key=lambda i: segs[i].num_samples) if batch_size else list(which)
         step = batch_size if batch_size else max(len(order), 1)
-        got = {}
+        got, pending = {}, []
         for lo in range(0, len(order), step):
             idx = order[lo:lo + step]
-            for i, r in zip(idx, self._predict_local([segs[i] for i in idx], decode_all_frames, as_tokens)):
+            # (beam search: the prefix search of this pass runs on a side stream under the encoder of the next pass)
+            pending.append((idx, self._predict_local([segs[i] for i in idx], decode_all_frames, as_tokens, defer=True)))
+        for idx, collect in pending:
+            for i, r in zip(idx, collect()):
                 got[i] = r
+        if pending and getattr(self, '_side', None) is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
         return [got[i] for i in which]
 
     def evaluate(self, manifest, batch_size=32, display_result=False, decode_all_frames=False):
