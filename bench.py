@@ -273,21 +273,23 @@ def run_contract(args, rank, world, local):
     dt_dev = parallel.timed_region(lambda i: cs.step(i, 'device'), args.steps, 1)
     dt_host = parallel.timed_region(lambda i: cs.step(i, 'host'), args.steps, 1, flush=cs.flush)
     others = []
-    if rank == 0:                        # the other heavy kernels, each timed the same way over a few more steps (rank-local)
-        for kind, frag, desc in ROOFLINE_KERNELS:
-            if kind == args.profile_kind:
-                continue
-            eng.profile_select(kind)
-            eng.profile_read(reset=True)
-            for i in range(3):
-                cs.step(i, 'device')
-            torch.cuda.synchronize() if torch.cuda.is_available() else None
-            ms, n, fl = eng.profile_read(reset=True)
-            if n > 0 and ms > 0:
-                ach = fl / (ms * 1e-3) / 1e12
-                others.append({'kernel': desc, 'rocprof_name': frag, 'achieved': round(ach, 2), 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                               'launches': int(n), 'avg_us': round(ms * 1e3 / n, 2), 'flops_per_launch': fl / n})
-        eng.profile_select(0)
+    # the other heavy kernels, each timed the same way over a few more steps (every rank runs the steps -- they contain the
+    # all-gather -- rank 0 keeps the numbers)
+    for kind, frag, desc in ROOFLINE_KERNELS:
+        if kind == args.profile_kind:
+            continue
+        eng.profile_select(kind)
+        eng.profile_read(reset=True)
+        for i in range(3):
+            cs.step(i, 'device')
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        ms, n, fl = eng.profile_read(reset=True)
+        if rank == 0 and n > 0 and ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            others.append({'kernel': desc, 'rocprof_name': frag, 'achieved': round(ach, 2), 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                           'launches': int(n), 'avg_us': round(ms * 1e3 / n, 2), 'flops_per_launch': fl / n})
+    eng.profile_select(0)
     res = None
     if rank == 0:
         audio_step = world * BATCH * (N_SAMPLES / 16000.0)

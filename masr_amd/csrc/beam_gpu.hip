@@ -155,7 +155,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     unsigned long long* lv_ctx = reinterpret_cast<unsigned long long*>(next + beam + (beam & 1));   // [2][beam] packed LM context
     float* lv_bo = reinterpret_cast<float*>(lv_ctx + 2 * beam);          // [2][beam][4] backoffs of the context's suffixes
     int* lv_m = reinterpret_cast<int*>(lv_bo + 8 * beam);                // [2][beam] m | oov << 8
-    int* c_idx = lv_m + 2 * beam;                                        // [BS_KMAX]
+    int* c_idx = lv_m + 2 * beam;                                        // [BS_KMAX]; bit 30 set = unknown to the language model
     float* c_lp = reinterpret_cast<float*>(c_idx + BS_KMAX);             // [BS_KMAX]
     int* hist = reinterpret_cast<int*>(c_lp + BS_KMAX);                  // [7][256]: one per radix pass of a step
     int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
@@ -225,7 +225,13 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         if (wave == 0) {
             const bool isb = lane < cnt && nx_c == a.blank;
             const unsigned long long bm = __ballot(isb);
-            if (lane < cnt) { c_idx[lane] = nx_c; c_lp[lane] = nx_lp; }
+            if (lane < cnt) {
+                // the scorer's known-word flag of this candidate rides in bit 30 of its index: one lookup per frame and
+                // candidate instead of one per (prefix, candidate) pair
+                const bool unk = use_lm && !(nx_c >= 0 && nx_c < a.lm.n_words && a.lm.known[nx_c]);
+                c_idx[lane] = nx_c | (unk ? (1 << 30) : 0);
+                c_lp[lane] = nx_lp;
+            }
             if (lane == 0) misc[0] = bm ? __ffsll((long long)bm) - 1 : -1;
         }
         if (t + 1 < T) {
@@ -271,7 +277,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 for (int j = 0; j < 4; ++j) sp.bo[j] = lv_bo[4 * (o + my_p) + j];
             }
             for (int k = my_g; k < cnt; k += G) {
-                const int c = c_idx[k];
+                const int craw = c_idx[k];
+                const int c = craw & ~(1 << 30);
                 const float lp = c_lp[k];
                 float val = -INFINITY;
                 if (c != a.blank) {
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                         val = lp + sc;
                     }
                     // the external scorer: every way into the prefix p + c carries the same alpha * ln P_LM + beta
-                    if (use_lm && val > -INFINITY) val += a.alpha * lm_cond(a.lm, sp, c) + a.beta;
+                    if (use_lm && val > -INFINITY) val += a.alpha * lm_cond(a.lm, sp, c, !(craw >> 30)) + a.beta;
                     for (int j = hd; j >= 0; j = next[j])
                         if (lv_ch[o + j] == c) {                    // the child (p, c) is a live prefix: merge into it
                             ext[j] = val;
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                     const int slot = n_exist + r, node = pool_count + r;
                     const int e = slist[tid + i * BS_THREADS];
                     const int p = e / cnt, k = e - p * cnt;
-                    const int c = c_idx[k];
+                    const int c = c_idx[k] & ~(1 << 30);
                     const float add = ikey(kk);           // the entry's own score (acoustic term + scorer term), as ranked
                     if (node < a.pool_cap) {
                         pool_parent[node] = lv_node[o + p];

@@ -37,11 +37,17 @@ struct LmView {
 
 static constexpr float LM_OOV_SCORE = -1000.0f;   // scorer.h OOV_SCORE: returned as it is (not converted from log10)
 
+// one word into the 64-bit chain state, on 32-bit halves: two 32-bit multiplies (a 64-bit multiply is ~8 quarter-rate
+// instructions on the vector ALU and this runs ~60 000 times per frame of a beam-300 search)
 LM_HD unsigned long long lm_mix(unsigned long long h, unsigned long long w) {
-    unsigned long long z = (h ^ (w + 1)) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
-    z ^= z >> 29;
-    return z;
+    unsigned a = (unsigned)h, b = (unsigned)(h >> 32);
+    a = (a ^ ((unsigned)w + 0x7F4A7C15u)) * 0x9E3779B1u;
+    a ^= a >> 15;
+    b = (b ^ a) * 0x85EBCA77u;
+    b ^= b >> 13;
+    a = (a + b) * 0xC2B2AE3Du;
+    a ^= a >> 16;
+    return ((unsigned long long)b << 32) | a;
 }
 // Keys are hash chains that start at the LAST word of the n-gram and walk backwards: h_1 = mix(seed, w_n), h_2 = mix(h_1, w_{n-1}),
 // ... ; key of the n-gram = fin(h_n, n).  One pass over a prefix's packed words (most recent in the low bits) therefore yields the
@@ -126,8 +132,9 @@ LM_HD unsigned long long lm_push(unsigned long long ctx, int w) { return (ctx <<
 
 // ln P(w | the state's words): Scorer::get_log_cond_prob on make_ngram(prefix + w) -- KenLM BaseScore from the null context
 // == the ARPA backoff recursion: the longest (suffix, w) n-gram in the model, plus the backoff weights of the longer suffixes
-LM_HD float lm_cond(const LmView& lm, const LmState& s, int w) {
-    if (s.oov || w >= lm.n_words || !lm.known[w]) return LM_OOV_SCORE;
+// (w_known: lm.known[w], looked up by the caller -- the GPU search does it once per frame and candidate, not once per pair)
+LM_HD float lm_cond(const LmView& lm, const LmState& s, int w, bool w_known) {
+    if (s.oov || !w_known) return LM_OOV_SCORE;
     // keys of (suffix of length len, w) for len = 0 .. m in one pass; their first probes are independent loads, all in flight
     // before the first is looked at (one memory round trip instead of m + 1); linear probing continues only on a collision
     unsigned long long key[5], k0[5];
@@ -136,7 +143,7 @@ LM_HD float lm_cond(const LmView& lm, const LmState& s, int w) {
 #pragma unroll
     for (int len = 0; len < 5; ++len) {
         key[len] = lm_fin(h, len + 1);
-        h = lm_mix(h, (s.ctx >> (16 * len)) & 0xFFFFull);
+        if (len < s.m) h = lm_mix(h, (s.ctx >> (16 * len)) & 0xFFFFull);
     }
 #pragma unroll
     for (int len = 0; len < 5; ++len)
@@ -153,5 +160,6 @@ LM_HD float lm_cond(const LmView& lm, const LmState& s, int w) {
     }
     return LM_OOV_SCORE;       // (a known word always has its unigram)
 }
+LM_HD float lm_cond(const LmView& lm, const LmState& s, int w) { return lm_cond(lm, s, w, w >= 0 && w < lm.n_words && lm.known[w] != 0); }
 
 }  // namespace masr

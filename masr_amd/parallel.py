@@ -46,6 +46,14 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def collectives_on(group=None):
+    """True when the exchange steps really run: more than one rank, or MASR_FORCE_DIST=1 with an initialised group (a
+    single-GPU box then goes through RCCL init, all-gather, all-reduce and barriers exactly like a multi-GPU job)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get('MASR_FORCE_DIST') == '1'
+
+
 def comm_device():
     """where collective payloads live: the current GPU under RCCL, the host under gloo"""
     if dist.is_initialized() and dist.get_backend() == 'nccl':
@@ -78,7 +86,7 @@ def sticky_stream_owner(stream_id, world):
 def gather_hypotheses(tokens, ntok, scores, group=None):
     """All-gather per-rank hypotheses.  tokens int32 [B, T'], ntok int32 [B], scores f32 [B] with the
     SAME shapes on every rank (pad shards with empty utterances).  Returns the concatenation over ranks."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not collectives_on(group):
         return tokens, ntok, scores
     w = dist.get_world_size(group)
     # one payload: [B, T' + 2] int32 rows = tokens | ntok | score bits
@@ -105,7 +113,7 @@ def gather_sharded_results(local_tokens, local_ntok, local_scores, shards, n_ite
     dev = comm_device()
     per = max(len(s) for s in shards) if shards else 0
     tp = torch.tensor([local_tokens.shape[1] if local_tokens.numel() else 0], dtype=torch.int32, device=dev)
-    if world > 1:
+    if collectives_on(group):
         dist.all_reduce(tp, op=dist.ReduceOp.MAX, group=group)
     Tp = max(int(tp.item()), 1)
     tok = torch.full((per, Tp), -1, dtype=torch.int32, device=dev)
@@ -145,7 +153,8 @@ def timed_region(step, steps, warmup, group=None, after_warmup=None, flush=None)
     _sync()
     if after_warmup is not None:
         after_warmup()
-    if world > 1:
+    coll = collectives_on(group)
+    if coll:
         dist.barrier(group=group)
     _sync()
     t0 = time.perf_counter()
@@ -154,10 +163,10 @@ def timed_region(step, steps, warmup, group=None, after_warmup=None, flush=None)
     if flush is not None:
         flush()
     _sync()
-    if world > 1:
+    if coll:
         dist.barrier(group=group)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if coll:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         dt = float(t.item())
@@ -167,7 +176,7 @@ def timed_region(step, steps, warmup, group=None, after_warmup=None, flush=None)
 def gather_floats(values, group=None):
     """concatenate a rank-local list of floats over ranks (latency samples), on every rank"""
     rank, world = world_info(group)
-    if world == 1:
+    if not collectives_on(group):
         return list(values)
     dev = comm_device()
     n = torch.tensor([len(values)], dtype=torch.int64, device=dev)
@@ -230,7 +239,7 @@ class ShardedStreamPool:
         res = self.pool.step()
         back = {h: g for g, h in self._local.items()}
         local = {back[h]: r for h, r in res.items()}
-        if not gather or self.world == 1:
+        if not gather or not collectives_on(self.group):
             return local
         # exchange: one int32 row per open session, [ntok (-1 = no result in this step) | score f64 bits (2) | tokens ...]
         gids = sorted(self._open)

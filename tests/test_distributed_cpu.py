@@ -260,3 +260,8 @@ def test_bench_cli_launches_ranks_and_rejects_mismatch():
     assert r1['n_gpus'] == 1 and r1['config']['global_batch'] == 32
     bad = subprocess.run(cmd + ['--gpus', '2'], env=dict(env, WORLD_SIZE='4', RANK='0'), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and 'WORLD_SIZE=4' in (bad.stderr + bad.stdout)
+    # configs[3] as its own workload on 2 ranks: 256 utterances sharded 128 / 128, gathered, 256 transcripts on rank 0
+    p3 = subprocess.run(cmd + ['--gpus', '2', '--workload', 'efficient_b256'], env=env, capture_output=True, text=True, timeout=600)
+    assert p3.returncode == 0, p3.stderr[-2000:]
+    r3 = json.loads([ln for ln in p3.stdout.splitlines() if ln.startswith('{')][0])
+    assert r3['n_gpus'] == 2 and r3['transcripts'] == 256 and r3['scaling'] == 'strong' and '128 on rank 0' in r3['workload']
