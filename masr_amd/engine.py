@@ -80,10 +80,13 @@ class HipEngine:
     (``encoder.*`` / ``ctc.*``; extra keys are ignored); ``state_dict=None`` gives a weight-less
     engine that can run the model-independent kernels (fbank, argmax, CTC collapse)."""
 
-    def __init__(self, state_dict, encoder_conf=None, vocab_size=None, streaming=True, n_mels=80, device=0,
+    def __init__(self, state_dict, encoder_conf=None, vocab_size=None, streaming=True, n_mels=80, device=None,
                  max_pos=5000, use_model='conformer'):
         if not torch.cuda.is_available():
             raise _lib.MasrError('no HIP device visible to torch: the MI355X engine has no CPU fallback')
+        if device is None:          # the calling rank's GPU (one process per GPU: torch.cuda.set_device(LOCAL_RANK) comes first)
+            device = torch.cuda.current_device()
+        device = int(device)
         self.lib = _lib.lib()
         enc = dict(encoder_conf or {})
         if vocab_size is None:

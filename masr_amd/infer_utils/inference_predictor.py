@@ -45,7 +45,7 @@ class InferencePredictor:
         if use_model not in ('conformer', 'squeezeformer', 'efficient_conformer', 'deepspeech2'):
             raise Exception(f'masr_amd implements conformer / squeezeformer / efficient_conformer / deepspeech2; '
                             f'got use_model={use_model}')
-        self.device = torch.device('cuda')
+        self.device = torch.device('cuda', torch.cuda.current_device())
         enc_conf = dict(configs.get('encoder_conf', {})) if configs is not None else {}
         # input feature size of the model = AudioFeaturizer.feature_dim (audio_featurizer.py:141-154)
         pc = configs.get('preprocess_conf', {}) if configs is not None else {}

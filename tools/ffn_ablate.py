@@ -7,7 +7,7 @@ from masr_amd.utils import synthetic
 e = HipEngine(synthetic.conformer_state_dict(0, 512), vocab_size=512)
 feats = torch.randn(32, 998, 80, device='cuda') * 3 + 13
 lens = torch.full((32,), 998, dtype=torch.int32, device='cuda')
-for kind, name in ((2, 'fused FFN'), (4, 'attention'), (3, 'conv2 gemm'), (1, 'all gemm-class')):
+for kind, name in ((6, 'FFN + QKV tail'), (7, 'conv head + FFN'), (4, 'attention'), (3, 'conv2 gemm'), (1, 'all gemm-class')):
     e.encode_full(feats, lens); torch.cuda.synchronize()
     e.profile_select(kind); e.profile_read()
     for _ in range(3): e.encode_full(feats, lens)
