@@ -71,8 +71,11 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
     float m_run = -INFINITY, l_run = 0.f;
 
     // visible keys for this query: j < klen and (chunk mask) j < (q_abs / cs + 1) * cs
+    // chunk_size counts frames of the encoder's input rate; a layer at 1/pos_stride of that rate sees rows and columns
+    // 0, s, 2s, ... of the chunk mask (time_reduction.py:62, efficient_conformer/encoder.py:254-256): key j is visible to
+    // query i iff s*j < ((s*i) / chunk + 1) * chunk
     int jlim = sq.klen;
-    if (chunk_size > 0) jlim = min(jlim, (q_abs / chunk_size + 1) * chunk_size);
+    if (chunk_size > 0) jlim = min(jlim, (((q_abs * pos_stride) / chunk_size + 1) * chunk_size + pos_stride - 1) / pos_stride);
     const int ntile = (sq.nk + 31) / 32;
     const int npair = (ntile + 1) / 2;
     // staging assignment: two 32x64 tiles per iteration; thread t -> tile t >> 8, 512 float4 per tile, 2 per thread
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
     int jlim = sq.klen;
-    if (chunk_size > 0) jlim = min(jlim, (q_abs / chunk_size + 1) * chunk_size);
+    if (chunk_size > 0) jlim = min(jlim, (((q_abs * pos_stride) / chunk_size + 1) * chunk_size + pos_stride - 1) / pos_stride);
     const int ntile = (sq.nk + 31) / 32;
 
     for (int t = wave; t < ntile; t += 8) {
@@ -401,7 +404,8 @@ template <int DKG, int NW>
 __global__ __launch_bounds__(64 * NW) void attention_grouped_kernel(const AttSeq* __restrict__ seqs, int row_stride,
                                                                       const float* __restrict__ ptab, int t_true,
                                                                       const float* __restrict__ bias_u,
-                                                                      const float* __restrict__ bias_v, float scale) {
+                                                                      const float* __restrict__ bias_v, float scale,
+                                                                      int chunk_size, int group) {
     constexpr int LD = DKG + 4;
     constexpr int NG = DKG / 8;       // 8-wide k groups per operand half
     constexpr int NT = DKG / 32;      // 32-row output tiles of O^T
@@ -432,7 +436,12 @@ __global__ __launch_bounds__(64 * NW) void attention_grouped_kernel(const AttSeq
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const int jlim = sq.klen;
+    // chunk mask of the grouped positions: rows and columns 0, g, 2g, ... of the frame-rate mask (pad4group, attention.py:35-69)
+    int jlim = sq.klen;
+    if (chunk_size > 0) {
+        const int qa = (q_ok ? qi : sq.nq - 1) * group;
+        jlim = min(jlim, ((qa / chunk_size + 1) * chunk_size + group - 1) / group);
+    }
     const int ntile = (sq.nk + 31) / 32;
     constexpr int F4_PER_ROW = DKG / 4;
     for (int kt = 0; kt < ntile; ++kt) {
@@ -521,14 +530,15 @@ __global__ __launch_bounds__(64 * NW) void attention_grouped_kernel(const AttSeq
 }
 
 void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int heads, int group, const float* ptab,
-                              int t_true, const float* bias_u, const float* bias_v, hipStream_t s) {
+                              int t_true, const float* bias_u, const float* bias_v, hipStream_t s, int chunk_size) {
     if (nseq <= 0 || max_nq <= 0 || group != 3) return;
     constexpr int DKG = 192, NW = 2;
     const size_t lds = (size_t)(3 * 32 * (DKG + 4) + 2 * DKG) * sizeof(float);
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(attention_grouped_kernel<DKG, NW>), lds, attr);
     hipLaunchKernelGGL((attention_grouped_kernel<DKG, NW>), dim3((max_nq + 32 * NW - 1) / (32 * NW), heads, nseq),
-                       dim3(64 * NW), lds, s, seqs, heads * DKG, ptab, t_true, bias_u, bias_v, 1.0f / sqrtf((float)DKG));
+                       dim3(64 * NW), lds, s, seqs, heads * DKG, ptab, t_true, bias_u, bias_v, 1.0f / sqrtf((float)DKG),
+                       chunk_size, group);
 }
 
 // descriptors for the grouped layout: planar q / k / v / out buffers [B][Tpad][256] == [B][Tg][H][g*dk];

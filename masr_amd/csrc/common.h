@@ -252,7 +252,7 @@ void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q
                       int chunk_size, int pos_stride, hipStream_t s);
 void set_attention_fewq(int on);     // diagnostics (masr_debug_set key 7): 0 = always the query-tiled kernel
 void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int heads, int group, const float* ptab,
-                              int t_true, const float* bias_u, const float* bias_v, hipStream_t s);
+                              int t_true, const float* bias_u, const float* bias_v, hipStream_t s, int chunk_size = 0);
 void launch_attseq_grouped(AttSeq* seqs, const float* q, const float* k, const float* v, float* out, const int* lens,
                            int B, int Tg, int group, int mstride, hipStream_t s);
 void launch_kv_append(const AttSeq* seqs, const float* qkv, int n, int Tq, hipStream_t s);

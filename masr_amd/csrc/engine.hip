@@ -346,8 +346,6 @@ int masr_create(const masr_config* cfg, masr_engine** out) {
     if (cfg->model_kind == 3) {
     } else if (cfg->model_kind == 0 || cfg->model_kind == 2) {
         if (cfg->cnn_kernel != 15) return fail("conformer: cnn_module_kernel must be 15");
-        if (!cfg->causal && cfg->model_kind == 2)
-            return fail("efficient_conformer: only the streaming-trained (causal conv) build is implemented");
     } else {
         if (cfg->cnn_kernel != 31) return fail("squeezeformer: cnn_module_kernel must be 31");
     }
@@ -949,7 +947,7 @@ static int finalize_squeezeformer(masr_engine* e, hipStream_t s) {
 
 // SqueezeformerEncoder.forward, streaming = False (squeezeformer/encoder.py:168-216)
 static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float* feats, const int* lens, int B, int T,
-                                     float* enc_out) {
+                                     float* enc_out, int chunk) {
     const int d = e->cfg.d_model, H = e->cfg.heads, K = e->cfg.cnn_kernel, half = (K - 1) / 2;
     int T0 = 0;
     CHK(embed(e, s, feats, B, T, &T0));
@@ -996,7 +994,8 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
                 3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
         {
             ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
-            launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v, 0, pstride, s);
+            // (chunk > 0: decoding_chunk_size of the streaming-trained build; the kernel thins the mask by the layer's rate)
+            launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v, chunk, pstride, s);
         }
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->att.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d, 1.f,
                 nullptr, 0, 0, 0, nullptr, nullptr);
@@ -1026,8 +1025,9 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
 // half frame rate + kernel 7 afterwards.  Weights share the Conformer key names (masr_finalize).
 // ------------------------------------------------------------------------------------------------
 static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* feats, const int* lens, int B, int T,
-                                 float* enc_out) {
+                                 float* enc_out, int chunk) {
     const int d = e->cfg.d_model, H = e->cfg.heads, G = e->group_size;
+    const bool causal = e->cfg.causal != 0;
     int T0 = 0;
     CHK(embed(e, s, feats, B, T, &T0));
     if (T0 >= e->cfg.max_pos) return fail("sequence longer than max_pos");
@@ -1046,6 +1046,9 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
     int Tq = T0, mstride = 4, pstride = 1;
     launch_attseq_grouped(seq_g, qp, qp + plane, qp + 2 * plane, e->attp.as<float>(), lens, B, Tg, G, mstride, s);
     launch_attseq_full(seq_r, e->qkv.as<float>(), e->att.as<float>(), lens, B, Tq, mstride, s);
+    // streaming: False build (symmetric conv): the (K - 1) / 2 zero rows on both sides of every sequence in the GLU buffer are
+    // cleared once per frame rate / kernel size (the layers only ever write the real rows)
+    if (!causal) HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + e->cfg.cnn_kernel - 1) * d * sizeof(float), s));
     const int L = e->cfg.num_blocks;
     for (int i = 0; i < L; ++i) {
         const LayerW& w = e->layers[i];
@@ -1062,7 +1065,7 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
                     0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride, Tq, 0, Tpad - Tq, d, (long)plane);
             {
                 ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B / G);
-                launch_attention_grouped(seq_g, B, Tg, H, G, w.ptab, Tq, w.pos_u, w.pos_v, s);
+                launch_attention_grouped(seq_g, B, Tg, H, G, w.ptab, Tq, w.pos_u, w.pos_v, s, chunk);
             }
             rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->attp.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d,
                     1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride, 0, 0, 0, 0, 0, Tq, Tpad);
@@ -1070,7 +1073,7 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
             if (!qkv_done) mhsa(e, s, w, M);
             {
                 ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
-                launch_attention(seq_r, B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v, 0, pstride, s);
+                launch_attention(seq_r, B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v, chunk, pstride, s);
             }
             mhsa_out(e, s, w, M);
         }
@@ -1078,12 +1081,18 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
         if (i == e->stride_idx) {
             // StrideConformerEncoderLayer (encoder.py:454-545): x = AvgPool(x) + conv_module_stride2(LN(x))
             const int K = layer_kernel(e, i), pad = K - 1, T2 = (Tq + 1) / 2;
-            rowgemm(e, s, RG_PRO_LN_PAD, RG_EPI_GLU, x, d, w.ln_conv_w, w.ln_conv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d,
-                    B * (Tq + pad), 2 * d, nullptr, 0, 1.f, lens, 0, Tq, pad, nullptr, nullptr, PROF_GEMM, mstride);
+            if (causal)      // the K - 1 history rows go through pointwise_conv1 + GLU like the reference's left padding
+                rowgemm(e, s, RG_PRO_LN_PAD, RG_EPI_GLU, x, d, w.ln_conv_w, w.ln_conv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d,
+                        B * (Tq + pad), 2 * d, nullptr, 0, 1.f, lens, 0, Tq, pad, nullptr, nullptr, PROF_GEMM, mstride);
+            else             // symmetric: the real rows land between (K - 1) / 2 zero rows on either side (same stride-2 window sum)
+                rowgemm(e, s, RG_PRO_LN_PAD, RG_EPI_GLU, x, d, w.ln_conv_w, w.ln_conv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d,
+                        M, 2 * d, nullptr, 0, 1.f, lens, 0, Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, Tq, pad / 2, pad);
             launch_dwconv_stride2_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), B, Tq, K,
                                           1e-5f, s);
             launch_avgpool2(x, e->xsave.as<float>(), B, Tq, s);
             Tq = T2; mstride *= 2; pstride *= 2; M = B * Tq;
+            if (!causal)     // half rate, kernel 7 from here on: a new padded layout
+                HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + layer_kernel(e, i + 1) - 1) * d * sizeof(float), s));
             rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d,
                     e->xsave.as<float>(), d, 1.f, lens, Tq, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
             launch_attseq_full(seq_r, e->qkv.as<float>(), e->att.as<float>(), lens, B, Tq, mstride, s);
@@ -1243,14 +1252,11 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     if (B <= 0) return fail("empty batch");
     hipStream_t s = (hipStream_t)stream;
     if (e->cfg.model_kind == 3) return ds2_forward(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev, nullptr, nullptr);
-    if (e->cfg.model_kind == 1) {
-        if (decoding_chunk_size > 0) return fail("squeezeformer (non-streaming): chunk masks are not available");
-        return encode_full_squeezeformer(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev);
-    }
-    if (e->cfg.model_kind == 2) {
-        if (decoding_chunk_size > 0) return fail("efficient_conformer: only full-context decoding is implemented");
-        return encode_full_efficient(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev);
-    }
+    // decoding_chunk_size > 0 limits the attention to chunks in the streaming-trained builds only (use_dynamic_chunk follows
+    // `streaming`, model.py of every family; utils/mask.py:117-143 ignores it otherwise)
+    const int chunk = (decoding_chunk_size > 0 && e->cfg.causal) ? decoding_chunk_size : 0;
+    if (e->cfg.model_kind == 1) return encode_full_squeezeformer(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev, chunk);
+    if (e->cfg.model_kind == 2) return encode_full_efficient(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev, chunk);
     const int d = e->cfg.d_model, H = e->cfg.heads, pad = e->cfg.cnn_kernel - 1;
     int Tq = 0;
     CHK(embed(e, s, feats_dev, B, T, &Tq));

@@ -31,54 +31,69 @@ def _grouped_attention(sd, p, x, pos_emb, key_mask, heads, g=3):
     qu = Q + sd[p + '.pos_bias_u'][None, :, None, :]
     qv = Q + sd[p + '.pos_bias_v'][None, :, None, :]
     scores = (qu @ K.transpose(-2, -1) + qv @ P.transpose(-2, -1)) / math.sqrt(dk * g)
-    m = ~key_mask[:, ::g][:, None, None, :]
+    if key_mask.dim() == 2:
+        m = ~key_mask[:, ::g][:, None, None, :]
+    else:                                              # (B, T, T) chunk mask: pad4group keeps rows and columns 0, g, 2g, ...
+        m = ~key_mask[:, ::g, ::g][:, None]
     scores = scores.masked_fill(m, -float('inf'))
     attn = torch.softmax(scores, dim=-1).masked_fill(m, 0.0)
     o = (attn @ V).transpose(1, 2).reshape(B, -1, d)[:, :T]
     return F.linear(o, sd[p + '.linear_out.weight'], sd[p + '.linear_out.bias'])
 
 
-def _conv_module(sd, p, x, pad_mask, stride=1):
-    """efficient_conformer/convolution.py:71-134, causal + layer_norm, optional stride in the depthwise conv."""
+def _conv_module(sd, p, x, pad_mask, stride=1, causal=True):
+    """efficient_conformer/convolution.py:71-134, layer_norm, optional stride in the depthwise conv; causal (streaming-trained
+    build: kernel - 1 zero frames in front of pointwise_conv1) or symmetric (Conv1d padding (kernel - 1) // 2)."""
     kernel = sd[p + '.depthwise_conv.weight'].shape[-1]
     x = x.transpose(1, 2).masked_fill(~pad_mask.unsqueeze(1), 0.0)
-    x = F.pad(x, (kernel - 1, 0))
+    if causal:
+        x = F.pad(x, (kernel - 1, 0))
     x = F.conv1d(x, sd[p + '.pointwise_conv1.weight'], sd[p + '.pointwise_conv1.bias'])
     x = F.glu(x, dim=1)
-    x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], stride=stride, groups=x.shape[1])
+    x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], stride=stride, groups=x.shape[1],
+                 padding=0 if causal else (kernel - 1) // 2)
     x = F.silu(oc._ln(sd, p + '.norm', x.transpose(1, 2))).transpose(1, 2)
     x = F.conv1d(x, sd[p + '.pointwise_conv2.weight'], sd[p + '.pointwise_conv2.bias'])
     pm = pad_mask if pad_mask.shape[1] == x.shape[2] else pad_mask[:, ::stride]
     return x.masked_fill(~pm.unsqueeze(1), 0.0).transpose(1, 2)
 
 
-def encoder_full(sd, feats, lens, heads=4, stride_layer_idx=(3,), stride=(2,), group_layer_idx=(0, 1, 2, 3), group_size=3):
-    """EfficientConformerEncoder.forward with decoding_chunk_size = -1 (efficient_conformer/encoder.py:213-265);
-    layer bodies: ConformerEncoderLayer (conformer/encoder.py:82-163) / StrideConformerEncoderLayer (:454-545)."""
+def encoder_full(sd, feats, lens, heads=4, stride_layer_idx=(3,), stride=(2,), group_layer_idx=(0, 1, 2, 3), group_size=3,
+                 streaming=True, decoding_chunk_size=-1):
+    """EfficientConformerEncoder.forward (efficient_conformer/encoder.py:213-265); layer bodies: ConformerEncoderLayer
+    (conformer/encoder.py:82-163) / StrideConformerEncoderLayer (:454-545).  ``streaming`` (model.py: causal convs +
+    use_dynamic_chunk): a positive decoding_chunk_size then masks the attention by chunks (utils/mask.py:78-143); the stride
+    layer keeps every second row and column of the mask (:254-256)."""
     B, T, _ = feats.shape
     pad = torch.arange(T)[None, :] < lens[:, None]
     x = oc.embed(sd, feats)
     Tp = x.shape[1]
     pad_s = pad[:, :-2:2][:, :-2:2]
     pos_emb = oc.positional_table(5000, x.shape[-1])[:Tp].unsqueeze(0)
+    att = None
+    if streaming and decoding_chunk_size > 0:
+        idx = torch.arange(Tp)
+        chunk = idx[None, :] < ((idx[:, None] // decoding_chunk_size + 1) * decoding_chunk_size)
+        att = pad_s[:, None, :] & chunk[None]                          # (B, T', T')
     for i in range(oc.num_blocks_of(sd)):
         p = f'encoder.encoders.{i}'
         x = x + 0.5 * oc._ffn(sd, p + '.feed_forward_macaron', oc._ln(sd, p + '.norm_ff_macaron', x))
         xn = oc._ln(sd, p + '.norm_mha', x)
         if i in group_layer_idx:
-            a = _grouped_attention(sd, p + '.self_attn', xn, pos_emb, pad_s, heads, group_size)
+            a = _grouped_attention(sd, p + '.self_attn', xn, pos_emb, pad_s if att is None else att, heads, group_size)
         else:
-            a, _ = oc._attention(sd, p + '.self_attn', xn, pos_emb, pad_s[:, None, :], heads)
+            a, _ = oc._attention(sd, p + '.self_attn', xn, pos_emb, pad_s[:, None, :] if att is None else att, heads)
         x = x + a
         if i in stride_layer_idx:
             st = stride[list(stride_layer_idx).index(i)]
-            c = _conv_module(sd, p + '.conv_module', oc._ln(sd, p + '.norm_conv', x), pad_s, st)
+            c = _conv_module(sd, p + '.conv_module', oc._ln(sd, p + '.norm_conv', x), pad_s, st, streaming)
             res = F.avg_pool1d(x.transpose(1, 2), st, st, 0, True, False).transpose(1, 2)
             x = res + c
             pad_s = pad_s[:, ::st]
             pos_emb = pos_emb[:, ::st, :]
+            att = None if att is None else att[:, ::st, ::st]
         else:
-            x = x + _conv_module(sd, p + '.conv_module', oc._ln(sd, p + '.norm_conv', x), pad_s)
+            x = x + _conv_module(sd, p + '.conv_module', oc._ln(sd, p + '.norm_conv', x), pad_s, causal=streaming)
         x = x + 0.5 * oc._ffn(sd, p + '.feed_forward', oc._ln(sd, p + '.norm_ff', x))
         x = oc._ln(sd, p + '.norm_final', x)
     return oc._ln(sd, 'encoder.after_norm', x)

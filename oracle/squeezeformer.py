@@ -77,10 +77,12 @@ def _conv_module(sd, p, x, pad_mask, kernel, causal=False):
     return x.transpose(1, 2)
 
 
-def _layer(sd, i, x, pos_emb, pad_mask, heads, kernel, causal=False):
-    """SqueezeformerEncoderLayer.forward, normalize_before=False (squeezeformer/encoder.py:412-463)."""
+def _layer(sd, i, x, pos_emb, pad_mask, heads, kernel, causal=False, att_mask=None):
+    """SqueezeformerEncoderLayer.forward, normalize_before=False (squeezeformer/encoder.py:412-463).  att_mask: the
+    (B, T, T) chunk mask of the attention, or None = the pad mask (B, 1, T)."""
     p = f'encoder.encoders.{i}'
-    x = _ln(sd, p + '.layer_norm1', x + _attention(sd, p + '.self_attn', x, pos_emb, pad_mask.unsqueeze(1), heads))
+    am = pad_mask.unsqueeze(1) if att_mask is None else att_mask
+    x = _ln(sd, p + '.layer_norm1', x + _attention(sd, p + '.self_attn', x, pos_emb, am, heads))
     x = _ln(sd, p + '.layer_norm2', x + _ffn(sd, p + '.ffn1', x))
     x = _ln(sd, p + '.layer_norm3', x + _conv_module(sd, p + '.conv_module', x, pad_mask, kernel, causal))
     x = _ln(sd, p + '.layer_norm4', x + _ffn(sd, p + '.ffn2', x))
@@ -108,9 +110,11 @@ def num_blocks_of(sd):
     return 1 + max(int(k.split('.')[2]) for k in sd if k.startswith('encoder.encoders.'))
 
 
-def encoder_full(sd, feats, lens, heads=4, kernel=31, reduce_idx=5, recover_idx=11, causal=False):
-    """SqueezeformerEncoder.forward, full context (squeezeformer/encoder.py:168-216); ``causal=True`` for the
-    streaming-trained build (model.py:37-41: causal convolution + stream time reduction)."""
+def encoder_full(sd, feats, lens, heads=4, kernel=31, reduce_idx=5, recover_idx=11, causal=False, decoding_chunk_size=-1):
+    """SqueezeformerEncoder.forward (squeezeformer/encoder.py:168-216); ``causal=True`` for the streaming-trained build
+    (model.py:37-41: causal convolution + stream time reduction + use_dynamic_chunk, so that a positive
+    ``decoding_chunk_size`` limits the attention to chunks: add_optional_chunk_mask, utils/mask.py:78-143; the time reduction
+    keeps every second row and column of that mask, time_reduction.py:62)."""
     B, T, _ = feats.shape
     pad = torch.arange(T)[None, :] < lens[:, None]
     x = embed(sd, feats)
@@ -118,19 +122,25 @@ def encoder_full(sd, feats, lens, heads=4, kernel=31, reduce_idx=5, recover_idx=
     pad_s = pad[:, :-2:2][:, :-2:2]
     pos_emb = positional_table(5000, x.shape[-1])[:Tp].unsqueeze(0)
     x = _ln(sd, 'encoder.preln', x)
+    att = None
+    if causal and decoding_chunk_size > 0:
+        idx = torch.arange(Tp)
+        chunk = idx[None, :] < ((idx[:, None] // decoding_chunk_size + 1) * decoding_chunk_size)
+        att = pad_s[:, None, :] & chunk[None]                          # (B, T', T')
     saved = None
     for i in range(num_blocks_of(sd)):
         if i == reduce_idx:
-            saved = (x, pad_s, pos_emb)
+            saved = (x, pad_s, pos_emb, att)
             x, pad_s = _time_reduce(sd, x, pad_s)
             pos_emb = pos_emb[:, ::2, :]
+            att = None if att is None else att[:, ::2, ::2]
         if i == recover_idx:
-            rx, rpad, rpos = saved
+            rx, rpad, rpos, ratt = saved
             y = torch.repeat_interleave(x, repeats=2, dim=1)
             y = F.linear(y, sd['encoder.time_recover_layer.weight'], sd['encoder.time_recover_layer.bias'])
             x = rx + y[:, :rx.shape[1], :]
-            pad_s, pos_emb = rpad, rpos
-        x = _layer(sd, i, x, pos_emb, pad_s, heads, kernel, causal)
+            pad_s, pos_emb, att = rpad, rpos, ratt
+        x = _layer(sd, i, x, pos_emb, pad_s, heads, kernel, causal, att)
     return x
 
 

@@ -210,3 +210,37 @@ def test_bounded_history_is_rejected_where_it_is_not_built():
         eng.stream_set_history(sid, -1)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('which,chunk', [('squeezeformer_streaming', 16), ('squeezeformer_streaming', 4), ('efficient_conformer', 16),
+                                         ('efficient_conformer', 6), ('efficient_nonstreaming', -1), ('squeezeformer', 16)])
+def test_chunk_masked_full_forward_and_nonstreaming_efficient_against_oracle(which, chunk):
+    """decoding_chunk_size > 0 in ``masr_encode_full`` for the Squeezeformer / Efficient-Conformer (the chunk mask is thinned
+    by the time reduction, the stride layer and the grouped attention) and the Efficient-Conformer ``streaming: False`` build;
+    the oracle branches used here are pinned against the live reference (tests/test_oracle_golden.py).  A non-streaming build
+    ignores the argument like the reference (use_dynamic_chunk off)."""
+    from masr_amd.engine import HipEngine
+    from oracle import efficient_conformer as oe, squeezeformer as osq, weights
+    V = 64
+    if which.startswith('squeezeformer'):
+        streaming = which.endswith('streaming')
+        sd = weights.squeezeformer_state_dict(0, V, streaming=streaming)
+        eng = HipEngine(sd, vocab_size=V, streaming=streaming, use_model='squeezeformer')
+        oracle = lambda f, l: osq.encoder_full(sd, f, l, causal=streaming, decoding_chunk_size=chunk)
+    else:
+        streaming = which == 'efficient_conformer'
+        sd = weights.efficient_conformer_state_dict(0, V)
+        eng = HipEngine(sd, vocab_size=V, streaming=streaming, use_model='efficient_conformer')
+        oracle = lambda f, l: oe.encoder_full(sd, f, l, streaming=streaming, decoding_chunk_size=chunk)
+    try:
+        for T in (331, 203):
+            feats, lens = _inputs(4, T, seed=T + chunk, ragged=True)
+            with torch.no_grad():
+                ref = oracle(feats, lens)
+            enc = eng.encode_full(dev(feats), dev(lens, torch.int32), chunk).cpu()
+            _compare(which, f'chunk {chunk}, T = {T}', enc, ref, eng.enc_frames(lens))
+        if chunk > 0 and streaming:                  # the mask is live: full-context output differs
+            full = eng.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
+            assert (full - enc).abs().max() > 1e-3
+    finally:
+        eng.close()

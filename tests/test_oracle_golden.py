@@ -247,3 +247,49 @@ def test_linear_and_mfcc_front_end_fixture():
         with torch.no_grad():
             probs = oc.get_encoder_out(sd, x, torch.tensor([x.shape[1]]))[0].numpy()
         np.testing.assert_allclose(probs, z[method + '_probs'], atol=5e-6)
+
+
+@pytest.mark.skipif(not shims.reference_available(), reason='/root/reference not present')
+def test_chunk_masks_and_nonstreaming_efficient_against_live_reference():
+    """decoding_chunk_size > 0 in the full forward of the streaming-trained Squeezeformer / Efficient-Conformer (the time
+    reduction / stride layer / grouped attention thin the chunk mask out) and the Efficient-Conformer ``streaming: False``
+    build (symmetric conv padding, stride layer included): oracle == the live reference encoders"""
+    import json
+    import tempfile
+    import yaml
+    from oracle import efficient_conformer as oe, squeezeformer as osq
+    shims.install()
+    from masr.model_utils.efficient_conformer.model import EfficientConformerModel
+    from masr.model_utils.squeezeformer.model import SqueezeformerModel
+    tmp = tempfile.mkdtemp()
+    torch.manual_seed(7)
+    x = torch.randn(2, 203, 80) * 3 + 13
+    lens = torch.tensor([203, 150])
+    x = x * (torch.arange(203)[None, :, None] < lens[:, None, None])
+
+    def build(cls, name, sd, streaming):
+        cfg = yaml.safe_load(open(os.path.join(shims.REFERENCE_ROOT, 'configs', name), encoding='utf-8'))
+        p = os.path.join(tmp, f'{name}_{streaming}.json')
+        json.dump({'mean': sd['encoder.global_cmvn.mean'].tolist(), 'istd': sd['encoder.global_cmvn.istd'].tolist()}, open(p, 'w'))
+        m = cls(input_dim=80, vocab_size=64, mean_istd_path=p, streaming=streaming, encoder_conf=cfg['encoder_conf'],
+                decoder_conf=cfg['decoder_conf'], **cfg['model_conf']).eval()
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected
+        return m
+
+    with torch.no_grad():
+        sd = weights.squeezeformer_state_dict(0, 64, streaming=True)
+        m = build(SqueezeformerModel, 'squeezeformer.yml', sd, True)
+        for chunk in (16, 8, 4):
+            ref, _ = m.encoder(x, lens, chunk, -1)
+            assert (ref - osq.encoder_full(sd, x, lens, causal=True, decoding_chunk_size=chunk)).abs().max() < 2e-5, chunk
+        sd = weights.efficient_conformer_state_dict(0, 64)
+        m = build(EfficientConformerModel, 'efficient_conformer.yml', sd, True)
+        for chunk in (16, 6):
+            ref, _ = m.encoder(x, lens, chunk, -1)
+            assert (ref - oe.encoder_full(sd, x, lens, decoding_chunk_size=chunk)).abs().max() < 2e-5, chunk
+        m = build(EfficientConformerModel, 'efficient_conformer.yml', sd, False)
+        ref, _ = m.encoder(x, lens, -1, -1)
+        assert (ref - oe.encoder_full(sd, x, lens, streaming=False)).abs().max() < 2e-5
+        ref16, _ = m.encoder(x, lens, 16, -1)                   # use_dynamic_chunk is off in this build: the argument is ignored
+        assert torch.equal(ref, ref16)
