@@ -15,6 +15,8 @@
 //    key (r&3)+8(r>>2)+4h -- exactly the row this lane holds in C-register r.  V is read from LDS
 //    with that key order as the A operand.  No shuffle, no LDS round trip for P.
 //  * 1/sqrt(64) = 0.125 is folded into the query fragment (exact power of two).
+//  * the softmax exponentials use __expf (v_exp_f32): 2.5 us of the kernel's 41.7 us at B = 32 x 10 s against the libm expf,
+//    encoder output moves by 4e-6 (tools/perf_ab.py of round 2); all three attention kernels use the same function.
 #include "common.h"
 
 namespace masr {
@@ -140,11 +142,11 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float corr = expf(m_run - m_safe);        // m_run = -inf -> 0
+        const float corr = __expf(m_run - m_safe);        // m_run = -inf -> 0
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            st[r] = expf(st[r] - m_safe);                 // masked (-inf) -> 0
+            st[r] = __expf(st[r] - m_safe);                 // masked (-inf) -> 0
             psum += st[r];
         }
         psum += __shfl_xor(psum, 32, 64);
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
         const float m1 = d[0], l1 = d[64];
         const float m = fmaxf(m_run, m1);
         const float ms = (m == -INFINITY) ? 0.f : m;
-        const float c0 = expf(m_run - ms), c1 = expf(m1 - ms);     // -inf -> 0
+        const float c0 = __expf(m_run - ms), c1 = __expf(m1 - ms);     // -inf -> 0
         l_run = l_run * c0 + l1 * c1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -296,11 +298,11 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float corr = expf(m_run - m_safe);
+        const float corr = __expf(m_run - m_safe);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            st[r] = expf(st[r] - m_safe);
+            st[r] = __expf(st[r] - m_safe);
             psum += st[r];
         }
         psum += __shfl_xor(psum, 32, 64);
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
         const float* d = mg + (size_t)w * 34 * 64 + lane;
-        const float c = expf(d[0] - ms);                                // -inf -> 0
+        const float c = __expf(d[0] - ms);                                // -inf -> 0
         l += d[64] * c;
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[s] += d[(rbase + s) * 64] * c;
@@ -492,11 +494,11 @@ __global__ __launch_bounds__(64 * NW) void attention_grouped_kernel(const AttSeq
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float corr = expf(m_run - m_safe);
+        const float corr = __expf(m_run - m_safe);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            st[r] = expf(st[r] - m_safe);
+            st[r] = __expf(st[r] - m_safe);
             psum += st[r];
         }
         psum += __shfl_xor(psum, 32, 64);
