@@ -1,16 +1,19 @@
-"""Config helpers with the reference's semantics (masr/utils/utils.py:45-56)."""
+"""Config helper: YAML mappings with attribute access, like the objects the reference's code reads its configs through
+(``configs.preprocess_conf.sample_rate``; masr/utils/utils.py:45-56)."""
 
 
-class Dict(dict):
-    __setattr__ = dict.__setitem__
-    __getattr__ = dict.__getitem__
+class AttrDict(dict):
+    """a dict whose keys are also attributes; a missing attribute raises KeyError like the reference's mapping does"""
+
+    def __getattr__(self, name):
+        return self[name]
+
+    def __setattr__(self, name, value):
+        self[name] = value
 
 
-def dict_to_object(dict_obj):
-    """YAML dict -> attribute-access dict, recursively."""
-    if not isinstance(dict_obj, dict):
-        return dict_obj
-    inst = Dict()
-    for k, v in dict_obj.items():
-        inst[k] = dict_to_object(v)
-    return inst
+def dict_to_object(config):
+    """nested dicts (also inside lists) -> AttrDict; everything else is returned as it is"""
+    if isinstance(config, dict):
+        return AttrDict((key, dict_to_object(value)) for key, value in config.items())
+    return config
