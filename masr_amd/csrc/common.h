@@ -147,6 +147,7 @@ struct RowGemmArgs {
 };
 bool launch_rowgemm(const RowGemmArgs& a, int pro, int epi, hipStream_t s);   // false: not applicable, nothing launched (HIST / DWCONV)
 bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s);   // rowgemm_small.hip; false = not applicable
+void set_rowgemm_small_blocks(int n);                                                // tuning (masr_debug_set key 12)
 void set_rowgemm_small(int on);                                                      // diagnostics (masr_debug_set key 6)
 
 // Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_pc.hip; ffn_fused.hip = previous kernel, kept for A/B)

@@ -70,6 +70,10 @@ void ensure_dynamic_lds(const void* fn, size_t bytes, LdsAttr& st) {
 #define ENTER(e) HIPCHK(hipSetDevice((e)->cfg.device_id))
 
 static int g_no_ffn_tail = 0;     // masr_debug_set key 8: 1 = the QKV projection as its own launch after the first FFN (A/B)
+// row blocks below which the FFN splits d_ff across workgroups (masr_debug_set key 13): up to 191 row blocks the split (256 /
+// rowblocks ways) + its reduction beat one full-d_ff workgroup per row block on a quarter to three quarters of the CUs
+// (128 streams: chunk call 5.34 -> 3.16 ms, 256 streams 6.52 -> 4.99 ms; tools/chunk_step_ab.py)
+static int g_ffn_split_blocks = 192;
 static int g_no_ffn_head = 0;     // masr_debug_set key 9: 1 = depthwise conv and pointwise_conv2 as their own launches before the second FFN (A/B)
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
@@ -594,8 +598,8 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
     int nsplit = 1;
     const int rowblocks = (M + 31) / 32;
     const FfnPostLn post{post_w, post_b, post_y, 1e-5f};
-    if (rowblocks < 64) {
-        nsplit = std::min(dff / 128, std::max(1, 128 / rowblocks));
+    if (rowblocks < g_ffn_split_blocks) {
+        nsplit = std::min(dff / 128, std::max(1, (rowblocks < 64 ? 128 : 256) / rowblocks));
         CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
     }
     const bool want_tail = tail && nsplit == 1 && !g_no_ffn_tail;
@@ -2147,6 +2151,8 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 7) set_attention_fewq(value);
     else if (key == 8) g_no_ffn_tail = value;
     else if (key == 9) g_no_ffn_head = value;
+    else if (key == 12) set_rowgemm_small_blocks(value);
+    else if (key == 13) g_ffn_split_blocks = value;
     else if (key == 2) {            // beam search phase profile of workgroup 0: value 1 = on, 0 = print + off
         if (value) {
             if (!e->beam_prof) {

@@ -322,8 +322,13 @@ static void launch_rs(const RowGemmArgs& a, hipStream_t s) {
 }
 
 // true when the small-M kernel took the launch
+// row blocks (of 32 rows) below which the K-split kernel takes the projection: 4x more, 4x shorter workgroups fill the chip
+// where a 32-row x N workgroup per row block leaves CUs idle (128 lock-step streams = 64 row blocks: chunk call 5.75 -> 5.34 ms;
+// tools/chunk_step_ab.py)
+static int g_small_blocks = 128;
+void set_rowgemm_small_blocks(int n) { g_small_blocks = n; }
 bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
-    if (a.M <= 0 || a.M >= 64 * 32) return false;
+    if (a.M <= 0 || a.M >= g_small_blocks * 32) return false;
     if (epi == RG_EPI_GLU ? a.N != 512 : (a.N % 64) != 0) return false;
     if (pro == RG_PRO_AFFINE && a.lens && a.seq_t > 0) return false;       // pad masking in the prologue: big kernel only
     if (pro == RG_PRO_LN && epi == RG_EPI_STORE) launch_rs<RG_PRO_LN, RG_EPI_STORE>(a, s);

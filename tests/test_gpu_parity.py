@@ -238,12 +238,12 @@ def test_streaming_multi_stream_lockstep(eng512, oracle_mods):
 
 
 def test_streaming_many_streams_take_the_throughput_kernels(eng512, oracle_mods):
-    """>= 128 lock-step streams (M = 2048 rows per chunk step) run on the row-block / query-tiled kernels with the separate
+    """>= 256 lock-step streams (M >= 4096 rows per chunk step) run on the row-block / query-tiled kernels with the separate
     cache-append launch; up to that the latency-cut small-M kernels do the same work -- same results either way."""
     e, sd = eng512
     gen = torch.Generator().manual_seed(12)
     feats = torch.randn(2, 131, 80, generator=gen) * 3 + 13
-    n = 130
+    n = 260                                                   # 4160 rows = 130 row blocks: above both small-M thresholds
     x = dev(feats[torch.arange(n) % 2])                       # streams alternate between two inputs
     sids = [e.stream_open(40) for _ in range(n)]
     solo = [e.stream_open(40) for _ in range(2)]

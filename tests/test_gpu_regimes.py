@@ -123,10 +123,10 @@ def test_deepspeech2_sizes_against_oracle():
         eng.close()
 
 
-@pytest.mark.parametrize('n_streams', [1, 130])
+@pytest.mark.parametrize('n_streams', [1, 130, 260])
 def test_chunk_steps_with_long_history_against_oracle(n_streams):
     """62 chunk steps of 16 encoder frames: the last ones attend over ~1000 cached keys (positional table offsets ~ 1000,
-    many key tiles, cache appends far into the stream's buffer).  130 lock-step streams take the throughput kernels, a single
+    many key tiles, cache appends far into the stream's buffer).  260 lock-step streams take the throughput kernels, 130 the split ones, a single
     stream the latency-cut ones; streams alternate between two inputs and every checked stream must match ITS oracle run."""
     from masr_amd.engine import HipEngine
     from oracle import conformer as oc, weights
