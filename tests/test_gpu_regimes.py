@@ -123,32 +123,42 @@ def test_deepspeech2_sizes_against_oracle():
         eng.close()
 
 
+_LONG = {}
+
+
+def _long_history_reference():
+    """the oracle's 62-step chunk run of the two inputs (CPU, the slow part): computed once for the three stream counts"""
+    if not _LONG:
+        from oracle import conformer as oc, weights
+        sd = weights.conformer_state_dict(0, 512)
+        steps, win, stride = 62, 67, 64
+        gen = torch.Generator().manual_seed(5)
+        feats = torch.randn(2, stride * (steps - 1) + win, 80, generator=gen) * 3 + 13
+        ref = []
+        with torch.no_grad():
+            for u in range(2):
+                att, cnn, off, tail = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0), 0, []
+                for k in range(steps):
+                    p, att, cnn = oc.get_encoder_out_chunk(sd, feats[u:u + 1, k * stride:k * stride + win], off, -1, att, cnn)
+                    off += p.shape[1]
+                    if k >= steps - 3:
+                        tail.append(p[0])
+                ref.append(torch.stack(tail))
+        assert off == 16 * steps
+        _LONG.update(sd=sd, feats=feats, ref=ref, steps=steps, win=win, stride=stride)
+    return _LONG
+
+
 @pytest.mark.parametrize('n_streams', [1, 130, 260])
 def test_chunk_steps_with_long_history_against_oracle(n_streams):
     """62 chunk steps of 16 encoder frames: the last ones attend over ~1000 cached keys (positional table offsets ~ 1000,
     many key tiles, cache appends far into the stream's buffer).  260 lock-step streams take the throughput kernels, 130 the split ones, a single
     stream the latency-cut ones; streams alternate between two inputs and every checked stream must match ITS oracle run."""
     from masr_amd.engine import HipEngine
-    from oracle import conformer as oc, weights
-    V = 512
-    sd = weights.conformer_state_dict(0, V)
-    eng = HipEngine(sd, vocab_size=V)
-    steps, win, stride = 62, 67, 64
-    T = stride * (steps - 1) + win
-    gen = torch.Generator().manual_seed(5)
-    feats = torch.randn(2, T, 80, generator=gen) * 3 + 13
+    L = _long_history_reference()
+    sd, feats, ref, steps, win, stride = L['sd'], L['feats'], L['ref'], L['steps'], L['win'], L['stride']
+    eng = HipEngine(sd, vocab_size=512)
     check_from = steps - 3
-    ref = []
-    with torch.no_grad():
-        for u in range(2 if n_streams > 1 else 1):
-            att, cnn, off, tail = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0), 0, []
-            for k in range(steps):
-                p, att, cnn = oc.get_encoder_out_chunk(sd, feats[u:u + 1, k * stride:k * stride + win], off, -1, att, cnn)
-                off += p.shape[1]
-                if k >= check_from:
-                    tail.append(p[0])
-            ref.append(torch.stack(tail))
-    assert off == 16 * steps
     try:
         sids = [eng.stream_open(16 * steps + 16) for _ in range(n_streams)]
         x = dev(feats[torch.arange(n_streams) % 2])
