@@ -392,7 +392,7 @@ def extra_stream128(args, rank, world, local):
     from masr_amd.utils import synthetic
     pred = facade('conformer', 'ctc_greedy', local)
     pool = parallel.ShardedStreamPool(StreamPool(pred, max_frames_out=320))
-    n_streams, chunk, n_chunks = 128, 8000, 20
+    n_streams, chunk, n_chunks = int(os.environ.get('MASR_BENCH_STREAMS', '128')), 8000, 20
     gids = [pool.open() for _ in range(n_streams)]
     mine = pool.local_ids()
     pcm = synthetic.synthetic_pcm(len(mine), chunk * n_chunks, seed=4321 + rank)
@@ -413,7 +413,7 @@ def extra_stream128(args, rank, world, local):
     dt = parallel.timed_region(lambda i: utterance(True), 2, 0)
     lat_all = parallel.gather_floats(lat)
     pred.predictor.engine.close()
-    return {'workload': f'configs[4]: conformer.yml streaming chunk = 0.5 s online, 128 concurrent synthetic streams over {world} '
+    return {'workload': f'configs[4]: conformer.yml streaming chunk = 0.5 s online, {n_streams} concurrent synthetic streams over {world} '
                         f'GPU(s) ({len(mine)} per GPU, sticky), real predict_stream framing, ctc_greedy partials every call',
             'value': round(n_streams * n_chunks * 0.5 * 2 / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world,
             'call_latency_ms': {'p50': round(float(np.percentile(lat_all, 50)) * 1e3, 3),
