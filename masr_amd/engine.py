@@ -340,6 +340,7 @@ class HipEngine:
     def stream_open(self, max_frames_out=0):
         sid = C.c_int32()
         check(self.lib.masr_stream_open(self.h, int(max_frames_out), C.byref(sid)))
+        self.__dict__.setdefault('_history', {}).pop(sid.value, None)      # a recycled id starts with the default (keep all)
         return sid.value
 
     def stream_reset(self, sid):
