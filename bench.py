@@ -511,7 +511,10 @@ def main():
             if extra is not None:
                 res['extra'] = extra
             if world == 1 and not args.no_cpu_baseline:
-                res['cpu_baseline'] = cpu_baseline()
+                try:
+                    res['cpu_baseline'] = cpu_baseline()
+                except Exception as exc:                                # noqa: BLE001  (the measured line must still print)
+                    res['cpu_baseline'] = {'error': f'{type(exc).__name__}: {exc}'}
             print(json.dumps(res, ensure_ascii=False), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
