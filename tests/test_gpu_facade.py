@@ -535,3 +535,32 @@ def test_facade_with_linear_and_mfcc_features(tmp_path, method):
     assert od.cer(text, res['text']) <= 0.1 and abs(res['score'] - score) < 0.5
     batch = p.predict_batch([z['pcm'].copy(), z['pcm'].copy()])
     assert od.cer(text, batch[0]['text']) <= 0.1 and batch[0]['text'] == batch[1]['text']
+
+
+def test_predict_batch_and_evaluate_through_the_rccl_exchange(predictor, tmp_path, monkeypatch):
+    """the multi-GPU path of predict_batch / evaluate on ONE rank with the exchange forced on (MASR_FORCE_DIST=1): process
+    group on the nccl (= RCCL) backend, length-balanced shard list, local decode as token ids, all-gather, text -- must return
+    exactly what the single-process call returns (the 2-rank logic is covered on gloo in tests/test_distributed_cpu.py)"""
+    import socket
+    import torch.distributed as dist
+    from masr_amd import parallel
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    pieces = [pcm[:32000].copy(), pcm[20000:68000].copy(), pcm[40000:56000].copy(), pcm[60000:124000].copy(), pcm[:900].copy()]
+    want = predictor.predict_batch(pieces, batch_size=2)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    for k, v in (('MASR_FORCE_DIST', '1'), ('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', str(port)), ('RANK', '0'),
+                 ('WORLD_SIZE', '1'), ('LOCAL_RANK', '0')):
+        monkeypatch.setenv(k, v)
+    assert not dist.is_initialized()
+    rank, world, local = parallel.init_from_env()
+    try:
+        assert dist.get_backend() == 'nccl' and parallel.collectives_on()
+        got = predictor.predict_batch(pieces, batch_size=2, distributed=True)
+        assert [g['text'] for g in got] == [w['text'] for w in want]
+        assert all(abs(g['score'] - w['score']) < 1e-3 for g, w in zip(got, want))
+        assert got[4] == {'text': '', 'score': 0.0} or got[4]['text'] == ''          # shorter than one decoding window
+    finally:
+        dist.destroy_process_group()
