@@ -238,7 +238,7 @@ class MASRPredictor:
         rank, world = parallel.world_info()
         if distributed is None:
             distributed = world > 1
-        if not distributed or world == 1:
+        if not distributed or not parallel.collectives_on():
             return self._run_sorted(segs, list(range(len(segs))), decode_all_frames, batch_size, as_tokens=False)
         shards = parallel.length_balanced_shards([s.num_samples for s in segs], world)
         mine = shards[rank]
