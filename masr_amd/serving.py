@@ -6,8 +6,10 @@ The reference server holds one MASRPredictor -- i.e. one stream -- per websocket
 feature frames not yet consumed, decoder history; predict.py:237-343) but the device work of all sessions that have audio
 pending is done together:
 
-  * ONE ragged feature launch for the new samples of all sessions (dB normalisation gains evaluated like the reference);
-  * the 67-frame decoding windows advance in lock-step through ``masr_encode_chunk`` (n streams per call);
+  * ONE ragged feature launch for the new samples of all sessions (dB normalisation gains evaluated like the reference); the
+    feature frames never leave the device: they are appended to a device-resident pool [session, frame, F] and the 67-frame
+    decoding windows are gathered from it;
+  * the windows advance in lock-step through ``masr_encode_chunk`` (n streams per call);
   * ``decoder: ctc_greedy`` -- only the per-frame (argmax, max prob) pairs leave the CTC head (never the [n, 16, V]
     probabilities); they are appended to a device-resident history [session, frame] and ONE ``masr_ctc_collapse`` launch per
     step turns the histories of all sessions that advanced into tokens + scores (the reference re-decodes its python lists
@@ -30,13 +32,14 @@ OVERLAP = CONTEXT - SUBSAMPLING                            # 3 frames carried ov
 
 
 class _Session:
-    __slots__ = ('sid', 'remained', 'cached_feat', 'row', 'frames', 'result', 'decoder', 'tokens')
+    __slots__ = ('sid', 'remained', 'f0', 'nf', 'row', 'frames', 'result', 'decoder', 'tokens')
 
     def __init__(self, sid, row, decoder=None):
         self.sid = sid
         self.remained = None          # float32 samples not yet turned into frames (re-normalised on every call, like the reference)
-        self.cached_feat = None       # [T, F] frames not yet consumed by a window
-        self.row = row                # row of the pool's device-resident (argmax, max prob) history
+        self.f0 = 0                   # feature frames not yet consumed by a window (the reference's cached_feat): frames
+        self.nf = 0                   # f0 .. f0 + nf of this session's row of the device-resident feature pool
+        self.row = row                # row of the pool's device-resident feature frames and (argmax, max prob) history
         self.frames = 0               # encoder frames decoded so far
         self.result = None
         self.decoder = decoder        # ctc_beam_search: this session's own search state
@@ -71,6 +74,9 @@ class StreamPool:
         self._free_rows = []
         self._hist_idx = torch.zeros(0, 0, dtype=torch.int32, device=self.engine.device)      # [rows, frames]
         self._hist_mp = torch.zeros(0, 0, dtype=torch.float32, device=self.engine.device)
+        self.feat_dim = {'linear': 161, 'mfcc': self.n_mfcc}.get(self.method, 80)
+        self._feat_cap = 512                                                                   # frames per session row
+        self._feat = torch.zeros(0, self._feat_cap, self.feat_dim, dtype=torch.float32, device=self.engine.device)
 
     # ---- session life cycle ---------------------------------------------------------------------------------------------
     def _grow(self, rows, frames):
@@ -84,6 +90,14 @@ class StreamPool:
             new = torch.zeros(r1, f1, dtype=dt, device=self.engine.device)
             new[:r0, :f0] = getattr(self, name)
             setattr(self, name, new)
+        if max(r1, rows) > self._feat.shape[0]:
+            new = torch.zeros(max(r1, rows), self._feat_cap, self.feat_dim, dtype=torch.float32, device=self.engine.device)
+            new[:self._feat.shape[0]] = self._feat
+            self._feat = new
+
+    def _dev_index(self, idx):
+        """host int64 index array -> device (one small H2D copy)"""
+        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(self.engine.device)
 
     def _new_decoder(self):
         return self.predictor.beam_search_decoder.fork() if self.beam else None
@@ -135,8 +149,9 @@ class StreamPool:
 
     # ---- one batched step -------------------------------------------------------------------------------------------------
     def _featurize(self, sess):
-        """features of all pending samples in one ragged launch (predict.py:274-281 per session); the carried-over samples
-        are re-normalised in place on every call, exactly like the reference (audio.py:304)"""
+        """features of all pending samples in one ragged launch (predict.py:274-281 per session), appended on the device to
+        the sessions' rows of the feature pool; the carried-over samples are re-normalised in place on every call, exactly
+        like the reference (audio.py:304).  Nothing but the gains' mean squares travels back to the host."""
         eng = self.engine
         lens = np.array([len(s.remained) for s in sess], np.int32)
         buf = np.zeros((len(sess), max(int(lens.max()), self.min_samples)), np.float32)
@@ -144,16 +159,33 @@ class StreamPool:
             buf[i, :lens[i]] = s.remained
         xs, ns = torch.from_numpy(buf).to(eng.device), torch.from_numpy(lens).to(eng.device)
         gain = eng.host_gains(xs, ns, self.target_db) if self.use_db else None
-        feats, frames = eng.features_batch(self.method, xs, ns, self.use_db, self.target_db, n_mfcc=self.n_mfcc, gain_in=gain)
-        feats, frames = feats.cpu().numpy(), frames.cpu().numpy()
+        feats, _ = eng.features_batch(self.method, xs, ns, self.use_db, self.target_db, n_mfcc=self.n_mfcc, gain_in=gain)
         gain = gain.cpu().numpy() if gain is not None else None
+        # frames per session: the front-end's own count (1 + (n - window) // 160), known without asking the device
+        new = np.where(lens >= self.min_samples, (lens.astype(np.int64) - self.min_samples) // 160 + 1, 0)
+        tmax = feats.shape[1]
+        need = max(s.nf + int(new[i]) for i, s in enumerate(sess))
+        if need > self._feat_cap:                                      # a whole utterance fed in one call: wider rows
+            cap = max(need, 2 * self._feat_cap)
+            wider = torch.zeros(self._feat.shape[0], cap, self.feat_dim, dtype=torch.float32, device=eng.device)
+            wider[:, :self._feat_cap] = self._feat
+            self._feat, self._feat_cap = wider, cap
+        src, dst = [], []
         for i, s in enumerate(sess):
             if self.use_db and lens[i] > 0:
                 s.remained = s.remained * np.float32(gain[i])          # normalised in place, like AudioSegment.normalize
-            nf = int(frames[i]) if lens[i] >= self.min_samples else 0
-            new = feats[i, :nf]
-            s.cached_feat = new if s.cached_feat is None else np.concatenate([s.cached_feat, new], axis=0)
+            nf = int(new[i])
+            if s.f0 + s.nf + nf > self._feat_cap:                      # make room: the live frames move to the front of the row
+                self._feat[s.row, :s.nf] = self._feat[s.row, s.f0:s.f0 + s.nf].clone()
+                s.f0 = 0
+            if nf:
+                src.append(i * tmax + np.arange(nf))
+                dst.append(s.row * self._feat_cap + s.f0 + s.nf + np.arange(nf))
+                s.nf += nf
             s.remained = s.remained[160 * nf:]
+        if src:
+            flat = self._feat.view(-1, self.feat_dim)
+            flat[self._dev_index(np.concatenate(dst))] = feats.view(-1, self.feat_dim)[self._dev_index(np.concatenate(src))]
 
     def step(self):
         fed, self._fed = self._fed, {}
@@ -165,7 +197,7 @@ class StreamPool:
         # windows of every session (predict.py:283-306), advanced in lock-step
         plans = []
         for s in sess:
-            nfr = s.cached_feat.shape[0]
+            nfr = s.nf
             is_end = fed[s.sid]
             s.result = None
             if (nfr < WINDOW and not is_end) or nfr < CONTEXT:
@@ -179,7 +211,9 @@ class StreamPool:
                 if k < len(p):
                     groups.setdefault(p[k][1] - p[k][0], []).append((s, p[k]))
             for length, items in groups.items():          # full windows together; a short last window on its own
-                x = torch.from_numpy(np.stack([s.cached_feat[a:b] for s, (a, b) in items])).to(eng.device)
+                # the windows are gathered from the device-resident feature pool: [items, length] flat frame indices
+                base = np.array([s.row * self._feat_cap + s.f0 + a for s, (a, _) in items], np.int64)
+                x = self._feat.view(-1, self.feat_dim)[self._dev_index(base[:, None] + np.arange(length)[None, :])]
                 sids = [s.sid for s, _ in items]
                 if self.beam:
                     probs, _, _ = eng.encode_chunk(sids, x, want_probs=True)
@@ -216,6 +250,8 @@ class StreamPool:
         out = {}
         for s, p in zip(sess, plans):
             if p:
-                s.cached_feat = s.cached_feat[p[-1][1] - OVERLAP:]            # keep the overlap frames (predict.py:329)
+                used = p[-1][1] - OVERLAP                                     # keep the overlap frames (predict.py:329)
+                s.f0 += used
+                s.nf -= used
             out[s.sid] = s.result
         return out
