@@ -101,6 +101,57 @@ struct DevBuf {
     }
 };
 
+// Pinned host staging for the per-call descriptor tables (AttSeq rows, cache pointers) of the streaming chunk step: the
+// copies to the device are truly asynchronous, so the chunk step does not stall the host on the work queued before it.
+// One call owns the area at a time: `begin` waits for the previous call's copies (normally long done).
+struct PinnedStage {
+    char* p = nullptr;
+    size_t bytes = 0, used = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int begin(size_t need) {
+        if (pending) {
+            HIPCHK(hipEventSynchronize(ev));
+            pending = false;
+        }
+        if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (need > bytes) {
+            if (p) HIPCHK(hipHostFree(p));
+            p = nullptr;
+            bytes = 0;
+            const size_t want = need + need / 4 + 4096;
+            HIPCHK(hipHostMalloc((void**)&p, want, hipHostMallocDefault));
+            bytes = want;
+        }
+        used = 0;
+        return 0;
+    }
+    // copy `n` bytes of `src` through the staging area to `dst` (device) on stream `s`
+    int push(void* dst, const void* src, size_t n, hipStream_t s) {
+        if (n == 0) return 0;
+        const size_t at = (used + 15) & ~(size_t)15;
+        if (at + n > bytes) return fail("descriptor staging area overflow");
+        memcpy(p + at, src, n);
+        used = at + n;
+        HIPCHK(hipMemcpyAsync(dst, p + at, n, hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    int end(hipStream_t s) {
+        HIPCHK(hipEventRecord(ev, s));
+        pending = true;
+        return 0;
+    }
+    void release() {
+        if (pending) (void)hipEventSynchronize(ev);
+        if (p) (void)hipHostFree(p);
+        if (ev) (void)hipEventDestroy(ev);
+        p = nullptr;
+        ev = nullptr;
+        bytes = 0;
+        pending = false;
+    }
+};
+
 struct LayerW {
     float *ln_ffm_w, *ln_ffm_b, *ffm_w1, *ffm_b1, *ffm_w2, *ffm_b2;
     float *ln_mha_w, *ln_mha_b, *wqkv, *bqkv, *wo, *bo, *pos_u, *pos_v, *wpos, *ptab;
@@ -172,6 +223,7 @@ struct masr_engine {
           *tr_pw_b = nullptr, *rec_w = nullptr, *rec_b = nullptr;
     int reduce_idx = -1, recover_idx = -1;
     int stride_idx = -1, n_group_layers = 0, group_size = 3;   // Efficient-Conformer (model_kind 2)
+    PinnedStage stage;
     DevBuf qplanes, attp, cnnptrs, ffpart;                                      // planar q|k|v and attention output, [B][Tpad][256]
     // fbank tables
     float *window = nullptr, *melw = nullptr, *tw256 = nullptr, *tw512 = nullptr;
@@ -384,6 +436,7 @@ void masr_destroy(masr_engine* e) {
                       &e->xred, &e->qplanes, &e->attp, &e->cnnptrs, &e->ffpart, &e->gx, &e->rnn_out, &e->hstate, &e->cstate,
                       &e->ds2_lens, &e->beam_pool, &e->beam_state};
     for (DevBuf* b : bufs) b->release();
+    e->stage.release();
     for (auto& s : e->streams) {
         s.att.release();
         s.cnn.release();
@@ -1794,9 +1847,10 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
         }
     }
     CHK(e->cnnptrs.ensure(sizeof(float*) * hp.size()));
-    HIPCHK(hipMemcpyAsync(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    CHK(e->stage.begin(sizeof(AttSeq) * hs.size() + sizeof(float*) * hp.size() + 64));
+    CHK(e->stage.push(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), s));
+    CHK(e->stage.push(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), s));
+    CHK(e->stage.end(s));
     float* x = e->x.as<float>();
     launch_layernorm(x, e->preln_w, e->preln_b, x, n * T0, 1e-5f, 0, 0, nullptr, s);
     CHK(e->enc.ensure((size_t)n * T0 * d * sizeof(float)));
@@ -1926,10 +1980,11 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
     }
     CHK(e->cnnptrs.ensure(sizeof(float*) * hp.size() + sizeof(PlaneCopy) * pcs.size()));
     PlaneCopy* pc_dev = reinterpret_cast<PlaneCopy*>(e->cnnptrs.as<float*>() + hp.size());
-    HIPCHK(hipMemcpyAsync(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice, s));
-    if (!pcs.empty()) HIPCHK(hipMemcpyAsync(pc_dev, pcs.data(), sizeof(PlaneCopy) * pcs.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    CHK(e->stage.begin(sizeof(AttSeq) * hs.size() + sizeof(float*) * hp.size() + sizeof(PlaneCopy) * pcs.size() + 64));
+    CHK(e->stage.push(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), s));
+    CHK(e->stage.push(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), s));
+    CHK(e->stage.push(pc_dev, pcs.data(), sizeof(PlaneCopy) * pcs.size(), s));
+    CHK(e->stage.end(s));
     float* x = e->x.as<float>();
     for (int l = 0; l < L; ++l) {
         const LayerW& w = e->layers[l];
@@ -2048,9 +2103,10 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
             hp[(size_t)(L + l) * n + i] = st[i]->cnn2.as<float>() + (size_t)l * pad * d;
         }
     CHK(e->cnnptrs.ensure(sizeof(float*) * hp.size()));
-    HIPCHK(hipMemcpyAsync(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // hs / hp are stack-lifetime host buffers
+    CHK(e->stage.begin(sizeof(AttSeq) * hs.size() + sizeof(float*) * hp.size() + 64));
+    CHK(e->stage.push(e->attseq.p, hs.data(), sizeof(AttSeq) * hs.size(), s));
+    CHK(e->stage.push(e->cnnptrs.p, hp.data(), sizeof(float*) * hp.size(), s));
+    CHK(e->stage.end(s));
     float* x = e->x.as<float>();
     EncodeCtx ctx{n, Tq, nullptr};
     for (int l = 0; l < L; ++l) {

@@ -23,6 +23,9 @@ import numpy as np
 import torch
 
 from masr_amd.data_utils.audio import AudioSegment
+from masr_amd.engine import reference_gains
+
+_PCM_SCALE = np.float32(1.0 / 32768.0)
 
 # chunked decoding geometry of the reference facade (predict.py:283-290): 16 encoder frames per chunk, subsampling 4, context 7
 DECODING_CHUNK, SUBSAMPLING, CONTEXT = 16, 4, 7
@@ -31,12 +34,63 @@ STRIDE = SUBSAMPLING * DECODING_CHUNK                      # 64
 OVERLAP = CONTEXT - SUBSAMPLING                            # 3 frames carried over
 
 
+class _HostStage:
+    """Pinned host memory for the per-call uploads of a pool (pending samples, lengths, index arrays): a bump allocator whose
+    copies to the device are asynchronous on the current stream, so the host never waits for the device between the launches
+    of a step.  ``begin()`` opens a call: it waits for the previous call's copies (long done) before the area is reused."""
+
+    def __init__(self, device, nbytes=1 << 20):
+        self.device = device
+        self._retired = []
+        self._event = None
+        self._alloc(nbytes)
+
+    def _alloc(self, nbytes):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        self.host = self.buf.numpy()
+        self.used = 0
+
+    def begin(self):
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+        elif self.used:                                      # a call that raised before end(): its copies may still be in flight
+            torch.cuda.current_stream().synchronize()
+        self._retired.clear()
+        self.used = 0
+
+    def take(self, shape, dtype):
+        """-> (numpy view [shape] of dtype inside the pinned area, upload() -> device tensor of the same shape)"""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        at = (self.used + 63) & ~63
+        if at + nbytes > self.host.size:                    # copies in flight keep the old area alive until the next begin()
+            self._retired.append(self.buf)
+            self._alloc(max(2 * self.host.size, 2 * nbytes))
+            at = 0
+        self.used = at + nbytes
+        view = self.host[at:at + nbytes].view(dtype).reshape(shape)
+        src = self.buf[at:at + nbytes].view({'float32': torch.float32, 'int32': torch.int32,
+                                             'int64': torch.int64}[dtype.name]).view(*shape)
+        return view, lambda: src.to(self.device, non_blocking=True)
+
+    def put(self, array, dtype=np.int64):
+        view, upload = self.take(np.shape(array), dtype)
+        view[...] = array
+        return upload()
+
+    def end(self):
+        self._event = torch.cuda.Event()
+        self._event.record()
+
+
 class _Session:
-    __slots__ = ('sid', 'remained', 'f0', 'nf', 'row', 'frames', 'result', 'decoder', 'tokens')
+    __slots__ = ('sid', 'remained', 'fresh', 'f0', 'nf', 'row', 'frames', 'result', 'decoder', 'tokens')
 
     def __init__(self, sid, row, decoder=None):
         self.sid = sid
         self.remained = None          # float32 samples not yet turned into frames (re-normalised on every call, like the reference)
+        self.fresh = []               # audio fed since the last step: int16 PCM views (scaled when staged) / float32 arrays
         self.f0 = 0                   # feature frames not yet consumed by a window (the reference's cached_feat): frames
         self.nf = 0                   # f0 .. f0 + nf of this session's row of the device-resident feature pool
         self.row = row                # row of the pool's device-resident feature frames and (argmax, max prob) history
@@ -77,6 +131,7 @@ class StreamPool:
         self.feat_dim = {'linear': 161, 'mfcc': self.n_mfcc}.get(self.method, 80)
         self._feat_cap = 512                                                                   # frames per session row
         self._feat = torch.zeros(0, self._feat_cap, self.feat_dim, dtype=torch.float32, device=self.engine.device)
+        self._stage = _HostStage(self.engine.device)
 
     # ---- session life cycle ---------------------------------------------------------------------------------------------
     def _grow(self, rows, frames):
@@ -96,8 +151,8 @@ class StreamPool:
             self._feat = new
 
     def _dev_index(self, idx):
-        """host int64 index array -> device (one small H2D copy)"""
-        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(self.engine.device)
+        """host int64 index array -> device (staged through pinned memory, asynchronous)"""
+        return self._stage.put(idx, np.int64)
 
     def _new_decoder(self):
         return self.predictor.beam_search_decoder.fork() if self.beam else None
@@ -130,17 +185,23 @@ class StreamPool:
     def feed(self, handle, audio_data, is_end=False, channels=1, samp_width=2, sample_rate=16000):
         """queue raw PCM bytes (or a float / int numpy array) for a session (predict.py:260-272); processed by the next
         ``step()``"""
-        if isinstance(audio_data, np.ndarray):
-            seg = AudioSegment.from_ndarray(audio_data, sample_rate)
-        elif isinstance(audio_data, (bytes, bytearray, memoryview)):
-            seg = AudioSegment.from_pcm_bytes(bytes(audio_data), channels=channels, samp_width=samp_width,
-                                              sample_rate=sample_rate)
-        else:
-            raise Exception(f'不支持该数据类型，当前数据类型为：{type(audio_data)}')
-        if seg.sample_rate != self.sample_rate:
-            seg.resample(self.sample_rate)
         s = self.sessions[handle]
-        s.remained = seg.samples if s.remained is None else np.concatenate([s.remained, seg.samples])
+        if isinstance(audio_data, (bytes, bytearray, memoryview)) and samp_width == 2 and channels == 1 and \
+                sample_rate == self.sample_rate:
+            # the common wire format: kept as int16 (a view of the caller's bytes); x / 2^15 -- the float32 value
+            # from_pcm_bytes produces -- happens when the step stages the samples for the device
+            s.fresh.append(np.frombuffer(bytes(audio_data) if isinstance(audio_data, bytearray) else audio_data, '<i2'))
+        else:
+            if isinstance(audio_data, np.ndarray):
+                seg = AudioSegment.from_ndarray(audio_data, sample_rate)
+            elif isinstance(audio_data, (bytes, bytearray, memoryview)):
+                seg = AudioSegment.from_pcm_bytes(bytes(audio_data), channels=channels, samp_width=samp_width,
+                                                  sample_rate=sample_rate)
+            else:
+                raise Exception(f'不支持该数据类型，当前数据类型为：{type(audio_data)}')
+            if seg.sample_rate != self.sample_rate:
+                seg.resample(self.sample_rate)
+            s.fresh.append(seg.samples)
         self._fed[handle] = bool(is_end) or self._fed.get(handle, False)
 
     def last_tokens(self, handle):
@@ -151,16 +212,30 @@ class StreamPool:
     def _featurize(self, sess):
         """features of all pending samples in one ragged launch (predict.py:274-281 per session), appended on the device to
         the sessions' rows of the feature pool; the carried-over samples are re-normalised in place on every call, exactly
-        like the reference (audio.py:304).  Nothing but the gains' mean squares travels back to the host."""
-        eng = self.engine
-        lens = np.array([len(s.remained) for s in sess], np.int32)
-        buf = np.zeros((len(sess), max(int(lens.max()), self.min_samples)), np.float32)
+        like the reference (audio.py:304).  The samples are assembled in pinned memory and copied asynchronously; nothing
+        but the gains' mean squares travels back to the host."""
+        eng, st = self.engine, self._stage
+        n = len(sess)
+        carried = [0 if s.remained is None else len(s.remained) for s in sess]
+        lens = np.array([c + sum(len(a) for a in s.fresh) for c, s in zip(carried, sess)], np.int32)
+        buf, upload_buf = st.take((n, max(int(lens.max()), self.min_samples)), np.float32)
         for i, s in enumerate(sess):
-            buf[i, :lens[i]] = s.remained
-        xs, ns = torch.from_numpy(buf).to(eng.device), torch.from_numpy(lens).to(eng.device)
-        gain = eng.host_gains(xs, ns, self.target_db) if self.use_db else None
+            row, at = buf[i], carried[i]
+            if at:
+                row[:at] = s.remained
+            for a in s.fresh:
+                if a.dtype == np.float32:
+                    row[at:at + len(a)] = a
+                else:                                                  # int16 PCM: x / 2^15 in float32 (buf_to_float)
+                    np.multiply(a, _PCM_SCALE, out=row[at:at + len(a)])
+                at += len(a)
+            row[at:] = 0
+        xs, ns = upload_buf(), st.put(lens, np.int32)
+        gain_h = gain = None
+        if self.use_db:                                                # the reference's scalar expressions on this host
+            gain_h = reference_gains(eng.mean_square(xs, ns).cpu().numpy(), self.target_db)
+            gain = st.put(gain_h, np.float32)
         feats, _ = eng.features_batch(self.method, xs, ns, self.use_db, self.target_db, n_mfcc=self.n_mfcc, gain_in=gain)
-        gain = gain.cpu().numpy() if gain is not None else None
         # frames per session: the front-end's own count (1 + (n - window) // 160), known without asking the device
         new = np.where(lens >= self.min_samples, (lens.astype(np.int64) - self.min_samples) // 160 + 1, 0)
         tmax = feats.shape[1]
@@ -170,22 +245,23 @@ class StreamPool:
             wider = torch.zeros(self._feat.shape[0], cap, self.feat_dim, dtype=torch.float32, device=eng.device)
             wider[:, :self._feat_cap] = self._feat
             self._feat, self._feat_cap = wider, cap
-        src, dst = [], []
+        first = np.zeros(n, np.int64)                                  # flat pool index of each session's first new frame
         for i, s in enumerate(sess):
-            if self.use_db and lens[i] > 0:
-                s.remained = s.remained * np.float32(gain[i])          # normalised in place, like AudioSegment.normalize
-            nf = int(new[i])
+            nf, L = int(new[i]), int(lens[i])
+            s.fresh = []
+            rest = buf[i, 160 * nf:L]                                  # normalised in place, like AudioSegment.normalize
+            s.remained = rest * np.float32(gain_h[i]) if self.use_db and L > 0 else rest.copy()
             if s.f0 + s.nf + nf > self._feat_cap:                      # make room: the live frames move to the front of the row
                 self._feat[s.row, :s.nf] = self._feat[s.row, s.f0:s.f0 + s.nf].clone()
                 s.f0 = 0
-            if nf:
-                src.append(i * tmax + np.arange(nf))
-                dst.append(s.row * self._feat_cap + s.f0 + s.nf + np.arange(nf))
-                s.nf += nf
-            s.remained = s.remained[160 * nf:]
-        if src:
-            flat = self._feat.view(-1, self.feat_dim)
-            flat[self._dev_index(np.concatenate(dst))] = feats.view(-1, self.feat_dim)[self._dev_index(np.concatenate(src))]
+            first[i] = s.row * self._feat_cap + s.f0 + s.nf
+            s.nf += nf
+        total = int(new.sum())
+        if total:
+            offs = np.arange(total) - np.repeat(np.cumsum(new) - new, new)
+            moves = self._dev_index(np.stack([np.repeat(np.arange(n, dtype=np.int64) * tmax, new) + offs,
+                                              np.repeat(first, new) + offs]))
+            self._feat.view(-1, self.feat_dim)[moves[1]] = feats.view(-1, self.feat_dim)[moves[0]]
 
     def step(self):
         fed, self._fed = self._fed, {}
@@ -193,6 +269,7 @@ class StreamPool:
             return {}
         eng = self.engine
         sess = [self.sessions[h] for h in fed]
+        self._stage.begin()
         self._featurize(sess)
         # windows of every session (predict.py:283-306), advanced in lock-step
         plans = []
@@ -226,27 +303,29 @@ class StreamPool:
                 _, idx, mp = eng.encode_chunk(sids, x, want_probs=False, want_argmax=True)
                 tq = idx.shape[1]
                 self._grow(0, max(s.frames for s, _ in items) + tq)
-                rows = torch.tensor([s.row for s, _ in items], device=eng.device)[:, None]
-                cols = torch.tensor([s.frames for s, _ in items], device=eng.device)[:, None] + \
-                    torch.arange(tq, device=eng.device)[None, :]
-                self._hist_idx[rows, cols] = idx                     # append this window's frames to the sessions' histories
-                self._hist_mp[rows, cols] = mp
+                at = self._dev_index(np.array([s.row * self._hist_idx.shape[1] + s.frames for s, _ in items],
+                                              np.int64)[:, None] + np.arange(tq)[None, :])
+                self._hist_idx.view(-1)[at] = idx                    # append this window's frames to the sessions' histories
+                self._hist_mp.view(-1)[at] = mp
                 for s, _ in items:
                     s.frames += tq
         # greedy: one collapse launch for every session that advanced -- full-history best path + score
         # (greedy_decoder_chunk semantics, ctc_greedy_decoder.py:52-89)
         adv = [s for s, p in zip(sess, plans) if p]
         if adv and not self.beam:
-            rows = torch.tensor([s.row for s in adv], device=eng.device)
+            rows = self._dev_index([s.row for s in adv])
             tmax = max(s.frames for s in adv)
-            nfr = torch.tensor([s.frames for s in adv], dtype=torch.int32, device=eng.device)
+            nfr = self._stage.put([s.frames for s in adv], np.int32)
             tok, ntok, score = eng.ctc_collapse(self._hist_idx[rows, :tmax].contiguous(), self._hist_mp[rows, :tmax].contiguous(), nfr)
-            tok, ntok, score = tok.cpu().numpy(), ntok.cpu().numpy(), score.cpu().numpy()
+            # one copy back: [tokens | count | score bits]
+            packed = torch.cat([tok, ntok[:, None], score.view(torch.int32)[:, None]], 1).cpu().numpy()
+            tok, ntok, score = packed[:, :tmax], packed[:, tmax], packed[:, tmax + 1].copy().view(np.float32)
             for j, s in enumerate(adv):
                 s.tokens = tok[j, :ntok[j]].tolist()
                 text = ''.join(self.vocab[t] for t in s.tokens).replace('<space>', ' ')
                 # the score counts every non-blank frame (repeats included); with none the reference returns 0
                 s.result = {'text': text, 'score': float(np.float32(score[j])) * 100.0 if ntok[j] > 0 else 0}
+        self._stage.end()
         out = {}
         for s, p in zip(sess, plans):
             if p:
