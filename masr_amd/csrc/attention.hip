@@ -28,15 +28,24 @@ static constexpr int V_LD = 68;
 // 8 waves per workgroup: wave w = (query group w & 3, key parity w >> 2).  The two waves of a query group walk the even and the
 // odd key tiles with their own online-softmax state and are merged once at the end, so every SIMD holds two waves (the softmax
 // VALU work of one overlaps the MFMAs of the other) although B*H*T'/32 is only ~4 waves per CU at B = 32 x 10 s.
+//
+// FOLD = 1 (default): the two score terms share the query, so the positional keys are folded into the keys while the tile
+// is staged:  (q+u).k + (q+v).p  =  q.(k+p) + (u.k + v.p).  The workgroup stages K' = k + p and the per-key constant
+// c_j = (u.k_j + v.p_j)/8 (16 lanes per key row, 4 xor-shuffles); the score accumulator starts at c_j and ONE 64-wide
+// contraction replaces the 128-wide one: 64 instead of 96 MFMAs per key tile, no P tile in LDS.  Same value up to fp32
+// rounding (the reference's own summation order is not reproduced by either form); FOLD = 0 (masr_debug_set key 14) keeps the
+// two-term contraction for A/B runs.
+template <int FOLD>
 __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict__ seqs, int q_stride, int kv_stride,
                                                         const float* __restrict__ ptab,
                                                         const float* __restrict__ bias_u,
                                                         const float* __restrict__ bias_v, int chunk_size,
                                                         int pos_stride) {
-    __shared__ __align__(16) float lds_att[2 * 32 * KP_LD * 2 + 2 * 32 * V_LD];
+    __shared__ __align__(16) float lds_att[2 * 32 * KP_LD * 2 + 2 * 32 * V_LD + 64];
     float* Ks = lds_att;                       // [2 tiles][32][68]
     float* Ps = Ks + 2 * 32 * KP_LD;
     float* Vs = Ps + 2 * 32 * KP_LD;
+    float* Cs = Vs + 2 * 32 * V_LD;            // FOLD: [2 tiles][32] per-key constants
 
     const AttSeq sq = seqs[blockIdx.z];
     const int head = blockIdx.y;
@@ -61,8 +70,8 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
             const f32x4 v = *reinterpret_cast<const f32x4*>(bias_v + head * DK + 8 * g + 4 * h);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                qu[g][s] = (q[s] + u[s]) * 0.125f;
-                qv[g][s] = (q[s] + v[s]) * 0.125f;
+                qu[g][s] = FOLD ? q[s] * 0.125f : (q[s] + u[s]) * 0.125f;
+                qv[g][s] = (q[s] + v[s]) * 0.125f;         // unused (dead) when FOLD
             }
         }
     }
@@ -84,6 +93,13 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
     const int sti = tid >> 8;             // which tile of the pair this thread stages
     const int srow = (tid & 255) >> 4;    // 0..15 (+16)
     const int sc4 = (tid & 15) * 4;       // float offset 0..60
+    f32x4 su = {0.f, 0.f, 0.f, 0.f}, sv = su;               // FOLD: u / 8 and v / 8 for this thread's 4 staged dims
+    if (FOLD) {
+        su = *reinterpret_cast<const f32x4*>(bias_u + head * DK + sc4);
+        sv = *reinterpret_cast<const f32x4*>(bias_v + head * DK + sc4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { su[s] *= 0.125f; sv[s] *= 0.125f; }
+    }
     // register-prefetched staging: pair kp+1 is fetched from global memory while pair kp is multiplied
     f32x4 pk[2], pp[2], pv[2];
     auto fetch = [&](int kp) {
@@ -104,8 +120,25 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = srow + 16 * i;
-            *reinterpret_cast<f32x4*>(&Ks[sti * 32 * KP_LD + r * KP_LD + sc4]) = pk[i];
-            *reinterpret_cast<f32x4*>(&Ps[sti * 32 * KP_LD + r * KP_LD + sc4]) = pp[i];
+            if (FOLD) {
+                float c = 0.f;
+                f32x4 kp4;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    c = fmaf(su[s], pk[i][s], c);
+                    c = fmaf(sv[s], pp[i][s], c);
+                    kp4[s] = pk[i][s] + pp[i][s];
+                }
+                c += __shfl_xor(c, 1, 64);
+                c += __shfl_xor(c, 2, 64);
+                c += __shfl_xor(c, 4, 64);
+                c += __shfl_xor(c, 8, 64);
+                *reinterpret_cast<f32x4*>(&Ks[sti * 32 * KP_LD + r * KP_LD + sc4]) = kp4;
+                if ((tid & 15) == 0) Cs[sti * 32 + r] = c;
+            } else {
+                *reinterpret_cast<f32x4*>(&Ks[sti * 32 * KP_LD + r * KP_LD + sc4]) = pk[i];
+                *reinterpret_cast<f32x4*>(&Ps[sti * 32 * KP_LD + r * KP_LD + sc4]) = pp[i];
+            }
             *reinterpret_cast<f32x4*>(&Vs[sti * 32 * V_LD + r * V_LD + sc4]) = pv[i];
         }
         __syncthreads();
@@ -115,7 +148,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
         // ---- S^T tile: rows = 32 keys, cols = this wave's 32 queries -------------------------
         f32x16 st;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        for (int r = 0; r < 16; ++r) st[r] = FOLD ? Cs[kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
         const float* kb = &Ks[kh * 32 * KP_LD + (lane & 31) * KP_LD + 4 * h];
         const float* pb = &Ps[kh * 32 * KP_LD + (lane & 31) * KP_LD + 4 * h];
 #pragma unroll
@@ -124,11 +157,13 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
 #pragma unroll
             for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qu[g][s], st, 0, 0, 0);
         }
+        if (!FOLD) {
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const f32x4 pf = *reinterpret_cast<const f32x4*>(pb + 8 * g);
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 pf = *reinterpret_cast<const f32x4*>(pb + 8 * g);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[s], qv[g][s], st, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[s], qv[g][s], st, 0, 0, 0);
+            }
         }
 
         // ---- mask + online softmax for this lane's query column --------------------------------
@@ -350,8 +385,9 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
     }
 }
 
-static int g_fewq = 1;
+static int g_fewq = 1, g_fold = 1;
 void set_attention_fewq(int on) { g_fewq = on; }
+void set_attention_fold(int on) { g_fold = on; }
 
 void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q_stride, int kv_stride,
                       const float* ptab, const float* bias_u, const float* bias_v, int chunk_size, int pos_stride,
@@ -362,8 +398,12 @@ void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q
                            bias_v, chunk_size, pos_stride);
         return;
     }
-    hipLaunchKernelGGL(attention_kernel, dim3((max_nq + 127) / 128, heads, nseq), dim3(512), 0, s, seqs, q_stride,
-                       kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride);
+    if (g_fold)
+        hipLaunchKernelGGL(attention_kernel<1>, dim3((max_nq + 127) / 128, heads, nseq), dim3(512), 0, s, seqs, q_stride,
+                           kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride);
+    else
+        hipLaunchKernelGGL(attention_kernel<0>, dim3((max_nq + 127) / 128, heads, nseq), dim3(512), 0, s, seqs, q_stride,
+                           kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride);
 }
 
 // Sequence descriptors for the full-context batch path: q/k/v interleaved in one [B*Tp, 768] buffer

@@ -2205,6 +2205,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 5) g_no_chain = value;
     else if (key == 6) set_rowgemm_small(value);
     else if (key == 7) set_attention_fewq(value);
+    else if (key == 14) set_attention_fold(value);
     else if (key == 8) g_no_ffn_tail = value;
     else if (key == 9) g_no_ffn_head = value;
     else if (key == 12) set_rowgemm_small_blocks(value);
