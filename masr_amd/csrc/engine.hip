@@ -681,6 +681,7 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
     return 0;
 }
 
+static int g_embed_split = 1;      // masr_debug_set key 15: 0 = the offline embed projection never splits K
 // feats [nseq, T, 80] -> x [nseq*Tq, d] (embed incl. x*sqrt(d))
 int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, int* Tq_out) {
     const int d = e->cfg.d_model, F = e->cfg.n_mels, F1 = (F - 1) / 2, F2 = (F1 - 1) / 2;
@@ -715,7 +716,13 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
         a.bias_after_alpha = e->cfg.model_kind == 1 ? 1 : 0;
         ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)d * F2 * d);
         const int tiles = ((M + 63) / 64) * ((d + 63) / 64);
-        if (tiles < 128) {              // few rows, K = 4864: split K so that ~256 workgroups share the weight stream
+        const long wide = (long)((M + 63) / 64) * ((d + 127) / 128);      // 64x128 tiles of the unsplit launch
+        if (g_embed_split && tiles >= 128 && wide >= 200 && wide <= 320) {
+            // about one 4-wave workgroup per CU (B = 32 x 10 s: 248): two K halves put two waves on every SIMD;
+            // 6.907 -> 6.892 ms per step including the reduction pass
+            CHK(e->ffpart.ensure((size_t)2 * M * d * sizeof(float)));
+            launch_gemm_splitk(a, e->ffpart.as<float>(), 2, s);
+        } else if (tiles < 128) {              // few rows, K = 4864: split K so that ~256 workgroups share the weight stream
             const int nsplit = std::min(F2 * d / 32, std::max(2, 256 / tiles));
             CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
             launch_gemm_splitk(a, e->ffpart.as<float>(), nsplit, s);
@@ -2206,6 +2213,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 6) set_rowgemm_small(value);
     else if (key == 7) set_attention_fewq(value);
     else if (key == 14) set_attention_fold(value);
+    else if (key == 15) g_embed_split = value;
     else if (key == 8) g_no_ffn_tail = value;
     else if (key == 9) g_no_ffn_head = value;
     else if (key == 12) set_rowgemm_small_blocks(value);

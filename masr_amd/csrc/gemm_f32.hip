@@ -244,7 +244,10 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
         return;
     }
     if (epi == EPI_SPLITK) {            // caller set a.C = partial buffer, a.nsplit, a.ksplit
-        launch_t<64, 64, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
+        // many rows (the offline embed projection: 248 tiles of 64x128 = one 4-wave workgroup per CU): the wide tile, so that
+        // the split doubles the waves per SIMD instead of the LDS traffic per MFMA
+        if ((long)((a.M + 63) / 64) * ((a.N + 127) / 128) >= 200) launch_t<64, 128, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
+        else launch_t<64, 64, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
         return;
     }
     // Tile choice: fill >= 256 CUs.  128x128 when that already yields enough workgroups,

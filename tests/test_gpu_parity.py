@@ -879,3 +879,36 @@ def test_ffn_head_stage_matches_separate_launches(oracle_mods, streaming):
         assert (fused[:3].cpu() - ref).abs().max() < 1e-3
     finally:
         e.close()
+
+
+@pytest.mark.parametrize('chunk', [-1, 16])
+def test_attention_folded_positional_keys_match_two_term_scores(oracle_mods, chunk):
+    """offline attention_kernel: scores as q.(k + p) + (u.k + v.p) (FOLD, the default) vs the two-term contraction
+    (q + u).k + (q + v).p (masr_debug_set key 14 = 0) -- the same value up to fp32 rounding: encoder outputs within 5e-5 of each
+    other (bar vs the oracle: 1e-3), both within 1e-3 of the oracle; ragged batch, full context and the chunk-16 mask."""
+    from masr_amd.engine import HipEngine
+    weights = oracle_mods[3]
+    sd = weights.conformer_state_dict(0, 512)
+    e = HipEngine(sd, vocab_size=512)
+    try:
+        gen = torch.Generator().manual_seed(23)
+        feats = torch.randn(6, 1003, 80, generator=gen) * 3 + 13
+        lens = torch.tensor([1003, 990, 700, 512, 333, 67], dtype=torch.int32)
+        feats = feats * (torch.arange(1003)[None, :, None] < lens[:, None, None])
+        x, n = dev(feats), dev(lens)
+        folded = e.encode_full(x, n, chunk).clone()
+        e.lib.masr_debug_set(e.h, 14, 0)
+        try:
+            two_term = e.encode_full(x, n, chunk).clone()
+        finally:
+            e.lib.masr_debug_set(e.h, 14, 1)
+        diff = (folded - two_term).abs().max().item()
+        print(f'attention fold vs two-term (chunk {chunk}): max |enc| diff {diff:.2e}')
+        assert torch.isfinite(folded).all() and diff < 5e-5
+        assert diff > 0 or chunk == 0          # the switch does select two different kernels
+        oc = oracle_mods[0]
+        with torch.no_grad():
+            ref = oc.encoder_full(sd, feats[:2], lens[:2].long(), chunk)
+        assert (folded[:2].cpu() - ref).abs().max() < 1e-3 and (two_term[:2].cpu() - ref).abs().max() < 1e-3
+    finally:
+        e.close()
