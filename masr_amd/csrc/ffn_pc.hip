@@ -130,6 +130,15 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
         __syncthreads();                                  // A tile complete
         {
             const float* xa = xn + frow * PC_XLD + 4 * fh;
+            // the epilogue's bias and residual rows are requested first and land under the MFMAs (x is not written before them)
+            const int col = wave * 32 + frow;
+            const float bv = head.bias[col];
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, M - 1);
+                res[r] = x[(size_t)row * PC_D + col];
+            }
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -157,14 +166,6 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-            }
-            const int col = wave * 32 + frow;
-            const float bv = head.bias[col];
-            float res[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, M - 1);
-                res[r] = x[(size_t)row * PC_D + col];
             }
             __syncthreads();                              // every wave has read its A fragments: the tile may be overwritten
 #pragma unroll
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
         const float* xa = xn + frow * PC_XLD + 4 * fh;
         f32x16 accp;                       // raw sums of the previous chunk
         float bvp = 0.f;
+        f32x4 resx[8];                     // drain phases: this wave's 8 residual rows on their way into the xn tile
 #pragma unroll
         for (int r = 0; r < 16; ++r) accp[r] = 0.f;
         for (int phase = 0; phase <= nchunk + 1; ++phase) {
@@ -334,6 +336,19 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
             } else if (phase == nchunk) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) finish(r);
+                // drain: the LayerNorm tile has had its last read (barrier of phase nchunk - 1).  The producers, idle from here
+                // on, bring the raw residual rows back into it (row 8 idx + i, one 1 KB row per load) while the consumers
+                // multiply their last two chunks; the epilogue then adds the residual from LDS instead of waiting for memory.
+                if (!SPLIT) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int row = min(row0 + idx * 8 + i, M - 1);
+                        resx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)row * PC_D + lane * 4);
+                    }
+                }
+            } else if (!SPLIT) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&xn[(idx * 8 + i) * PC_XLD + lane * 4]) = resx[i];
             }
             __syncthreads();
         }
@@ -341,6 +356,8 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
         f32x16 acc2[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
+        float bv2n[2] = {0.f, 0.f};
+        if (!SPLIT) { bv2n[0] = b2[idx * 64 + frow]; bv2n[1] = b2[idx * 64 + 32 + frow]; }
         for (int phase = 0; phase <= nchunk + 1; ++phase) {
             if (phase >= 2) {
                 const int chunk = chunk_lo + phase - 2;
@@ -380,17 +397,11 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                     if (row < M) pp[(size_t)row * PC_D + col] = acc2[n][r];
                 }
             } else {
-                const float bv2 = b2[col];
-                float res[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, M - 1);
-                    res[r] = x[(size_t)row * PC_D + col];
-                }
+                const float bv2 = bv2n[n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    const float v = res[r] + scale * (acc2[n][r] + bv2);
+                    const float v = xn[lr * PC_XLD + col] + scale * (acc2[n][r] + bv2);       // residual row: put there by the producers
                     if (row0 + lr < M) x[(size_t)(row0 + lr) * PC_D + col] = v;
                     if (TAIL) xn[lr * PC_XLD + col] = v;          // the LayerNorm tile is free: every producer passed its last read
                 }
@@ -400,10 +411,10 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     if (!TAIL) return;
 
     // ---- tail stage: out[32 rows, tail.N] = LayerNorm_tail(x_new) . Wt^T + bt, all 8 waves -----------------------------------
-    __syncthreads();
     {
         const f32x4 gw = *reinterpret_cast<const f32x4*>(tail.lnw + lane * 4);
         const f32x4 gb = *reinterpret_cast<const f32x4*>(tail.lnb + lane * 4);
+        __syncthreads();
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int lr = wave * 4 + rr;
@@ -441,6 +452,8 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     {
         const float* xa = xn + frow * PC_XLD + 4 * fh;
         for (int t = 0; t < ntile; ++t) {
+            const int col = t * 256 + wave * 32 + frow;
+            const float bv = tail.bias[min(col, tail.N - 1)];      // requested before the tile's MFMAs
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -470,9 +483,7 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                     }
                 }
             }
-            const int col = t * 256 + wave * 32 + frow;
             if (col < tail.N) {
-                const float bv = tail.bias[col];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;

@@ -163,6 +163,23 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
     int ci = 0x7fffffff;
 
     f32x16 accv;      // value tile of the GLU pair
+    // CHAIN: the residual rows of the out-projection are requested now and land under tile 0's MFMAs (R is not written by this
+    // kernel; R2 is the output) instead of costing a memory round trip between tile 0 and the LayerNorm
+    float res0[16];
+    f32x4 cgw = {0.f, 0.f, 0.f, 0.f}, cgb = cgw;
+    float cbo = 0.f, cba = 0.f, cbg = 0.f;
+    if (EPI == RG_EPI_CHAIN) {
+        cgw = *reinterpret_cast<const f32x4*>(p.lnw + lane * 4);
+        cgb = *reinterpret_cast<const f32x4*>(p.lnb + lane * 4);
+        cbo = p.bias[wave * 32 + frow];
+        cba = p.bias[256 + wave * 32 + frow];
+        cbg = p.bias[512 + wave * 32 + frow];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, p.M - 1);
+            res0[r] = p.R[(size_t)row * p.ldr + wave * 32 + frow];
+        }
+    }
     for (int t = 0; t < ntiles; ++t) {
         f32x16 acc;
 #pragma unroll
@@ -250,24 +267,17 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
             const int ch = wave * 32 + frow;
             if (t == 0) {
                 // x <- x + (att . Wo^T + bo): to global (residual base of pointwise_conv2) and, raw, into the second LDS tile
-                const float bv = p.bias[ch];
-                float res[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, p.M - 1);
-                    res[r] = p.R[(size_t)row * p.ldr + ch];
-                }
+                const float bv = cbo;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    const float v = res[r] + (acc[r] + bv);
+                    const float v = res0[r] + (acc[r] + bv);
                     if (row0 + lr < p.M) p.R2[(size_t)(row0 + lr) * p.ldr + ch] = v;
                     red[lr * RG_ALD + ch] = v;
                 }
                 __syncthreads();
                 {   // LayerNorm (conv module) + pad mask in place: wave w owns rows 4w .. 4w+3
-                    const f32x4 gw = *reinterpret_cast<const f32x4*>(p.lnw + lane * 4);
-                    const f32x4 gb = *reinterpret_cast<const f32x4*>(p.lnb + lane * 4);
+                    const f32x4 gw = cgw, gb = cgb;
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int lr = wave * 4 + rr, row = row0 + lr;
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
             } else if (t == 1) {
                 accv = acc;
             } else {
-                const float bva = p.bias[256 + ch], bvg = p.bias[512 + ch];
+                const float bva = cba, bvg = cbg;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
