@@ -58,44 +58,53 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     auto dst_of = [&](int s, int i) -> float* { return wmine + (s & 1) * PC_WSLAB + (lr8 + 8 * i) * PC_WLD + lc4; };
     const float* wfrag = wmine + frow * PC_WLD + 4 * fh;
 
+    f32x4 gw_head = {0.f, 0.f, 0.f, 0.f}, gb_head = gw_head;
     if (HEADK > 0) {
         // ---- head 1: depthwise conv of my 32 rows -> xn tile.  Thread = (channel c, 16-row half); the window slides down the
         // rows like dwconv_ln_silu_kernel's and is reloaded where a new sequence starts (rows are (b, t) = divmod(row, seq_t)).
         {
             constexpr int KT = HEADK > 0 ? HEADK : 1, pad = KT - 1;      // (KT: no zero-length arrays in the HEADK = 0 kernels)
             const int c = tid & 255, half = tid >> 8;
-            float w[KT], win[KT];
+            float w[KT], win[KT], nw[16];
 #pragma unroll
             for (int j = 0; j < KT; ++j) w[j] = head.dw_w[j * 256 + c];
             const float bv = head.dw_b[c];
             const float gc = head.gconst ? head.gconst[c] : 0.f;
             const bool has_gc = head.gconst != nullptr;
+            // the newest window element of every row (padded row t + pad) is requested up front: 16 loads in flight instead of
+            // one exposed memory round trip per row of the sliding loop
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = min(row0 + half * 16 + rr, M - 1);
+                const int b = row / head.seq_t, t = row - b * head.seq_t;
+                nw[rr] = head.glu[((size_t)b * (pad + head.seq_t) + t + pad) * 256 + c];
+            }
 #pragma unroll
             for (int j = 0; j < KT; ++j) win[j] = 0.f;
-#pragma unroll 1
+#pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int lr = half * 16 + rr;
                 const int row = min(row0 + lr, M - 1);
                 const int b = row / head.seq_t, t = row - b * head.seq_t;
-                const float* gin = head.glu + ((size_t)b * (pad + head.seq_t) + t) * 256 + c;     // padded rows t .. t + pad
                 if (rr == 0 || t == 0 || row0 + lr >= M) {
+                    const float* gin = head.glu + ((size_t)b * (pad + head.seq_t) + t) * 256 + c;     // padded rows t .. t + pad
 #pragma unroll
                     for (int j = 0; j < pad; ++j) win[j + 1] = (has_gc && t + j < pad) ? gc : gin[(size_t)j * 256];
                 }
 #pragma unroll
                 for (int j = 0; j < pad; ++j) win[j] = win[j + 1];
-                win[pad] = gin[(size_t)pad * 256];
+                win[pad] = nw[rr];
                 float acc = bv;                       // out[t] = b + sum_j w[j] * gpad[t + j]
 #pragma unroll
                 for (int j = 0; j < KT; ++j) acc = fmaf(w[j], win[j], acc);
                 xn[lr * PC_XLD + c] = acc;
             }
         }
-        __syncthreads();
         // ---- head 2: LayerNorm + SiLU per row (wave w: rows 4w .. 4w+3), in place: the A tile of pointwise_conv2 ------------
         {
-            const f32x4 ww = *reinterpret_cast<const f32x4*>(head.lnw + lane * 4);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(head.lnw + lane * 4);       // (requested before the barrier)
             const f32x4 bb = *reinterpret_cast<const f32x4*>(head.lnb + lane * 4);
+            __syncthreads();
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int lr = wave * 4 + rr;
@@ -134,11 +143,18 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
             const int col = wave * 32 + frow;
             const float bv = head.bias[col];
             float res[16];
+            unsigned padded = 0;                          // bit r: row r of this lane is a padded frame (pad mask of the conv module)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, M - 1);
                 res[r] = x[(size_t)row * PC_D + col];
+                if (head.lens) {
+                    const int b = row / head.seq_t, tt = row - b * head.seq_t;
+                    if (head.mstride * tt >= head.lens[b]) padded |= 1u << r;
+                }
             }
+            gw_head = *reinterpret_cast<const f32x4*>(lnw + lane * 4);      // the FFN's own LayerNorm, for the prologue below
+            gb_head = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -173,11 +189,7 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                 const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
                 const int row = row0 + lr;
                 float v = acc[r] + bv;
-                if (head.lens) {
-                    const int rc = min(row, M - 1);
-                    const int b = rc / head.seq_t, tt = rc - b * head.seq_t;
-                    if (head.mstride * tt >= head.lens[b]) v = 0.f;
-                }
+                if (padded & (1u << r)) v = 0.f;
                 v = res[r] + v;
                 if (row < M) x[(size_t)row * PC_D + col] = v;
                 xn[lr * PC_XLD + col] = v;
@@ -188,8 +200,8 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
 
     // ---- LayerNorm prologue: wave w normalises rows 4w..4w+3 ----------------------------------------
     {
-        const f32x4 gw = *reinterpret_cast<const f32x4*>(lnw + lane * 4);
-        const f32x4 gb = *reinterpret_cast<const f32x4*>(lnb + lane * 4);
+        const f32x4 gw = HEADK > 0 ? gw_head : *reinterpret_cast<const f32x4*>(lnw + lane * 4);
+        const f32x4 gb = HEADK > 0 ? gb_head : *reinterpret_cast<const f32x4*>(lnb + lane * 4);
         f32x4 v4[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
