@@ -324,8 +324,10 @@ static void launch_rs(const RowGemmArgs& a, hipStream_t s) {
 // true when the small-M kernel took the launch
 // row blocks (of 32 rows) below which the K-split kernel takes the projection: 4x more, 4x shorter workgroups fill the chip
 // where a 32-row x N workgroup per row block leaves CUs idle (128 lock-step streams = 64 row blocks: chunk call 5.75 -> 5.34 ms;
-// tools/chunk_step_ab.py)
-static int g_small_blocks = 128;
+// tools/chunk_step_ab.py).  At 124 row blocks (16 x 10 s; the Efficient Conformer's half-rate layers at 32 x 10 s) the row-block
+// kernel is ahead again: 4.56 -> 4.42 ms per forward, 6.11 -> 6.04 ms per Efficient-Conformer pass (tools/offline_size_ab.py,
+// tools/efficient_size_ab.py); 93 row blocks are indifferent
+static int g_small_blocks = 112;
 void set_rowgemm_small_blocks(int n) { g_small_blocks = n; }
 bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
     if (a.M <= 0 || a.M >= g_small_blocks * 32) return false;

@@ -29,7 +29,7 @@ for B, T in ((4, 998), (8, 998), (12, 998), (16, 998), (20, 998), (24, 998), (28
     lens = torch.full((B,), T, dtype=torch.int32, device='cuda')
     rows = B * (((T - 1) // 2 - 1) // 2)
     out = []
-    for small, split in ((64, 64), (128, 192), (128, 256), (256, 256), (128, 128)):
+    for small, split in ((64, 64), (128, 192), (112, 192), (96, 192), (128, 256)):
         e.lib.masr_debug_set(e.h, 12, small)
         e.lib.masr_debug_set(e.h, 13, split)
         out.append(f'{small}/{split}: {whole(feats, lens):.3f}')
