@@ -87,6 +87,8 @@ def data_tag():
 
 # ---- evidence helpers ------------------------------------------------------------------------------------------------------
 # kernels timed with HIP events inside the engine (masr_profile_*): (profile kind, rocprof kernel-name fragment, description)
+PROF_STRIDE = 5          # the timed region brackets every 5th launch of the roofline kernel with HIP events
+
 ROOFLINE_KERNELS = [
     (6, 'ffn_pc_kernel<0, 0, 0, 1, 0>', "ffn_pc_kernel TAIL: LN + [B*T',256]x[256,2048] + SiLU + x[2048,256] + 1/2 residual, then LN + fused "
         "QKV projection [256,768] on the same rows (16.64 + 3.12 GFLOP per launch)"),
@@ -199,7 +201,11 @@ def cpu_baseline(budget_s=24.0):
 # ---- the contract workload ----------------------------------------------------------------------------------------------
 class ContractStep:
     """one rank's step of configs[1]; ``mode``: 'full' (HBM-resident PCM -> text on host, pipelined), 'device' (-> token ids
-    on the device, nothing synchronised), 'host' (pinned host PCM -> H2D -> ... -> text on host)"""
+    on the device, nothing synchronised), 'host' (pinned host PCM -> H2D -> ... -> text on host).
+
+    The exchange of a step -- pack the hypotheses, RCCL all-gather (N > 1), copy to the host -- runs on a side stream behind
+    an event of the compute stream, so the next step's kernels start while the collective of this one is in flight; the
+    device outputs and the pinned host buffers are double-buffered (slot = step parity)."""
 
     def __init__(self, eng, rank, world, vocab):
         from masr_amd import parallel
@@ -208,18 +214,21 @@ class ContractStep:
         self.dev = eng.device
         self.vocab = np.array(vocab, dtype=object)
         pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234 + rank))
-        pin = self.dev.type == 'cuda'
-        self.pcm_host = pcm.pin_memory() if pin else pcm
+        gpu = self.dev.type == 'cuda'
+        self.pcm_host = pcm.pin_memory() if gpu else pcm
         self.pcm = pcm.to(self.dev)
         self.n = torch.full((BATCH,), N_SAMPLES, dtype=torch.int32, device=self.dev)
         self.Tp = eng.out_frames(1 + (N_SAMPLES - 400) // 160)
-        self.out = (torch.empty(BATCH, self.Tp, dtype=torch.int32, device=self.dev),
-                    torch.empty(BATCH, dtype=torch.int32, device=self.dev),
-                    torch.empty(BATCH, dtype=torch.float32, device=self.dev))
+        self.out = [(torch.empty(BATCH, self.Tp, dtype=torch.int32, device=self.dev),
+                     torch.empty(BATCH, dtype=torch.int32, device=self.dev),
+                     torch.empty(BATCH, dtype=torch.float32, device=self.dev)) for _ in range(2)]
         rows = world * BATCH
-        mk = lambda *shape, dt: torch.empty(*shape, dtype=dt, pin_memory=pin)
-        self.host = [(mk(rows, self.Tp, dt=torch.int32), mk(rows, dt=torch.int32), mk(rows, dt=torch.float32)) for _ in range(2)]
-        self.events = [torch.cuda.Event() if pin else None for _ in range(2)]
+        # hypotheses travel as ONE int32 payload [rows, T' + 2] (tokens | count | score bits): one collective, one copy back
+        self.host = [torch.empty(rows, self.Tp + 2, dtype=torch.int32, pin_memory=gpu) for _ in range(2)]
+        self.side = torch.cuda.Stream(device=self.dev) if gpu else None
+        self.computed = [torch.cuda.Event() if gpu else None for _ in range(2)]      # compute stream: outputs of the slot written
+        self.events = [torch.cuda.Event() if gpu else None for _ in range(2)]        # side stream: slot gathered (and on the host)
+        self.used = [False, False]
         self.pending = None
         self.texts = None
         self.n_texts = 0
@@ -228,9 +237,9 @@ class ContractStep:
         """hypotheses of a finished step as text on the host (rank 0: of all ranks' utterances; others: their own shard)"""
         if self.events[slot] is not None:
             self.events[slot].synchronize()
-        tok, nt, _ = self.host[slot]
+        tok, nt, _ = self.parallel.unpack_hypothesis_rows(self.host[slot].numpy())
         lo, hi = (0, self.world * BATCH) if self.rank == 0 else (self.rank * BATCH, (self.rank + 1) * BATCH)
-        self.texts = self.parallel.tokens_to_text(tok[lo:hi].numpy(), nt[lo:hi].numpy(), self.vocab)
+        self.texts = self.parallel.tokens_to_text(tok[lo:hi], nt[lo:hi], self.vocab)
         self.n_texts += len(self.texts)
 
     def flush(self):
@@ -238,19 +247,30 @@ class ContractStep:
             self._finish(self.pending)
             self.pending = None
 
+    def _exchange(self, slot, mode):
+        rows = self.parallel.gather_hypothesis_rows(*self.out[slot])   # RCCL all-gather of [32, T'+2] int32 per rank (N > 1)
+        if mode != 'device':
+            self.host[slot].copy_(rows, non_blocking=True)
+
     def step(self, i, mode='full'):
+        slot = i & 1
         pcm = self.pcm
         if mode == 'host':
             pcm = self.pcm_host.to(self.dev, non_blocking=True)         # 10.2 MB over PCIe, same stream as the kernels
-        self.eng.transcribe_batch(pcm, self.n, out=self.out)
-        tok, nt, sc = self.parallel.gather_hypotheses(*self.out)       # RCCL all-gather of [32, T'+2] int32 per rank (N > 1)
+        if self.side is not None and self.used[slot]:
+            torch.cuda.current_stream().wait_event(self.events[slot])   # the slot's previous exchange has read its outputs
+        self.eng.transcribe_batch(pcm, self.n, out=self.out[slot])
+        if self.side is None:
+            self._exchange(slot, mode)
+        else:
+            self.computed[slot].record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.computed[slot])
+                self._exchange(slot, mode)
+                self.events[slot].record()
+            self.used[slot] = True
         if mode == 'device':
             return
-        slot = i & 1
-        for dst, src in zip(self.host[slot], (tok, nt, sc)):
-            dst.copy_(src, non_blocking=True)
-        if self.events[slot] is not None:
-            self.events[slot].record()
         self.flush()                                                    # text of the previous step, under this step's kernels
         self.pending = slot
 
@@ -263,12 +283,19 @@ def run_contract(args, rank, world, local):
     log(f'rank {rank}/{world}: engine ready on device {local}, warmup {args.warmup}')
 
     def prof_on():
+        # the roofline kernel is timed live over the timed region, on a sample of its launches: every PROF_STRIDE-th one (the
+        # stride is coprime to the 12 launches of a step, so every layer is sampled) -- two HIP event records per timed launch
+        # cost ~6 us of stream time, 0.07 ms per step when every launch is bracketed
+        if hasattr(eng, 'lib'):
+            eng.lib.masr_debug_set(eng.h, 16, PROF_STRIDE)
         eng.profile_select(args.profile_kind)
         eng.profile_read(reset=True)
 
     dt = parallel.timed_region(lambda i: cs.step(i, 'full'), args.steps, args.warmup, after_warmup=prof_on, flush=cs.flush)
     prof_ms, prof_n, prof_flops = eng.profile_read(reset=True)
     eng.profile_select(0)
+    if hasattr(eng, 'lib'):
+        eng.lib.masr_debug_set(eng.h, 16, 1)
     n_texts, sample_text = cs.n_texts, (cs.texts[0] if cs.texts else '')
     log(f'rank {rank}: timed region done: {dt * 1e3 / args.steps:.3f} ms/step')
     dt_dev = parallel.timed_region(lambda i: cs.step(i, 'device'), args.steps, 1)
@@ -305,7 +332,8 @@ def run_contract(args, rank, world, local):
                         'traffic_note': f'HBM bytes per launch from the committed PMC passes (profiles/{tfile}); algorithmic bytes '
                                         'per launch = x in/out 16.3 MB + qkv out 24.4 MB + weights 5.0 MB; the weights are fetched '
                                         'once by each of the 8 XCD L2s (Infinity Cache hits after the first)',
-                        'launches': int(prof_n), 'avg_us': round(prof_ms * 1e3 / prof_n, 2),
+                        'launches': int(prof_n), 'sampling': f'every {PROF_STRIDE}th launch of the timed region bracketed by HIP events',
+                        'avg_us': round(prof_ms * 1e3 / prof_n, 2),
                         'flops_per_launch': prof_flops / prof_n, 'other_kernels': others}
         per = lambda t: {'value': round(audio_step * args.steps / t, 1), 'ms_per_step': round(t * 1e3 / args.steps, 3)}
         res = {'metric': 'audio-seconds/sec (RTF^-1), conformer_streaming_fbank b32x10s, PCM->fbank->encoder->ctc_greedy->text',

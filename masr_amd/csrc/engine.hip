@@ -241,6 +241,7 @@ struct masr_engine {
     std::vector<Stream> streams;
     // profiling
     int prof_kind = 0;
+    int prof_stride = 1, prof_seen = 0;                     // every prof_stride-th matching launch is timed (masr_debug_set key 16)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
     double prof_flops = 0.0;
@@ -283,7 +284,8 @@ struct ProfScope {
     bool on;
     ProfScope(masr_engine* e_, hipStream_t s_, int kind, double flops) : e(e_), s(s_) {
         on = e->prof_kind != 0 && (e->prof_kind == kind || (e->prof_kind == PROF_GEMM && (kind == PROF_FFN1 || kind == PROF_CONV2 || kind == PROF_FFN_TAIL || kind == PROF_FFN_HEAD)));
-        if (!on) return;
+        if (on && e->prof_stride > 1) on = (e->prof_seen++ % e->prof_stride) == 0;     // a sample of the launches: two event
+        if (!on) return;                                                                // records cost ~6 us of stream time
         if (e->prof_used == e->prof_events.size()) {
             hipEvent_t a, b;
             hipEventCreate(&a);
@@ -2214,6 +2216,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 7) set_attention_fewq(value);
     else if (key == 14) set_attention_fold(value);
     else if (key == 15) g_embed_split = value;
+    else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }
     else if (key == 8) g_no_ffn_tail = value;
     else if (key == 9) g_no_ffn_head = value;
     else if (key == 12) set_rowgemm_small_blocks(value);

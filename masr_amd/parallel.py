@@ -83,18 +83,34 @@ def sticky_stream_owner(stream_id, world):
 
 
 # ---- the exchange step -----------------------------------------------------------------------------------------------
+def gather_hypothesis_rows(tokens, ntok, scores, group=None):
+    """Per-rank hypotheses packed as ONE int32 payload [B, T' + 2] (tokens | count | score bits) and all-gathered over the
+    ranks -> [world * B, T' + 2] on every rank (world 1: the packed rows themselves).  One tensor means one collective and one
+    copy to the host; ``unpack_hypothesis_rows`` splits it again."""
+    payload = torch.cat([tokens, ntok.view(-1, 1), scores.view(-1, 1).view(torch.int32)], dim=1).contiguous()
+    if not collectives_on(group):
+        return payload
+    w = dist.get_world_size(group)
+    out = torch.empty((w * payload.shape[0], payload.shape[1]), dtype=payload.dtype, device=payload.device)
+    dist.all_gather_into_tensor(out, payload, group=group)
+    return out
+
+
+def unpack_hypothesis_rows(rows):
+    """[R, T' + 2] int32 rows (tensor or numpy array) -> tokens [R, T'], counts [R], scores f32 [R] (views where possible)"""
+    Tp = rows.shape[1] - 2
+    if torch.is_tensor(rows):
+        return rows[:, :Tp], rows[:, Tp], rows[:, Tp + 1].contiguous().view(torch.float32)
+    return rows[:, :Tp], rows[:, Tp], np.ascontiguousarray(rows[:, Tp + 1]).view(np.float32)
+
+
 def gather_hypotheses(tokens, ntok, scores, group=None):
     """All-gather per-rank hypotheses.  tokens int32 [B, T'], ntok int32 [B], scores f32 [B] with the
     SAME shapes on every rank (pad shards with empty utterances).  Returns the concatenation over ranks."""
     if not collectives_on(group):
         return tokens, ntok, scores
-    w = dist.get_world_size(group)
-    # one payload: [B, T' + 2] int32 rows = tokens | ntok | score bits
-    payload = torch.cat([tokens, ntok.view(-1, 1), scores.view(-1, 1).view(torch.int32)], dim=1).contiguous()
-    out = torch.empty((w * payload.shape[0], payload.shape[1]), dtype=payload.dtype, device=payload.device)
-    dist.all_gather_into_tensor(out, payload, group=group)
-    Tp = tokens.shape[1]
-    return out[:, :Tp].contiguous(), out[:, Tp].contiguous(), out[:, Tp + 1].contiguous().view(torch.float32)
+    tok, nt, sc = unpack_hypothesis_rows(gather_hypothesis_rows(tokens, ntok, scores, group))
+    return tok.contiguous(), nt.contiguous(), sc
 
 
 def tokens_to_text(tokens, ntok, vocab):
