@@ -1,0 +1,55 @@
+"""bench.py's timed step on the GPU: the pipelined exchange (side stream, double-buffered outputs and host buffers, packed
+hypothesis rows) must hand every step's own transcripts to the host -- compared with the engine called directly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.mark.parametrize('force_dist', [False, True])
+def test_contract_step_texts_are_the_steps_own(force_dist, monkeypatch):
+    import bench
+    from masr_amd import parallel
+    from masr_amd.utils import synthetic
+    if force_dist:
+        monkeypatch.setenv('MASR_FORCE_DIST', '1')
+        if not torch.distributed.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29613')
+            torch.distributed.init_process_group('nccl', rank=0, world_size=1)
+    torch.cuda.set_device(0)
+    eng = bench.make_engine('conformer', 0)
+    try:
+        vocab = synthetic.synthetic_vocab(bench.VOCAB)
+        cs = bench.ContractStep(eng, 0, 1, vocab)
+        # a different batch per step: the texts of step k must come from batch k, whatever is in flight
+        batches = [torch.from_numpy(synthetic.synthetic_pcm(bench.BATCH, bench.N_SAMPLES, seed=900 + k)).to(eng.device)
+                   for k in range(5)]
+        want = []
+        for b in batches:
+            tok, nt, _ = eng.transcribe_batch(b, cs.n)
+            want.append(parallel.tokens_to_text(tok, nt, np.array(vocab, dtype=object)))
+        torch.cuda.synchronize()
+        assert len({tuple(w) for w in want}) == 5
+        got = []
+        for k, b in enumerate(batches):
+            cs.pcm = b
+            cs.step(k, 'full')
+            if k:
+                got.append(list(cs.texts))            # step k delivers the text of step k - 1
+        cs.flush()
+        got.append(list(cs.texts))
+        assert got == want
+        assert cs.n_texts == 5 * bench.BATCH
+        for k in range(3):                            # the unsynchronised mode leaves nothing pending
+            cs.step(k, 'device')
+        torch.cuda.synchronize()
+        assert cs.pending is None
+    finally:
+        eng.close()
