@@ -17,12 +17,14 @@ def test_contract_step_texts_are_the_steps_own(force_dist, monkeypatch):
     import bench
     from masr_amd import parallel
     from masr_amd.utils import synthetic
+    made_group = False
     if force_dist:
         monkeypatch.setenv('MASR_FORCE_DIST', '1')
         if not torch.distributed.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29613')
             torch.distributed.init_process_group('nccl', rank=0, world_size=1)
+            made_group = True
     torch.cuda.set_device(0)
     eng = bench.make_engine('conformer', 0)
     try:
@@ -53,3 +55,6 @@ def test_contract_step_texts_are_the_steps_own(force_dist, monkeypatch):
         assert cs.pending is None
     finally:
         eng.close()
+        if made_group:
+            torch.cuda.synchronize()
+            torch.distributed.destroy_process_group()
