@@ -24,6 +24,21 @@ void note_launch_error(const char* what, hipError_t e);
 // Sum over the 64 lanes of a wave, result in every lane.  DPP row shifts / row broadcasts (a scan whose last lane holds the
 // total) + one readlane: ~10 VALU instructions.  __shfl_xor lowers to ds_bpermute_b32, i.e. six dependent LDS round trips
 // (~600 cycles) per sum -- measurable in the LayerNorm prologues of the latency-bound streaming kernels.
+// (sequence, frame) of row `row0 + lr` of a [b][T] row space, from (b0, t0) = divmod(row0, T) computed once per block: a carry
+// loop instead of an integer division per row (a division by a run-time divisor is ~40 instructions; the row-local stages did
+// 16-32 of them per lane)
+struct SeqRow {
+    int b, t;
+};
+__device__ __forceinline__ SeqRow seq_row(int b0, int t0, int T, int lr) {
+    SeqRow r{b0, t0 + lr};
+    while (r.t >= T) {
+        r.t -= T;
+        ++r.b;
+    }
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum_dpp(float v) {
 #define MASR_DPP_F(x, ctrl, rows) \
     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rows), 0xf, false))

@@ -73,19 +73,19 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
             const bool has_gc = head.gconst != nullptr;
             // the newest window element of every row (padded row t + pad) is requested up front: 16 loads in flight instead of
             // one exposed memory round trip per row of the sliding loop
+            const int hb0 = row0 / head.seq_t, ht0 = row0 - hb0 * head.seq_t, lr_last = M - 1 - row0;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
-                const int row = min(row0 + half * 16 + rr, M - 1);
-                const int b = row / head.seq_t, t = row - b * head.seq_t;
-                nw[rr] = head.glu[((size_t)b * (pad + head.seq_t) + t + pad) * 256 + c];
+                const SeqRow q = seq_row(hb0, ht0, head.seq_t, min(half * 16 + rr, lr_last));
+                nw[rr] = head.glu[((size_t)q.b * (pad + head.seq_t) + q.t + pad) * 256 + c];
             }
 #pragma unroll
             for (int j = 0; j < KT; ++j) win[j] = 0.f;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int lr = half * 16 + rr;
-                const int row = min(row0 + lr, M - 1);
-                const int b = row / head.seq_t, t = row - b * head.seq_t;
+                const SeqRow q = seq_row(hb0, ht0, head.seq_t, min(lr, lr_last));
+                const int b = q.b, t = q.t;
                 if (rr == 0 || t == 0 || row0 + lr >= M) {
                     const float* gin = head.glu + ((size_t)b * (pad + head.seq_t) + t) * 256 + c;     // padded rows t .. t + pad
 #pragma unroll
@@ -144,13 +144,14 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
             const float bv = head.bias[col];
             float res[16];
             unsigned padded = 0;                          // bit r: row r of this lane is a padded frame (pad mask of the conv module)
+            const int mb0 = row0 / head.seq_t, mt0 = row0 - mb0 * head.seq_t;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * fh, M - 1);
-                res[r] = x[(size_t)row * PC_D + col];
+                const int lrc = min((r & 3) + 8 * (r >> 2) + 4 * fh, M - 1 - row0);
+                res[r] = x[(size_t)(row0 + lrc) * PC_D + col];
                 if (head.lens) {
-                    const int b = row / head.seq_t, tt = row - b * head.seq_t;
-                    if (head.mstride * tt >= head.lens[b]) padded |= 1u << r;
+                    const SeqRow q = seq_row(mb0, mt0, head.seq_t, lrc);
+                    if (head.mstride * q.t >= head.lens[q.b]) padded |= 1u << r;
                 }
             }
             gw_head = *reinterpret_cast<const f32x4*>(lnw + lane * 4);      // the FFN's own LayerNorm, for the prologue below

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
     f32x16 accv;      // value tile of the GLU pair
     // CHAIN: the residual rows of the out-projection are requested now and land under tile 0's MFMAs (R is not written by this
     // kernel; R2 is the output) instead of costing a memory round trip between tile 0 and the LayerNorm
+    // (sequence, frame) of the block's first row in the mask's and in the output's row space: one division per block each
+    const int cb0 = p.seq_t > 0 ? row0 / p.seq_t : 0, ct0 = p.seq_t > 0 ? row0 - cb0 * p.seq_t : 0;
+    const int ob0 = p.out_seq_t > 0 ? row0 / p.out_seq_t : 0, ot0 = p.out_seq_t > 0 ? row0 - ob0 * p.out_seq_t : 0;
     float res0[16];
     f32x4 cgw = {0.f, 0.f, 0.f, 0.f}, cgb = cgw;
     float cbo = 0.f, cba = 0.f, cbg = 0.f;
@@ -283,8 +286,8 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
                         const int lr = wave * 4 + rr, row = row0 + lr;
                         bool live = row < p.M;
                         if (live && p.lens && p.seq_t > 0) {
-                            const int b = row / p.seq_t, tt = row - b * p.seq_t;
-                            live = p.mstride * tt < p.lens[b];
+                            const SeqRow q = seq_row(cb0, ct0, p.seq_t, lr);
+                            live = p.mstride * q.t < p.lens[q.b];
                         }
                         const f32x4 v = *reinterpret_cast<const f32x4*>(&red[lr * RG_ALD + lane * 4]);
                         const float mean = rg_wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
@@ -308,12 +311,13 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
                 const float bva = cba, bvg = cbg;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int row = row0 + lr;
                     if (row >= p.M) continue;
                     size_t crow = row;
                     if (p.out_seq_t > 0) {
-                        const int b = row / p.out_seq_t, tt = row - b * p.out_seq_t;
-                        crow = (size_t)b * (p.out_seq_t + p.out_pad_tot) + p.out_pad_l + tt;
+                        const SeqRow q = seq_row(ob0, ot0, p.out_seq_t, lr);
+                        crow = (size_t)q.b * (p.out_seq_t + p.out_pad_tot) + p.out_pad_l + q.t;
                     }
                     const float g = acc[r] + bvg;
                     p.C[crow * p.ldc + ch] = (accv[r] + bva) * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
@@ -327,12 +331,13 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
                 const float bva = p.bias[ch], bvg = p.bias[256 + ch];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int row = row0 + lr;
                     if (row >= p.M) continue;
                     size_t crow = row;
                     if (p.out_seq_t > 0) {               // symmetric-padded layout for the non-causal depthwise conv
-                        const int b = row / p.out_seq_t, t = row - b * p.out_seq_t;
-                        crow = (size_t)b * (p.out_seq_t + p.out_pad_tot) + p.out_pad_l + t;
+                        const SeqRow q = seq_row(ob0, ot0, p.out_seq_t, lr);
+                        crow = (size_t)q.b * (p.out_seq_t + p.out_pad_tot) + p.out_pad_l + q.t;
                     }
                     const float g = acc[r] + bvg;
                     p.C[crow * p.ldc + ch] = (accv[r] + bva) * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
