@@ -265,3 +265,22 @@ def test_bench_cli_launches_ranks_and_rejects_mismatch():
     assert p3.returncode == 0, p3.stderr[-2000:]
     r3 = json.loads([ln for ln in p3.stdout.splitlines() if ln.startswith('{')][0])
     assert r3['n_gpus'] == 2 and r3['transcripts'] == 256 and r3['scaling'] == 'strong' and '128 on rank 0' in r3['workload']
+
+
+def test_hypothesis_rows_pack_and_unpack_round_trip():
+    """the one-payload form of a batch of hypotheses ([B, T'+2] int32: tokens | count | score bits) -- what travels through the
+    all-gather and the single copy to the host -- unpacks to the same tokens, counts and float32 scores (tensor and numpy)"""
+    import numpy as np
+    import torch
+    from masr_amd import parallel
+    g = torch.Generator().manual_seed(5)
+    tok = torch.randint(0, 4233, (7, 13), generator=g, dtype=torch.int32)
+    nt = torch.randint(0, 14, (7,), generator=g, dtype=torch.int32)
+    sc = torch.randn(7, generator=g) * 50
+    rows = parallel.gather_hypothesis_rows(tok, nt, sc)          # no process group: the packed rows themselves
+    assert rows.shape == (7, 15) and rows.dtype == torch.int32
+    for unpacked in (parallel.unpack_hypothesis_rows(rows), parallel.unpack_hypothesis_rows(rows.numpy())):
+        t, n, s = (torch.as_tensor(np.asarray(u)) for u in unpacked)
+        assert torch.equal(t, tok) and torch.equal(n, nt) and torch.equal(s, sc)
+    t, n, s = parallel.gather_hypotheses(tok, nt, sc)
+    assert torch.equal(t, tok) and torch.equal(n, nt) and torch.equal(s, sc)
