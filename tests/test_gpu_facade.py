@@ -564,3 +564,41 @@ def test_predict_batch_and_evaluate_through_the_rccl_exchange(predictor, tmp_pat
         assert got[4] == {'text': '', 'score': 0.0} or got[4]['text'] == ''          # shorter than one decoding window
     finally:
         dist.destroy_process_group()
+
+
+def test_stream_pool_feed_forms_are_equivalent(predictor):
+    """StreamPool.feed: int16 PCM bytes (kept raw until the step stages them), the same samples as an int16 / float32 ndarray,
+    as a bytearray, and a chunk split over two feed calls must give identical partial results; audio at another sample rate
+    takes the resampling path."""
+    from masr_amd.serving import StreamPool
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm'][:64000]
+    step = 8000
+    forms = {
+        'bytes': lambda c: [c.tobytes()],
+        'bytearray': lambda c: [bytearray(c.tobytes())],
+        'int16 ndarray': lambda c: [c.copy()],
+        'float32 ndarray': lambda c: [c.astype(np.float32) * np.float32(1.0 / 32768.0)],
+        'two feeds': lambda c: [c[:3001].tobytes(), c[3001:].tobytes()],
+    }
+    pool = StreamPool(predictor)
+    hs = {name: pool.open() for name in forms}
+    got = {name: [] for name in forms}
+    for s in range(0, len(pcm), step):
+        chunk, end = pcm[s:s + step], s + step >= len(pcm)
+        for name, make in forms.items():
+            parts = make(chunk)
+            for j, part in enumerate(parts):
+                pool.feed(hs[name], part, is_end=end and j == len(parts) - 1)
+        out = pool.step()
+        for name in forms:
+            got[name].append(out[hs[name]])
+    assert any(r is not None and r['text'] for r in got['bytes'])
+    for name in forms:
+        assert got[name] == got['bytes'], name
+    # 8 kHz input: resampled to the model's rate before it is queued
+    h8 = pool.open()
+    pool.feed(h8, pcm[::2].copy().tobytes(), is_end=True, sample_rate=8000)
+    r8 = pool.step()[h8]
+    assert r8 is not None and isinstance(r8['text'], str)
+    for h in list(hs.values()) + [h8]:
+        pool.close(h)
