@@ -49,6 +49,15 @@ def test_contract_step_texts_are_the_steps_own(force_dist, monkeypatch):
         got.append(list(cs.texts))
         assert got == want
         assert cs.n_texts == 5 * bench.BATCH
+        # 'host' mode: the PCM comes over PCIe on a copy stream, one step ahead; every step must still transcribe that batch
+        tok, nt, _ = eng.transcribe_batch(cs.pcm_host.to(eng.device), cs.n)
+        host_want = parallel.tokens_to_text(tok, nt, np.array(vocab, dtype=object))
+        for k in range(4):
+            cs.step(k, 'host')
+            if k:
+                assert list(cs.texts) == host_want
+        cs.flush()
+        assert list(cs.texts) == host_want
         for k in range(3):                            # the unsynchronised mode leaves nothing pending
             cs.step(k, 'device')
         torch.cuda.synchronize()
