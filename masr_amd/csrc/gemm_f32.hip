@@ -28,12 +28,14 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // (p.ksplit slabs per range); splitk_reduce_kernel applies the epilogue.  For M so small that the tile grid cannot fill
 // the chip while K is deep (embed projection of a streaming chunk step: M = 256, K = 4864).
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-    static_assert(WM * WN == 4, "4 waves");
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    constexpr int NT = 64 * WM * WN;
+    constexpr int RPP = NT / 8;   // slab rows staged per pass of the workgroup (8 threads x float4 per 32-wide row)
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
-    constexpr int AL = BM / 32;   // float4 loads per thread for the A slab
-    constexpr int WL = BN / 32;
+    constexpr int AL = BM / RPP;  // float4 loads per thread for the A slab
+    constexpr int WL = BN / RPP;
     extern __shared__ __align__(16) float smem[];
     float* As = smem;                       // [2][BM][LDP]
     float* Ws = smem + 2 * BM * LDP;        // [2][BN][LDP]
@@ -56,13 +58,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     const int bn = (bid % nbn) * BN;
 
     // ---- per-thread global source pointers ------------------------------------------------
-    const int lrow = tid >> 3;          // 0..31
+    const int lrow = tid >> 3;          // 0..RPP-1
     const int lc4 = (tid & 7) * 4;      // float offset inside the 32-wide slab
     const float* aptr[AL];
     bool aok[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-        const int m = bm + lrow + 32 * i;
+        const int m = bm + lrow + RPP * i;
         aok[i] = m < p.M;
         const int mm = aok[i] ? m : 0;
         if (AMODE == A_PLAIN) {
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     bool wok[WL];
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-        const int n = bn + lrow + 32 * i;
+        const int n = bn + lrow + RPP * i;
         wok[i] = n < p.N;
         wptr[i] = p.W + (size_t)(wok[i] ? n : 0) * p.K + lc4;
     }
@@ -106,10 +108,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     auto store_slab = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AL; ++i)
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDP + lc4]) = areg[i];
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + RPP * i) * LDP + lc4]) = areg[i];
 #pragma unroll
         for (int i = 0; i < WL; ++i)
-            *reinterpret_cast<f32x4*>(&Ws[(buf * BN + lrow + 32 * i) * LDP + lc4]) = wreg[i];
+            *reinterpret_cast<f32x4*>(&Ws[(buf * BN + lrow + RPP * i) * LDP + lc4]) = wreg[i];
     };
 
     f32x16 acc[TM][TN];
@@ -206,6 +208,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     }
 }
 
+// waves per workgroup of the two big launches of the offline front-end (conv2 implicit GEMM on 128x128 tiles, the embed
+// projection's K halves on 64x128 tiles): 8 (default) or 4 (masr_debug_set key 17).  Step at B = 32 x 10 s: -0.08 ms with 8.
+static int g_gemm_waves = 8;
+void set_gemm_waves(int n) { g_gemm_waves = n; }
+
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 static void launch_t(const GemmArgs& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
@@ -213,7 +220,7 @@ static void launch_t(const GemmArgs& a, hipStream_t s) {
     auto k = gemm_f32_kernel<BM, BN, WM, WN, AMODE, EPI>;
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, attr);
-    hipLaunchKernelGGL(k, dim3(nbm * nbn, EPI == EPI_SPLITK ? a.nsplit : 1), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(nbm * nbn, EPI == EPI_SPLITK ? a.nsplit : 1), dim3(64 * WM * WN), lds, s, a);
 }
 
 // out = R + alpha * act(sum_s partial[s] + bias) [+ bias after alpha]; partials added in ascending s (deterministic)
@@ -240,13 +247,20 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     if (amode == A_CONV2) {
         // few output rows (streaming chunk steps): 64x64 tiles so that the grid still covers the chip
         if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 200) launch_t<64, 64, 2, 2, A_CONV2, EPI_STD>(a, s);
+        // 8 waves (2 x 4 grid, 64 x 32 per wave) on the 128x128 tile: two workgroups per CU = four waves per SIMD cover each
+        // other's slab barriers; 1 494 -> 1 457 us at B = 32 x 10 s.  (4 x 2 grid: 1 488 us; 128x256 / 256x128 tiles with 8
+        // waves, one workgroup per CU: 1 540 us.)
+        else if (g_gemm_waves == 8) launch_t<128, 128, 2, 4, A_CONV2, EPI_STD>(a, s);
         else launch_t<128, 128, 2, 2, A_CONV2, EPI_STD>(a, s);
         return;
     }
     if (epi == EPI_SPLITK) {            // caller set a.C = partial buffer, a.nsplit, a.ksplit
         // many rows (the offline embed projection: 248 tiles of 64x128 = one 4-wave workgroup per CU): the wide tile, so that
         // the split doubles the waves per SIMD instead of the LDS traffic per MFMA
-        if ((long)((a.M + 63) / 64) * ((a.N + 127) / 128) >= 200) launch_t<64, 128, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
+        if ((long)((a.M + 63) / 64) * ((a.N + 127) / 128) >= 200) {
+            if (g_gemm_waves == 8) launch_t<64, 128, 2, 4, A_PLAIN, EPI_SPLITK>(a, s);     // 32 x 32 per wave, 4 waves per SIMD
+            else launch_t<64, 128, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
+        }
         else launch_t<64, 64, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
         return;
     }
