@@ -208,8 +208,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
     }
 }
 
-// waves per workgroup of the two big launches of the offline front-end (conv2 implicit GEMM on 128x128 tiles, the embed
-// projection's K halves on 64x128 tiles): 8 (default) or 4 (masr_debug_set key 17).  Step at B = 32 x 10 s: -0.08 ms with 8.
+// waves per workgroup of the conv2 implicit GEMM on 128x128 tiles: 8 (default) or 4 (masr_debug_set key 17).  In one kernel
+// trace with both shapes alternating (tools/gemm_waves_trace.py): 1 467 vs 1 486 us on average, 1 437 vs 1 480 us at best.
 static int g_gemm_waves = 8;
 void set_gemm_waves(int n) { g_gemm_waves = n; }
 
@@ -248,7 +248,7 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
         // few output rows (streaming chunk steps): 64x64 tiles so that the grid still covers the chip
         if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 200) launch_t<64, 64, 2, 2, A_CONV2, EPI_STD>(a, s);
         // 8 waves (2 x 4 grid, 64 x 32 per wave) on the 128x128 tile: two workgroups per CU = four waves per SIMD cover each
-        // other's slab barriers; 1 494 -> 1 457 us at B = 32 x 10 s.  (4 x 2 grid: 1 488 us; 128x256 / 256x128 tiles with 8
+        // other's slab barriers; 1 494 -> 1 457 us at B = 32 x 10 s by HIP events.  (4 x 2 grid: 1 488 us; 128x256 / 256x128 tiles with 8
         // waves, one workgroup per CU: 1 540 us.)
         else if (g_gemm_waves == 8) launch_t<128, 128, 2, 4, A_CONV2, EPI_STD>(a, s);
         else launch_t<128, 128, 2, 2, A_CONV2, EPI_STD>(a, s);
@@ -257,10 +257,9 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     if (epi == EPI_SPLITK) {            // caller set a.C = partial buffer, a.nsplit, a.ksplit
         // many rows (the offline embed projection: 248 tiles of 64x128 = one 4-wave workgroup per CU): the wide tile, so that
         // the split doubles the waves per SIMD instead of the LDS traffic per MFMA
-        if ((long)((a.M + 63) / 64) * ((a.N + 127) / 128) >= 200) {
-            if (g_gemm_waves == 8) launch_t<64, 128, 2, 4, A_PLAIN, EPI_SPLITK>(a, s);     // 32 x 32 per wave, 4 waves per SIMD
-            else launch_t<64, 128, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
-        }
+        // (four waves: as a 2 x 4 grid of eight waves, 32 x 32 per wave, this launch is slower -- 183.6 vs 177.4 us in one
+        // kernel trace, tools/gemm_waves_trace.py -- the LDS reads per MFMA double)
+        if ((long)((a.M + 63) / 64) * ((a.N + 127) / 128) >= 200) launch_t<64, 128, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
         else launch_t<64, 64, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
         return;
     }
