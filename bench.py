@@ -94,7 +94,7 @@ ROOFLINE_KERNELS = [
         "QKV projection [256,768] on the same rows (16.64 + 3.12 GFLOP per launch)"),
     (7, 'ffn_pc_kernel<0, 0, 0, 0, 15>', 'ffn_pc_kernel HEAD: depthwise conv + LN + SiLU + pointwise_conv2 [256,256] + residual, then '
         'LN + FFN + 1/2 residual (1.04 + 16.64 GFLOP per launch)'),
-    (3, 'gemm_f32_kernel<128, 128, 2, 2, 1, 0>', 'Conv2d(256,256,3,stride 2) of the subsampling front-end as an implicit GEMM (177.9 GFLOP)'),
+    (3, 'gemm_f32_kernel<128, 128, 2, 4, 1, 0>', 'Conv2d(256,256,3,stride 2) of the subsampling front-end as an implicit GEMM (177.9 GFLOP)'),
     (4, 'attention_kernel', 'rel-pos multi-head self-attention (algorithmic 6 * d * T\'^2 * B = 3.0 GFLOP per launch: the reference\'s '
         'two score terms + the value product; the kernel folds the positional keys into the keys and issues 2.0 GFLOP of MFMAs)'),
 ]
