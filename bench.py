@@ -230,7 +230,7 @@ class ContractStep:
         self.events = [torch.cuda.Event() if gpu else None for _ in range(2)]        # side stream: slot gathered (and on the host)
         self.used = [False, False]
         self.h2d = None
-        self._after_enqueue = None
+        self.prefetch_pcm_for = None
         self.pending = None
         self.texts = None
         self.n_texts = 0
@@ -249,6 +249,16 @@ class ContractStep:
             self._finish(self.pending)
             self.pending = None
 
+    def _copy_pcm(self, k):
+        """enqueue the host -> device copy of step k's PCM on the copy stream (buffer k & 1)"""
+        h = self.h2d
+        with torch.cuda.stream(h['stream']):
+            if self.used[k & 1]:
+                h['stream'].wait_event(self.computed[k & 1])           # the kernels that read this buffer two steps ago are done
+            h['buf'][k & 1].copy_(self.pcm_host, non_blocking=True)
+            h['ready'][k & 1].record()
+        h['issued'] = k
+
     def _pcm_from_host(self, i):
         """'host' mode: this step's PCM from pinned host memory.  On the GPU the copy of step i + 1 is issued on a copy stream
         as soon as step i is enqueued (two device buffers), so PCIe time hides under the previous step's kernels; the very
@@ -257,20 +267,12 @@ class ContractStep:
             return self.pcm_host.to(self.dev)
         if self.h2d is None:
             self.h2d = {'stream': torch.cuda.Stream(device=self.dev), 'buf': [torch.empty_like(self.pcm) for _ in range(2)],
-                        'ready': [torch.cuda.Event() for _ in range(2)], 'next': None}
-        h, main, slot = self.h2d, torch.cuda.current_stream(), i & 1
-
-        def copy(k):
-            with torch.cuda.stream(h['stream']):
-                if self.used[k & 1]:
-                    h['stream'].wait_event(self.computed[k & 1])       # the kernels that read this buffer two steps ago are done
-                h['buf'][k & 1].copy_(self.pcm_host, non_blocking=True)
-                h['ready'][k & 1].record()
-        if h['next'] != i:
-            copy(i)
-        main.wait_event(h['ready'][slot])
-        self._after_enqueue = lambda: (copy(i + 1), h.__setitem__('next', i + 1))
-        return h['buf'][slot]
+                        'ready': [torch.cuda.Event() for _ in range(2)], 'issued': None}
+        if self.h2d['issued'] != i:
+            self._copy_pcm(i)
+        torch.cuda.current_stream().wait_event(self.h2d['ready'][i & 1])
+        self.prefetch_pcm_for = i + 1                                    # issued by step() right after this step's kernels
+        return self.h2d['buf'][i & 1]
 
     def _exchange(self, slot, mode):
         rows = self.parallel.gather_hypothesis_rows(*self.out[slot])   # RCCL all-gather of [32, T'+2] int32 per rank (N > 1)
@@ -289,9 +291,9 @@ class ContractStep:
             self._exchange(slot, mode)
         else:
             self.computed[slot].record()
-            if self._after_enqueue is not None:                         # 'host' mode: the next step's PCM starts its way over PCIe
-                self._after_enqueue()
-                self._after_enqueue = None
+            if self.prefetch_pcm_for is not None:                       # 'host' mode: the next step's PCM starts its way over PCIe
+                self._copy_pcm(self.prefetch_pcm_for)
+                self.prefetch_pcm_for = None
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.computed[slot])
                 self._exchange(slot, mode)
