@@ -235,7 +235,14 @@ int masr_op_layernorm(masr_engine* e, const float* x_dev, const float* w_dev, co
 int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
                  float* c_dev, int32_t M, int32_t N, int32_t K, int32_t act, float alpha, void* stream);
 
-/* Diagnostics (kernel ablation switches for profiling; key 1 = fused-FFN variant, 0 = production). */
+/* Diagnostics: A/B switches of the kernels, for in-process measurements (tools/ *_ab.py); production = the defaults.
+ *   1  fused-FFN variant (0 production, 1 without weight loads)      2  beam-search phase profile of workgroup 0
+ *   5  1 = no out-proj + pw1 chain kernel                            6  0 = no K-split projection kernel
+ *   7  0 = always the query-tiled attention kernel                   8  1 = no QKV tail stage on the first FFN
+ *   9  1 = no conv-module head stage on the second FFN              12  row blocks below which the K-split projection kernel runs
+ *  13  row blocks below which the FFN splits d_ff                   14  0 = two-term attention scores (no positional-key fold)
+ *  15  0 = the offline embed projection never splits K              16  time every n-th matching launch (masr_profile_*)
+ *  17  waves per workgroup of the offline conv2 launch (8 | 4) */
 int masr_debug_set(masr_engine* e, int32_t key, int32_t value);
 
 /* Profiling: time every launch of one kernel class with HIP events on the launch stream.
