@@ -242,7 +242,7 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
  *   9  1 = no conv-module head stage on the second FFN              12  row blocks below which the K-split projection kernel runs
  *  13  row blocks below which the FFN splits d_ff                   14  0 = two-term attention scores (no positional-key fold)
  *  15  0 = the offline embed projection never splits K              16  time every n-th matching launch (masr_profile_*)
- *  17  waves per workgroup of the offline conv2 launch (8 | 4) */
+ *  17  waves per workgroup of the offline conv2 launch (8 | 4)   18  0 = conv1 writes with plain instead of streaming stores */
 int masr_debug_set(masr_engine* e, int32_t key, int32_t value);
 
 /* Profiling: time every launch of one kernel class with HIP events on the launch stream.

@@ -88,6 +88,7 @@ void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream
 void launch_layernorm(const float* x, const float* w, const float* b, float* y, int M, float eps,
                       int seq_t, int pad, const int* lens, hipStream_t s);
 // CMVN + Conv2d(1->C,3x3,s2) + ReLU, output channels-last [B,T1,F1,C]
+void set_conv1_nt(int on);           // diagnostics (masr_debug_set key 18): 0 = conv1 writes its output with plain stores
 void launch_conv1(const float* feats, const float* mean, const float* istd, const float* w9c, const float* bias,
                   float* out, int B, int T, int F, int C, hipStream_t s);
 // depthwise causal conv (k taps) + LayerNorm(C=256) + SiLU on padded layout [nseq, pad+Tq, 256] -> [nseq*Tq, 256]

@@ -83,6 +83,7 @@ void launch_affine_rows(const float* x, const float* w, const float* b, float* y
 // the 3 x F input rows are normalised once into LDS and broadcast-read.
 // Output is channels-last [B, T1, F1, C] so that the conv2 implicit GEMM reads contiguous K.
 // ------------------------------------------------------------------------------------------
+template <int NT>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ feats, const float* __restrict__ mean,
                                                     const float* __restrict__ istd, const float* __restrict__ w9c,
                                                     const float* __restrict__ bias, float* __restrict__ out, int T,
@@ -109,16 +110,26 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ fe
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) acc = fmaf(w[kh * 3 + kw], sm[kh * F + 2 * f1 + kw], acc);
-        o[(size_t)f1 * C] = fmaxf(acc, 0.f);
+        if (NT) __builtin_nontemporal_store(fmaxf(acc, 0.f), &o[(size_t)f1 * C]);
+        else o[(size_t)f1 * C] = fmaxf(acc, 0.f);
     }
 }
+
+// the 636 MB of conv1 output (B = 32 x 10 s) are written once and read back from HBM by conv2 whatever the caches do: streaming
+// (non-temporal) stores, 135.3 -> 125.6 us in one kernel trace with both forms alternating, conv2 behind it unchanged
+static int g_conv1_nt = 1;
+void set_conv1_nt(int on) { g_conv1_nt = on; }
 
 void launch_conv1(const float* feats, const float* mean, const float* istd, const float* w9c, const float* bias,
                   float* out, int B, int T, int F, int C, hipStream_t s) {
     const int T1 = (T - 1) / 2, F1 = (F - 1) / 2;
     if (B * T1 <= 0) return;
-    hipLaunchKernelGGL(conv1_kernel, dim3(B * T1), dim3(256), 3 * F * sizeof(float), s, feats, mean, istd, w9c, bias,
-                       out, T, F, T1, F1, C);
+    if (g_conv1_nt)
+        hipLaunchKernelGGL(conv1_kernel<1>, dim3(B * T1), dim3(256), 3 * F * sizeof(float), s, feats, mean, istd, w9c, bias,
+                           out, T, F, T1, F1, C);
+    else
+        hipLaunchKernelGGL(conv1_kernel<0>, dim3(B * T1), dim3(256), 3 * F * sizeof(float), s, feats, mean, istd, w9c, bias,
+                           out, T, F, T1, F1, C);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -2217,6 +2217,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 14) set_attention_fold(value);
     else if (key == 15) g_embed_split = value;
     else if (key == 17) set_gemm_waves(value);
+    else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }
     else if (key == 8) g_no_ffn_tail = value;
     else if (key == 9) g_no_ffn_head = value;
