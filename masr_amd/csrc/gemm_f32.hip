@@ -248,8 +248,8 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
         // few output rows (streaming chunk steps): 64x64 tiles so that the grid still covers the chip
         if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 200) launch_t<64, 64, 2, 2, A_CONV2, EPI_STD>(a, s);
         // 8 waves (2 x 4 grid, 64 x 32 per wave) on the 128x128 tile: two workgroups per CU = four waves per SIMD cover each
-        // other's slab barriers; 1 494 -> 1 457 us at B = 32 x 10 s by HIP events.  (4 x 2 grid: 1 488 us; 128x256 / 256x128 tiles with 8
-        // waves, one workgroup per CU: 1 540 us.)
+        // other's slab barriers; 1 494 -> 1 457 us at B = 32 x 10 s by HIP events.  (4 x 2 grid: 1 488 us; 16 waves as a 4 x 4 grid: 1 624 us; 128x256 /
+        // 256x128 tiles with 8 waves, one workgroup per CU: 1 540 us.)
         else if (g_gemm_waves == 8) launch_t<128, 128, 2, 4, A_CONV2, EPI_STD>(a, s);
         else launch_t<128, 128, 2, 2, A_CONV2, EPI_STD>(a, s);
         return;
