@@ -719,9 +719,14 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
         ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)d * F2 * d);
         const int tiles = ((M + 63) / 64) * ((d + 63) / 64);
         const long wide = (long)((M + 63) / 64) * ((d + 127) / 128);      // 64x128 tiles of the unsplit launch
-        if (g_embed_split && tiles >= 128 && wide >= 200 && wide <= 320) {
-            // about one 4-wave workgroup per CU (B = 32 x 10 s: 248): two K halves put two waves on every SIMD;
-            // 6.907 -> 6.892 ms per step including the reduction pass
+        const long t128 = (long)((M + 127) / 128) * ((d + 127) / 128);
+        if (g_embed_split && tiles >= 128 && t128 >= 100 && t128 <= 128) {
+            // B = 32 x 10 s: 124 tiles of 128x128 -- four K quarters on 8-wave workgroups = 496 workgroups, two per CU, four
+            // waves per SIMD: 163 + 11 us (GEMM + reduction) against 180 + 9 us for two K halves on 64x128 tiles and 203 us unsplit
+            CHK(e->ffpart.ensure((size_t)4 * M * d * sizeof(float)));
+            launch_gemm_splitk(a, e->ffpart.as<float>(), 4, s);
+        } else if (g_embed_split && tiles >= 128 && wide >= 200 && wide <= 320) {
+            // about one 4-wave workgroup per CU: two K halves put two waves on every SIMD
             CHK(e->ffpart.ensure((size_t)2 * M * d * sizeof(float)));
             launch_gemm_splitk(a, e->ffpart.as<float>(), 2, s);
         } else if (tiles < 128) {              // few rows, K = 4864: split K so that ~256 workgroups share the weight stream

@@ -259,7 +259,8 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
         // the split doubles the waves per SIMD instead of the LDS traffic per MFMA
         // (four waves: as a 2 x 4 grid of eight waves, 32 x 32 per wave, this launch is slower -- 183.6 vs 177.4 us in one
         // kernel trace, tools/gemm_waves_trace.py -- the LDS reads per MFMA double)
-        if ((long)((a.M + 63) / 64) * ((a.N + 127) / 128) >= 200) launch_t<64, 128, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
+        if (a.nsplit >= 4 && (long)((a.M + 127) / 128) * ((a.N + 127) / 128) >= 100) launch_t<128, 128, 2, 4, A_PLAIN, EPI_SPLITK>(a, s);
+        else if ((long)((a.M + 63) / 64) * ((a.N + 127) / 128) >= 200) launch_t<64, 128, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
         else launch_t<64, 64, 2, 2, A_PLAIN, EPI_SPLITK>(a, s);
         return;
     }
