@@ -85,3 +85,29 @@ def test_reference_gains_equal_audio_segment_normalize():
     with pytest.raises(ValueError):                              # silence: gain above max_gain_db (audio.py:300-303)
         reference_gains(np.array([1e-38], np.float32), -20, max_gain_db=300.0)
     assert reference_gains(np.array([0.0], np.float32), -20)[0] == np.float32(10.) ** (np.float32(-20) / np.float32(20.))
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r02_bench_line.json -- the line `python bench.py` printed on the GPU box for the final build of the round --
+    carries every field of the driver's contract, and its numbers are consistent with each other"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = open(os.path.join(root, 'profiles', 'r02_bench_line.json')).read().strip().splitlines()[-1]
+    r = json.loads(line)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in r, key
+    assert r['n_gpus'] == 1 and r['higher_is_better'] is True and r['scaling'] == 'weak' and r['vs_baseline'] is None
+    assert r['dtype'] == 'f32' and 'synthetic' in r['data'] and 'workload' in r['config'] and 'model' not in r['config']
+    assert abs(r['value'] - 320.0 / (r['ms_per_step'] * 1e-3)) / r['value'] < 1e-3          # 32 x 10 s per step
+    rf = r['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in rf, key
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+    assert abs(rf['achieved'] - rf['flops_per_launch'] / (rf['avg_us'] * 1e-6) / 1e12) / rf['achieved'] < 1e-2
+    cb = r['cpu_baseline']
+    for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert key in cb, key
+    assert cb['kind'] in ('port', 'reference') and cb['cores'] >= 1
+    assert set(r['extra']) >= {'efficient_b256', 'stream128', 'squeezeformer_b64_beam'}
