@@ -494,6 +494,8 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True):
         from masr_amd.decoders.lm_scorer import write_synthetic_arpa
         d = tempfile.mkdtemp(prefix='masr_lm_')
         conf['language_model_path'] = write_synthetic_arpa(os.path.join(d, 'lm.arpa'), synthetic.synthetic_vocab(VOCAB), seed=5)
+    else:
+        conf['language_model_path'] = None           # explicit scorer-free search (not a reference configuration)
     pred = facade('squeezeformer', 'ctc_beam_search', local, streaming=False, beam_conf=conf)
     steps = 2
     pred.predict_batch(audio, batch_size=32)

@@ -140,6 +140,12 @@ const char* masr_lm_last_error(void);
 int masr_lm_info(const masr_lm* lm, int32_t* max_order, int64_t* n_ngrams, int32_t* char_based, int64_t* skipped);
 int masr_lm_cond_log_prob(const masr_lm* lm, const int32_t* ids, int32_t n, float* out);
 int masr_lm_sentence_log_prob(const masr_lm* lm, const int32_t* ids, int32_t n, float* out);
+/* Word-based models (an LM word longer than one character: Scorer::is_character_based() false, scorer.cpp load_lm): the words get
+ * their own ids -- masr_lm_word_id (-1: not an LM word; the two scoring calls above then take word ids) -- and the scorer owns the
+ * spelling dictionary of Scorer::fill_dictionary (every LM word spelled with vocabulary tokens + the space token);
+ * masr_lm_dict_size = the number of words in it (Scorer::get_dict_size, printed by beam_search_decoder.py:38-42). */
+int masr_lm_word_id(const masr_lm* lm, const char* word_utf8, int32_t* id);
+int masr_lm_dict_size(const masr_lm* lm, int32_t* dict_size);
 
 /* CTC prefix beam search.  Replaces BeamSearchDecoder.* -> paddlespeech_ctcdecoders
  * (masr/decoders/beam_search_decoder.py:45-96, swig_wrapper.py:35-121; third-party, un-vendored: parity
@@ -153,11 +159,20 @@ int masr_lm_sentence_log_prob(const masr_lm* lm, const int32_t* ids, int32_t n, 
 typedef struct masr_beam masr_beam;
 int masr_ctc_topk(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t top_n, float cutoff_prob,
                   int32_t* idx_dev, float* logp_dev, int32_t* count_dev, void* stream);
+/* the same + blank_logp_dev [M] = ln p(blank) of every frame: the input of the decoder's pruning rule when an external scorer is
+ * bound (ctc_beam_search_decoder.cpp: with a full beam, (prefix, c) is skipped once log p(c) + score(prefix) <
+ * min_cutoff = score(worst live prefix) + ln p(blank) - max(0, beta)).  The *_lm searches below take that array
+ * (blank_logp_*; NULL = rule off, every candidate of a frame is scored -- not what the reference decoder does). */
+int masr_ctc_topk_blank(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t top_n, float cutoff_prob,
+                        int32_t blank, int32_t* idx_dev, float* logp_dev, int32_t* count_dev, float* blank_logp_dev,
+                        void* stream);
 int masr_beam_create(int32_t beam_size, int32_t blank, masr_beam** out);
 void masr_beam_destroy(masr_beam* h);
 int masr_beam_reset(masr_beam* h);
 int masr_beam_advance(masr_beam* h, const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
                       int32_t T, int32_t K);
+int masr_beam_advance_lm(masr_beam* h, const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
+                         const float* blank_logp_host, int32_t T, int32_t K);
 int masr_beam_result(masr_beam* h, int32_t* tokens_host, int32_t max_len, int32_t* len, float* score);
 /* binds the external scorer (or NULL) and restarts the search: a prefix extended by a character adds
  * alpha * ln P_LM(character | last words of the prefix) + beta to its score (ctc_beam_search_decoder.cpp); the reported score is
@@ -170,7 +185,8 @@ int masr_beam_search_batch(const int32_t* idx_host, const float* logp_host, cons
 int masr_beam_search_batch_lm(const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
                               const int32_t* frames_host, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
                               int32_t blank, int32_t num_threads, const masr_lm* lm, float alpha, float beta,
-                              int32_t* tokens_host, int32_t max_len, int32_t* len_host, float* score_host);
+                              const float* blank_logp_host, int32_t* tokens_host, int32_t max_len, int32_t* len_host,
+                              float* score_host);
 
 /* CTC prefix beam search of a whole batch ON THE GPU (one workgroup per utterance; live prefixes, candidate scores and
  * the top-`beam_size` selection live in LDS, trie nodes of survivors in HBM).  Same inputs as masr_beam_search_batch but
@@ -186,8 +202,8 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
  * packed last words, matched context length and backoff weights in LDS) */
 int masr_beam_search_gpu_lm(masr_engine* e, const int32_t* idx_dev, const float* logp_dev, const int32_t* count_dev,
                             const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
-                            int32_t blank, masr_lm* lm, float alpha, float beta, int32_t* tokens_dev, int32_t max_len,
-                            int32_t* len_dev, float* score_dev, void* stream);
+                            int32_t blank, masr_lm* lm, float alpha, float beta, const float* blank_logp_dev,
+                            int32_t* tokens_dev, int32_t max_len, int32_t* len_dev, float* score_dev, void* stream);
 
 /* Streaming variant: a device-resident search per stream.  masr_gbeam_advance consumes the pruned candidates of the next T
  * frames (device arrays from masr_ctc_topk) and returns the best prefix so far (tokens/len/score device arrays); the
@@ -198,6 +214,9 @@ int masr_gbeam_open(masr_engine* e, int32_t beam_size, int32_t blank, int32_t ma
 int masr_gbeam_advance(masr_engine* e, int32_t handle, const int32_t* idx_dev, const float* logp_dev,
                        const int32_t* count_dev, int32_t T, int32_t K, int32_t* tokens_dev, int32_t max_len,
                        int32_t* len_dev, float* score_dev, void* stream);
+int masr_gbeam_advance_lm(masr_engine* e, int32_t handle, const int32_t* idx_dev, const float* logp_dev,
+                          const int32_t* count_dev, const float* blank_logp_dev, int32_t T, int32_t K, int32_t* tokens_dev,
+                          int32_t max_len, int32_t* len_dev, float* score_dev, void* stream);
 int masr_gbeam_reset(masr_engine* e, int32_t handle);
 int masr_gbeam_close(masr_engine* e, int32_t handle);
 /* external scorer of a streaming search (between utterances only: after open or reset) */

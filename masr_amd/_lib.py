@@ -41,27 +41,32 @@ SIGNATURES = {
     'masr_ctc_collapse': [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     'masr_argmax_rows': [_P, _P, _I, _I, _P, _P, _P],
     'masr_ctc_topk': [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
+    'masr_ctc_topk_blank': [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     'masr_beam_create': [_I, _I, C.POINTER(_P)],
     'masr_beam_destroy': [_P],
     'masr_beam_reset': [_P],
     'masr_beam_advance': [_P, _P, _P, _P, _I, _I],
+    'masr_beam_advance_lm': [_P, _P, _P, _P, _P, _I, _I],
     'masr_beam_result': [_P, _P, _I, C.POINTER(_I), C.POINTER(_F)],
     'masr_beam_search_batch': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     'masr_beam_search_gpu': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'masr_gbeam_open': [_P, _I, _I, _I, C.POINTER(_I)],
     'masr_gbeam_advance': [_P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P],
+    'masr_gbeam_advance_lm': [_P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P],
     'masr_gbeam_reset': [_P, _I],
     'masr_gbeam_close': [_P, _I],
     'masr_gbeam_set_lm': [_P, _I, _P, _F, _F],
     'masr_beam_set_lm': [_P, _P, _F, _F],
-    'masr_beam_search_batch_lm': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _F, _P, _I, _P, _P],
-    'masr_beam_search_gpu_lm': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _F, _F, _P, _I, _P, _P, _P],
+    'masr_beam_search_batch_lm': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _F, _P, _P, _I, _P, _P],
+    'masr_beam_search_gpu_lm': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _F, _F, _P, _P, _I, _P, _P, _P],
     'masr_lm_load_arpa': [C.c_char_p, C.POINTER(C.c_char_p), _I, C.POINTER(_P)],
     'masr_lm_destroy': [_P],
     'masr_lm_last_error': [],
     'masr_lm_info': [_P, C.POINTER(_I), C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(C.c_int64)],
     'masr_lm_cond_log_prob': [_P, C.POINTER(_I), _I, C.POINTER(_F)],
     'masr_lm_sentence_log_prob': [_P, C.POINTER(_I), _I, C.POINTER(_F)],
+    'masr_lm_word_id': [_P, C.c_char_p, C.POINTER(_I)],
+    'masr_lm_dict_size': [_P, C.POINTER(_I)],
     'masr_mean_square': [_P, _P, _I, _P, _I, _I, _P, _P],
     'masr_mfcc_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     'masr_linear_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _P],

@@ -20,6 +20,11 @@
 //      discards ~95 % of the entries; an exact 4-pass radix select over the survivors gives the threshold; ordered
 //      (deterministic) compaction.  Survivors that are new get trie nodes (parent pointer + character) appended to the
 //      utterance's node pool in HBM -- only survivors ever get a node.
+// With the external scorer bound the decoder's own pruning rule applies (ctc_beam_search_decoder.cpp: min_cutoff / full_beam):
+// when the beam is full, a pair (p, c) is skipped -- blank, repeat and extension terms alike -- once
+// log p(c) + score(p) < score(worst live prefix) + ln p(blank) - max(0, beta).  The reference walks the prefixes in descending
+// score order and breaks at the first one that fails; the test is monotone in score(p), so it is the same set of pairs.
+// Pairs that are cut cost no language-model lookups.
 // Entries with score -inf are never revived except through their parent's extension, which re-creates them, so dropping
 // them is equivalent to the pointer trie that keeps them.
 // The best prefix is read back by walking parent pointers.
@@ -155,7 +160,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     unsigned long long* lv_ctx = reinterpret_cast<unsigned long long*>(next + beam + (beam & 1));   // [2][beam] packed LM context
     float* lv_bo = reinterpret_cast<float*>(lv_ctx + 2 * beam);          // [2][beam][4] backoffs of the context's suffixes
     int* lv_m = reinterpret_cast<int*>(lv_bo + 8 * beam);                // [2][beam] m | oov << 8
-    int* c_idx = lv_m + 2 * beam;                                        // [BS_KMAX]; bit 30 set = unknown to the language model
+    // (the scorer's 14 words per live prefix exist only when a language model is bound: an LM-free beam 500 x 40 fits without them)
+    int* c_idx = a.use_lm ? lv_m + 2 * beam : reinterpret_cast<int*>(lv_ctx);   // [BS_KMAX]; bit 30 set = unknown to the language model
     float* c_lp = reinterpret_cast<float*>(c_idx + BS_KMAX);             // [BS_KMAX]
     int* hist = reinterpret_cast<int*>(c_lp + BS_KMAX);                  // [7][256]: one per radix pass of a step
     int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
@@ -204,10 +210,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     // candidates of the next frame are fetched one step ahead (registers of threads 0..K-1)
     const size_t row0 = (size_t)u * a.T_stride;
     int nx_cnt = 0, nx_c = 0;
-    float nx_lp = 0.f;
+    float nx_lp = 0.f, nx_blp = 0.f;
+    const bool cutting = use_lm && a.blank_lp != nullptr;       // the decoder's min_cutoff rule (needs ln p(blank) per frame)
     if (T > 0) {
         nx_cnt = min(a.ccount[row0], K);
         if (tid < K) { nx_c = a.cidx[row0 * K + tid]; nx_lp = a.clp[row0 * K + tid]; }
+        if (cutting && tid == 0) nx_blp = a.blank_lp[row0];
     }
     long long pc[6] = {0, 0, 0, 0, 0, 0};
     const bool prof = a.prof && u == 0 && tid == 0;
@@ -232,11 +240,16 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 c_idx[lane] = nx_c | (unk ? (1 << 30) : 0);
                 c_lp[lane] = nx_lp;
             }
-            if (lane == 0) misc[0] = bm ? __ffsll((long long)bm) - 1 : -1;
+            if (lane == 0) {
+                misc[0] = bm ? __ffsll((long long)bm) - 1 : -1;
+                misc[3] = (int)0xFFFFFFFFu;                  // min over the live prefixes' score keys (phase 1)
+                misc[4] = __float_as_int(nx_blp);
+            }
         }
         if (t + 1 < T) {
             nx_cnt = min(a.ccount[row0 + t + 1], K);
             if (tid < K) { nx_c = a.cidx[(row0 + t + 1) * K + tid]; nx_lp = a.clp[(row0 + t + 1) * K + tid]; }
+            if (cutting && tid == 0) nx_blp = a.blank_lp[row0 + t + 1];
         }
         __syncthreads();
         // ---- 1. live children lists; blank term ------------------------------------------------------------------
@@ -246,10 +259,24 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
             while (atomicCAS(&hkey[h], 0ull, key) != 0ull) h = (h + 1) & (BS_HASH - 1);
             hval[h] = tid;
-            bcur[tid] = blank_k >= 0 ? c_lp[blank_k] + lv_sc[o + tid] : -INFINITY;
+        }
+        const bool full_beam = cutting && n == beam;
+        if (full_beam && tid < ((n + 63) & ~63)) {      // score of the worst live prefix: wave minimum, one LDS atomic per wave
+            unsigned k = tid < n ? okey(lv_sc[o + tid]) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) k = min(k, (unsigned)__shfl_xor((int)k, off, 64));
+            if (lane == 0) atomicMin(reinterpret_cast<unsigned*>(&misc[3]), k);
         }
         __syncthreads();
+        // min_cutoff in the host search's arithmetic (double, rounded once)
+        const float min_cut = full_beam ? (float)((double)ikey((unsigned)misc[3]) + (double)__int_as_float(misc[4]) -
+                                                  fmax(0.0, (double)a.beta))
+                                        : -INFINITY;
         if (tid < n) {                                  // is my parent prefix live?  then I am on its children list
+            {
+                const float lpb = blank_k >= 0 ? c_lp[blank_k] : -INFINITY, scb = lv_sc[o + tid];
+                bcur[tid] = blank_k >= 0 && !(lpb + scb < min_cut) ? lpb + scb : -INFINITY;
+            }
             const unsigned long long key = lv_phid[o + tid];
             unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
             int par = -1;
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 const int c = craw & ~(1 << 30);
                 const float lp = c_lp[k];
                 float val = -INFINITY;
-                if (c != a.blank) {
+                if (c != a.blank && !(lp + sc < min_cut)) {
                     if (c == ch) {
                         rep[my_p] = lp + pnb;                       // only this k repeats the last character of p
                         val = pb > -INFINITY ? lp + pb : -INFINITY;
@@ -521,8 +548,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     }
 }
 
-size_t beam_gpu_lds_bytes(int beam, int K) {
-    return (size_t)beam * K * 6 + (size_t)(26 + 14) * beam * 4 + 8 + BS_HASH * 12 + 2 * BS_KMAX * 4 + 7 * 256 * 4 + (6 + 32) * BS_WAVES * 4 + 8 * 4 + 128;
+size_t beam_gpu_lds_bytes(int beam, int K, bool use_lm) {
+    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 14 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 2 * BS_KMAX * 4 + 7 * 256 * 4 +
+           (6 + 32) * BS_WAVES * 4 + 8 * 4 + 128;
 }
 
 template <int NPT>
@@ -536,7 +564,7 @@ static void launch_beam_t(const BeamGpuArgs& a, int B, size_t lds, hipStream_t s
 int launch_beam_search(const BeamGpuArgs& a, int B, hipStream_t s) {
     if (B <= 0) return 0;
     if (a.K > BS_KMAX || a.beam > 512 || a.beam < 1 || a.pool_cap > (1 << 30)) return 1;
-    const size_t lds = beam_gpu_lds_bytes(a.beam, a.K);
+    const size_t lds = beam_gpu_lds_bytes(a.beam, a.K, a.use_lm != 0);
     if (lds > 160 * 1024) return 1;
     const int per = (a.beam * a.K + BS_THREADS - 1) / BS_THREADS;
     if (per <= 4) launch_beam_t<4>(a, B, lds, s);

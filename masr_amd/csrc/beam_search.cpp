@@ -22,6 +22,13 @@
 
 namespace masr {
 LmView lm_host_view(const masr_lm* lm);       // lm_scorer.cpp
+bool lm_word_based(const masr_lm* lm);
+int lm_space_id(const masr_lm* lm);
+int lm_dict_next(const masr_lm* lm, int state, int token);
+bool lm_dict_final(const masr_lm* lm, int state);
+int lm_dict_word(const masr_lm* lm, int state);
+float lm_cond_words(const LmView& v, const int* ctx, int n_ctx, int w);
+float lm_sentence_words(const LmView& v, const int* ids, int n);
 }
 using masr::LmState;
 using masr::LmView;
@@ -42,7 +49,11 @@ struct Node {
     int ch = -1;          // character of this node (-1 = root)
     int parent = -1;
     bool exists = true;
-    LmState lm{};         // external scorer state of this prefix (its last words; lm_scorer.h)
+    LmState lm{};         // character-based scorer: state of this prefix (its last words; lm_scorer.h)
+    // word-based scorer: state of the spelling dictionary after this prefix (PathTrie::dictionary_state_) and the ids of the
+    // complete words before the one being spelled, most recent first (what Scorer::make_ngram walks the trie for)
+    int dstate = 0;
+    int wctx[4] = {0, 0, 0, 0};
     std::vector<std::pair<int, int>> kids;   // (character, node index)
 };
 
@@ -54,12 +65,19 @@ struct Beam {
     const masr_lm* lm = nullptr;
     LmView view{};
     float alpha = 0.f, beta = 0.f;
+    bool word_based = false;
+    int space_id = -2;
 
     void set_lm(const masr_lm* m, float a, float b) {
         lm = m;
         alpha = a;
         beta = b;
-        if (lm) view = masr::lm_host_view(lm);
+        word_based = false;
+        if (lm) {
+            view = masr::lm_host_view(lm);
+            word_based = masr::lm_word_based(lm);
+            space_id = masr::lm_space_id(lm);
+        }
     }
 
     void reset() {
@@ -67,11 +85,16 @@ struct Beam {
         pool.emplace_back();
         pool[0].score = 0.f;
         pool[0].b_prev = 0.f;
-        if (lm) pool[0].lm = masr::lm_state_of(view, masr::lm_root_ctx(view));
+        if (lm && !word_based) pool[0].lm = masr::lm_state_of(view, masr::lm_root_ctx(view));
+        if (lm && word_based)
+            for (int j = 0; j < 4; ++j) pool[0].wctx[j] = view.bos;
         prefixes.assign(1, 0);
     }
 
-    int child(int n, int c) {                // PathTrie::get_path_trie(new_char): find or create
+    // PathTrie::get_path_trie(new_char): find (reviving a dead node) or create; -1 when a word-based scorer's dictionary has no
+    // such continuation -- and if the prefix just completed a word, THAT failed attempt moves it to the dictionary's start (the
+    // published code's `if (is_final && reset) dictionary_state_ = dictionary_->Start()`): the next attempt starts a new word
+    int child(int n, int c) {
         for (auto& kv : pool[n].kids)
             if (kv.first == c) {
                 Node& k = pool[kv.second];
@@ -84,11 +107,42 @@ struct Beam {
         Node k;
         k.ch = c;
         k.parent = n;
-        if (lm) k.lm = masr::lm_state_of(view, masr::lm_push(pool[n].lm.ctx, c));
+        if (lm && !word_based) k.lm = masr::lm_state_of(view, masr::lm_push(pool[n].lm.ctx, c));
+        if (lm && word_based) {
+            const int nx = masr::lm_dict_next(lm, pool[n].dstate, c);
+            if (nx < 0) {
+                if (masr::lm_dict_final(lm, pool[n].dstate)) pool[n].dstate = 0;
+                return -1;
+            }
+            k.dstate = nx;
+            for (int j = 0; j < 4; ++j) k.wctx[j] = pool[n].wctx[j];
+            if (c == space_id) {             // the word spelled up to n is complete: it joins the context of what follows
+                for (int j = 3; j > 0; --j) k.wctx[j] = k.wctx[j - 1];
+                k.wctx[0] = word_of(n);
+            }
+        }
         pool.push_back(k);
         const int id = (int)pool.size() - 1;
         pool[n].kids.emplace_back(c, id);
         return id;
+    }
+
+    // id of the LM word that the characters since the last space spell (-1: none, e.g. an unfinished word).  The dictionary state
+    // cannot be used after the start-over quirk above, so the trie is walked like Scorer::make_ngram does
+    int word_of(int n) const {
+        std::vector<int> rev;
+        while (n > 0 && pool[n].ch != space_id) {
+            rev.push_back(pool[n].ch);
+            n = pool[n].parent;
+        }
+        int st = 0;
+        for (size_t i = rev.size(); i-- > 0 && st >= 0;) st = masr::lm_dict_next(lm, st, rev[i]);
+        return st > 0 ? masr::lm_dict_word(lm, st) : -1;
+    }
+
+    // word-based: alpha * ln P_LM(word ending at n | the words before it) + beta  (make_ngram(prefix) + get_log_cond_prob)
+    float word_score(int n) const {
+        return alpha * masr::lm_cond_words(view, pool[n].wctx, view.max_order - 1, word_of(n)) + beta;
     }
 
     void collect(int n, std::vector<int>& out) {   // PathTrie::iterate_to_vec
@@ -123,14 +177,26 @@ struct Beam {
         return x.score > y.score;
     }
 
-    // one time step: cand = (index, log prob) pairs in descending probability order
-    void step(const int32_t* idx, const float* logp, int count) {
+    // one time step: cand = (index, log prob) pairs in descending probability order.  `blank_lp` = ln p(blank) of the frame, the
+    // input of the decoder's pruning rule (NaN: rule off): with a scorer bound and a full beam, (prefix, c) -- and every prefix
+    // behind it in score order -- is skipped once log p(c) + score(prefix) < score(worst live prefix) + ln p(blank) - max(0, beta)
+    void step(const int32_t* idx, const float* logp, int count, float blank_lp) {
         const size_t live = std::min(prefixes.size(), (size_t)beam_size);
+        float min_cutoff = NEG_INF;
+        bool full_beam = false;
+        if (lm) {
+            std::sort(prefixes.begin(), prefixes.begin() + live, [this](int a, int b) { return better(a, b); });
+            if (blank_lp == blank_lp) {
+                min_cutoff = (float)((double)pool[prefixes[live - 1]].score + (double)blank_lp - std::max(0.0, (double)beta));
+                full_beam = (int)live == beam_size;
+            }
+        }
         for (int k = 0; k < count; ++k) {
             const int c = idx[k];
             const float lp = logp[k];
             for (size_t i = 0; i < live; ++i) {
                 const int p = prefixes[i];
+                if (full_beam && lp + pool[p].score < min_cutoff) break;
                 if (c == blank) {
                     pool[p].b_cur = log_sum_exp(pool[p].b_cur, lp + pool[p].score);
                     continue;
@@ -141,8 +207,10 @@ struct Beam {
                 float add = NEG_INF;
                 if (c == pc && pb > NEG_INF) add = lp + pb;
                 else if (c != pc) add = lp + pscore;
-                if (lm && add > NEG_INF) add += alpha * masr::lm_cond(view, pool[p].lm, c) + beta;
+                if (lm && !word_based && add > NEG_INF) add += alpha * masr::lm_cond(view, pool[p].lm, c) + beta;
                 const int q = child(p, c);          // may reallocate the pool: no references held across it
+                if (q < 0) continue;                // the dictionary of a word-based scorer has no such continuation
+                if (lm && word_based && c == space_id && add > NEG_INF) add += word_score(p);
                 pool[q].nb_cur = log_sum_exp(pool[q].nb_cur, add);
             }
         }
@@ -159,9 +227,21 @@ struct Beam {
     // best hypothesis so far: token ids (root -> leaf) and its log probability
     int best(int32_t* tokens, int max_len, float* score) {
         const size_t live = std::min(prefixes.size(), (size_t)beam_size);
-        std::sort(prefixes.begin(), prefixes.begin() + live, [this](int a, int b) { return better(a, b); });
-        int n = prefixes[0];
-        *score = pool[n].score;
+        // a word-based scorer also scores the unfinished last word of every prefix (end of ctc_beam_search_decoder); done on a
+        // copy of the scores so that a streaming search can be asked for its best prefix between chunks
+        std::vector<float> final_score(live);
+        for (size_t i = 0; i < live; ++i) {
+            const int n = prefixes[i];
+            final_score[i] = pool[n].score;
+            if (lm && word_based && n > 0 && pool[n].ch != space_id) final_score[i] += word_score(n);
+        }
+        size_t bi = 0;
+        for (size_t i = 1; i < live; ++i) {
+            const Node &x = pool[prefixes[i]], &y = pool[prefixes[bi]];
+            if (final_score[i] > final_score[bi] || (final_score[i] == final_score[bi] && x.ch < y.ch)) bi = i;
+        }
+        int n = prefixes[bi];
+        *score = final_score[bi];
         std::vector<int> rev;
         while (n > 0) {
             rev.push_back(pool[n].ch);
@@ -173,12 +253,34 @@ struct Beam {
             // approx_ctc: the scorer's share is taken out of the reported score again -- |prefix| * beta and
             // alpha * ln P_LM(sentence), the sentence probability counting </s> too (Scorer::get_sent_log_prob)
             const int L = (int)rev.size();
-            unsigned long long ctx = masr::lm_root_ctx(view);
-            float sent = L == 0 ? masr::lm_cond(view, masr::lm_state_of(view, ctx), view.bos) : 0.f;
-            for (int i = 0; i <= L; ++i) {
-                const int w = i < L ? rev[L - 1 - i] : view.eos;
-                sent += masr::lm_cond(view, masr::lm_state_of(view, ctx), w);
-                ctx = masr::lm_push(ctx, w);
+            float sent = 0.f;
+            if (!word_based) {
+                unsigned long long ctx = masr::lm_root_ctx(view);
+                sent = L == 0 ? masr::lm_cond(view, masr::lm_state_of(view, ctx), view.bos) : 0.f;
+                for (int i = 0; i <= L; ++i) {
+                    const int w = i < L ? rev[L - 1 - i] : view.eos;
+                    sent += masr::lm_cond(view, masr::lm_state_of(view, ctx), w);
+                    ctx = masr::lm_push(ctx, w);
+                }
+            } else {
+                // Scorer::split_labels: the space-separated words of the transcript
+                std::vector<int> words;
+                if (L > 0) {
+                    int st = 0;
+                    bool bad = false;
+                    for (int i = L - 1; i >= -1; --i) {
+                        const int c = i >= 0 ? rev[i] : space_id;
+                        if (c == space_id) {
+                            words.push_back(!bad && st > 0 ? masr::lm_dict_word(lm, st) : -1);
+                            st = 0;
+                            bad = false;
+                        } else if (!bad) {
+                            st = masr::lm_dict_next(lm, st, c);
+                            if (st < 0) bad = true;
+                        }
+                    }
+                }
+                sent = masr::lm_sentence_words(view, words.data(), (int)words.size());
             }
             *score = *score - (float)L * beta - alpha * sent;
         }
@@ -221,8 +323,15 @@ int masr_beam_reset(masr_beam* h) {
 
 int masr_beam_advance(masr_beam* h, const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
                       int32_t T, int32_t K) {
+    return masr_beam_advance_lm(h, idx_host, logp_host, count_host, nullptr, T, K);
+}
+
+int masr_beam_advance_lm(masr_beam* h, const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
+                         const float* blank_logp_host, int32_t T, int32_t K) {
     if (!h || !idx_host || !logp_host || !count_host) return 1;
-    for (int t = 0; t < T; ++t) h->b.step(idx_host + (size_t)t * K, logp_host + (size_t)t * K, std::min(count_host[t], K));
+    for (int t = 0; t < T; ++t)
+        h->b.step(idx_host + (size_t)t * K, logp_host + (size_t)t * K, std::min(count_host[t], K),
+                  blank_logp_host ? blank_logp_host[t] : NAN);
     return 0;
 }
 
@@ -237,13 +346,14 @@ int masr_beam_search_batch(const int32_t* idx_host, const float* logp_host, cons
                            int32_t blank, int32_t num_threads, int32_t* tokens_host, int32_t max_len, int32_t* len_host,
                            float* score_host) {
     return masr_beam_search_batch_lm(idx_host, logp_host, count_host, frames_host, B, T_stride, K, beam_size, blank, num_threads,
-                                     nullptr, 0.f, 0.f, tokens_host, max_len, len_host, score_host);
+                                     nullptr, 0.f, 0.f, nullptr, tokens_host, max_len, len_host, score_host);
 }
 
 int masr_beam_search_batch_lm(const int32_t* idx_host, const float* logp_host, const int32_t* count_host,
                               const int32_t* frames_host, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size,
                               int32_t blank, int32_t num_threads, const masr_lm* lm, float alpha, float beta,
-                              int32_t* tokens_host, int32_t max_len, int32_t* len_host, float* score_host) {
+                              const float* blank_logp_host, int32_t* tokens_host, int32_t max_len, int32_t* len_host,
+                              float* score_host) {
     if (B <= 0) return 0;
     if (num_threads <= 0) num_threads = 1;
     num_threads = std::min(num_threads, B);
@@ -257,7 +367,8 @@ int masr_beam_search_batch_lm(const int32_t* idx_host, const float* logp_host, c
             const size_t base = (size_t)b * T_stride;
             const int T = std::min(frames_host[b], T_stride);
             for (int t = 0; t < T; ++t)
-                bm.step(idx_host + (base + t) * K, logp_host + (base + t) * K, std::min(count_host[base + t], K));
+                bm.step(idx_host + (base + t) * K, logp_host + (base + t) * K, std::min(count_host[base + t], K),
+                        blank_logp_host ? blank_logp_host[base + t] : NAN);
             len_host[b] = bm.best(tokens_host + (size_t)b * max_len, max_len, score_host + b);
         }
     };

@@ -114,7 +114,7 @@ void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs
 void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank,
                          int* tokens, int* ntok, float* score, hipStream_t s);
 void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff_prob, int* out_idx, float* out_logp,
-                       int* out_cnt, hipStream_t s);
+                       int* out_cnt, int blank, float* out_blank_lp, hipStream_t s);
 void launch_argmax_rows(const float* probs, int M, int V, int* idx, float* maxp, hipStream_t s);
 void launch_frame_counts(const int* nsamp, int B, int* nfr, int* nenc, int halve, hipStream_t s);
 void launch_export_att(const float* cache, float* out, int L, int H, int cap, int t, int dk, hipStream_t s, int rate = 1,
@@ -218,6 +218,7 @@ struct BeamGpuArgs {
     const int* cidx;       // [B * T_stride, K]
     const float* clp;      // [B * T_stride, K]
     const int* ccount;     // [B * T_stride]
+    const float* blank_lp; // [B * T_stride] ln p(blank) of every frame: input of the decoder's min_cutoff rule (nullptr: rule off)
     const int* frames;     // [B] frames to consume per utterance (nullptr: T_stride)
     int T_stride, K, beam, blank, max_len;
     int* pool_parent;      // [B][pool_cap]
@@ -243,7 +244,7 @@ inline void beam_state_carve(void* base, int B, int beam, unsigned long long** h
     *i = reinterpret_cast<int*>(*h + (size_t)B * 3 * beam);                 // [B][2 + 3 * beam]
     *f = reinterpret_cast<float*>(*i + (size_t)B * (2 + 3 * (size_t)beam)); // [B][7 * beam]
 }
-size_t beam_gpu_lds_bytes(int beam, int K);
+size_t beam_gpu_lds_bytes(int beam, int K, bool use_lm);
 int launch_beam_search(const BeamGpuArgs& a, int B, hipStream_t s);   // 1: sizes not supported
 
 // ---- DeepSpeech2 (lstm.hip) --------------------------------------------------------------------

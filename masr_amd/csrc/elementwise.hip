@@ -563,10 +563,13 @@ void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hi
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void topk_prune_kernel(const float* __restrict__ probs, int V, int top_n,
                                                          float cutoff_prob, int* __restrict__ out_idx,
-                                                         float* __restrict__ out_logp, int* __restrict__ out_cnt) {
+                                                         float* __restrict__ out_logp, int* __restrict__ out_cnt, int blank,
+                                                         float* __restrict__ out_blank_lp) {
     __shared__ float red_v[4];
     __shared__ int red_i[4];
     const float* x = probs + (size_t)blockIdx.x * V;
+    // ln p(blank) of the frame as the decoder's min_cutoff rule takes it (std::log(prob[blank_id]), no FLT_MIN added)
+    if (out_blank_lp && threadIdx.x == 0) out_blank_lp[blockIdx.x] = logf(x[blank]);
     float v[SM_MAXPT];
 #pragma unroll
     for (int i = 0; i < SM_MAXPT; ++i) {
@@ -614,9 +617,10 @@ __global__ __launch_bounds__(256) void topk_prune_kernel(const float* __restrict
 }
 
 void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff_prob, int* out_idx, float* out_logp,
-                       int* out_cnt, hipStream_t s) {
+                       int* out_cnt, int blank, float* out_blank_lp, hipStream_t s) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(topk_prune_kernel, dim3(M), dim3(256), 0, s, probs, V, top_n, cutoff_prob, out_idx, out_logp, out_cnt);
+    hipLaunchKernelGGL(topk_prune_kernel, dim3(M), dim3(256), 0, s, probs, V, top_n, cutoff_prob, out_idx, out_logp, out_cnt,
+                       blank, out_blank_lp);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 using namespace masr;
 namespace masr {
 int lm_device_view(masr_lm* lm, LmView* out);      // lm_scorer.cpp: the LM table in the memory of the current device
+bool lm_word_based(const masr_lm* lm);
 }
 extern "C" const char* masr_lm_last_error(void);
 
@@ -1438,7 +1439,21 @@ int masr_ctc_topk(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, 
     ENTER(e);
     if (V > 8192) return fail("V > 8192 not supported");
     if (top_n <= 0) return fail("top_n must be positive");
-    launch_topk_prune(probs_dev, M, V, top_n, cutoff_prob, idx_dev, logp_dev, count_dev, (hipStream_t)stream);
+    launch_topk_prune(probs_dev, M, V, top_n, cutoff_prob, idx_dev, logp_dev, count_dev, -1, nullptr, (hipStream_t)stream);
+    LAUNCHCHK();
+    return 0;
+}
+
+int masr_ctc_topk_blank(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, int32_t top_n, float cutoff_prob,
+                        int32_t blank, int32_t* idx_dev, float* logp_dev, int32_t* count_dev, float* blank_logp_dev,
+                        void* stream) {
+    if (!e) return fail("null engine");
+    ENTER(e);
+    if (V > 8192) return fail("V > 8192 not supported");
+    if (top_n <= 0) return fail("top_n must be positive");
+    if (blank < 0 || blank >= V || !blank_logp_dev) return fail("masr_ctc_topk_blank: blank id out of range or null output");
+    launch_topk_prune(probs_dev, M, V, top_n, cutoff_prob, idx_dev, logp_dev, count_dev, blank, blank_logp_dev,
+                      (hipStream_t)stream);
     LAUNCHCHK();
     return 0;
 }
@@ -1457,22 +1472,26 @@ int masr_beam_search_gpu(masr_engine* e, const int32_t* idx_dev, const float* lo
                          const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size, int32_t blank,
                          int32_t* tokens_dev, int32_t max_len, int32_t* len_dev, float* score_dev, void* stream) {
     return masr_beam_search_gpu_lm(e, idx_dev, logp_dev, count_dev, frames_dev, B, T_stride, K, beam_size, blank, nullptr, 0.f,
-                                   0.f, tokens_dev, max_len, len_dev, score_dev, stream);
+                                   0.f, nullptr, tokens_dev, max_len, len_dev, score_dev, stream);
 }
 
 int masr_beam_search_gpu_lm(masr_engine* e, const int32_t* idx_dev, const float* logp_dev, const int32_t* count_dev,
                             const int32_t* frames_dev, int32_t B, int32_t T_stride, int32_t K, int32_t beam_size, int32_t blank,
-                            masr_lm* lm, float alpha, float beta, int32_t* tokens_dev, int32_t max_len, int32_t* len_dev,
-                            float* score_dev, void* stream) {
+                            masr_lm* lm, float alpha, float beta, const float* blank_logp_dev, int32_t* tokens_dev,
+                            int32_t max_len, int32_t* len_dev, float* score_dev, void* stream) {
     if (!e) return fail("null engine");
     ENTER(e);
     if (B <= 0 || T_stride <= 0) return fail("empty batch");
     if (e->cfg.vocab_size > 8192 && e->finalized) return fail("vocab_size > 8192 not supported");
     BeamGpuArgs a{};
     a.cidx = idx_dev; a.clp = logp_dev; a.ccount = count_dev; a.frames = frames_dev;
+    a.blank_lp = lm ? blank_logp_dev : nullptr;
     a.T_stride = T_stride; a.K = K; a.beam = beam_size; a.blank = blank; a.max_len = max_len;
     a.pool_cap = T_stride * beam_size + 1;
-    if (K > 64 || beam_size > 512 || beam_size < 1 || beam_gpu_lds_bytes(beam_size, K) > 160 * 1024)
+    if (lm && lm_word_based(lm))
+        return fail("word-based language models are searched on host threads (masr_beam_search_batch_lm): the spelling "
+                    "dictionary is not in the GPU kernel");
+    if (K > 64 || beam_size > 512 || beam_size < 1 || beam_gpu_lds_bytes(beam_size, K, lm != nullptr) > 160 * 1024)
         return fail("beam search on the GPU needs cutoff_top_n <= 64, beam_size <= 512 and beam_size*cutoff_top_n*4 B + tables "
                     "within 160 KB of LDS; use masr_beam_search_batch (host threads) beyond that");
     CHK(e->beam_pool.ensure((size_t)B * a.pool_cap * 2 * sizeof(int)));
@@ -1534,6 +1553,7 @@ int masr_gbeam_set_lm(masr_engine* e, int32_t handle, masr_lm* lm, float alpha, 
     GBeam* g;
     CHK(gbeam_of(e, handle, &g));
     if (g->started) return fail("the language model of a stream can only change between utterances (after masr_gbeam_reset)");
+    if (lm && lm_word_based(lm)) return fail("word-based language models are searched on host threads (masr_beam_*)");
     g->lm = lm;
     g->alpha = alpha;
     g->beta = beta;
@@ -1561,12 +1581,21 @@ int masr_gbeam_close(masr_engine* e, int32_t handle) {
 int masr_gbeam_advance(masr_engine* e, int32_t handle, const int32_t* idx_dev, const float* logp_dev,
                        const int32_t* count_dev, int32_t T, int32_t K, int32_t* tokens_dev, int32_t max_len,
                        int32_t* len_dev, float* score_dev, void* stream) {
+    return masr_gbeam_advance_lm(e, handle, idx_dev, logp_dev, count_dev, nullptr, T, K, tokens_dev, max_len, len_dev, score_dev,
+                                 stream);
+}
+
+int masr_gbeam_advance_lm(masr_engine* e, int32_t handle, const int32_t* idx_dev, const float* logp_dev,
+                          const int32_t* count_dev, const float* blank_logp_dev, int32_t T, int32_t K, int32_t* tokens_dev,
+                          int32_t max_len, int32_t* len_dev, float* score_dev, void* stream) {
     GBeam* g;
     CHK(gbeam_of(e, handle, &g));
     ENTER(e);
-    if (T < 0 || K > 64 || beam_gpu_lds_bytes(g->beam, K) > 160 * 1024) return fail("unsupported chunk / cutoff_top_n");
+    if (T < 0 || K > 64 || beam_gpu_lds_bytes(g->beam, K, g->lm != nullptr) > 160 * 1024)
+        return fail("unsupported chunk / cutoff_top_n");
     BeamGpuArgs a{};
     a.cidx = idx_dev; a.clp = logp_dev; a.ccount = count_dev; a.frames = nullptr;
+    a.blank_lp = g->lm ? blank_logp_dev : nullptr;
     a.T_stride = T; a.K = K; a.beam = g->beam; a.blank = g->blank; a.max_len = max_len;
     gbeam_args(*g, a);
     CHK(bind_lm(a, g->lm, g->alpha, g->beta));

@@ -6,11 +6,17 @@ on the GPU (masr_ctc_topk) and so does the CTC prefix beam search of whole utter
 between decode_chunk calls); sizes beyond the kernel's limits use the host-thread search inside libmasr_hip.so
 (masr_beam_*).
 
-External scorer (alpha, beta): ``language_model_path`` is read as a character-based ARPA n-gram model (decoders/lm_scorer.py;
-KenLM's binary .klm format is not parsed -> an error that says so) and applied inside the search, on the GPU table or the
-host table: a prefix extended by a character adds alpha * ln P_LM + beta; the returned score is the decoder's approx_ctc.
-When the file does not exist (the reference would download 2.8 GB, beam_search_decoder.py:19-28 -- there is no network
-here) the decoder logs a warning and searches with the acoustic scores only (alpha = beta = 0)."""
+External scorer (alpha, beta): ``language_model_path`` is read as an ARPA n-gram model (decoders/lm_scorer.py; KenLM's binary
+.klm format is not parsed -> an error that says so).  Character-based models (every LM word one character, the reference's
+Mandarin models) are applied inside the search on the GPU table or the host table: a prefix extended by a character adds
+alpha * ln P_LM + beta.  Word-based models (an LM word longer than one character, the English configurations): the scorer owns
+the spelling dictionary, a word is scored when its space arrives and the unfinished last word at the end of the utterance;
+that search runs on host threads.  With a scorer bound the decoder's min_cutoff / full_beam pruning applies (ln p(blank) of
+every frame comes out of the pruning kernel).  The returned score is the decoder's approx_ctc.
+
+A missing language model file: the reference downloads its default model and otherwise ASSERTS
+(beam_search_decoder.py:19-28) -- there is no network here, so the assertion is what a caller sees.  The scorer-free search
+(alpha = beta = 0, no pruning rule) is still available, but only when asked for: ``language_model_path=None``."""
 import ctypes as C
 import logging
 
@@ -39,18 +45,20 @@ class BeamSearchDecoder:
         self.last_tokens = []            # token ids of the last decode_chunk result
         self._lib = _lib.lib()
         self._ext_scorer = None
-        if alpha or beta:
+        self.prune_min_cutoff = True     # the decoder's min_cutoff / full_beam rule (only ever applies with a scorer bound)
+        if language_model_path is None:
+            # explicit scorer-free mode (not a reference configuration: its decoder always owns a Scorer)
+            logger.info('masr_amd BeamSearchDecoder: language_model_path=None, searching with the acoustic CTC scores only')
+            self.alpha = self.beta = 0
+        else:
             import os
-            if language_model_path and os.path.exists(language_model_path):
-                from masr_amd.decoders.lm_scorer import LanguageModel
-                self._ext_scorer = LanguageModel(language_model_path, vocab_list)
-                logger.info(f'language model: model path = {language_model_path}, is_character_based = '
-                            f'{self._ext_scorer.is_character_based}, max_order = {self._ext_scorer.get_max_order()}, '
-                            f'dict_size = {self._ext_scorer.get_dict_size()}')
-            else:
-                logger.warning(f'masr_amd BeamSearchDecoder: language model {language_model_path} not found (nothing can be '
-                               f'downloaded here); decoding with the acoustic CTC scores only (alpha = beta = 0)')
-                self.alpha = self.beta = 0
+            # beam_search_decoder.py:28 (the download of the default model that precedes it needs a network)
+            assert os.path.exists(language_model_path), f'语言模型不存在：{language_model_path}'
+            from masr_amd.decoders.lm_scorer import LanguageModel
+            self._ext_scorer = LanguageModel(language_model_path, vocab_list)
+            logger.info(f'language model: model path = {language_model_path}, is_character_based = '
+                        f'{self._ext_scorer.is_character_based}, max_order = {self._ext_scorer.get_max_order()}, '
+                        f'dict_size = {self._ext_scorer.get_dict_size()}')
         h = C.c_void_p()
         if self._lib.masr_beam_create(self.beam_size, self.blank_id, C.byref(h)) != 0:
             raise _lib.MasrError('masr_beam_create failed')
@@ -97,7 +105,8 @@ class BeamSearchDecoder:
 
     # ---- GPU: per-frame candidate pruning ----------------------------------------------------------
     def _candidates(self, probs, to_host=True):
-        """probs np/torch [M, V] -> idx [M,K] int32, logp [M,K] f32, count [M] int32 (host arrays, or device tensors)."""
+        """probs np/torch [M, V] -> idx [M,K] int32, logp [M,K] f32, count [M] int32, blank_lp [M] f32 or None, K (host arrays,
+        or device tensors).  blank_lp = ln p(blank) per frame, produced when a scorer is bound (the pruning rule's input)."""
         eng = runtime.aux_engine()
         p = torch.as_tensor(np.asarray(probs) if not torch.is_tensor(probs) else probs, dtype=torch.float32)
         p = p.to(eng.device).contiguous()
@@ -106,20 +115,41 @@ class BeamSearchDecoder:
         idx = torch.zeros(M, K, dtype=torch.int32, device=eng.device)
         logp = torch.zeros(M, K, dtype=torch.float32, device=eng.device)
         cnt = torch.zeros(M, dtype=torch.int32, device=eng.device)
+        blp = None
+        if self._ext_scorer is not None and self.prune_min_cutoff:
+            blp = torch.zeros(max(M, 1), dtype=torch.float32, device=eng.device)
         if M:
-            check(self._lib.masr_ctc_topk(eng.h, C.c_void_p(p.data_ptr()), M, V, K, C.c_float(self.cutoff_prob),
-                                          C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
-                                          C.c_void_p(cnt.data_ptr()),
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if blp is None:
+                check(self._lib.masr_ctc_topk(eng.h, C.c_void_p(p.data_ptr()), M, V, K, C.c_float(self.cutoff_prob),
+                                              C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                              C.c_void_p(cnt.data_ptr()), stream))
+            else:
+                check(self._lib.masr_ctc_topk_blank(eng.h, C.c_void_p(p.data_ptr()), M, V, K, C.c_float(self.cutoff_prob),
+                                                    self.blank_id, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                                    C.c_void_p(cnt.data_ptr()), C.c_void_p(blp.data_ptr()), stream))
         if not to_host:
-            return idx, logp, cnt, K
-        return idx.cpu().numpy(), logp.cpu().numpy(), cnt.cpu().numpy(), K
+            return idx, logp, cnt, blp, K
+        return idx.cpu().numpy(), logp.cpu().numpy(), cnt.cpu().numpy(), None if blp is None else blp.cpu().numpy(), K
+
+    @staticmethod
+    def _ptr(x):
+        """device tensor / host array / None -> void* for the C ABI"""
+        if x is None:
+            return C.c_void_p(0)
+        return C.c_void_p(x.data_ptr()) if torch.is_tensor(x) else x.ctypes.data_as(C.c_void_p)
 
     def gpu_search_supported(self, T, V):
-        """limits of masr_beam_search_gpu (include/masr_hip.h): LDS-resident entry table and 32-bit trie keys."""
+        """limits of masr_beam_search_gpu (include/masr_hip.h): LDS-resident entry table and 32-bit trie keys; word-based
+        scorers (spelling dictionary) are searched on host threads."""
         K = min(self.cutoff_top_n, V)
-        # beam_gpu_lds_bytes (beam_gpu.hip): extension keys + survivor list, 40 words of live-prefix state, fixed tables
-        return K <= 64 and 2 <= self.beam_size <= 512 and self.beam_size * K * 6 + 160 * self.beam_size + 22568 <= 160 * 1024
+        lm = self._ext_scorer is not None
+        if lm and not self._ext_scorer.is_character_based:
+            return False
+        # beam_gpu_lds_bytes (beam_gpu.hip): extension keys + survivor list, 26 (+ 14 with a scorer) words of live-prefix state,
+        # fixed tables
+        return (K <= 64 and 2 <= self.beam_size <= 512 and
+                self.beam_size * K * 6 + (160 if lm else 104) * self.beam_size + 22568 <= 160 * 1024)
 
     def _text(self, toks):
         return ''.join(self.vocab_list[t] for t in toks).replace('<space>', ' ')
@@ -161,35 +191,43 @@ class BeamSearchDecoder:
         if B and Ts and self.use_gpu_search and self.gpu_search_supported(Ts, V):
             # whole search on the device: candidates never leave HBM, one workgroup per utterance
             eng = runtime.aux_engine()
-            idx, logp, cnt, K = self._candidates(stacked.reshape(B * Ts, V), to_host=False)
+            idx, logp, cnt, blp, K = self._candidates(stacked.reshape(B * Ts, V), to_host=False)
             fr = torch.from_numpy(frames).to(eng.device)
             toks = torch.zeros(B, max_len, dtype=torch.int32, device=eng.device)
             lens = torch.zeros(B, dtype=torch.int32, device=eng.device)
             scores = torch.zeros(B, dtype=torch.float32, device=eng.device)
             check(self._lib.masr_beam_search_gpu_lm(eng.h, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
                                                     C.c_void_p(cnt.data_ptr()), C.c_void_p(fr.data_ptr()), B, Ts, K,
-                                                    self.beam_size, self.blank_id, *self._lm_args(),
+                                                    self.beam_size, self.blank_id, *self._lm_args(), self._ptr(blp),
                                                     C.c_void_p(toks.data_ptr()), max_len,
                                                     C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             if defer:                      # nothing has been synchronised: _batch_collect() fetches the result later
                 ev = torch.cuda.Event()
                 ev.record()
-                return ('gpu', toks, lens, scores, (stacked, idx, logp, cnt, fr, probs_list), ev)
+                return ('gpu', toks, lens, scores, (stacked, idx, logp, cnt, blp, fr, probs_list), ev)
             toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
             if want_tokens:          # (token ids, score): what a multi-GPU caller gathers instead of text
                 return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(B)]
             return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(B)]
         if defer:
             raise Exception('deferred batch search needs the GPU search (device-resident probabilities within its limits)')
-        idx, logp, cnt, K = self._candidates(stacked.reshape(B * Ts, V))
+        if self._ext_scorer is not None and not self._ext_scorer.is_character_based and not getattr(self, '_said_host', False):
+            self._said_host = True
+            logger.info('masr_amd BeamSearchDecoder: word-based language model -> prefix search on host threads')
+        elif self.use_gpu_search and B and Ts and not getattr(self, '_said_host', False):
+            self._said_host = True
+            logger.warning(f'masr_amd BeamSearchDecoder: beam_size={self.beam_size} x cutoff_top_n={self.cutoff_top_n} is beyond the '
+                           f'GPU search (LDS), using {self.num_processes} host threads')
+        idx, logp, cnt, blp, K = self._candidates(stacked.reshape(B * Ts, V))
         toks = np.zeros((B, max_len), np.int32)
         lens = np.zeros(B, np.int32)
         scores = np.zeros(B, np.float32)
         rc = self._lib.masr_beam_search_batch_lm(idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
                                                  cnt.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.c_void_p), B, Ts, K,
                                                  self.beam_size, self.blank_id, self.num_processes, *self._lm_args(),
-                                                 toks.ctypes.data_as(C.c_void_p), max_len, lens.ctypes.data_as(C.c_void_p),
+                                                 self._ptr(blp), toks.ctypes.data_as(C.c_void_p), max_len,
+                                                 lens.ctypes.data_as(C.c_void_p),
                                                  scores.ctypes.data_as(C.c_void_p))
         if rc != 0:
             raise _lib.MasrError('masr_beam_search_batch failed')
@@ -204,10 +242,10 @@ class BeamSearchDecoder:
         p = probs[0][:n_valid] if torch.is_tensor(probs) else np.asarray(probs)[0][:n_valid]     # device tensors stay there
         if self.use_gpu_search and self.gpu_search_supported(1, p.shape[1]):
             return self._decode_chunk_gpu(p)
-        idx, logp, cnt, K = self._candidates(p)
+        idx, logp, cnt, blp, K = self._candidates(p)
         if p.shape[0]:
-            self._lib.masr_beam_advance(self._stream, idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
-                                        cnt.ctypes.data_as(C.c_void_p), p.shape[0], K)
+            self._lib.masr_beam_advance_lm(self._stream, idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
+                                           cnt.ctypes.data_as(C.c_void_p), self._ptr(blp), p.shape[0], K)
         toks = np.zeros(4096, np.int32)
         n, sc = C.c_int32(), C.c_float()
         self._lib.masr_beam_result(self._stream, toks.ctypes.data_as(C.c_void_p), 4096, C.byref(n), C.byref(sc))
@@ -224,17 +262,17 @@ class BeamSearchDecoder:
             if self._ext_scorer is not None:
                 check(self._lib.masr_gbeam_set_lm(eng.h, self._gstream, *self._lm_args()))
         T = p.shape[0]
-        idx, logp, cnt, K = self._candidates(p, to_host=False)
+        idx, logp, cnt, blp, K = self._candidates(p, to_host=False)
         max_len = 5000
         if self._gout is None:
             self._gout = (torch.zeros(1, max_len, dtype=torch.int32, device=eng.device),
                           torch.zeros(1, dtype=torch.int32, device=eng.device),
                           torch.zeros(1, dtype=torch.float32, device=eng.device))
         toks, lens, scores = self._gout
-        check(self._lib.masr_gbeam_advance(eng.h, self._gstream, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
-                                           C.c_void_p(cnt.data_ptr()), T, K, C.c_void_p(toks.data_ptr()), max_len,
-                                           C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
-                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        check(self._lib.masr_gbeam_advance_lm(eng.h, self._gstream, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                              C.c_void_p(cnt.data_ptr()), self._ptr(blp), T, K, C.c_void_p(toks.data_ptr()),
+                                              max_len, C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         n = int(lens.item())
         self.last_tokens = toks[0, :n].cpu().numpy().tolist()
         return float(scores.item()), self._text(self.last_tokens)

@@ -27,6 +27,9 @@ class LanguageModel:
         self._lib.masr_lm_info(self.h, C.byref(mo), C.byref(n), C.byref(cb), C.byref(sk))
         self.max_order, self.n_ngrams, self.is_character_based, self.skipped = mo.value, n.value, bool(cb.value), sk.value
         self.bos, self.eos = self.vocab_size, self.vocab_size + 1
+        ds = C.c_int32()
+        self._lib.masr_lm_dict_size(self.h, C.byref(ds))
+        self.dict_size = ds.value         # word-based models: words in the spelling dictionary (Scorer::get_dict_size)
 
     def close(self):
         if getattr(self, 'h', None):
@@ -44,7 +47,14 @@ class LanguageModel:
         return self.max_order
 
     def get_dict_size(self):
-        return self.n_ngrams
+        return self.dict_size
+
+    def word_id(self, word):
+        """word-based models: the id ``cond_log_prob`` / ``sentence_log_prob`` take for an LM word (-1: not an LM word)"""
+        out = C.c_int32()
+        if self._lib.masr_lm_word_id(self.h, word.encode('utf-8'), C.byref(out)) != 0:
+            raise _lib.MasrError(self._lib.masr_lm_last_error().decode('utf-8', 'replace'))
+        return out.value
 
     def cond_log_prob(self, ids):
         """ln P(ids[-1] | ids[:-1]) with the <s>-padded window of Scorer::make_ngram / get_log_cond_prob"""
@@ -89,6 +99,39 @@ def write_synthetic_arpa(path, vocab_list, order=3, seed=0, n_higher=20000, skip
                     if '<s>' in sub_[1:] or sub_[0] == '</s>':
                         continue
                     grams[k - 1].setdefault(sub_, (float(rng.uniform(-3.5, -0.5)), float(rng.uniform(-0.8, -0.02))))
+    with open(path, 'w', encoding='utf-8') as f:
+        f.write('\\data\\\n')
+        for n in range(order):
+            f.write(f'ngram {n + 1}={len(grams[n])}\n')
+        for n in range(order):
+            f.write(f'\n\\{n + 1}-grams:\n')
+            for g, (p, b) in grams[n].items():
+                f.write(f'{p:.6f}\t{" ".join(g)}' + (f'\t{b:.6f}\n' if n + 1 < order else '\n'))
+        f.write('\n\\end\\\n')
+    return path
+
+
+def write_synthetic_word_arpa(path, words, order=3, seed=0, n_higher=400):
+    """A random, prefix- and suffix-closed WORD ``order``-gram model in ARPA text over ``words`` (tests / benchmarks of the
+    word-based scorer: spelling dictionary, scoring at the space token).  Returns ``path``."""
+    rng = np.random.default_rng(seed)
+    words = list(words)
+    grams = [dict() for _ in range(order)]
+    for w in ['<unk>', '<s>', '</s>'] + words:
+        grams[0][(w,)] = (-99.0 if w == '<s>' else float(rng.uniform(-4.0, -1.0)), float(rng.uniform(-1.0, -0.05)))
+    ctxs = words + ['<s>']
+    for n in range(1, order):
+        for _ in range(n_higher):
+            g = tuple(ctxs[int(i)] for i in rng.integers(0, len(ctxs), n)) + ((words + ['</s>'])[int(rng.integers(0, len(words) + 1))],)
+            if any(w == '<s>' for w in g[1:]):
+                continue
+            grams[n][g] = (float(rng.uniform(-2.5, -0.1)), float(rng.uniform(-0.8, -0.02)))
+    for n in range(order - 1, 0, -1):                                 # closure: every prefix and suffix n-gram exists
+        for g in list(grams[n]):
+            for sub_ in (g[:-1], g[1:]):
+                if '<s>' in sub_[1:] or sub_[0] == '</s>':
+                    continue
+                grams[n - 1].setdefault(sub_, (float(rng.uniform(-3.0, -0.5)), float(rng.uniform(-0.8, -0.02))))
     with open(path, 'w', encoding='utf-8') as f:
         f.write('\\data\\\n')
         for n in range(order):

@@ -91,10 +91,10 @@ def test_gpu_pruning_and_decoder_api():
     V = 300
     vocab = ['<blank>', '<unk>', '<space>'] + [chr(0x4e00 + i) for i in range(V - 4)] + ['<eos>']
     dec = BeamSearchDecoder(alpha=2.2, beta=4.3, beam_size=20, cutoff_prob=0.99, cutoff_top_n=40, vocab_list=vocab,
-                            num_processes=4)
+                            num_processes=4, language_model_path=None)
     probs = [rng.dirichlet(np.ones(V) * 0.02, size=T).astype(np.float32) for T in (37, 12, 25)]
     # pruning kernel == oracle pruning
-    idx, logp, cnt, K = dec._candidates(probs[0])
+    idx, logp, cnt, _, K = dec._candidates(probs[0])
     for t in range(37):
         ref = obs.pruned_log_probs(probs[0][t], 0.99, 40)
         assert cnt[t] == len(ref)
@@ -122,7 +122,7 @@ def _gpu_vs_host(probs_list, beam, cut, topn):
     V = probs_list[0].shape[1]
     vocab = ['<blank>'] + [chr(0x4e00 + i) for i in range(V - 1)]
     dec = BeamSearchDecoder(alpha=0, beta=0, beam_size=beam, cutoff_prob=cut, cutoff_top_n=topn, vocab_list=vocab,
-                            num_processes=4)
+                            num_processes=4, language_model_path=None)
     assert dec.gpu_search_supported(max(p.shape[0] for p in probs_list), V)
     gpu = dec._batch(probs_list)
     dec.use_gpu_search = False
@@ -187,7 +187,7 @@ def test_gpu_streaming_search_equals_offline_and_host(beam):
     alpha[[0, 5, 9, 11]] = 1.0
     probs = rng.dirichlet(alpha, size=T).astype(np.float32)
     vocab = ['<blank>'] + [chr(0x4e00 + i) for i in range(V - 1)]
-    dec = BeamSearchDecoder(0, 0, beam, 0.99, 40, vocab)
+    dec = BeamSearchDecoder(0, 0, beam, 0.99, 40, vocab, language_model_path=None)
     off = dec.decode_beam_search_offline(probs)
     for use_gpu in (True, False, True):                 # the second GPU pass also checks reset_decoder on a used stream
         dec.use_gpu_search = use_gpu
@@ -266,7 +266,7 @@ def _host_search_lm(cands, beam, lm, alpha, beta, blank=0):
     toks, lens, score = np.zeros((1, T + 1), np.int32), np.zeros(1, np.int32), np.zeros(1, np.float32)
     rc = lib.masr_beam_search_batch_lm(idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
                                        cnt.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.c_void_p), 1, T, K, beam, blank, 2,
-                                       lm.h, C.c_float(alpha), C.c_float(beta), toks.ctypes.data_as(C.c_void_p), T + 1,
+                                       lm.h, C.c_float(alpha), C.c_float(beta), None, toks.ctypes.data_as(C.c_void_p), T + 1,
                                        lens.ctypes.data_as(C.c_void_p), score.ctypes.data_as(C.c_void_p))
     assert rc == 0
     return float(score[0]), list(toks[0, :lens[0]])
@@ -327,13 +327,17 @@ def _lm_decoder(tmp, V, beam, cut, topn, alpha=2.2, beta=4.3, order=3, seed=4):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('prune', [True, False])
 @pytest.mark.parametrize('seed,V,Ts,beam,cut,topn,conc,order', [
     (0, 30, (14, 9), 6, 1.0, 40, 0.3, 3), (1, 60, (30, 30, 7), 12, 0.99, 8, 0.2, 3), (2, 300, (60, 41, 1), 20, 0.99, 40, 0.05, 4),
     (3, 12, (40,), 300, 1.0, 40, 0.4, 5), (4, 4233, (100, 77, 33), 300, 0.99, 40, 0.002, 3)])
-def test_gpu_search_with_language_model_matches_host_and_oracle(tmp_path, seed, V, Ts, beam, cut, topn, conc, order):
+def test_gpu_search_with_language_model_matches_host_and_oracle(tmp_path, seed, V, Ts, beam, cut, topn, conc, order, prune):
+    """prune=True: the decoder as the reference runs it (min_cutoff / full_beam rule on, ln p(blank) from the pruning kernel);
+    prune=False: every candidate of a frame scored"""
     rng = np.random.default_rng(seed)
     probs = [rng.dirichlet(np.ones(V) * conc, size=T).astype(np.float32) for T in Ts]
     dec, vocab, olm = _lm_decoder(tmp_path, V, beam, cut, topn, order=order)
+    dec.prune_min_cutoff = prune
     assert dec.gpu_search_supported(max(Ts), V)
     gpu = dec._batch(probs)
     dec.use_gpu_search = False
@@ -342,13 +346,63 @@ def test_gpu_search_with_language_model_matches_host_and_oracle(tmp_path, seed, 
         assert tg == th, (tg, th)
         assert abs(sg - sh) < 2e-3 * max(1.0, abs(sh)), (sg, sh)
     if V <= 300:                                           # the pure-Python oracle on the smaller cases
+        sc = obs.Scorer(olm, vocab, 2.2, 4.3)
         for p, (sg, tg) in zip(probs, gpu):
-            s_ref, t_ref = obs.decode_lm(p, vocab, olm, 2.2, 4.3, beam, cut, topn)
+            s_ref, toks_ref, _ = obs.ctc_beam_search_decoder(p, vocab, beam, cut, topn, sc, 0, prune=prune)
+            t_ref = ''.join(vocab[t] for t in toks_ref).replace('<space>', ' ')
             assert tg == t_ref and abs(sg - s_ref) < 2e-3 * max(1.0, abs(s_ref)), (sg, s_ref)
     # the scorer is live: the LM-free search of the same candidates differs somewhere
     from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
-    plain = BeamSearchDecoder(0, 0, beam, cut, topn, vocab)._batch(probs)
+    plain = BeamSearchDecoder(0, 0, beam, cut, topn, vocab, language_model_path=None)._batch(probs)
     assert any(tp != tg or abs(sp - sg) > 1e-2 for (sp, tp), (sg, tg) in zip(plain, gpu))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed,alpha,beta,beam', [(0, 1.0, 0.0, 8), (1, 0.5, 0.3, 300), (2, 1.0, -0.5, 40)])
+def test_gpu_pruning_rule_at_settings_where_it_cuts(tmp_path, seed, alpha, beta, beam):
+    """low beta: every candidate less likely than blank is cut for the prefixes at the bottom of a full beam -- GPU == host ==
+    oracle with the rule on, and the rule-off search differs"""
+    rng = np.random.default_rng(300 + seed)
+    V = 40
+    conc = np.full(V, 0.05)
+    conc[0] = 2.0
+    probs = [rng.dirichlet(conc, size=T).astype(np.float32) for T in (80, 55)]
+    dec, vocab, olm = _lm_decoder(tmp_path, V, beam, 1.0, 40, alpha=alpha, beta=beta)
+    gpu = dec._batch(probs)
+    dec.use_gpu_search = False
+    host = dec._batch(probs)
+    sc = obs.Scorer(olm, vocab, alpha, beta)
+    differs = False
+    for p, (sg, tg), (sh, th) in zip(probs, gpu, host):
+        assert tg == th and abs(sg - sh) < 2e-3 * max(1.0, abs(sh))
+        s_ref, toks_ref, _ = obs.ctc_beam_search_decoder(p, vocab, beam, 1.0, 40, sc, 0, prune=True)
+        assert tg == ''.join(vocab[t] for t in toks_ref).replace('<space>', ' ')
+        assert abs(sg - s_ref) < 2e-3 * max(1.0, abs(s_ref))
+        s_off, toks_off, _ = obs.ctc_beam_search_decoder(p, vocab, beam, 1.0, 40, sc, 0, prune=False)
+        differs |= toks_off != toks_ref or abs(s_off - s_ref) > 1e-3
+    assert differs
+
+
+@pytest.mark.gpu
+def test_word_based_scorer_through_the_decoder_api(word_lm):
+    """a space-delimited LM through BeamSearchDecoder: the GPU prunes the vocabulary, the prefix search (spelling dictionary)
+    runs on host threads; offline == streaming == oracle"""
+    from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    vocab, words, lm, olm, path = word_lm
+    rng = np.random.default_rng(5)
+    probs = [_word_probs(rng, vocab, words, T, 0.3) for T in (60, 37)]
+    dec = BeamSearchDecoder(2.2, 4.3, 20, 0.99, 40, vocab, num_processes=2, language_model_path=path)
+    assert not dec.gpu_search_supported(60, len(vocab)) and dec._ext_scorer.get_dict_size() == len(words) - 1
+    texts = dec.decode_batch_beam_search_offline(probs)
+    sc = obs.Scorer(olm, vocab, 2.2, 4.3)
+    for p, text in zip(probs, texts):
+        s_ref, toks_ref, _ = obs.ctc_beam_search_decoder(p, vocab, 20, 0.99, 40, sc, 0)
+        assert text == ''.join(vocab[t] for t in toks_ref).replace('<space>', ' ')
+    out = None
+    for lo in range(0, 60, 16):
+        out = dec.decode_chunk(probs[0][None, lo:lo + 16], np.array([min(16, 60 - lo)]))
+    assert out[1] == texts[0]
+    dec.reset_decoder()
 
 
 @pytest.mark.gpu
@@ -375,3 +429,314 @@ def test_gpu_streaming_search_with_language_model(tmp_path, beam):
         assert abs(out[0] - off[0]) < 2e-3 * max(1.0, abs(off[0]))
     twin.close()
     dec.reset_decoder()
+
+
+# ---- the decoder's min_cutoff / full_beam pruning (with a scorer bound) and word-based scorers: host search == oracle (CPU) ------
+def _arrays(cands):
+    T, K = len(cands), max(len(c) for c in cands)
+    idx, logp, cnt = np.zeros((T, K), np.int32), np.zeros((T, K), np.float32), np.zeros(T, np.int32)
+    for t, c in enumerate(cands):
+        cnt[t] = len(c)
+        for k, (i, lp) in enumerate(c):
+            idx[t, k], logp[t, k] = i, lp
+    return idx, logp, cnt, T, K
+
+
+def _host_search_pruned(cands, blank_lp, beam, lm, alpha, beta, blank=0):
+    """masr_beam_search_batch_lm with ln p(blank) per frame: the pruning rule is on"""
+    from masr_amd import _lib
+    lib = _lib.lib()
+    idx, logp, cnt, T, K = _arrays(cands)
+    blp = np.asarray(blank_lp, np.float32)
+    frames = np.array([T], np.int32)
+    toks, lens, score = np.zeros((1, T + 1), np.int32), np.zeros(1, np.int32), np.zeros(1, np.float32)
+    rc = lib.masr_beam_search_batch_lm(idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
+                                       cnt.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.c_void_p), 1, T, K, beam, blank, 2,
+                                       lm.h, C.c_float(alpha), C.c_float(beta), blp.ctypes.data_as(C.c_void_p),
+                                       toks.ctypes.data_as(C.c_void_p), T + 1, lens.ctypes.data_as(C.c_void_p),
+                                       score.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return float(score[0]), list(toks[0, :lens[0]])
+
+
+def _blank_lp(probs, blank=0):
+    return [float(np.log(np.float32(p[blank]))) for p in probs]
+
+
+@pytest.mark.parametrize('seed,T,beam,cut,topn,alpha,beta', [(0, 30, 6, 1.0, 40, 2.2, 4.3), (1, 40, 12, 0.99, 8, 2.2, 4.3),
+                                                             (2, 35, 40, 0.95, 10, 0.7, 1.5), (3, 25, 300, 1.0, 40, 2.2, 4.3),
+                                                             (4, 30, 5, 0.9, 40, 0.0, 3.0), (5, 30, 9, 1.0, 12, 1.3, -0.5)])
+def test_host_search_with_min_cutoff_pruning_matches_oracle(lm_pair, seed, T, beam, cut, topn, alpha, beta):
+    vocab, lm, olm = lm_pair
+    rng = np.random.default_rng(50 + seed)
+    probs = rng.dirichlet(np.ones(len(vocab)) * 0.25, size=T).astype(np.float32)
+    cands = [obs.pruned_log_probs(p, cut, topn) for p in probs]
+    blp = _blank_lp(probs)
+    sc = obs.Scorer(olm, vocab, alpha, beta)
+    a_ref, t_ref, _ = obs.ctc_beam_search_decoder(None, vocab, beam, scorer=sc, cands=cands, blank_logp=blp)
+    s, t = _host_search_pruned(cands, blp, beam, lm, alpha, beta)
+    assert t == t_ref, (t, t_ref)
+    assert abs(s - a_ref) < 2e-3 * max(1.0, abs(a_ref)), (s, a_ref)
+
+
+def test_min_cutoff_pruning_changes_the_search(built_lib, tmp_path):
+    """five frames, beam 2, on which the decoder's rule changes the transcript: without it the search returns 'ba', with it
+    (what the published decoder does whenever a scorer is bound) the extension that leads there is cut in a full beam and the
+    result is 'b'.  Oracle and host search agree in both modes."""
+    from masr_amd.decoders.lm_scorer import LanguageModel
+    vocab = ['<blank>', 'a', 'b', 'c']
+    path = str(tmp_path / 'uni.arpa')
+    with open(path, 'w') as f:
+        f.write('\\data\\\nngram 1=6\n\n\\1-grams:\n-99\t<s>\n-1\t</s>\n-1\t<unk>\n-0.5\ta\n-0.7\tb\n-0.9\tc\n\n\\end\\\n')
+    olm = obs.ArpaLM(path)
+    sc = obs.Scorer(olm, vocab, 0.5, 0.3)
+    frames = np.array([[0.23, 0.08, 0.64, 0.05], [0.39, 0.37, 0.05, 0.19], [0.91, 0.01, 0.03, 0.05], [0.61, 0.18, 0.11, 0.10],
+                       [0.59, 0.21, 0.15, 0.05]], np.float32)
+    full, tf, _ = obs.ctc_beam_search_decoder(frames, vocab, 2, 1.0, 40, sc, 0, prune=False)
+    cut_, tc, _ = obs.ctc_beam_search_decoder(frames, vocab, 2, 1.0, 40, sc, 0, prune=True)
+    assert tf == [2, 1] and tc == [2]
+    lm = LanguageModel(path, vocab)
+    cands = [obs.pruned_log_probs(p, 1.0, 40) for p in frames]
+    s_cut, t_cut = _host_search_pruned(cands, _blank_lp(frames), 2, lm, 0.5, 0.3)
+    s_full, t_full = _host_search_lm(cands, 2, lm, 0.5, 0.3)
+    assert t_cut == tc and t_full == tf
+    assert abs(s_cut - cut_) < 1e-4 and abs(s_full - full) < 1e-4
+
+
+@pytest.fixture(scope='module')
+def word_lm(built_lib, tmp_path_factory):
+    from masr_amd.decoders.lm_scorer import LanguageModel, write_synthetic_word_arpa
+    vocab = ['<blank>', '<unk>', '<space>', "'"] + [chr(97 + i) for i in range(12)]
+    rng = np.random.default_rng(8)
+    letters = vocab[3:]
+    words = sorted({''.join(letters[int(i)] for i in rng.integers(0, len(letters), int(rng.integers(1, 5)))) for _ in range(60)})
+    words += ['z' + words[0]]                                          # a word the acoustic model cannot spell: not in the dictionary
+    path = write_synthetic_word_arpa(str(tmp_path_factory.mktemp('wlm') / 'words.arpa'), words, order=3, seed=2)
+    return vocab, words, LanguageModel(path, vocab), obs.ArpaLM(path), path
+
+
+def test_word_based_scorer_loads_and_scores_like_the_oracle(word_lm):
+    vocab, words, lm, olm, _ = word_lm
+    sc = obs.Scorer(olm, vocab, 1.0, 1.0)
+    assert not lm.is_character_based and not sc.is_character_based and lm.max_order == 3
+    assert lm.get_dict_size() == sc.dict_size == len(words) - 1 and lm.word_id('nope') == -1
+    rng = np.random.default_rng(1)
+    hit = back = 0
+    for k in range(2000):
+        n = int(rng.integers(1, 5))
+        ws = [words[int(rng.integers(0, len(words)))] for _ in range(n)]
+        if k % 9 == 0:
+            ws[int(rng.integers(0, n))] = 'qqq'                        # not an LM word: OOV
+        ids = [lm.word_id(w) for w in ws]
+        want = olm.cond_log_prob(olm.make_ngram(ws))
+        got = lm.cond_log_prob(ids)
+        assert abs(got - want) < 2e-4 * max(1.0, abs(want)), (ws, got, want)
+        hit += tuple(olm.make_ngram(ws)) in olm.grams
+        back += tuple(olm.make_ngram(ws)) not in olm.grams and want > -999
+        sw, sg = olm.sent_log_prob(ws), lm.sentence_log_prob(ids)
+        assert abs(sg - sw) < 2e-4 * max(1.0, abs(sw)), (ws, sg, sw)
+    assert hit > 5 and back > 300
+    assert abs(lm.sentence_log_prob([]) - olm.sent_log_prob([])) < 1e-4
+
+
+def _word_probs(rng, vocab, words, T, noise):
+    """frames that spell a few dictionary words (with blanks, repeats and noise) so that spaces and word scores matter"""
+    ids = []
+    while len(ids) < T:
+        w = words[int(rng.integers(0, len(words) - 1))]
+        for ch in w:
+            ids += [vocab.index(ch)] * int(rng.integers(1, 3)) + [0] * int(rng.integers(0, 2))
+        ids += [2] * int(rng.integers(1, 3))
+    ids = ids[:T]
+    probs = rng.dirichlet(np.ones(len(vocab)) * noise, size=T)
+    for t, i in enumerate(ids):
+        probs[t] = 0.55 * probs[t]
+        probs[t, i] += 0.45
+    return probs.astype(np.float32)
+
+
+@pytest.mark.parametrize('seed,T,beam,cut,topn,alpha,beta,prune', [(0, 40, 8, 1.0, 40, 2.2, 4.3, True), (1, 60, 25, 0.99, 10, 1.5, 0.8, True),
+                                                                   (2, 50, 300, 1.0, 40, 2.2, 4.3, True), (3, 45, 6, 0.95, 40, 0.6, 2.0, False),
+                                                                   (4, 70, 16, 1.0, 40, 2.2, 4.3, False), (5, 30, 3, 1.0, 40, 3.0, 1.0, True)])
+def test_host_search_with_word_based_scorer_matches_oracle(word_lm, seed, T, beam, cut, topn, alpha, beta, prune):
+    """space-delimited LM: extensions are confined to the spelling dictionary (with the published code's start-over quirk after
+    a complete word), a word is scored when its space arrives, the unfinished last word at the end, approx_ctc over the words"""
+    vocab, words, lm, olm, _ = word_lm
+    rng = np.random.default_rng(70 + seed)
+    probs = _word_probs(rng, vocab, words, T, 0.3)
+    cands = [obs.pruned_log_probs(p, cut, topn) for p in probs]
+    blp = _blank_lp(probs)
+    sc = obs.Scorer(olm, vocab, alpha, beta)
+    a_ref, t_ref, _ = obs.ctc_beam_search_decoder(None, vocab, beam, scorer=sc, cands=cands, blank_logp=blp, prune=prune)
+    if prune:
+        s, t = _host_search_pruned(cands, blp, beam, lm, alpha, beta)
+    else:
+        s, t = _host_search_lm(cands, beam, lm, alpha, beta)
+    assert t == t_ref, (t, t_ref)
+    assert abs(s - a_ref) < 2e-3 * max(1.0, abs(a_ref)), (s, a_ref)
+    text = ''.join(vocab[i] for i in t).replace('<space>', ' ')
+    assert all(w in words for w in text.split(' ')[:-1])             # every finished word is a dictionary word
+    # the LM-free search of the same frames leaves the dictionary
+    _, t0 = obs.prefix_beam_search(cands, beam, 0)
+    assert t0 != t_ref
+
+
+def test_streaming_host_search_with_word_based_scorer(word_lm):
+    from masr_amd import _lib
+    lib = _lib.lib()
+    vocab, words, lm, olm, _ = word_lm
+    rng = np.random.default_rng(123)
+    probs = _word_probs(rng, vocab, words, 48, 0.3)
+    cands = [obs.pruned_log_probs(p, 1.0, 16) for p in probs]
+    blp = np.asarray(_blank_lp(probs), np.float32)
+    s_ref, t_ref = _host_search_pruned(cands, blp, 12, lm, 2.2, 4.3)
+    h = C.c_void_p()
+    assert lib.masr_beam_create(12, 0, C.byref(h)) == 0
+    assert lib.masr_beam_set_lm(h, lm.h, C.c_float(2.2), C.c_float(4.3)) == 0
+    toks = np.zeros(64, np.int32)
+    n, sc = C.c_int32(), C.c_float()
+    for lo in range(0, 48, 7):
+        idx, lp, cnt, Tn, K = _arrays(cands[lo:lo + 7])
+        b = blp[lo:lo + 7].copy()
+        assert lib.masr_beam_advance_lm(h, idx.ctypes.data_as(C.c_void_p), lp.ctypes.data_as(C.c_void_p),
+                                        cnt.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), Tn, K) == 0
+        lib.masr_beam_result(h, toks.ctypes.data_as(C.c_void_p), 64, C.byref(n), C.byref(sc))   # asking in between changes nothing
+    assert list(toks[:n.value]) == t_ref and abs(sc.value - s_ref) < 1e-4
+    lib.masr_beam_destroy(h)
+
+
+def test_missing_language_model_is_the_reference_assertion(built_lib, tmp_path):
+    """beam_search_decoder.py:28 asserts on a missing model file; the scorer-free search needs language_model_path=None"""
+    from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    vocab = ['<blank>', 'a', 'b']
+    with pytest.raises(AssertionError, match='语言模型不存在'):
+        BeamSearchDecoder(2.2, 4.3, 10, 0.99, 40, vocab, language_model_path=str(tmp_path / 'absent.klm'))
+    with pytest.raises(AssertionError, match='语言模型不存在'):
+        BeamSearchDecoder(2.2, 4.3, 10, 0.99, 40, vocab)              # the reference's default path: nothing to download here
+    dec = BeamSearchDecoder(2.2, 4.3, 10, 0.99, 40, vocab, language_model_path=None)
+    assert dec._ext_scorer is None and dec.alpha == 0 and dec.beta == 0
+    dec.close()
+
+
+# ---- BASELINE configs[2]'s size regime: T' = 498, V = 4233, beam 300, top-n 40, alpha 2.2 / beta 4.3, 3- and 5-gram LM ---------
+# The pure-Python oracle needs minutes here: its answers are the committed fixture tests/golden/beam_regime.npz
+# (oracle/make_beam_golden.py); the language models are re-created from the same seeds.
+import os
+
+REGIME = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'beam_regime.npz')
+REGIME_CASES = [('lm3', 2.2, 4.3, True), ('lm3', 2.2, 4.3, False), ('lm5', 2.2, 4.3, True), ('lm5', 2.2, 4.3, False),
+                ('lm3_a1b0', 1.0, 0.0, True), ('lm3_a1b0', 1.0, 0.0, False)]
+
+
+@pytest.fixture(scope='module')
+def regime(built_lib, tmp_path_factory):
+    from masr_amd.decoders.lm_scorer import LanguageModel, write_synthetic_arpa
+    from masr_amd.utils import synthetic
+    from oracle.make_beam_golden import LMS
+    z = np.load(REGIME)
+    T, V, beam, K = (int(x) for x in z['meta'])
+    vocab = synthetic.synthetic_vocab(V)
+    d = tmp_path_factory.mktemp('regime_lm')
+    lms = {name: LanguageModel(write_synthetic_arpa(str(d / (name + '.arpa')), vocab, **kw), vocab) for name, kw in LMS.items()}
+    lms['lm3_a1b0'] = lms['lm3']
+    return z, T, V, beam, K, vocab, lms
+
+
+@pytest.mark.parametrize('name,alpha,beta,prune', REGIME_CASES)
+def test_host_search_at_config2_size_matches_the_oracle_fixture(regime, name, alpha, beta, prune):
+    from masr_amd import _lib
+    lib = _lib.lib()
+    z, T, V, beam, K, vocab, lms = regime
+    idx, logp, cnt = z['idx'].astype(np.int32), z['logp'], z['cnt']
+    blp = z['blank_lp'].astype(np.float32)
+    frames = np.array([T], np.int32)
+    toks, lens, score = np.zeros((1, T + 1), np.int32), np.zeros(1, np.int32), np.zeros(1, np.float32)
+    rc = lib.masr_beam_search_batch_lm(idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
+                                       cnt.ctypes.data_as(C.c_void_p), frames.ctypes.data_as(C.c_void_p), 1, T, K, beam, 0, 1,
+                                       lms[name].h, C.c_float(alpha), C.c_float(beta),
+                                       blp.ctypes.data_as(C.c_void_p) if prune else None, toks.ctypes.data_as(C.c_void_p),
+                                       T + 1, lens.ctypes.data_as(C.c_void_p), score.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    tag = f'{name}_{"pruned" if prune else "full"}'
+    assert list(toks[0, :lens[0]]) == list(z[tag + '_tokens'])
+    want = float(z[tag + '_score'][0])
+    assert abs(float(score[0]) - want) < 1e-3 * abs(want), (float(score[0]), want)
+
+
+def test_the_regime_fixture_is_the_size_it_claims(regime):
+    z, T, V, beam, K = regime[:5]
+    assert (T, V, beam, K) == (498, 4233, 300, 40)
+    assert (z['cnt'] == 40).sum() > 100 and len(z['lm3_pruned_tokens']) > 200 and len(z['lm5_pruned_tokens']) > 200
+    assert list(z['lm3_pruned_tokens']) != list(z['lm5_pruned_tokens']) != list(z['nolm_tokens'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,alpha,beta,prune', REGIME_CASES)
+def test_gpu_search_at_config2_size_matches_host_and_the_oracle_fixture(regime, name, alpha, beta, prune):
+    """the GPU kernel on the stored candidates of one 498-frame utterance (x 3 copies in one launch, one of them cut short):
+    150 k-entry LM table in HBM, 64-bit prefix identities over ~500 extensions, fp32 log-sum-exp over 498 frames"""
+    import torch
+    from masr_amd import _lib, runtime
+    from masr_amd._lib import check
+    lib = _lib.lib()
+    z, T, V, beam, K, vocab, lms = regime
+    eng = runtime.aux_engine()
+    dev = eng.device
+    B = 3
+    fr_h = np.array([T, T, 301], np.int32)
+    idx = torch.from_numpy(np.tile(z['idx'].astype(np.int32)[None], (B, 1, 1))).to(dev).contiguous()
+    logp = torch.from_numpy(np.tile(z['logp'][None], (B, 1, 1))).to(dev).contiguous()
+    cnt = torch.from_numpy(np.tile(z['cnt'][None], (B, 1))).to(dev).contiguous()
+    blp = torch.from_numpy(np.tile(z['blank_lp'].astype(np.float32)[None], (B, 1))).to(dev).contiguous()
+    fr = torch.from_numpy(fr_h).to(dev)
+    toks = torch.zeros(B, T + 1, dtype=torch.int32, device=dev)
+    lens = torch.zeros(B, dtype=torch.int32, device=dev)
+    score = torch.zeros(B, dtype=torch.float32, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    check(lib.masr_beam_search_gpu_lm(eng.h, P(idx), P(logp), P(cnt), P(fr), B, T, K, beam, 0, lms[name].h, C.c_float(alpha),
+                                      C.c_float(beta), P(blp) if prune else None, P(toks), T + 1, P(lens), P(score),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    toks, lens, score = toks.cpu().numpy(), lens.cpu().numpy(), score.cpu().numpy()
+    tag = f'{name}_{"pruned" if prune else "full"}'
+    want_t, want_s = list(z[tag + '_tokens']), float(z[tag + '_score'][0])
+    for b in (0, 1):
+        assert list(toks[b, :lens[b]]) == want_t
+        assert abs(float(score[b]) - want_s) < 1e-3 * abs(want_s), (float(score[b]), want_s)
+    # the shortened copy against the host search of the same 301 frames
+    h_idx, h_logp, h_cnt = z['idx'].astype(np.int32)[:301].copy(), z['logp'][:301].copy(), z['cnt'][:301].copy()
+    h_blp = z['blank_lp'].astype(np.float32)[:301].copy()
+    ht, hl, hs = np.zeros((1, 302), np.int32), np.zeros(1, np.int32), np.zeros(1, np.float32)
+    f1 = np.array([301], np.int32)
+    assert lib.masr_beam_search_batch_lm(h_idx.ctypes.data_as(C.c_void_p), h_logp.ctypes.data_as(C.c_void_p),
+                                         h_cnt.ctypes.data_as(C.c_void_p), f1.ctypes.data_as(C.c_void_p), 1, 301, K, beam, 0, 1,
+                                         lms[name].h, C.c_float(alpha), C.c_float(beta),
+                                         h_blp.ctypes.data_as(C.c_void_p) if prune else None, ht.ctypes.data_as(C.c_void_p), 302,
+                                         hl.ctypes.data_as(C.c_void_p), hs.ctypes.data_as(C.c_void_p)) == 0
+    assert list(toks[2, :lens[2]]) == list(ht[0, :hl[0]])
+    assert abs(float(score[2]) - float(hs[0])) < 1e-3 * abs(float(hs[0]))
+
+
+@pytest.mark.gpu
+def test_gpu_search_without_scorer_at_config2_size_matches_the_oracle_fixture(regime):
+    import torch
+    from masr_amd import _lib, runtime
+    from masr_amd._lib import check
+    lib = _lib.lib()
+    z, T, V, beam, K, vocab, lms = regime
+    eng = runtime.aux_engine()
+    dev = eng.device
+    idx = torch.from_numpy(z['idx'].astype(np.int32)).to(dev).contiguous()
+    logp = torch.from_numpy(z['logp']).to(dev).contiguous()
+    cnt = torch.from_numpy(z['cnt']).to(dev).contiguous()
+    fr = torch.tensor([T], dtype=torch.int32, device=dev)
+    toks = torch.zeros(1, T + 1, dtype=torch.int32, device=dev)
+    lens = torch.zeros(1, dtype=torch.int32, device=dev)
+    score = torch.zeros(1, dtype=torch.float32, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    check(lib.masr_beam_search_gpu(eng.h, P(idx), P(logp), P(cnt), P(fr), 1, T, K, beam, 0, P(toks), T + 1, P(lens), P(score),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    n = int(lens.item())
+    assert toks[0, :n].cpu().tolist() == list(z['nolm_tokens'])
+    assert abs(float(score.item()) - float(z['nolm_score'][0])) < 1e-3 * abs(float(z['nolm_score'][0]))

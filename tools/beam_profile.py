@@ -1,6 +1,6 @@
 """Phase breakdown (cycles of workgroup 0) of the GPU CTC prefix beam search on flat posteriors (worst case: every
 frame keeps cutoff_top_n candidates), without and with the external n-gram scorer.
-usage: python tools/beam_profile.py [T] [V] [beam] [lm_order (0 = no LM)]"""
+usage: python tools/beam_profile.py [T] [V] [beam] [lm_order (0 = no LM)] [prune (1)]"""
 import os
 import sys
 import tempfile
@@ -21,10 +21,12 @@ rng = np.random.default_rng(0)
 logits = rng.normal(0, 1.0, (8, T, V)).astype(np.float32)
 probs = torch.softmax(torch.from_numpy(logits), -1).cuda()
 vocab = ['<blank>', '<unk>', '<space>'] + [chr(0x4e00 + i) for i in range(V - 3)]
-kw = {}
+kw = {'language_model_path': None}
+prune = int(sys.argv[5]) if len(sys.argv) > 5 else 1      # 0: the decoder's min_cutoff rule off (every candidate scored)
 if order:
     kw['language_model_path'] = write_synthetic_arpa(os.path.join(tempfile.mkdtemp(), 'lm.arpa'), vocab, order=order, seed=5)
 dec = BeamSearchDecoder(2.2 if order else 0, 4.3 if order else 0, beam, 0.99, 40, vocab, **kw)
+dec.prune_min_cutoff = bool(prune)
 eng = runtime.aux_engine()
 dec._batch([probs[i] for i in range(8)])
 torch.cuda.synchronize()
