@@ -35,10 +35,13 @@ def subsampled_len(t):
 def reference_gains(mean_square, target_db, max_gain_db=300.0):
     """float32 mean squares [B] -> linear gains [B] with the reference's own scalar expressions, verbatim in numpy on this host:
     ``rms_db = 10 * np.log10(mean_square)`` (audio.py:524-529), ``gain = target_db - rms_db`` and the max_gain_db check
-    (:300-304), ``samples *= 10. ** (gain / 20.)`` (:256-264)."""
+    (:300-304), ``samples *= 10. ** (gain / 20.)`` (:256-264).  A zero mean square (digital silence) counts as 1, like the
+    reference's ``rms_db`` -- the gain is then just target_dB and nothing raises; a NaN mean square (NaN samples in the input) is
+    NOT special-cased there either: it propagates into the gain, and the transcript of that utterance is whatever NaN features
+    decode to, as in the reference."""
     out = np.empty(len(mean_square), np.float32)
     for i, ms in enumerate(np.asarray(mean_square, np.float32)):
-        if ms == 0 or ms != ms:
+        if ms == 0:
             ms = 1
         rms_db = 10 * np.log10(ms)
         gain = target_db - rms_db

@@ -147,28 +147,37 @@ class MASRPredictor:
         return {'text': texts, 'score': round(sum(scores) / len(scores), 2) if scores else 0}
 
     def _stage_batch(self, segs, n):
-        """padded batch in a reused pinned staging buffer -> device (int16 when every utterance still is the PCM it was
-        loaded from: half the bytes over PCIe, x / 2^15 happens in the kernel)"""
+        """padded batch through a pinned staging buffer -> device (int16 when every utterance still is the PCM it was
+        loaded from: half the bytes over PCIe, x / 2^15 happens in the kernel).  Two staging buffers per sample type take
+        turns; each carries the event of its last upload, so filling one never waits for the device unless that very
+        buffer's previous copy (two passes ago) is still in flight."""
         eng = self.predictor.engine
         as_pcm = all(s._pcm16 is not None for s in segs)
         dt = torch.int16 if as_pcm else torch.float32
         need = len(segs) * int(n.max())
-        if dt not in self._stage or self._stage[dt].numel() < need:
-            self._stage[dt] = torch.zeros(need + need // 4, dtype=dt, pin_memory=True)
-        stage = self._stage[dt][:need].view(len(segs), int(n.max()))
+        ring = self._stage.setdefault(dt, {'bufs': [None, None], 'events': [None, None], 'turn': 0})
+        k = ring['turn']
+        ring['turn'] = k ^ 1
+        if ring['events'][k] is not None:
+            ring['events'][k].synchronize()
+        if ring['bufs'][k] is None or ring['bufs'][k].numel() < need:
+            ring['bufs'][k] = torch.zeros(need + need // 4, dtype=dt, pin_memory=True)
+        stage = ring['bufs'][k][:need].view(len(segs), int(n.max()))
         buf = stage.numpy()
         buf[:] = 0
         for i, s in enumerate(segs):
             buf[i, :n[i]] = s._pcm16 if as_pcm else s._samples
         xs = stage.to(eng.device, non_blocking=True)
         ns = torch.from_numpy(n).to(eng.device)
-        torch.cuda.current_stream().synchronize()          # the staging buffer is reused by the next call
+        ev = torch.cuda.Event()
+        ev.record()
+        ring['events'][k] = ev
         return xs, ns
 
     def _predict_local(self, segs, decode_all_frames=False, as_tokens=False, defer=False):
         """AudioSegments -> [{'text','score'}] on THIS rank's engine.  Utterances too short for one feature frame decode to
-        the empty transcript (the reference's encoder cannot take them either); a silent utterance raises like
-        ``AudioSegment.normalize`` (audio.py:300-303).  ``defer=True`` (beam search on the GPU): the prefix search is launched
+        the empty transcript (the reference's encoder cannot take them either); a digitally silent utterance (mean square 0) is
+        normalised with gain = target_dB like the reference (audio.py:519-529), only a gain above max_gain_db raises (:300-303).  ``defer=True`` (beam search on the GPU): the prefix search is launched
         on a side stream and a zero-argument function that returns the results is handed back -- the caller runs the next
         device pass (features + encoder on the main stream) underneath it."""
         eng = self.predictor.engine
@@ -225,24 +234,46 @@ class MASRPredictor:
             out[i] = (ids.tolist(), sc) if as_tokens else {'text': self._text(ids), 'score': sc}
         return (lambda: out) if defer else out
 
-    def predict_batch(self, audio_list, sample_rate=16000, decode_all_frames=False, batch_size=0, distributed=None):
+    def _length_hint(self, audio_data, sample_rate):
+        """number of samples an utterance will have at the model's rate, WITHOUT decoding it where that is possible (wav
+        path / wav bytes: the header; ndarray: its length) -- what sorting into passes and sharding over ranks need"""
+        rate = int(self.configs.preprocess_conf.get('sample_rate', 16000))
+        try:
+            if isinstance(audio_data, np.ndarray):
+                return int(audio_data.shape[0] * rate // max(int(sample_rate), 1))
+            if isinstance(audio_data, (str, bytes)):
+                import io
+                import wave
+                with wave.open(audio_data if isinstance(audio_data, str) else io.BytesIO(audio_data), 'rb') as w:
+                    return int(w.getnframes() * rate // max(w.getframerate(), 1))
+        except Exception:
+            pass
+        return self._load_audio(audio_data, sample_rate).num_samples        # file objects and anything odd: decode
+
+    def predict_batch(self, audio_list, sample_rate=16000, decode_all_frames=False, batch_size=0, distributed=None,
+                      lengths=None):
         """Batched offline path (an addition; the reference's only batched consumer is MASRTrainer.evaluate,
         trainer.py:592-651): a list of utterances -> [{'text','score'}] in input order.
 
         ``decode_all_frames=True`` reproduces the reference's batch evaluation quirk of decoding padded frames
-        (trainer.py:340).  ``batch_size`` > 0 cuts the (length-sorted) work into device passes of that many utterances.
+        (trainer.py:340).  ``batch_size`` > 0 cuts the (length-sorted) work into device passes of that many utterances; the
+        audio of a pass is decoded when the pass is formed and dropped when its results are in, at most two passes are in
+        flight (features + encoder of pass k under the prefix search of pass k - 1), so host memory and HBM hold two passes
+        whatever the list's length.  ``lengths`` (samples or seconds, any common unit): known durations, e.g. a manifest's,
+        used for sorting and sharding instead of reading every file's header.
         With an initialised ``torch.distributed`` group (``distributed=None``: automatically when world > 1) the utterances
-        are dealt out length-balanced over the ranks -- every rank must call with the same list -- each rank decodes its
-        shard on its own GPU and ONE all-gather of the token ids returns all hypotheses to every rank."""
-        segs = [self._load_audio(a, sample_rate) for a in audio_list]
+        are dealt out length-balanced over the ranks -- every rank must call with the same list -- each rank decodes ONLY
+        its shard on its own GPU and ONE all-gather of the token ids returns all hypotheses to every rank."""
+        hints = list(lengths) if lengths is not None else [self._length_hint(a, sample_rate) for a in audio_list]
         rank, world = parallel.world_info()
         if distributed is None:
             distributed = world > 1
         if not distributed or not parallel.collectives_on():
-            return self._run_sorted(segs, list(range(len(segs))), decode_all_frames, batch_size, as_tokens=False)
-        shards = parallel.length_balanced_shards([s.num_samples for s in segs], world)
+            return self._run_sorted(audio_list, sample_rate, hints, list(range(len(audio_list))), decode_all_frames, batch_size,
+                                    as_tokens=False)
+        shards = parallel.length_balanced_shards(hints, world)
         mine = shards[rank]
-        local = self._run_sorted(segs, mine, decode_all_frames, batch_size, as_tokens=True, keep_order_of=mine)
+        local = self._run_sorted(audio_list, sample_rate, hints, mine, decode_all_frames, batch_size, as_tokens=True)
         tmax = max([len(t) for t, _ in local], default=0)
         tok = torch.full((len(mine), max(tmax, 1)), -1, dtype=torch.int32)
         nt = torch.zeros(len(mine), dtype=torch.int32)
@@ -250,24 +281,35 @@ class MASRPredictor:
         for j, (t, s) in enumerate(local):
             tok[j, :len(t)] = torch.tensor(t, dtype=torch.int32)
             nt[j], sc[j] = len(t), s
-        tok, nt, sc = parallel.gather_sharded_results(tok, nt, sc, shards, len(segs))
-        return [{'text': self._text(tok[i, :nt[i]]), 'score': float(sc[i])} for i in range(len(segs))]
+        tok, nt, sc = parallel.gather_sharded_results(tok, nt, sc, shards, len(audio_list))
+        return [{'text': self._text(tok[i, :nt[i]]), 'score': float(sc[i])} for i in range(len(audio_list))]
 
-    def _run_sorted(self, segs, which, decode_all_frames, batch_size, as_tokens, keep_order_of=None):
-        """decode ``segs[i] for i in which`` in length-sorted device passes (shortest first, ties in input order -- the batches
-        ``evaluate`` forms from a duration-sorted manifest); results in the order of ``which``"""
-        order = sorted(which, key=lambda i: segs[i].num_samples) if batch_size else list(which)
+    def _run_sorted(self, audio_list, sample_rate, hints, which, decode_all_frames, batch_size, as_tokens):
+        """decode ``audio_list[i] for i in which`` in length-sorted device passes (shortest first, ties in input order -- the
+        batches ``evaluate`` forms from a duration-sorted manifest); results in the order of ``which``.  Pipeline depth 2:
+        pass k is launched (its prefix search on a side stream), then pass k - 1 is collected and its audio dropped."""
+        order = sorted(which, key=lambda i: hints[i]) if batch_size else list(which)
         step = batch_size if batch_size else max(len(order), 1)
-        got, pending = {}, []
+        got, prev = {}, None
+
+        def collect(item):
+            idx, fetch = item
+            for i, r in zip(idx, fetch()):
+                got[i] = r
+
         for lo in range(0, len(order), step):
             idx = order[lo:lo + step]
+            segs = [self._load_audio(audio_list[i], sample_rate) for i in idx]
             # (beam search: the prefix search of this pass runs on a side stream under the encoder of the next pass)
-            pending.append((idx, self._predict_local([segs[i] for i in idx], decode_all_frames, as_tokens, defer=True)))
-        for idx, collect in pending:
-            for i, r in zip(idx, collect()):
-                got[i] = r
-        if pending and getattr(self, '_side', None) is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            cur = (idx, self._predict_local(segs, decode_all_frames, as_tokens, defer=True))
+            del segs
+            if prev is not None:
+                collect(prev)
+            prev = cur
+        if prev is not None:
+            collect(prev)
+            if getattr(self, '_side', None) is not None:
+                torch.cuda.current_stream().wait_stream(self._side)
         return [got[i] for i in which]
 
     def evaluate(self, manifest, batch_size=32, display_result=False, decode_all_frames=False):
@@ -288,7 +330,10 @@ class MASRPredictor:
                     items.append((d['audio_filepath'], d['text'], float(d.get('duration', 0.0))))
         items.sort(key=lambda it: it[2])
         metric = wer if self.configs.metrics_type == 'wer' else cer
-        results = self.predict_batch([it[0] for it in items], decode_all_frames=decode_all_frames, batch_size=batch_size)
+        # manifest durations sort and shard the work: a rank opens only the files of its own shard, one pass at a time
+        known = [it[2] for it in items] if all(it[2] > 0 for it in items) else None
+        results = self.predict_batch([it[0] for it in items], decode_all_frames=decode_all_frames, batch_size=batch_size,
+                                     lengths=known)
         errors = []
         for (path, label, _), res in zip(items, results):
             err = metric(res['text'], label)

@@ -13,7 +13,7 @@ class AttrDict(dict):
 
 
 def dict_to_object(config):
-    """nested dicts (also inside lists) -> AttrDict; everything else is returned as it is"""
+    """nested dicts -> AttrDict (utils.py:37-45 of the reference); lists and everything else are returned as they are"""
     if isinstance(config, dict):
         return AttrDict((key, dict_to_object(value)) for key, value in config.items())
     return config

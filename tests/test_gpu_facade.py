@@ -636,10 +636,17 @@ def test_config2_bucketed_batch_gpu_search_equals_host_search(tmp_path):
     audio = [pcm[i, :lens[i]].copy() for i in range(64)]
     dec = pred.beam_search_decoder
     assert dec.gpu_search_supported(498, V)
-    gpu = pred.predict_batch(audio, batch_size=32)
-    dec.use_gpu_search = False
-    host = pred.predict_batch(audio, batch_size=32)
-    assert max(len(r['text']) for r in gpu) > 50
-    for g, h in zip(gpu, host):
-        assert g['text'] == h['text']
-        assert abs(g['score'] - h['score']) < 1e-3 * max(1.0, abs(h['score'])), (g['score'], h['score'])
+    # the shipped alpha 2.2 / beta 4.3 (on these noise posteriors the scorer keeps the transcripts short), then a setting that
+    # rewards characters (long transcripts: hundreds of trie extensions per utterance)
+    longest = []
+    for alpha, beta in ((2.2, 4.3), (0.2, 8.0)):
+        dec.alpha, dec.beta = alpha, beta
+        dec.use_gpu_search = True
+        gpu = pred.predict_batch(audio, batch_size=32)
+        dec.use_gpu_search = False
+        host = pred.predict_batch(audio, batch_size=32)
+        longest.append(max(len(r['text']) for r in gpu))
+        for g, h in zip(gpu, host):
+            assert g['text'] == h['text']
+            assert abs(g['score'] - h['score']) < 1e-3 * max(1.0, abs(h['score'])), (g['score'], h['score'])
+    assert longest[1] > 50, longest
