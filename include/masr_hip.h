@@ -222,6 +222,23 @@ int masr_gbeam_close(masr_engine* e, int32_t handle);
 /* external scorer of a streaming search (between utterances only: after open or reset) */
 int masr_gbeam_set_lm(masr_engine* e, int32_t handle, masr_lm* lm, float alpha, float beta);
 
+/* Silero VAD network (the segmentation model of MASRPredictor.predict_long).  Replaces the onnxruntime session of the reference's
+ * VADPredictor (masr/infer_utils/vad_predictor.py:36 InferenceSession(silero_vad.onnx), :83-104 session.run per window): the
+ * weights are read out of the user's copy of that ONNX file by the host side (masr_amd/infer_utils/silero_vad.py) and handed
+ * over tensor by tensor (names and shapes: csrc/silero.hip masr_vad_finalize), per sample rate (the file holds a 16 kHz and an
+ * 8 kHz model).  masr_vad_forward runs B sequences x n_win consecutive windows of `window` samples (audio_dev [B, n_win * window]
+ * float32, zero-padded by the caller like vad_predictor.py:126-127) from the LSTM state h_dev / c_dev [2, B, 64] (updated in
+ * place: the reference's self._h / self._c) to probs_dev [B, n_win] -- n_win = 1 is one session.run, n_win = all windows of a
+ * recording is the loop of get_speech_timestamps (:122-129) in two launches.  No CPU path: masr_vad_create fails without a GPU. */
+typedef struct masr_vad masr_vad;
+int masr_vad_create(int32_t device_id, masr_vad** out);
+void masr_vad_destroy(masr_vad* v);
+const char* masr_vad_last_error(void);
+int masr_vad_load_tensor(masr_vad* v, int32_t sample_rate, const char* name, const float* data_host, int64_t n);
+int masr_vad_finalize(masr_vad* v, int32_t sample_rate);
+int masr_vad_forward(masr_vad* v, int32_t sample_rate, const float* audio_dev, int32_t B, int32_t n_win, int32_t window,
+                     float* h_dev, float* c_dev, float* probs_dev, void* stream);
+
 /* One call for the whole offline hot path (MASRPredictor.predict semantics, masr/predict.py:167-192,
  * batched like MASRTrainer.evaluate, trainer.py:632): PCM -> fbank -> encoder -> CTC greedy.
  * decode_all_frames != 0 reproduces the reference batch quirk of decoding padded frames. */

@@ -67,6 +67,12 @@ SIGNATURES = {
     'masr_lm_sentence_log_prob': [_P, C.POINTER(_I), _I, C.POINTER(_F)],
     'masr_lm_word_id': [_P, C.c_char_p, C.POINTER(_I)],
     'masr_lm_dict_size': [_P, C.POINTER(_I)],
+    'masr_vad_create': [_I, C.POINTER(_P)],
+    'masr_vad_destroy': [_P],
+    'masr_vad_last_error': [],
+    'masr_vad_load_tensor': [_P, _I, C.c_char_p, _P, C.c_int64],
+    'masr_vad_finalize': [_P, _I],
+    'masr_vad_forward': [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P],
     'masr_mean_square': [_P, _P, _I, _P, _I, _I, _P, _P],
     'masr_mfcc_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     'masr_linear_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _P],
@@ -85,7 +91,7 @@ SIGNATURES = {
     'masr_profile_read': [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _I],
 }
 _RESTYPE = {'masr_last_error': C.c_char_p, 'masr_destroy': None, 'masr_beam_destroy': None, 'masr_lm_destroy': None,
-            'masr_lm_last_error': C.c_char_p}
+            'masr_lm_last_error': C.c_char_p, 'masr_vad_last_error': C.c_char_p, 'masr_vad_destroy': None}
 
 
 def lib():

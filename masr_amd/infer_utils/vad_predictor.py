@@ -1,18 +1,20 @@
 """Voice-activity segmentation for ``MASRPredictor.predict_long``.
 
-The reference cuts long audio with Silero VAD: a small third-party ONNX network (``silero_vad.onnx``, run through onnxruntime)
-that maps a 512-sample window + LSTM state to a speech probability, followed by a hysteresis / minimum-duration / padding
-state machine in plain Python (masr/infer_utils/vad_predictor.py:13-175, predict.py:195-234).  What belongs to this repo:
+The reference cuts long audio with Silero VAD: a small ONNX network (``silero_vad.onnx``, shipped next to its vad_predictor.py and
+run through onnxruntime) that maps a 512-sample window + LSTM state to a speech probability, followed by a hysteresis /
+minimum-duration / padding state machine in plain Python (masr/infer_utils/vad_predictor.py:13-175, predict.py:195-234).  Here:
 
 * ``VADPredictor`` -- the reference class's interface and its segmentation logic (``get_speech_timestamps`` :106-175,
-  ``stream_vad`` :177-216, ``reset_states`` :73-81, the chunk validation :53-71), written out here and pinned against the
-  reference class on scripted probability sequences (tests/test_vad_cpu.py).  The network itself is a pluggable ``session``
-  with onnxruntime's ``run(None, {'input', 'h', 'c', 'sr'}) -> (prob, h, c)`` signature: the ONNX file is third-party weights
-  that are neither in the reference repository nor in this image, so without a session (or onnxruntime + a model path) the
-  class refuses to construct -- it never guesses probabilities.
-* ``EnergyVAD`` -- the built-in stand-in used by ``predict_long`` when no VAD is supplied: short-time energy against an
-  adaptive noise floor with hysteresis, minimum speech / silence durations and padding (the same knobs as the reference class,
-  :19-35).  It is NOT Silero and will not cut at the same samples.
+  ``stream_vad`` :177-216, ``reset_states`` :73-81, the chunk validation :53-71), pinned against the reference class on scripted
+  probability sequences and on ``dataset/test.wav`` (tests/test_vad_cpu.py, tests/test_silero.py).  The network behind it is a
+  ``session`` with onnxruntime's ``run(None, {'input', 'h', 'c', 'sr'}) -> (prob, h, c)`` signature; the default is
+  ``infer_utils.silero_vad.SileroVAD``: the network on the GPU (csrc/silero.hip) with the weights read out of the user's copy of
+  the ONNX file (no onnxruntime involved).  When the session can score a whole recording at once (``speech_probs``: two launches
+  instead of one session.run per window) ``get_speech_timestamps`` uses that -- same probabilities, same state afterwards.
+  Without a model file the class refuses to construct; it never guesses probabilities.
+* ``EnergyVAD`` -- a stand-in for callers WITHOUT the Silero file (explicit opt-in: ``predict_long(vad_predictor=EnergyVAD())``):
+  short-time energy against an adaptive noise floor with hysteresis, minimum speech / silence durations and padding (the same knobs
+  as the reference class, :19-35).  It is NOT Silero and will not cut at the same samples.
 
 ``predict_long`` takes ANY object with ``get_speech_timestamps(audio: np.float32[N], sampling_rate) -> [{'start', 'end'}]``.
 """
@@ -92,16 +94,9 @@ class VADPredictor(object):
     def __init__(self, path=None, threshold: float = 0.5, min_speech_duration_ms: int = 250, min_silence_duration_ms: int = 100,
                  window_size_samples: int = 512, speech_pad_ms: int = 30, session=None):
         if session is None:
-            try:
-                import onnxruntime
-            except ImportError as exc:
-                raise Exception('VADPredictor needs the Silero network: pass session=<object with onnxruntime\'s run()> or '
-                                'install onnxruntime and give the path of silero_vad.onnx') from exc
-            if path is None or not os.path.exists(path):
-                raise Exception(f'Silero VAD model not found: {path}')
-            session = onnxruntime.InferenceSession(path)
-            session.intra_op_num_threads = 1
-            session.inter_op_num_threads = 1
+            # vad_predictor.py:33-36 builds an onnxruntime session on silero_vad.onnx; here the same file feeds the GPU network
+            from masr_amd.infer_utils.silero_vad import SileroVAD
+            session = SileroVAD(path)
         self.session = session
         self.threshold = threshold
         self.min_speech_duration_ms = min_speech_duration_ms
@@ -148,7 +143,21 @@ class VADPredictor(object):
 
     # ---- offline segmentation (:106-175) ------------------------------------------------------------------------------------
     def speech_probabilities(self, audio, sampling_rate):
+        """the per-window loop of get_speech_timestamps (:122-129).  A session that scores whole recordings (SileroVAD) does it
+        in one call; the state bookkeeping of ``__call__`` is kept identical (same self._h / self._c afterwards)."""
         w = self.window_size_samples
+        batched = getattr(self.session, 'speech_probs', None)
+        if batched is not None and len(audio) > 0:
+            head = np.asarray(audio[:w])
+            if len(head) < w:
+                head = np.pad(head, (0, w - len(head)))
+            _, sr = self._validate_input(head, sampling_rate)
+            if sr == sampling_rate:                          # (a multiple of 16 kHz goes through the per-window path as written)
+                if not self._last_batch_size or (self._last_sr and self._last_sr != sr) or self._last_batch_size != 1:
+                    self.reset_states(1)
+                probs, self._h, self._c = batched(audio, sr, w, self._h, self._c)
+                self._last_sr, self._last_batch_size = sr, 1
+                return [float(p) for p in probs]
         probs = []
         for start in range(0, len(audio), w):
             chunk = audio[start:start + w]

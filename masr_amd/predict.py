@@ -105,13 +105,15 @@ class MASRPredictor:
         return self._predict_local([self._load_audio(audio_data, sample_rate)])[0]
 
     def init_vad(self, vad_predictor=None):
-        """predict.py:110-115.  ``vad_predictor``: any object with the reference VADPredictor's ``get_speech_timestamps``;
-        default: the built-in energy VAD (Silero / onnxruntime are outside this path, see infer_utils/vad_predictor.py)."""
+        """predict.py:110-115: ``VADPredictor()`` -- the Silero network (on the GPU, weights from the reference's
+        ``silero_vad.onnx``: infer_utils/silero_vad.py says where the file is looked for; without it this raises).
+        ``vad_predictor``: any object with the reference VADPredictor's ``get_speech_timestamps`` instead, e.g. the built-in
+        ``EnergyVAD`` stand-in for callers without the Silero file."""
         if vad_predictor is not None:
             self.vad_predictor = vad_predictor
         elif getattr(self, 'vad_predictor', None) is None:
-            from masr_amd.infer_utils.vad_predictor import EnergyVAD
-            self.vad_predictor = EnergyVAD()
+            from masr_amd.infer_utils.vad_predictor import VADPredictor
+            self.vad_predictor = VADPredictor()
 
     def predict_long(self, audio_data, use_pun=False, is_itn=False, sample_rate=16000, vad_predictor=None, batch_size=32):
         """predict.py:195-234: long audio -> VAD segments -> text.  The reference recognises the segments one after the
