@@ -11,6 +11,9 @@ starts; the token ids come back through a pinned buffer and step k's text is bui
 already running under such a launcher (WORLD_SIZE set, as the driver does); a WORLD_SIZE that disagrees with ``--gpus`` is an
 error.  Rank 0 prints ONE JSON line (contract in the task statement) with these additions:
   roofline      the fused FFN kernel: algorithmic FLOPs / HIP-event time of its launches inside the timed region
+  value_host_to_host  SURVEY 8(d) / BASELINE.md's definition of the metric (pinned host PCM -> ... -> text on the host); ``value``
+                follows the task contract (inputs resident in HBM when the timed region starts, the PCIe-inclusive rate never
+                the headline) -- both are in the line, 1-3 % apart
   timing        the same step measured two more ways: ``device_only`` (no D2H, no text: round 1's number) and
                 ``host_to_host`` (pinned host PCM -> H2D -> ... -> text, SURVEY 8(d)'s "PCM-on-host to hypotheses-on-host")
   cpu_baseline  the reference's CPU path on this node's host cores, bounded sample (N = 1 only)
@@ -136,7 +139,7 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(budget_s=24.0):
+def cpu_baseline(budget_s=30.0):
     """MASR's own CPU predict path on this node's host cores, on a bounded sample of the contract workload.  Two legs
     (SURVEY 8(d)): (i) the batched ``get_encoder_out`` path (trainer.py:632) on 4 x 10 s, (ii) the per-utterance
     ``MASRPredictor.predict`` loop (featurize + encoder + greedy, B = 1 calls, predict.py:167-192) -- ``value`` is leg (ii),
@@ -170,12 +173,12 @@ def cpu_baseline(budget_s=24.0):
         return 40.0
 
     def leg_predict_loop():
-        for i in range(2):
+        for i in range(4):
             feat = ofb.featurize_pcm16(pcm[i])[0][None]
             with torch.no_grad():
                 probs = encode(torch.from_numpy(feat), torch.tensor([feat.shape[1]])).numpy()[0]
             od.greedy_decoder(probs, vocab)
-        return 20.0
+        return 40.0
 
     out = {}
     for name, leg in (('batched', leg_batched), ('predict_loop', leg_predict_loop)):
@@ -192,7 +195,7 @@ def cpu_baseline(budget_s=24.0):
         log(f'cpu_baseline {name}: {out[name]}')
     return {'value': out['predict_loop']['value'], 'unit': 'audio-seconds/sec', 'cores': cores, 'kind': kind,
             'cpu_model': cpu_model(),
-            'sample': f'leg (ii) per-utterance predict loop: 2 x 10 s utterances, B = 1 calls (featurize + get_encoder_out + '
+            'sample': f'leg (ii) per-utterance predict loop: 4 x 10 s utterances, B = 1 calls (featurize + get_encoder_out + '
                       f'greedy), median of {out["predict_loop"]["reps"]} reps, torch threads = {cores}',
             'batched': {'value': out['batched']['value'], 'reps': out['batched']['reps'],
                         'sample': 'leg (i) batched get_encoder_out path (trainer.py:632): 4 x 10 s in one padded batch'}}
@@ -378,6 +381,7 @@ def run_contract(args, rank, world, local):
                           'algorithmic_gflop_per_step_per_gpu': GFLOP_PER_STEP,
                           'timed_region': 'int16 PCM resident in HBM -> token ids -> (all-gather) -> D2H -> text on host; '
                                           f'{n_texts} transcripts built inside it, e.g. {sample_text[:12]!r}'},
+               'value_host_to_host': per(dt_host)['value'],
                'roofline': roofline,
                'timing': {'device_only': dict(per(dt_dev), note='PCM in HBM -> token ids in HBM, nothing synchronised per step'),
                           'host_to_host': dict(per(dt_host), note='pinned host int16 PCM -> H2D (copy stream, under the previous step) -> ... -> D2H -> text on host')}}
@@ -433,7 +437,7 @@ def extra_efficient_b256(args, rank, world, local):
         t, c, _ = parallel.gather_hypotheses(tok, nt, sc)
         if rank == 0:
             texts[:] = parallel.tokens_to_text(t.cpu().numpy(), c.cpu().numpy(), vocab)
-    steps = max(2, args.steps // 4)
+    steps = max(10, args.steps // 2)
     dt = parallel.timed_region(step, steps, 1)
     eng.close()
     return {'workload': f'configs[3]: efficient_conformer.yml streaming fbank, 256 x 10 s utterances sharded over {world} GPU(s) '
@@ -442,7 +446,7 @@ def extra_efficient_b256(args, rank, world, local):
             'ms_per_step': round(dt * 1e3 / steps, 3), 'scaling': 'strong', 'transcripts': len(texts)}
 
 
-def extra_stream128(args, rank, world, local):
+def extra_stream128(args, rank, world, local, n_streams=None, reps=None):
     """configs[4]: conformer.yml streaming, 128 concurrent synthetic streams (128 / N sticky per GPU) fed 0.5 s (8000-sample)
     int16 PCM chunks in lock-step through the REAL stream framing (StreamPool.feed / step: ragged fbank of the pending
     samples, 67-frame windows, greedy history collapse); per-call latency p50 / p95 and aggregate audio-s/s"""
@@ -451,7 +455,9 @@ def extra_stream128(args, rank, world, local):
     from masr_amd.utils import synthetic
     pred = facade('conformer', 'ctc_greedy', local)
     pool = parallel.ShardedStreamPool(StreamPool(pred, max_frames_out=320))
-    n_streams, chunk, n_chunks = int(os.environ.get('MASR_BENCH_STREAMS', '128')), 8000, 20
+    n_streams = n_streams or int(os.environ.get('MASR_BENCH_STREAMS', '128'))
+    chunk, n_chunks = 8000, 20
+    reps = reps or (10 if n_streams <= 32 else 4)              # 20 calls per utterance: >= 80 timed calls (stream128), 200 (stream16)
     gids = [pool.open() for _ in range(n_streams)]
     mine = pool.local_ids()
     pcm = synthetic.synthetic_pcm(len(mine), chunk * n_chunks, seed=4321 + rank)
@@ -469,12 +475,13 @@ def extra_stream128(args, rank, world, local):
                 lat.append(time.perf_counter() - t0)
 
     utterance(False)
-    dt = parallel.timed_region(lambda i: utterance(True), 2, 0)
+    dt = parallel.timed_region(lambda i: utterance(True), reps, 0)
     lat_all = parallel.gather_floats(lat)
     pred.predictor.engine.close()
     return {'workload': f'configs[4]: conformer.yml streaming chunk = 0.5 s online, {n_streams} concurrent synthetic streams over {world} '
                         f'GPU(s) ({len(mine)} per GPU, sticky), real predict_stream framing, ctc_greedy partials every call',
-            'value': round(n_streams * n_chunks * 0.5 * 2 / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world,
+            'value': round(n_streams * n_chunks * 0.5 * reps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world,
+            'steps': reps * n_chunks,
             'call_latency_ms': {'p50': round(float(np.percentile(lat_all, 50)) * 1e3, 3),
                                 'p95': round(float(np.percentile(lat_all, 95)) * 1e3, 3), 'calls': len(lat_all),
                                 'note': 'one call = feed + step of all streams of a GPU for one 0.5 s chunk (python framing included)'}}
@@ -497,7 +504,7 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True):
     else:
         conf['language_model_path'] = None           # explicit scorer-free search (not a reference configuration)
     pred = facade('squeezeformer', 'ctc_beam_search', local, streaming=False, beam_conf=conf)
-    steps = 2
+    steps = 10
     pred.predict_batch(audio, batch_size=32)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -518,6 +525,8 @@ def run_extras(args, rank, world, local):
     out = {}
     jobs = [('efficient_b256', extra_efficient_b256), ('stream128', extra_stream128)]
     if world == 1:
+        # the per-GPU share of configs[4] on an 8-GPU node (128 streams / 8), measured on this one GPU
+        jobs.append(('stream16', lambda a, r, w, l: extra_stream128(a, r, w, l, n_streams=16)))
         jobs.append(('squeezeformer_b64_beam', extra_squeezeformer_beam))
     for name, fn in jobs:
         try:

@@ -1,4 +1,4 @@
-"""Batched serving front-end on one engine.
+"""Batched serving front-end: one ``EngineWorker`` per GPU, a router in front of them.
 
 The reference server owns ONE MASRPredictor and runs every request inline in the asyncio handler: one utterance per
 ``predict`` call and at most one websocket stream at a time (``predictor.running``; infer_server.py:42-46,48-71,103-156).
@@ -16,6 +16,13 @@ The MI355X engine only reaches its throughput with batches, so this front-end ke
 * every websocket is its own ``StreamPool`` session; chunks that arrive within a tick are fed together and advanced by ONE
   ``StreamPool.step()`` (one ragged fbank launch, lock-step ``masr_encode_chunk`` calls);
 * the worker is the only thread that touches the engine (the C-ABI handle is not thread-safe, include/masr_hip.h).
+
+Several GPUs (BASELINE configs[4]: 128 streams sticky over the 8 GPUs of a node): ``create_app(predictors=[...])`` with one
+predictor per GPU builds one worker thread per engine in ONE process (every C-ABI entry point selects its engine's device;
+the worker thread makes it torch's current device too) behind a ``WorkerRouter``: a websocket session lives on the worker it
+was opened on for its whole life (its caches never move), sessions go round-robin over the workers; an offline request goes
+to the worker with the least queued work.  Nothing is exchanged between the GPUs: the path's only collective (the all-gather
+of hypotheses, parallel.py) belongs to batch jobs, not to a request/response server.
 
 No static pages, templates or upload archive: the web UI is outside the hot path.  ``uvicorn`` needs the ``websockets`` or
 ``wsproto`` package to serve the websocket route; the in-process test client does not.
@@ -43,6 +50,7 @@ class EngineWorker(object):
         self._feeds = []            # (handle, pcm bytes, is_end, future)
         self._stop = False
         self.stats = {'batches': 0, 'utterances': 0, 'steps': 0, 'chunks': 0}
+        self._busy = 0              # requests taken off the queues and not finished yet
         self._thread = threading.Thread(target=self._run, name='masr-engine-worker', daemon=True)
         self._thread.start()
 
@@ -80,6 +88,11 @@ class EngineWorker(object):
             self._cv.notify()
         return fut
 
+    def load(self):
+        """queued + running requests (what the router balances offline requests on)"""
+        with self._cv:
+            return len(self._offline) + len(self._feeds) + len(self._calls) + self._busy
+
     def shutdown(self):
         with self._cv:
             self._stop = True
@@ -102,13 +115,25 @@ class EngineWorker(object):
                     batch = []
                     if batch_ready:
                         batch, self._offline = self._offline[:self.max_batch], self._offline[self.max_batch:]
+                    self._busy = len(calls) + len(batch) + len(feeds)
                     return calls, batch, feeds
                 timeout = None
                 if self._offline:
                     timeout = max(0.0, self.max_wait - (now - self._offline[0][0]))
                 self._cv.wait(timeout)
 
+    def _enter_device(self):
+        """this thread works for ONE engine: make its GPU torch's current device here (allocations, current stream)"""
+        try:
+            dev = self.predictor.predictor.engine.device
+            import torch
+            if dev.type == 'cuda':
+                torch.cuda.set_device(dev)
+        except AttributeError:
+            pass                      # stand-in predictors of the CPU tests have no engine
+
     def _run(self):
+        self._enter_device()
         while True:
             work = self._take()
             if work is None:
@@ -120,6 +145,8 @@ class EngineWorker(object):
                 self._step_streams(feeds)
             if batch:
                 self._run_batch(batch)
+            with self._cv:
+                self._busy = 0
 
     @staticmethod
     def _resolve(fut, fn, *args, **kwargs):
@@ -181,6 +208,71 @@ class EngineWorker(object):
             feeds = later
 
 
+class WorkerRouter(object):
+    """N EngineWorkers (one per GPU) behind the interface of one.  Stream sessions are sticky: handle = local handle * N +
+    worker index, opened round-robin; offline requests go to the least loaded worker (ties: lowest index)."""
+
+    def __init__(self, workers):
+        self.workers = list(workers)
+        if not self.workers:
+            raise ValueError('WorkerRouter needs at least one worker')
+        self._lock = threading.Lock()
+        self._next = 0
+
+    @property
+    def n(self):
+        return len(self.workers)
+
+    @property
+    def stats(self):
+        out = {}
+        for w in self.workers:
+            for k, v in w.stats.items():
+                out[k] = out.get(k, 0) + v
+        out['per_worker'] = [dict(w.stats) for w in self.workers]
+        return out
+
+    def _pick(self):
+        loads = [w.load() for w in self.workers]
+        return self.workers[loads.index(min(loads))]
+
+    def recognize(self, audio):
+        return self._pick().recognize(audio)
+
+    def recognize_long(self, audio, **kwargs):
+        return self._pick().recognize_long(audio, **kwargs)
+
+    def call(self, fn, *args, **kwargs):
+        return self.workers[0].call(fn, *args, **kwargs)
+
+    def owner(self, handle):
+        return handle % self.n
+
+    def stream_open(self):
+        with self._lock:
+            i = self._next % self.n
+            self._next += 1
+        inner, out = self.workers[i].stream_open(), Future()
+
+        def done(f):
+            try:
+                out.set_result(f.result() * self.n + i)
+            except BaseException as e:
+                out.set_exception(e)
+        inner.add_done_callback(done)
+        return out
+
+    def stream_feed(self, handle, pcm_bytes, is_end=False):
+        return self.workers[handle % self.n].stream_feed(handle // self.n, pcm_bytes, is_end)
+
+    def stream_close(self, handle):
+        return self.workers[handle % self.n].stream_close(handle // self.n)
+
+    def shutdown(self):
+        for w in self.workers:
+            w.shutdown()
+
+
 def _multipart_file(content_type, body, field='audio'):
     """the bytes of multipart form field ``field`` (python-multipart is not a dependency); raw bodies pass through"""
     if not content_type or 'multipart/form-data' not in content_type:
@@ -192,18 +284,30 @@ def _multipart_file(content_type, body, field='audio'):
     raise ValueError(f'multipart field {field!r} missing')
 
 
-def create_app(predictor, max_batch=32, max_wait_ms=10.0, max_frames_out=0, pool=None):
-    """FastAPI application speaking the reference server's protocol on top of an EngineWorker.  ``app.state.worker`` is the
-    worker (``.stats`` counts batches / utterances / steps / chunks).  ``pool``: a StreamPool to use for the websocket
-    sessions (default: one is built for a streaming ctc_greedy predictor)."""
+def create_app(predictor=None, max_batch=32, max_wait_ms=10.0, max_frames_out=0, pool=None, predictors=None, pools=None):
+    """FastAPI application speaking the reference server's protocol on top of an EngineWorker -- or, with
+    ``predictors=[one MASRPredictor per GPU]``, on a ``WorkerRouter`` over one worker per GPU (sticky websocket sessions,
+    least-loaded offline requests).  ``app.state.worker`` is the worker / router (``.stats`` counts batches / utterances /
+    steps / chunks).  ``pool`` / ``pools``: the StreamPool(s) of the websocket sessions (default: one is built per streaming
+    ctc_greedy predictor)."""
     from fastapi import FastAPI, Request, WebSocket
     from starlette.websockets import WebSocketDisconnect
 
-    cfg = predictor.configs
-    if pool is None and cfg.streaming and cfg.decoder == 'ctc_greedy':
-        from masr_amd.serving import StreamPool
-        pool = StreamPool(predictor, max_frames_out=max_frames_out)
-    worker = EngineWorker(predictor, pool, max_batch=max_batch, max_wait_ms=max_wait_ms)
+    if predictors is None:
+        if predictor is None:
+            raise ValueError('create_app needs a predictor (or predictors=[...])')
+        predictors, pools = [predictor], [pool]
+    elif pools is None:
+        pools = [None] * len(predictors)
+    workers = []
+    for pr, pl in zip(predictors, pools):
+        cfg = pr.configs
+        if pl is None and cfg.streaming and cfg.decoder == 'ctc_greedy':
+            from masr_amd.serving import StreamPool
+            pl = StreamPool(pr, max_frames_out=max_frames_out)
+        workers.append(EngineWorker(pr, pl, max_batch=max_batch, max_wait_ms=max_wait_ms))
+    worker = workers[0] if len(workers) == 1 else WorkerRouter(workers)
+    pool = workers[0].pool if all(w.pool is not None for w in workers) else None
     app = FastAPI(title='MASR')
     app.state.worker = worker
 

@@ -161,3 +161,54 @@ def test_packed_weight_artefact_round_trip(tmp_path):
     mpath = os.path.join(tmp_path, 'model.pt')
     torch.save(sd, mpath)
     assert not packed.is_packed(mpath)
+
+
+def test_worker_router_sticky_streams_and_least_loaded_offline():
+    """multi-GPU front-end (SURVEY 8e, configs[4]): one worker per engine, websocket sessions sticky to the worker they were
+    opened on (round-robin), offline requests to the least loaded worker"""
+    import time
+    from masr_amd.server import EngineWorker, WorkerRouter
+    preds, pools = [_FakePredictor(), _FakePredictor()], [_FakePool(), _FakePool()]
+    r = WorkerRouter([EngineWorker(p, pl, max_batch=4, max_wait_ms=1.0) for p, pl in zip(preds, pools)])
+    hs = [r.stream_open().result(timeout=10) for _ in range(5)]
+    assert [r.owner(h) for h in hs] == [0, 1, 0, 1, 0] and len(set(hs)) == 5
+    for k, h in enumerate(hs):
+        assert r.stream_feed(h, b'x' * (4 + k)).result(timeout=10)['text'] == f'b{4 + k}'
+    assert r.stream_feed(hs[1], b'yy', is_end=True).result(timeout=10)['text'] == 'b7'       # 5 + 2 on the same session
+    assert sorted(pools[0].sessions.values()) == [4, 6, 8] and sorted(pools[1].sessions.values()) == [5 + 2, 7]
+    for h in hs:
+        r.stream_close(h).result(timeout=10)
+    assert len(pools[0].closed) == 3 and len(pools[1].closed) == 2
+    # worker 0 is kept busy: new offline requests go to worker 1
+    gate = r.workers[0].call(time.sleep, 0.4)
+    more = [r.workers[0].call(time.sleep, 0.0) for _ in range(4)]             # load of worker 0: 5 queued / running calls
+    time.sleep(0.05)
+    futs = [r.recognize(b'z' * (i + 1)) for i in range(3)]
+    assert [f.result(timeout=10)['text'] for f in futs] == ['n1', 'n2', 'n3']
+    assert sum(preds[1].batches) == 3 and sum(preds[0].batches) == 0
+    gate.result(timeout=10)
+    [m.result(timeout=10) for m in more]
+    assert r.recognize_long(b'123').result(timeout=10)['text'] == 'long3'
+    st = r.stats
+    assert st['utterances'] == 3 and st['chunks'] == 6 and len(st['per_worker']) == 2
+    r.shutdown()
+
+
+def test_server_app_on_two_workers():
+    import warnings
+    warnings.simplefilter('ignore')
+    from starlette.testclient import TestClient
+    from masr_amd.server import WorkerRouter, create_app
+    preds, pools = [_FakePredictor(), _FakePredictor()], [_FakePool(), _FakePool()]
+    app = create_app(predictors=preds, pools=pools, max_batch=8, max_wait_ms=1.0)
+    assert isinstance(app.state.worker, WorkerRouter)
+    with TestClient(app) as c:
+        assert c.post('/recognition', content=b'12345').json() == {'code': 0, 'msg': 'success', 'result': 'n5', 'score': 50.0}
+        with c.websocket_connect('/') as a, c.websocket_connect('/') as b:
+            a.send_bytes(b'1234')
+            b.send_bytes(b'123456')
+            assert a.receive_json() == {'code': 0, 'result': 'b4'} and b.receive_json() == {'code': 0, 'result': 'b6'}
+            a.send_bytes(b'5end')
+            assert a.receive_json() == {'code': 0, 'result': 'b5'}
+            b.send_bytes(b'end')
+        assert len(pools[0].sessions) == 1 and len(pools[1].sessions) == 1      # one session on each worker
