@@ -257,30 +257,37 @@ class ShardedStreamPool:
         local = {back[h]: r for h, r in res.items()}
         if not gather or not collectives_on(self.group):
             return local
-        # exchange: one int32 row per open session, [ntok (-1 = no result in this step) | score f64 bits (2) | tokens ...]
+        # exchange: one int32 row per open session, [ntok (-1 = no result in this step) | score f64 bits (2) | tokens ...], rows
+        # of a FIXED width (the pool's frame capacity bounds a transcript), so the step needs no size agreement: ONE all-gather.
+        # A greedy StreamPool hands over the packed rows it already has on the device; nothing is rebuilt on the host.
         gids = sorted(self._open)
         per = max(sum(1 for g in gids if self.owner(g) == r) for r in range(self.world))
         mine = [g for g in gids if self.owner(g) == self.rank]
-        rows, tmax = {}, 1
-        for g in mine:
-            r = local.get(g)
-            if r is not None:
-                toks = np.asarray(self.pool.last_tokens(self._local[g]), np.int32)
-                rows[g] = (toks, np.float64(r['score']))
-                tmax = max(tmax, len(toks))
+        width = int(getattr(self.pool, 'max_frames_out', 0) or 1024)
         dev = comm_device()
-        t = torch.tensor([tmax], dtype=torch.int32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        tmax = int(t.item())
-        payload = np.full((per, 3 + tmax), -1, np.int32)
-        for j, g in enumerate(mine):
-            if g in rows:
-                toks, score = rows[g]
-                payload[j, 0] = len(toks)
-                payload[j, 1:3] = np.array([score], np.float64).view(np.int32)
-                payload[j, 3:3 + len(toks)] = toks
-        mine_t = torch.from_numpy(payload).to(dev)
-        allp = torch.empty((self.world * per, 3 + tmax), dtype=torch.int32, device=dev)
+        packed = getattr(self.pool, 'last_packed', None)
+        if packed is not None and packed[0].device.type == dev.type:
+            rows_dev, tmax, sids = packed
+            slot = {g: j for j, g in enumerate(mine)}
+            at = torch.tensor([slot[back[h]] for h in sids], dtype=torch.long, device=rows_dev.device)
+            ntok = rows_dev[:, tmax]
+            score = rows_dev[:, tmax + 1].contiguous().view(torch.float32).double() * 100.0
+            score = torch.where(ntok > 0, score, torch.zeros_like(score))
+            mine_t = torch.full((per, 3 + width), -1, dtype=torch.int32, device=rows_dev.device)
+            mine_t[at, 0] = ntok
+            mine_t[at, 1:3] = score.view(torch.int32).view(-1, 2)
+            mine_t[at, 3:3 + min(tmax, width)] = rows_dev[:, :min(tmax, width)]
+        else:
+            payload = np.full((per, 3 + width), -1, np.int32)
+            for j, g in enumerate(mine):
+                r = local.get(g)
+                if r is not None:
+                    toks = np.asarray(self.pool.last_tokens(self._local[g]), np.int32)[:width]
+                    payload[j, 0] = len(toks)
+                    payload[j, 1:3] = np.array([r['score']], np.float64).view(np.int32)
+                    payload[j, 3:3 + len(toks)] = toks
+            mine_t = torch.from_numpy(payload).to(dev)
+        allp = torch.empty((self.world * per, 3 + width), dtype=torch.int32, device=mine_t.device)
         dist.all_gather_into_tensor(allp, mine_t, group=self.group)
         allp = allp.cpu().numpy()
         out = {}

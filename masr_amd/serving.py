@@ -264,6 +264,7 @@ class StreamPool:
             self._feat.view(-1, self.feat_dim)[moves[1]] = feats.view(-1, self.feat_dim)[moves[0]]
 
     def step(self):
+        self.last_packed = None
         fed, self._fed = self._fed, {}
         if not fed:
             return {}
@@ -318,7 +319,9 @@ class StreamPool:
             nfr = self._stage.put([s.frames for s in adv], np.int32)
             tok, ntok, score = eng.ctc_collapse(self._hist_idx[rows, :tmax].contiguous(), self._hist_mp[rows, :tmax].contiguous(), nfr)
             # one copy back: [tokens | count | score bits]
-            packed = torch.cat([tok, ntok[:, None], score.view(torch.int32)[:, None]], 1).cpu().numpy()
+            packed_dev = torch.cat([tok, ntok[:, None], score.view(torch.int32)[:, None]], 1)
+            self.last_packed = (packed_dev, tmax, [s.sid for s in adv])       # device copy: what a multi-GPU gather ships
+            packed = packed_dev.cpu().numpy()
             tok, ntok, score = packed[:, :tmax], packed[:, tmax], packed[:, tmax + 1].copy().view(np.float32)
             for j, s in enumerate(adv):
                 s.tokens = tok[j, :ntok[j]].tolist()

@@ -575,6 +575,22 @@ def test_predict_batch_and_evaluate_through_the_rccl_exchange(predictor, tmp_pat
         assert [g['text'] for g in got] == [w['text'] for w in want]
         assert all(abs(g['score'] - w['score']) < 1e-3 for g, w in zip(got, want))
         assert got[4] == {'text': '', 'score': 0.0} or got[4]['text'] == ''          # shorter than one decoding window
+        # the stream router's exchange: the pool's device-packed rows through ONE fixed-width all-gather == the local partials
+        from masr_amd.serving import StreamPool
+        local_pool, sharded = StreamPool(predictor), parallel.ShardedStreamPool(StreamPool(predictor, max_frames_out=400))
+        hl = [local_pool.open() for _ in range(3)]
+        hg = [sharded.open() for _ in range(3)]
+        for lo in range(0, 48000, 8000):
+            for k in range(3):
+                chunk = pcm[10000 * k + lo:10000 * k + lo + 8000].tobytes()
+                local_pool.feed(hl[k], chunk, is_end=lo + 8000 >= 48000)
+                sharded.feed(hg[k], chunk, is_end=lo + 8000 >= 48000)
+            a, b = local_pool.step(), sharded.step(gather=True)
+            for k in range(3):
+                assert (a[hl[k]] is None) == (b[hg[k]] is None)
+                if a[hl[k]] is not None:
+                    assert a[hl[k]]['text'] == b[hg[k]]['text'] and abs(a[hl[k]]['score'] - b[hg[k]]['score']) < 1e-3
+        assert any(v is not None and v['text'] for v in b.values())
     finally:
         dist.destroy_process_group()
 
