@@ -167,7 +167,7 @@ bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s)
 void set_rowgemm_small_blocks(int n);                                                // tuning (masr_debug_set key 12)
 void set_rowgemm_small(int on);                                                      // diagnostics (masr_debug_set key 6)
 
-// Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_pc.hip; ffn_fused.hip = previous kernel, kept for A/B)
+// Fused FFN block, in place: x <- x + scale * (W2 . silu(W1 . LN(x) + b1) + b2)   (ffn_pc.hip; launched through launch_ffn_fused in ffn_reduce.hip)
 // partial/nsplit: split-d_ff mode for small M (streaming).  post: LayerNorm that follows the block in the layer; it is fused into
 // the split-mode reduction (return value 1), otherwise the caller runs it (return value 0)
 struct FfnPostLn {

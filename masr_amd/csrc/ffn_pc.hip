@@ -1,5 +1,5 @@
-// Fused position-wise feed-forward block, producer/consumer wave specialisation (same math, layout and interface as
-// ffn_fused.hip; reference conformer/positionwise.py:30-37, conformer/encoder.py:113-121,150-158):
+// Fused position-wise feed-forward block, producer/consumer wave specialisation (reference conformer/positionwise.py:30-37,
+// conformer/encoder.py:113-121,150-158):
 //     x <- x + scale * ( W2 . silu( W1 . LayerNorm(x) + b1 ) + b2 )
 // One workgroup = 32 rows, 8 waves = 2 per SIMD.  The two waves of a SIMD have DIFFERENT jobs:
 //   producer  wave p (0..3): hidden tile  h[32 rows, 32 units]  = silu(xn . W1[chunk*128 + 32p .. +31, 0..255]^T + b1)
@@ -8,8 +8,9 @@
 //                            (128 MFMA per chunk, K = 128 from hs[(phase-1) & 1])
 // In phase k the producers work on chunk k while the consumers work on chunk k-1: the bias + SiLU + LDS traffic of one
 // wave overlaps with the matrix work of the other wave on the same SIMD, and there is ONE workgroup barrier per chunk
-// (the k-split partial-sum exchange of ffn_fused.hip is gone).  Weights stream through the same wave-private,
-// double-buffered LDS slabs with a 4-deep register prefetch rotation; no barrier on the weight path.
+// (round 1's first version split K of the first GEMM over the waves and exchanged partial sums through LDS, two barriers per
+// chunk; that kernel is gone).  Weights stream through wave-private, double-buffered LDS slabs [32][36] filled by the consuming
+// wave itself with a 4-deep register prefetch rotation; no barrier on the weight path.
 // TAIL = 1 (first macaron FFN of an offline Conformer layer): the 32 finished rows do not leave the CU before the next
 // row-local stage -- they are put back into the LayerNorm tile, normalised with the attention block's LayerNorm, and all 8 waves
 // run the fused QKV projection on them ([768, 256] weights through the same wave-private slab stream, 3 output tiles per
