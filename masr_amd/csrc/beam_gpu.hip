@@ -135,9 +135,12 @@ __device__ __forceinline__ void pick_bin(const int* hist, int need, int& bin, in
 }
 
 // NPT = extension entries per thread in the selection phase, strided (beam * K <= 1024 * NPT)
-template <int NPT>
+// ORD = 0: no external scorer; 3 | 5: a language model of order <= ORD is bound (bounds the probes per scored extension, which
+//       live in registers while a batch of extensions is in flight)
+template <int NPT, int ORD>
 __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr bool use_lm = ORD > 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = blockIdx.x;
     const int beam = a.beam, K = a.K;
@@ -161,9 +164,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     float* lv_bo = reinterpret_cast<float*>(lv_ctx + 2 * beam);          // [2][beam][4] backoffs of the context's suffixes
     int* lv_m = reinterpret_cast<int*>(lv_bo + 8 * beam);                // [2][beam] m | oov << 8
     // (the scorer's 14 words per live prefix exist only when a language model is bound: an LM-free beam 500 x 40 fits without them)
-    int* c_idx = a.use_lm ? lv_m + 2 * beam : reinterpret_cast<int*>(lv_ctx);   // [BS_KMAX]; bit 30 set = unknown to the language model
+    int* c_idx = use_lm ? lv_m + 2 * beam : reinterpret_cast<int*>(lv_ctx);   // [BS_KMAX]; bit 30 set = unknown to the language model
     float* c_lp = reinterpret_cast<float*>(c_idx + BS_KMAX);             // [BS_KMAX]
-    int* hist = reinterpret_cast<int*>(c_lp + BS_KMAX);                  // [7][256]: one per radix pass of a step
+    float* c_uni = c_lp + BS_KMAX;                                       // [BS_KMAX] ln P_LM(candidate) (unigram), per frame
+    int* hist = reinterpret_cast<int*>(c_uni + BS_KMAX);                 // [7][256]: one per radix pass of a step
     int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
     int* misc = wsum + (6 + NPT) * BS_WAVES;                                         // [8]: 0 blank_k, 1 sel_bin, 2 need
     unsigned short* slist = reinterpret_cast<unsigned short*>(misc + 8);  // [beam * K] surviving extension entries
@@ -173,8 +177,6 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     int* st_i = a.state_i + (size_t)u * (2 + 3 * beam);
     float* st_f = a.state_f + (size_t)u * (7 * beam);
     unsigned long long* st_h = a.state_h + (size_t)u * (3 * beam);
-    const bool use_lm = a.use_lm != 0;
-
     int n, pool_count, cur = 0;
     if (a.init) {
         n = 1;
@@ -239,6 +241,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 const bool unk = use_lm && !(nx_c >= 0 && nx_c < a.lm.n_words && a.lm.known[nx_c]);
                 c_idx[lane] = nx_c | (unk ? (1 << 30) : 0);
                 c_lp[lane] = nx_lp;
+                if (use_lm) {                             // the candidate's unigram: one lookup per frame and candidate
+                    float up = LM_OOV_SCORE, ub;
+                    if (!unk) lm_find(a.lm, lm_key(0ull, 0, nx_c), &up, &ub);
+                    c_uni[lane] = up;
+                }
             }
             if (lane == 0) {
                 misc[0] = bm ? __ffsll((long long)bm) - 1 : -1;
@@ -316,7 +323,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                         val = lp + sc;
                     }
                     // the external scorer: every way into the prefix p + c carries the same alpha * ln P_LM + beta
-                    if (use_lm && val > -INFINITY) val += a.alpha * lm_cond(a.lm, sp, c, !(craw >> 30)) + a.beta;
+                    if (use_lm && val > -INFINITY) {
+                        const float lmp = (sp.oov || (craw >> 30)) ? LM_OOV_SCORE
+                                                                   : lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, sp, c, c_uni[k]);
+                        val += a.alpha * lmp + a.beta;
+                    }
                     for (int j = hd; j >= 0; j = next[j])
                         if (lv_ch[o + j] == c) {                    // the child (p, c) is a live prefix: merge into it
                             ext[j] = val;
@@ -549,30 +560,36 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 }
 
 size_t beam_gpu_lds_bytes(int beam, int K, bool use_lm) {
-    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 14 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 2 * BS_KMAX * 4 + 7 * 256 * 4 +
+    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 14 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 3 * BS_KMAX * 4 + 7 * 256 * 4 +
            (6 + 32) * BS_WAVES * 4 + 8 * 4 + 128;
 }
 
-template <int NPT>
+template <int NPT, int ORD>
 static void launch_beam_t(const BeamGpuArgs& a, int B, size_t lds, hipStream_t s) {
-    auto k = beam_search_kernel<NPT>;
+    auto k = beam_search_kernel<NPT, ORD>;
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds, attr);
     hipLaunchKernelGGL(k, dim3(B), dim3(BS_THREADS), lds, s, a);
+}
+template <int ORD>
+static int launch_beam_o(const BeamGpuArgs& a, int B, size_t lds, int per, hipStream_t s) {
+    if (per <= 4) launch_beam_t<4, ORD>(a, B, lds, s);
+    else if (per <= 12) launch_beam_t<12, ORD>(a, B, lds, s);
+    else if (per <= 20) launch_beam_t<20, ORD>(a, B, lds, s);
+    else if (per <= 32) launch_beam_t<32, ORD>(a, B, lds, s);
+    else return 1;
+    return 0;
 }
 
 int launch_beam_search(const BeamGpuArgs& a, int B, hipStream_t s) {
     if (B <= 0) return 0;
     if (a.K > BS_KMAX || a.beam > 512 || a.beam < 1 || a.pool_cap > (1 << 30)) return 1;
+    if (a.use_lm && (a.lm.max_order < 1 || a.lm.max_order > 5)) return 1;
     const size_t lds = beam_gpu_lds_bytes(a.beam, a.K, a.use_lm != 0);
     if (lds > 160 * 1024) return 1;
     const int per = (a.beam * a.K + BS_THREADS - 1) / BS_THREADS;
-    if (per <= 4) launch_beam_t<4>(a, B, lds, s);
-    else if (per <= 12) launch_beam_t<12>(a, B, lds, s);
-    else if (per <= 20) launch_beam_t<20>(a, B, lds, s);
-    else if (per <= 32) launch_beam_t<32>(a, B, lds, s);
-    else return 1;
-    return 0;
+    if (!a.use_lm) return launch_beam_o<0>(a, B, lds, per, s);
+    return a.lm.max_order <= 3 ? launch_beam_o<3>(a, B, lds, per, s) : launch_beam_o<5>(a, B, lds, per, s);
 }
 
 }  // namespace masr

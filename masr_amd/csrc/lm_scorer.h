@@ -116,9 +116,32 @@ LM_HD LmState lm_state_of(const LmView& lm, unsigned long long ctx) {
         const int w = (int)((ctx >> (16 * j)) & 0xFFFFull);
         if (w >= lm.n_words || !lm.known[w]) s.oov = 1;
     }
-    for (int len = 1; len <= k; ++len) {
-        float p, b;
-        if (!lm_find(lm, lm_key_ctx(ctx, len), &p, &b)) break;
+    // keys of the 1 .. k word suffixes in one pass over the packed words, their first probes issued together (one memory round
+    // trip instead of one per suffix length); linear probing continues only where a slot is taken by another n-gram
+    unsigned long long key[4], k0[4];
+    float p0[4], b0[4];
+    unsigned long long h = LM_SEED;
+#pragma unroll
+    for (int len = 1; len <= 4; ++len) {
+        if (len <= k) {
+            h = lm_mix(h, (ctx >> (16 * (len - 1))) & 0xFFFFull);
+            key[len - 1] = lm_fin(h, len);
+        }
+    }
+#pragma unroll
+    for (int len = 1; len <= 4; ++len)
+        if (len <= k) lm_load_entry(lm, key[len - 1] & lm.mask, &k0[len - 1], &p0[len - 1], &b0[len - 1]);
+    bool open = true;
+#pragma unroll
+    for (int len = 1; len <= 4; ++len) {
+        if (len > k || !open) continue;
+        bool hit = k0[len - 1] == key[len - 1];
+        float p = p0[len - 1], b = b0[len - 1];
+        if (!hit && k0[len - 1] != 0ull) hit = lm_find(lm, key[len - 1], &p, &b);
+        if (!hit) {
+            open = false;
+            continue;
+        }
         s.bo[len - 1] = b;
         s.m = len;
     }
@@ -161,5 +184,31 @@ LM_HD float lm_cond(const LmView& lm, const LmState& s, int w, bool w_known) {
     return LM_OOV_SCORE;       // (a known word always has its unigram)
 }
 LM_HD float lm_cond(const LmView& lm, const LmState& s, int w) { return lm_cond(lm, s, w, w >= 0 && w < lm.n_words && lm.known[w] != 0); }
+
+// The same score with as few table probes as possible, for the GPU search: that kernel is bound by the number of divergent
+// 16-byte loads it issues (12 000 extensions per frame, measured: putting MORE probes in flight per thread makes it slower), not
+// by their latency.  Longest n-gram first, stop at the first hit; the unigram never goes to memory -- `uni` is ln P(w) as the
+// caller looked it up once per frame and candidate.  ORD >= the model's order bounds the keys held in registers.
+template <int ORD>
+LM_HD float lm_cond_desc(const LmView& lm, const LmState& s, int w, float uni) {
+    unsigned long long key[ORD > 1 ? ORD - 1 : 1];
+    unsigned long long h = lm_mix(LM_SEED, (unsigned long long)w);
+#pragma unroll
+    for (int len = 1; len < ORD; ++len) {
+        if (len <= s.m) {
+            h = lm_mix(h, (s.ctx >> (16 * (len - 1))) & 0xFFFFull);
+            key[len - 1] = lm_fin(h, len + 1);
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int len = ORD - 1; len >= 1; --len) {
+        if (len > s.m) continue;
+        float p, b;
+        if (lm_find(lm, key[len - 1], &p, &b)) return acc + p;
+        acc += s.bo[len - 1];
+    }
+    return acc + uni;
+}
 
 }  // namespace masr

@@ -9,6 +9,8 @@ import time
 import numpy as np
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 from masr_amd import runtime
 from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
 from masr_amd.decoders.lm_scorer import write_synthetic_arpa
