@@ -684,6 +684,7 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
     return 0;
 }
 
+static int g_hot_weights = 0;      // masr_debug_set key 19 (timing experiment only): every chunk-step layer runs on layer 0's weights
 static int g_embed_split = 1;      // masr_debug_set key 15: 0 = the offline embed projection never splits K
 // feats [nseq, T, 80] -> x [nseq*Tq, d] (embed incl. x*sqrt(d))
 int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, int* Tq_out) {
@@ -2153,7 +2154,7 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
     float* x = e->x.as<float>();
     EncodeCtx ctx{n, Tq, nullptr};
     for (int l = 0; l < L; ++l) {
-        const LayerW& w = e->layers[l];
+        const LayerW& w = e->layers[g_hot_weights ? 0 : l];
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2));
         mhsa(e, s, w, M, e->attseq.as<AttSeq>() + (size_t)l * n, Tq);     // q -> qkv buffer, k|v rows -> the streams' caches
         launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, 1, s);
@@ -2250,6 +2251,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 7) set_attention_fewq(value);
     else if (key == 14) set_attention_fold(value);
     else if (key == 15) g_embed_split = value;
+    else if (key == 19) g_hot_weights = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }
