@@ -521,6 +521,46 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True):
             'ms_per_step': round(dt * 1e3 / steps, 3), 'transcripts': len(res)}
 
 
+def extra_bf16x3(args, rank, world, local):
+    """EXPLORATORY, never the contract line: configs[1]'s step with conv2, the embed projection and the FFN GEMMs as split-bf16
+    products on the bf16 matrix pipe (masr_debug_set key 20, csrc/gemm_bf16x3.hip: a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32
+    accumulation).  Reported with the distance to the exact-fp32 kernels on the same batch; dtype "bf16x3"."""
+    from masr_amd.utils import synthetic
+    eng = make_engine('conformer', local)
+    pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234 + rank)).to(eng.device)
+    n = torch.full((BATCH,), N_SAMPLES, dtype=torch.int32, device=eng.device)
+    feats, frames = eng.fbank_batch(pcm, n)
+    enc32 = eng.encode_full(feats, frames, -1).clone()
+    tok32, nt32, _ = [t.clone() for t in eng.transcribe_batch(pcm, n)]
+    steps = max(10, args.steps)
+    out = {}
+    for mode in (0, 1):
+        eng.lib.masr_debug_set(eng.h, 20, mode)
+        for _ in range(3):
+            eng.transcribe_batch(pcm, n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.transcribe_batch(pcm, n)
+        torch.cuda.synchronize()
+        out[mode] = (time.perf_counter() - t0) / steps
+    eng.lib.masr_debug_set(eng.h, 20, 1)
+    enc3 = eng.encode_full(feats, frames, -1).clone()
+    tok3, nt3, _ = [t.clone() for t in eng.transcribe_batch(pcm, n)]
+    eng.lib.masr_debug_set(eng.h, 20, 0)
+    torch.cuda.synchronize()
+    same = int(sum(int(nt32[i]) == int(nt3[i]) and torch.equal(tok32[i, :int(nt32[i])], tok3[i, :int(nt3[i])]) for i in range(BATCH)))
+    eng.close()
+    audio = BATCH * N_SAMPLES / 16000.0
+    return {'workload': 'configs[1] in the EXPLORATORY split-bf16 mode (device-only step: PCM in HBM -> token ids in HBM): conv2, embed '
+                        'projection and FFN GEMMs on the bf16 matrix pipe, everything else as in the contract line',
+            'value': round(audio / out[1], 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps, 'dtype': 'bf16x3',
+            'ms_per_step': round(out[1] * 1e3, 3), 'fp32_ms_per_step_same_loop': round(out[0] * 1e3, 3),
+            'max_abs_diff_encoder_output_vs_fp32_kernels': float((enc32 - enc3).abs().max()),
+            'utterances_with_identical_greedy_tokens': f'{same}/{BATCH}',
+            'note': 'not the reference arithmetic (fp32): never the headline; tests/test_gpu_bf16x3.py holds it to the 1e-3 bars'}
+
+
 def run_extras(args, rank, world, local):
     out = {}
     jobs = [('efficient_b256', extra_efficient_b256), ('stream128', extra_stream128)]
@@ -528,6 +568,7 @@ def run_extras(args, rank, world, local):
         # the per-GPU share of configs[4] on an 8-GPU node (128 streams / 8), measured on this one GPU
         jobs.append(('stream16', lambda a, r, w, l: extra_stream128(a, r, w, l, n_streams=16)))
         jobs.append(('squeezeformer_b64_beam', extra_squeezeformer_beam))
+        jobs.append(('conformer_b32_bf16x3_exploratory', extra_bf16x3))
     for name, fn in jobs:
         try:
             t0 = time.perf_counter()
@@ -567,12 +608,12 @@ def main():
         torch.cuda.set_device(local)
 
     if args.workload != 'conformer_b32':
-        fn = {'efficient_b256': extra_efficient_b256, 'stream128': extra_stream128,
+        fn = {'efficient_b256': extra_efficient_b256, 'stream128': extra_stream128, 'bf16x3': extra_bf16x3,
               'squeezeformer_b64_beam': extra_squeezeformer_beam,
               'squeezeformer_b64_beam_nolm': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, lm=False)}[args.workload]
         res = fn(args, rank, world, local)
         if rank == 0:
-            print(json.dumps(dict(res, dtype='f32', data=data_tag()), ensure_ascii=False), flush=True)
+            print(json.dumps(dict({'dtype': 'f32'}, **res, data=data_tag()), ensure_ascii=False), flush=True)
     else:
         eng, res = run_contract(args, rank, world, local)
         eng.close()

@@ -278,7 +278,11 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
  *   9  1 = no conv-module head stage on the second FFN              12  row blocks below which the K-split projection kernel runs
  *  13  row blocks below which the FFN splits d_ff                   14  0 = two-term attention scores (no positional-key fold)
  *  15  0 = the offline embed projection never splits K              16  time every n-th matching launch (masr_profile_*)
- *  17  waves per workgroup of the offline conv2 launch (8 | 4)   18  0 = conv1 writes with plain instead of streaming stores */
+ *  17  waves per workgroup of the offline conv2 launch (8 | 4)   18  0 = conv1 writes with plain instead of streaming stores
+ *  19  timing experiment: every chunk-step layer on layer 0's weights
+ *  20  1 = EXPLORATORY split-bf16 precision mode (not the reference's fp32 arithmetic, never the contract path): conv2, the embed
+ *      projection and the other launches of the generic GEMM in the offline forward as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on
+ *      the bf16 matrix pipe, fp32 accumulation (csrc/gemm_bf16x3.hip); 3 = also the FFN, unfused (slower than the fused fp32 FFN) */
 int masr_debug_set(masr_engine* e, int32_t key, int32_t value);
 
 /* Profiling: time every launch of one kernel class with HIP events on the launch stream.

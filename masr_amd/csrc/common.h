@@ -81,6 +81,9 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s);
 void set_gemm_waves(int n);          // diagnostics (masr_debug_set key 17): waves per workgroup of the large conv2 launch, 8 (default) or 4
 // deep-K, few-row GEMM: split K over workgroups into `partial` [nsplit][M][N], then reduce + epilogue into a.C
 void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream_t s, int amode = A_PLAIN);
+// exploratory split-bf16 variant (gemm_bf16x3.hip; masr_debug_set key 20): standard epilogue only; false = not taken
+bool launch_gemm_bf16x3(const GemmArgs& a, int amode, hipStream_t s);
+void set_gemm_bf16x3_waves(int n);
 
 // ---- elementwise / reductions ------------------------------------------------------------
 // LayerNorm over rows of width 256.  If seq_t > 0 the output row is remapped to

@@ -303,6 +303,10 @@ struct ProfScope {
     }
 };
 
+// masr_debug_set key 20 -- EXPLORATORY precision mode, never the contract path: the big offline GEMMs (conv2, embed projection,
+// the two FFN GEMMs, unfused) run as split-bf16 products on the bf16 matrix pipe (gemm_bf16x3.hip)
+static int g_bf16x3 = 0;
+
 void gemm(masr_engine* e, hipStream_t s, const float* A, int lda, const float* W, const float* bias, float* C, int ldc,
           int M, int N, int K, int act, float alpha, const float* R, int ldr, int kind = PROF_GEMM,
           const int* lens = nullptr, int mask_tp = 0) {
@@ -311,6 +315,7 @@ void gemm(masr_engine* e, hipStream_t s, const float* A, int lda, const float* W
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr;
     a.act = act; a.alpha = alpha; a.mask_tp = mask_tp;
     ProfScope ps(e, s, kind, 2.0 * M * (double)N * K);
+    if (g_bf16x3 && launch_gemm_bf16x3(a, A_PLAIN, s)) return;
     launch_gemm(a, A_PLAIN, EPI_STD, s);
 }
 
@@ -658,8 +663,12 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         nsplit = std::min(dff / 128, std::max(1, (rowblocks < 64 ? 128 : 256) / rowblocks));
         CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
     }
-    const bool want_tail = tail && nsplit == 1 && !g_no_ffn_tail;
-    const bool want_head = head && head->glu && nsplit == 1 && !want_tail && !g_no_ffn_head && !affine &&
+    // exploratory, value 3 only: LayerNorm, then two split-bf16 GEMMs with the hidden tensor in HBM.  Measured at B = 32 x 10 s:
+    // 44 + 82 + 6 us against the 144 us of the fused exact-fp32 kernel -- the 65 MB round trip of the hidden tensor eats what
+    // the bf16 pipe saves, so mode 1 leaves the FFN on ffn_pc.hip
+    const bool x3 = (g_bf16x3 & 2) && nsplit == 1 && !affine;
+    const bool want_tail = tail && nsplit == 1 && !g_no_ffn_tail && !x3;
+    const bool want_head = head && head->glu && nsplit == 1 && !want_tail && !g_no_ffn_head && !affine && !x3 &&
                            (head->ktaps == 15 || head->ktaps == 7);
     if (head_done) *head_done = want_head;
     if (head && head->glu && !want_head) {
@@ -673,6 +682,17 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
     }
     if (tail && tail->pre_lnw && !want_tail)          // the deferred LayerNorm of the previous layer, as its own launch
         launch_layernorm(e->x.as<float>(), tail->pre_lnw, tail->pre_lnb, e->x.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
+    if (x3) {
+        float* x = e->x.as<float>();
+        CHK(e->ln.ensure((size_t)M * d * sizeof(float)));
+        CHK(e->hid.ensure((size_t)M * dff * sizeof(float)));
+        launch_layernorm(x, lnw, lnb, e->ln.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
+        gemm(e, s, e->ln.as<float>(), d, w1, b1, e->hid.as<float>(), dff, M, dff, d, ACT_SILU, 1.f, nullptr, 0, PROF_FFN1);
+        gemm(e, s, e->hid.as<float>(), dff, w2, b2, x, d, M, d, dff, ACT_NONE, scale, x, d, PROF_FFN1);
+        if (tail_done) *tail_done = false;
+        if (post_y) launch_layernorm(x, post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
+        return 0;
+    }
     ProfScope ps(e, s, want_tail ? PROF_FFN_TAIL : want_head ? PROF_FFN_HEAD : PROF_FFN1,
                  4.0 * M * (double)dff * d + (want_tail ? 2.0 * M * (double)tail->N * d : 0.0) + (want_head ? 2.0 * M * (double)d * d : 0.0));
     const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine,
@@ -703,7 +723,9 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
         a.T1 = T1; a.F1 = F1; a.T2 = Tq; a.F2 = F2; a.Cc = d;
         ProfScope ps(e, s, PROF_CONV2, 2.0 * a.M * (double)a.N * a.K);
         const int tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
-        if (tiles < 640) {
+        if (g_bf16x3 && tiles >= 640 && launch_gemm_bf16x3(a, A_CONV2, s)) {
+            // exploratory split-bf16 mode
+        } else if (tiles < 640) {
             // streaming chunk steps: ~1 workgroup of 4 waves per CU leaves the load -> LDS -> MFMA chain of every 32-wide K slab
             // exposed (2.5 us per slab, 72 slabs); split K so that ~4-5 workgroups per CU overlap each other's latencies
             const int nsplit = std::min(8, std::max(2, 1280 / tiles));
@@ -722,7 +744,9 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
         const int tiles = ((M + 63) / 64) * ((d + 63) / 64);
         const long wide = (long)((M + 63) / 64) * ((d + 127) / 128);      // 64x128 tiles of the unsplit launch
         const long t128 = (long)((M + 127) / 128) * ((d + 127) / 128);
-        if (g_embed_split && tiles >= 128 && t128 >= 100 && t128 <= 128) {
+        if (g_bf16x3 && tiles >= 128 && launch_gemm_bf16x3(a, A_PLAIN, s)) {
+            // exploratory split-bf16 mode: 5x less matrix-pipe time, no K split needed
+        } else if (g_embed_split && tiles >= 128 && t128 >= 100 && t128 <= 128) {
             // B = 32 x 10 s: 124 tiles of 128x128 -- four K quarters on 8-wave workgroups = 496 workgroups, two per CU, four
             // waves per SIMD: 163 + 11 us (GEMM + reduction) against 180 + 9 us for two K halves on 64x128 tiles and 203 us unsplit
             CHK(e->ffpart.ensure((size_t)4 * M * d * sizeof(float)));
@@ -2252,6 +2276,8 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 14) set_attention_fold(value);
     else if (key == 15) g_embed_split = value;
     else if (key == 19) g_hot_weights = value;
+    else if (key == 20) g_bf16x3 = value;
+    else if (key == 21) set_gemm_bf16x3_waves(value);
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }
