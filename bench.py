@@ -522,9 +522,9 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True):
 
 
 def extra_bf16x3(args, rank, world, local):
-    """EXPLORATORY, never the contract line: configs[1]'s step with conv2, the embed projection and the FFN GEMMs as split-bf16
-    products on the bf16 matrix pipe (masr_debug_set key 20, csrc/gemm_bf16x3.hip: a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32
-    accumulation).  Reported with the distance to the exact-fp32 kernels on the same batch; dtype "bf16x3"."""
+    """EXPLORATORY, never the contract line: configs[1]'s step with conv2, the embed projection and the fused FFN blocks as
+    split-bf16 products on the bf16 matrix pipe (masr_debug_set key 20 = 3; csrc/gemm_bf16x3.hip, csrc/ffn_x3.hip:
+    a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32 accumulation).  Reported with the distance to the exact-fp32 kernels on the same batch; dtype "bf16x3"."""
     from masr_amd.utils import synthetic
     eng = make_engine('conformer', local)
     pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234 + rank)).to(eng.device)
@@ -535,7 +535,7 @@ def extra_bf16x3(args, rank, world, local):
     steps = max(10, args.steps)
     out = {}
     for mode in (0, 1):
-        eng.lib.masr_debug_set(eng.h, 20, mode)
+        eng.lib.masr_debug_set(eng.h, 20, 3 if mode else 0)
         for _ in range(3):
             eng.transcribe_batch(pcm, n)
         torch.cuda.synchronize()
@@ -544,7 +544,7 @@ def extra_bf16x3(args, rank, world, local):
             eng.transcribe_batch(pcm, n)
         torch.cuda.synchronize()
         out[mode] = (time.perf_counter() - t0) / steps
-    eng.lib.masr_debug_set(eng.h, 20, 1)
+    eng.lib.masr_debug_set(eng.h, 20, 3)
     enc3 = eng.encode_full(feats, frames, -1).clone()
     tok3, nt3, _ = [t.clone() for t in eng.transcribe_batch(pcm, n)]
     eng.lib.masr_debug_set(eng.h, 20, 0)
@@ -553,7 +553,7 @@ def extra_bf16x3(args, rank, world, local):
     eng.close()
     audio = BATCH * N_SAMPLES / 16000.0
     return {'workload': 'configs[1] in the EXPLORATORY split-bf16 mode (device-only step: PCM in HBM -> token ids in HBM): conv2, embed '
-                        'projection and FFN GEMMs on the bf16 matrix pipe, everything else as in the contract line',
+                        'projection and the fused FFN blocks on the bf16 matrix pipe, everything else as in the contract line',
             'value': round(audio / out[1], 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps, 'dtype': 'bf16x3',
             'ms_per_step': round(out[1] * 1e3, 3), 'fp32_ms_per_step_same_loop': round(out[0] * 1e3, 3),
             'max_abs_diff_encoder_output_vs_fp32_kernels': float((enc32 - enc3).abs().max()),

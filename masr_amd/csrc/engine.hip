@@ -219,6 +219,7 @@ struct masr_engine {
     DevBuf gx, rnn_out, hstate, cstate, ds2_lens;
     std::vector<GBeam> gbeams;
     DevBuf beam_pool, beam_state;
+    std::map<const float*, std::pair<DevBuf, DevBuf>> x3_packed;   // exploratory split-bf16 FFN: packed weights per FFN (W1 pointer)
     long long* beam_prof = nullptr;                                             // debug: phase cycle counters (masr_debug_set key 2)                                               // GPU beam search scratch                               // DeepSpeech2 workspaces
     float *preln_w = nullptr, *preln_b = nullptr, *tr_dw_w = nullptr, *tr_dw_b = nullptr, *tr_pw_w = nullptr,
           *tr_pw_b = nullptr, *rec_w = nullptr, *rec_b = nullptr;
@@ -454,6 +455,10 @@ void masr_destroy(masr_engine* e) {
         g.pool.release();
         g.state.release();
     }
+    for (auto& kv : e->x3_packed) {
+        kv.second.first.release();
+        kv.second.second.release();
+    }
     for (auto& ev : e->prof_events) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
@@ -663,10 +668,10 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         nsplit = std::min(dff / 128, std::max(1, (rowblocks < 64 ? 128 : 256) / rowblocks));
         CHK(e->ffpart.ensure((size_t)nsplit * M * d * sizeof(float)));
     }
-    // exploratory, value 3 only: LayerNorm, then two split-bf16 GEMMs with the hidden tensor in HBM.  Measured at B = 32 x 10 s:
-    // 44 + 82 + 6 us against the 144 us of the fused exact-fp32 kernel -- the 65 MB round trip of the hidden tensor eats what
-    // the bf16 pipe saves, so mode 1 leaves the FFN on ffn_pc.hip
-    const bool x3 = (g_bf16x3 & 2) && nsplit == 1 && !affine;
+    // exploratory, bit 2 of key 20: the fused split-bf16 FFN (ffn_x3.hip).  (An unfused version -- LayerNorm, then two split-bf16
+    // GEMMs with the hidden tensor in HBM -- measured 44 + 82 + 6 us against the 144 us of the fused exact-fp32 kernel at
+    // B = 32 x 10 s: the 65 MB round trip of the hidden tensor ate what the bf16 pipe saved.)
+    const bool x3 = (g_bf16x3 & 2) && nsplit == 1 && !affine && d == 256 && dff % 128 == 0;
     const bool want_tail = tail && nsplit == 1 && !g_no_ffn_tail && !x3;
     const bool want_head = head && head->glu && nsplit == 1 && !want_tail && !g_no_ffn_head && !affine && !x3 &&
                            (head->ktaps == 15 || head->ktaps == 7);
@@ -683,12 +688,22 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
     if (tail && tail->pre_lnw && !want_tail)          // the deferred LayerNorm of the previous layer, as its own launch
         launch_layernorm(e->x.as<float>(), tail->pre_lnw, tail->pre_lnb, e->x.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
     if (x3) {
+        // packed (hi, lo) weights of this FFN, built on first use and kept (keyed by the W1 pointer): + 4 MB per FFN
+        auto it = e->x3_packed.find(w1);
+        if (it == e->x3_packed.end()) {
+            std::pair<DevBuf, DevBuf> pk;
+            CHK(pk.first.ensure(ffn_x3_packed_elems(dff) * sizeof(unsigned short)));
+            CHK(pk.second.ensure(ffn_x3_packed_elems(dff) * sizeof(unsigned short)));
+            launch_pack_ffn_x3(w1, w2, pk.first.as<unsigned short>(), pk.second.as<unsigned short>(), dff, s);
+            it = e->x3_packed.emplace(w1, pk).first;
+        }
         float* x = e->x.as<float>();
-        CHK(e->ln.ensure((size_t)M * d * sizeof(float)));
-        CHK(e->hid.ensure((size_t)M * dff * sizeof(float)));
-        launch_layernorm(x, lnw, lnb, e->ln.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
-        gemm(e, s, e->ln.as<float>(), d, w1, b1, e->hid.as<float>(), dff, M, dff, d, ACT_SILU, 1.f, nullptr, 0, PROF_FFN1);
-        gemm(e, s, e->hid.as<float>(), dff, w2, b2, x, d, M, d, dff, ACT_NONE, scale, x, d, PROF_FFN1);
+        {
+            ProfScope ps(e, s, PROF_FFN1, 4.0 * M * (double)dff * d);
+            if (!launch_ffn_x3(x, lnw, lnb, it->second.first.as<unsigned short>(), b1, it->second.second.as<unsigned short>(), b2, M,
+                               dff, 1e-5f, scale, s))
+                return fail("ffn(): the split-bf16 FFN kernel rejected the sizes");
+        }
         if (tail_done) *tail_done = false;
         if (post_y) launch_layernorm(x, post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
         return 0;
