@@ -86,6 +86,7 @@ bool launch_gemm_bf16x3(const GemmArgs& a, int amode, hipStream_t s);
 void set_gemm_bf16x3_waves(int n);
 // fused split-bf16 FFN (ffn_x3.hip): weights packed once per FFN (hi / lo pieces in fragment order)
 size_t ffn_x3_packed_elems(int dff);
+void set_ffn_x3_rotation(int on);
 void launch_pack_ffn_x3(const float* w1, const float* w2, unsigned short* p1, unsigned short* p2, int dff, hipStream_t s);
 bool launch_ffn_x3(float* x, const float* lnw, const float* lnb, const unsigned short* p1, const float* b1,
                    const unsigned short* p2, const float* b2, int M, int dff, float eps, float scale, hipStream_t s);

@@ -2293,6 +2293,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 19) g_hot_weights = value;
     else if (key == 20) g_bf16x3 = value;
     else if (key == 21) set_gemm_bf16x3_waves(value);
+    else if (key == 22) set_ffn_x3_rotation(value);
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

@@ -13,8 +13,12 @@
 //     in exactly the order the waves consume them -- [chunk][tile][k-step][hi | lo][lane][8] -- so every B fragment is ONE
 //     fully coalesced global_load_dwordx4 per lane (1 KB per wave instruction) straight into MFMA operand layout: no LDS staging,
 //     no conversion, no barrier on the weight path; an 8-deep (producers) / 4-deep (consumers) register ring hides the latency.
-//   * What bounds the kernel: each workgroup pulls the whole 4 MB of (hi, lo) weights through its CU's L1 port (64 B / clock:
-//     ~27 us) against ~21 us of matrix-pipe time -- the fp32 kernel needs 116 us of matrix-pipe time for the same block.
+//   * What bounds the kernel (measured 72 us per block at B = 32 x 10 s; the fp32 kernel: 144 us, of which 116 us are matrix-pipe
+//     time): each workgroup pulls the whole 4 MB of (hi, lo) weights through its own CU -- 57 GB/s per CU, the same with 248, 124
+//     or 62 workgroups in flight, i.e. a per-CU L2 -> L1 streaming rate, not the L2s' aggregate bandwidth; the matrix pipe needs
+//     21 us.  Tried: the whole next chunk's weights in flight (16 / 8-deep rings, LayerNorm tile in LDS instead of registers):
+//     77 us -- latency is not what the stream waits for.  More rows per workgroup would halve the bytes per flop but leaves half
+//     the CUs idle at this batch size.
 #include "common.h"
 
 namespace masr {
@@ -83,7 +87,8 @@ __global__ __launch_bounds__(256) void pack_ffn_x3_kernel(const float* __restric
 __global__ __launch_bounds__(512) void ffn_x3_kernel(float* __restrict__ x, const float* __restrict__ lnw,
                                                      const float* __restrict__ lnb, const unsigned short* __restrict__ p1,
                                                      const float* __restrict__ b1, const unsigned short* __restrict__ p2,
-                                                     const float* __restrict__ b2, int M, int dff, float eps, float scale) {
+                                                     const float* __restrict__ b2, int M, int dff, float eps, float scale,
+                                                     int rot_on) {
     // one LDS area, two lives: the fp32 LayerNorm tile xs [32][260] during the prologue (33 280 B), then the hidden tiles
     // hh / hl [2 buffers][32][136] bf16 hi and lo pieces (34 816 B) -- a barrier separates the two uses
     __shared__ __align__(16) unsigned char fx_smem[4 * 32 * FX_HLD * 2];
@@ -96,6 +101,10 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(float* __restrict__ x, cons
     const int row0 = blockIdx.x * 32;
     const int frow = lane & 31, kb = lane >> 5;
     const int nchunk = dff / FX_CH;
+    // every workgroup walks the chunks in its own rotation: 248 workgroups asking the L2s for the SAME weight lines in the same
+    // microsecond serialise on the channels that hold them (no rotation: 84 us per block, with it 72 us).  Workgroup b runs on
+    // XCD b % 8, so b / 8 gives the ~31 workgroups that share an L2 different rotations.
+    const int rot = rot_on ? (int)((blockIdx.x / 8) % (unsigned)nchunk) : 0;
 
     // ---- prologue: LayerNorm of the 32 rows -> xs (wave w: rows 4w .. 4w+3, lane: 4 channels) ------------------------------
     {
@@ -129,7 +138,11 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(float* __restrict__ x, cons
         __syncthreads();                        // xs is dead from here on: the hidden tiles take its place
         // weight stream of this wave: (c, p, s) blocks of 2 KB (hi 1 KB | lo 1 KB), lane's 16 bytes inside each
         const unsigned short* wbase = p1 + (size_t)lane * 8;
-        auto wptr = [&](int c, int s) { return wbase + (((size_t)(c * 4 + p) * 16 + s) * 2) * 512; };
+        auto wptr = [&](int c, int s) {
+            int cr = c + rot;
+            if (cr >= nchunk) cr -= nchunk;
+            return wbase + (((size_t)(cr * 4 + p) * 16 + s) * 2) * 512;
+        };
         bf16x8 rh[8], rl[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(float* __restrict__ x, cons
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const float bias = b1[c * FX_CH + p * 32 + frow];
+                const float bias = b1[((c + rot) % nchunk) * FX_CH + p * 32 + frow];
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const bf16x8 wh = rh[s & 7], wl = rl[s & 7];
@@ -180,7 +193,11 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(float* __restrict__ x, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         const unsigned short* wbase = p2 + (size_t)lane * 8;
-        auto wptr = [&](int c, int t, int s) { return wbase + (((size_t)(c * 8 + 2 * q + t) * 8 + s) * 2) * 512; };
+        auto wptr = [&](int c, int t, int s) {
+            int cr = c + rot;
+            if (cr >= nchunk) cr -= nchunk;
+            return wbase + (((size_t)(cr * 8 + 2 * q + t) * 8 + s) * 2) * 512;
+        };
         bf16x8 rh[4][2], rl[4][2];               // ring over k-steps (4 deep), two column tiles each
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -238,6 +255,9 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(float* __restrict__ x, cons
 
 }  // namespace
 
+static int g_x3_rot = 1;
+void set_ffn_x3_rotation(int on) { g_x3_rot = on; }
+
 size_t ffn_x3_packed_elems(int dff) { return (size_t)2 * dff * FX_D; }      // bf16 elements per packed matrix (hi + lo)
 
 void launch_pack_ffn_x3(const float* w1, const float* w2, unsigned short* p1, unsigned short* p2, int dff, hipStream_t s) {
@@ -249,7 +269,8 @@ void launch_pack_ffn_x3(const float* w1, const float* w2, unsigned short* p1, un
 bool launch_ffn_x3(float* x, const float* lnw, const float* lnb, const unsigned short* p1, const float* b1,
                    const unsigned short* p2, const float* b2, int M, int dff, float eps, float scale, hipStream_t s) {
     if (M <= 0 || dff % FX_CH != 0 || dff / FX_CH < 1) return false;
-    hipLaunchKernelGGL(ffn_x3_kernel, dim3((M + 31) / 32), dim3(512), 0, s, x, lnw, lnb, p1, b1, p2, b2, M, dff, eps, scale);
+    hipLaunchKernelGGL(ffn_x3_kernel, dim3((M + 31) / 32), dim3(512), 0, s, x, lnw, lnb, p1, b1, p2, b2, M, dff, eps, scale,
+                       g_x3_rot);
     return true;
 }
 
