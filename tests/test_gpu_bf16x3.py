@@ -136,3 +136,23 @@ def test_sibling_encoders_in_split_bf16_mode(x3, kind):
     torch.cuda.synchronize()
     assert not torch.equal(a, b) and float((a - b).abs().max()) < 3e-4
     eng.close()
+
+
+def test_reference_facade_transcript_identical_in_split_bf16_mode(x3, tmp_path):
+    """the facade fixture of tests/test_gpu_identity.py (a): the REFERENCE MASRPredictor's offline transcript of test.wav with
+    normalisation off -- identical with the mode on (text ==, score to 1e-3); the streaming path keeps the fp32 kernels"""
+    import os
+    from tests.test_gpu_identity import GOLDEN, _predictor
+    on, off = x3
+    pred = _predictor(str(tmp_path), False)
+    z = np.load(os.path.join(GOLDEN, 'predictor_nonorm.npz'), allow_pickle=True)
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    base = pred.predict(audio_data=pcm.copy())
+    on(pred.predictor.engine)
+    got = pred.predict(audio_data=pcm.copy())
+    batch = pred.predict_batch([pcm.copy(), pcm[:70000].copy(), pcm.copy()])
+    off(pred.predictor.engine)
+    assert got['text'] == base['text'] == str(z['offline_text'])
+    assert abs(got['score'] - float(z['offline_score'])) < 1e-3 * max(1.0, abs(float(z['offline_score'])))
+    assert batch[0]['text'] == batch[2]['text'] == got['text']
+    pred.predictor.engine.close()

@@ -15,7 +15,11 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/$D/pf -o f -- $B2 > $R/$D/pf.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/$D/pw -o w -- $B2 > $R/$D/pw.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d $R/$D/pm -o m -- $B2 > $R/$D/pm.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/$D/kts -o s -- env MASR_BENCH_STREAMS=16 python $R/bench.py --workload stream128 > $R/$D/kts.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/$D/ktx -o x -- python $R/bench.py --workload bf16x3 --steps 10 > $R/$D/ktx.log 2>&1
 cd $R
+python tools/serve_bench.py > $D/serving.json 2> $D/serving.err
+for o in 0 3 5; do python tools/beam_profile.py 498 4233 300 $o 2>&1 | tail -2; done > $D/beam_profile.txt 2>&1
+python profiles/summarize_rocpd.py $(find $D/ktx -name "*.db") > $D/x3_kernel_stats.txt
 python profiles/summarize_rocpd.py $(find $D/kt -name "*.db") 44 > $D/kernel_stats.txt
 python profiles/summarize_rocpd.py $(find $D/kts -name "*.db") > $D/stream16_kernel_stats.txt
 python profiles/summarize_pmc.py $(find $D/pf -name "*.db") $(find $D/pw -name "*.db") $D/hbm_traffic.json > $D/hbm.txt 2>&1
