@@ -219,6 +219,7 @@ struct masr_engine {
     DevBuf gx, rnn_out, hstate, cstate, ds2_lens;
     std::vector<GBeam> gbeams;
     DevBuf beam_pool, beam_state;
+    std::map<const float*, std::pair<DevBuf, DevBuf>> ffn_packed;  // fp32 FFN weights in fragment order (ffn_pc.hip VAR == 2), per W1 pointer
     std::map<const float*, std::pair<DevBuf, DevBuf>> x3_packed;   // exploratory split-bf16 FFN: packed weights per FFN (W1 pointer)
     long long* beam_prof = nullptr;                                             // debug: phase cycle counters (masr_debug_set key 2)                                               // GPU beam search scratch                               // DeepSpeech2 workspaces
     float *preln_w = nullptr, *preln_b = nullptr, *tr_dw_w = nullptr, *tr_dw_b = nullptr, *tr_pw_w = nullptr,
@@ -304,6 +305,7 @@ struct ProfScope {
     }
 };
 
+static int g_ffn_packed = 1;       // masr_debug_set key 23: 0 = the full FFN launches stream their weights through the wave-private LDS slabs (A/B)
 // masr_debug_set key 20 -- EXPLORATORY precision mode, never the contract path: the big offline GEMMs (conv2, embed projection,
 // the two FFN GEMMs, unfused) run as split-bf16 products on the bf16 matrix pipe (gemm_bf16x3.hip)
 static int g_bf16x3 = 0;
@@ -456,6 +458,10 @@ void masr_destroy(masr_engine* e) {
         g.state.release();
     }
     for (auto& kv : e->x3_packed) {
+        kv.second.first.release();
+        kv.second.second.release();
+    }
+    for (auto& kv : e->ffn_packed) {
         kv.second.first.release();
         kv.second.second.release();
     }
@@ -710,9 +716,25 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
     }
     ProfScope ps(e, s, want_tail ? PROF_FFN_TAIL : want_head ? PROF_FFN_HEAD : PROF_FFN1,
                  4.0 * M * (double)dff * d + (want_tail ? 2.0 * M * (double)tail->N * d : 0.0) + (want_head ? 2.0 * M * (double)d * d : 0.0));
-    const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, w1, b1, w2, b2, M, dff, 1e-5f, scale, affine,
+    // full launches stream PACKED weight copies straight into registers (ffn_pc.hip VAR == 2; built on first use, + 4 MB per FFN)
+    const float *kw1 = w1, *kw2 = w2;
+    const bool packed = g_ffn_packed && nsplit == 1 && d == 256;
+    if (packed) {
+        auto it = e->ffn_packed.find(w1);
+        if (it == e->ffn_packed.end()) {
+            std::pair<DevBuf, DevBuf> pk;
+            CHK(pk.first.ensure((size_t)dff * d * sizeof(float)));
+            CHK(pk.second.ensure((size_t)dff * d * sizeof(float)));
+            launch_pack_ffn_pc(w1, w2, pk.first.as<float>(), pk.second.as<float>(), dff, s);
+            it = e->ffn_packed.emplace(w1, pk).first;
+        }
+        kw1 = it->second.first.as<float>();
+        kw2 = it->second.second.as<float>();
+    }
+    const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, kw1, b1, kw2, b2, M, dff, 1e-5f, scale, affine,
                                       nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s, post_y ? &post : nullptr,
-                                      want_tail ? tail : nullptr, want_head ? head : nullptr);
+                                      want_tail ? tail : nullptr, want_head ? head : nullptr, packed);
+    if (done < 0) return fail("ffn(): launch rejected");
     if (want_head && done != 4) return fail("ffn(): head stage was not launched");
     if (tail_done) *tail_done = done == 2;
     if (post_y && done != 1) launch_layernorm(e->x.as<float>(), post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
@@ -2294,6 +2316,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 20) g_bf16x3 = value;
     else if (key == 21) set_gemm_bf16x3_waves(value);
     else if (key == 22) set_ffn_x3_rotation(value);
+    else if (key == 23) g_ffn_packed = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

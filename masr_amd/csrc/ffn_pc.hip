@@ -28,6 +28,11 @@ static constexpr int PC_HLD = PC_CH + 4;   // 132
 static constexpr int PC_WLD = 32 + 4;
 static constexpr int PC_WSLAB = 32 * PC_WLD;
 static constexpr int PC_NSET = 4;
+#ifdef PC_NOFENCE_PACKED
+#define PC_FENCE(var) do { if ((var) != 2) __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PC_FENCE(var) __builtin_amdgcn_sched_barrier(0)
+#endif
 
 __device__ __forceinline__ float pc_wsum(float v) {
     return wave_sum_dpp(v);
@@ -274,9 +279,24 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
         return wlane + (size_t)(8 * i) * rs + (size_t)chunk * cs + joff;
     };
     const int nlast = chunk_hi - 1;
+    // VAR == 2: w1 / w2 point to PACKED copies (pack_ffn_pc_kernel below) laid out in the order the waves consume them --
+    // [chunk][wave idx][slab j][group g][lane][4] -- so that the B fragment of four MFMAs is ONE coalesced 16-byte-per-lane
+    // load straight into operand layout: the wave-private LDS slabs and their ds_write / ds_read pairs drop out of the main
+    // loops (same operand values in the same MFMA order: bit-identical results).  `pre[s & 3][g]` then holds the fragments of
+    // slab s, refilled with slab s + 4 as soon as the group's last MFMA has issued.
+    const float* pbase = (role == 0 ? w1 : w2) + (size_t)lane * 4;
+    auto psrc = [&](int chunk, int j, int g) -> const float* {
+        return pbase + ((((size_t)chunk * 4 + idx) * 8 + j) * 4 + g) * 256;
+    };
     // side work in the MFMA issue slots of slab (c, j): store slab s+1 (set (j+1)%NSET) to LDS, refill that set with slab
     // s+1+NSET (chunk index clamped past the end: re-fetches land in buffers nobody reads any more)
     auto side_work = [&](int chunk, int j, int slot) {
+        if (VAR == 2) {
+            if ((slot & 3) == 3)
+                pre[j % PC_NSET][slot >> 2] = *reinterpret_cast<const f32x4*>(
+                    psrc(min(chunk + (j + PC_NSET) / 8, nlast), (j + PC_NSET) & 7, slot >> 2));
+            return;
+        }
         const int p = (j + 1) % PC_NSET;
         if (slot < 8) {
             if ((slot & 1) == 0) *reinterpret_cast<f32x4*>(dst_of(j + 1, slot >> 1)) = pre[p][slot >> 1];
@@ -286,14 +306,21 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
         }
     };
 
+    if (VAR == 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, 0, i));
+        for (int k = 0; k < PC_NSET; ++k)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+            for (int g = 0; g < 4; ++g) pre[k][g] = *reinterpret_cast<const f32x4*>(psrc(chunk_lo, k, g));
+    } else {
 #pragma unroll
-    for (int k = 1; k <= PC_NSET; ++k)
+        for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, 0, i));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, k, i));
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+#pragma unroll
+        for (int k = 1; k <= PC_NSET; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, k, i));
+    }
     __syncthreads();                                 // xn tile complete
 
     // Phases p = 0 .. nchunk+1, one workgroup barrier at the end of each:
@@ -326,21 +353,22 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                     const float* wp = wfrag + (j & 1) * PC_WSLAB;
                     f32x4 a[2], b[2];
                     a[0] = *reinterpret_cast<const f32x4*>(xa + j * 32);
-                    b[0] = *reinterpret_cast<const f32x4*>(wp);
+                    if (VAR != 2) b[0] = *reinterpret_cast<const f32x4*>(wp);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if (g + 1 < 4) {
                             a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(xa + j * 32 + 8 * (g + 1));
-                            b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                            if (VAR != 2) b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
                         }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], VAR == 2 ? pre[j % PC_NSET][g][q] : b[g & 1][q],
+                                                                        acc1, 0, 0, 0);
                             side_work(chunk, j, g * 4 + q);
                             // odd slots 1 and 9 of every slab: one element of the previous chunk's epilogue each
                             if (phase > 0 && g * 4 + q == 1) finish(2 * j);
                             if (phase > 0 && g * 4 + q == 9) finish(2 * j + 1);
-                            __builtin_amdgcn_sched_barrier(0);   // keep the written MFMA / load / LDS-store interleave
+                            PC_FENCE(VAR);   // keep the written MFMA / load / LDS-store interleave
                         }
                     }
                 }
@@ -381,18 +409,19 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                     const float* wp = wfrag + (j & 1) * PC_WSLAB;
                     f32x4 a[2], b[2];
                     a[0] = *reinterpret_cast<const f32x4*>(ha + (j >> 1) * 32);
-                    b[0] = *reinterpret_cast<const f32x4*>(wp);
+                    if (VAR != 2) b[0] = *reinterpret_cast<const f32x4*>(wp);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if (g + 1 < 4) {
                             a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(ha + (j >> 1) * 32 + 8 * (g + 1));
-                            b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                            if (VAR != 2) b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
                         }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            acc2[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc2[j & 1], 0, 0, 0);
+                            acc2[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], VAR == 2 ? pre[j % PC_NSET][g][q] : b[g & 1][q],
+                                                                               acc2[j & 1], 0, 0, 0);
                             side_work(chunk, j, g * 4 + q);
-                            __builtin_amdgcn_sched_barrier(0);
+                            PC_FENCE(VAR);
                         }
                     }
                 }
@@ -509,38 +538,63 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
 }
 
 
-template <int HEADK>
+// W1 [dff, 256], W2 [256, dff] -> the VAR == 2 layout [chunk][idx][slab j][group g][lane][4]:
+//   p1: W1[chunk*128 + 32 idx + (lane & 31)][32 j + 8 g + 4 (lane >> 5) + q]
+//   p2: W2[64 idx + 32 (j & 1) + (lane & 31)][chunk*128 + 32 (j >> 1) + 8 g + 4 (lane >> 5) + q]
+__global__ __launch_bounds__(256) void pack_ffn_pc_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                          float* __restrict__ p1, float* __restrict__ p2, int dff) {
+    const size_t n = (size_t)dff * PC_D;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * n) return;
+    const bool second = t >= n;
+    const size_t e = second ? t - n : t;
+    const int q = (int)(e & 3), lane = (int)((e >> 2) & 63), g = (int)((e >> 8) & 3), j = (int)((e >> 10) & 7),
+              idx = (int)((e >> 13) & 3), chunk = (int)(e >> 15);
+    const int frow = lane & 31, fh = lane >> 5;
+    if (!second) p1[e] = w1[(size_t)(chunk * PC_CH + 32 * idx + frow) * PC_D + 32 * j + 8 * g + 4 * fh + q];
+    else p2[e] = w2[(size_t)(64 * idx + 32 * (j & 1) + frow) * dff + chunk * PC_CH + 32 * (j >> 1) + 8 * g + 4 * fh + q];
+}
+void launch_pack_ffn_pc(const float* w1, const float* w2, float* p1, float* p2, int dff, hipStream_t s) {
+    const size_t n = (size_t)2 * dff * PC_D;
+    hipLaunchKernelGGL(pack_ffn_pc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w1, w2, p1, p2, dff);
+}
+
+template <int HEADK, int VAR>
 static void launch_head_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                           const float* b2, int M, int dff, float eps, float scale, hipStream_t s, const FfnHead& head, size_t lds) {
     static LdsAttr attr;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, 0, 0, HEADK>), lds, attr);
-    hipLaunchKernelGGL((ffn_pc_kernel<0, 0, 0, 0, HEADK>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, VAR, 0, HEADK>), lds, attr);
+    hipLaunchKernelGGL((ffn_pc_kernel<0, 0, VAR, 0, HEADK>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
                        b2, M, dff, eps, scale, (float*)nullptr, 0, FfnTail{}, head);
 }
 
+// VAR: 0 production slab pipeline | 1 without weight loads (floor measurement) | 2 packed weights straight into registers
+// (w1 / w2 are then the packed copies; full kernels only -- the d_ff-split launches of small M keep the slab pipeline)
 template <int AFFINE, int VAR>
 static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                        const float* b2, int M, int dff, float eps, float scale, float* partial, int nsplit, hipStream_t s,
                        const FfnPostLn* post, const FfnTail* tail, const FfnHead* head) {
     const size_t lds = (size_t)(PC_BM * PC_XLD + 2 * PC_BM * PC_HLD + 8 * 2 * PC_WSLAB) * sizeof(float);
+    constexpr int TV = VAR == 1 ? 0 : VAR;               // variant of the tail / head kernels (never built for VAR == 1)
     static LdsAttr attr_full, attr_split, attr_tail;
     ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 0, VAR, 0, 0>), lds, attr_full);
     ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, 0, 0, 0>), lds, attr_split);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, 0, 1, 0>), lds, attr_tail);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, TV, 1, 0>), lds, attr_tail);
     const int nchunk = dff / PC_CH;
     if (partial && nsplit > 1) {
+        if (VAR == 2) return -1;                          // caller error: packed weights with a split launch
         const int cpb = (nchunk + nsplit - 1) / nsplit;
         const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
         hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, 0, 0, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
                            b1, w2, b2, M, dff, eps, scale, partial, cpb, FfnTail{}, FfnHead{});
         launch_ffn_reduce(x, partial, b2, M, ny, scale, s, post);
         return post && post->y ? 1 : 0;
-    } else if (head && head->glu && (head->ktaps == 15 || head->ktaps == 7) && !AFFINE && VAR == 0 && !(tail && tail->out)) {
-        if (head->ktaps == 15) launch_head_t<15>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s, *head, lds);
-        else launch_head_t<7>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s, *head, lds);
+    } else if (head && head->glu && (head->ktaps == 15 || head->ktaps == 7) && !AFFINE && VAR != 1 && !(tail && tail->out)) {
+        if (head->ktaps == 15) launch_head_t<15, TV>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s, *head, lds);
+        else launch_head_t<7, TV>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, s, *head, lds);
         return 4;                                         // head stage done
-    } else if (tail && tail->out && tail->N % 256 == 0 && !AFFINE && VAR == 0) {
-        hipLaunchKernelGGL((ffn_pc_kernel<0, 0, 0, 1, 0>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
+    } else if (tail && tail->out && tail->N % 256 == 0 && !AFFINE && VAR != 1) {
+        hipLaunchKernelGGL((ffn_pc_kernel<0, 0, TV, 1, 0>), dim3((M + PC_BM - 1) / PC_BM), dim3(512), lds, s, x, lnw, lnb, w1, b1, w2,
                            b2, M, dff, eps, scale, (float*)nullptr, 0, *tail, FfnHead{});
         return 2;                                         // tail stage done
     } else {
@@ -556,8 +610,10 @@ int launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1,
                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,
                   hipStream_t s, int variant, const FfnPostLn* post, const FfnTail* tail, const FfnHead* head) {
     if (M <= 0) return 0;
+    if (affine_prologue && variant == 2) return launch_pc_t<1, 2>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, nullptr, nullptr);
     if (affine_prologue) return launch_pc_t<1, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, nullptr, nullptr);
     if (variant == 1) return launch_pc_t<0, 1>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, nullptr, nullptr);
+    if (variant == 2) return launch_pc_t<0, 2>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, tail, head);
     return launch_pc_t<0, 0>(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, partial, nsplit, s, post, tail, head);
 }
 

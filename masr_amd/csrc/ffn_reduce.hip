@@ -86,10 +86,11 @@ void set_ffn_variant(int v) { g_ffn_variant = v; }   // masr_debug_set(1, v): 81
 
 int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
-                     int nsplit, hipStream_t s, const FfnPostLn* post, const FfnTail* tail, const FfnHead* head) {
+                     int nsplit, hipStream_t s, const FfnPostLn* post, const FfnTail* tail, const FfnHead* head, bool packed) {
     if (M <= 0) return 0;
+    // packed: w1 / w2 are the fragment-ordered copies of launch_pack_ffn_pc (full, non-split launches only)
     return launch_ffn_pc(x, lnw, lnb, w1, b1, w2, b2, M, dff, eps, scale, affine_prologue, partial, nsplit, s,
-                         g_ffn_variant == 81 ? 1 : 0, post, tail, head);
+                         packed ? 2 : g_ffn_variant == 81 ? 1 : 0, post, tail, head);
 }
 
 }  // namespace masr

@@ -1,0 +1,38 @@
+"""The full (non-split) FFN launches read PACKED weight copies straight into MFMA operand registers (ffn_pc.hip VAR == 2,
+round 3) instead of staging them through wave-private LDS slabs: the same operand values in the same MFMA order, so the encoder
+output must be BIT-identical with the switch (masr_debug_set key 23) on and off -- for every family that uses the kernel, with
+the QKV tail and conv-module head stages riding on it."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('kind,streaming', [('conformer', True), ('conformer', False), ('squeezeformer', False),
+                                            ('efficient_conformer', True)])
+def test_packed_weights_are_bit_identical_to_the_slab_pipeline(kind, streaming):
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    V = 512
+    sd = getattr(synthetic, kind + '_state_dict')(0, V)
+    eng = HipEngine(sd, vocab_size=V, use_model=kind, streaming=streaming)
+    rng = np.random.default_rng(3)
+    lens = rng.integers(60000, 160001, 32).astype(np.int32)
+    pcm = synthetic.synthetic_pcm(32, 160000, seed=9)
+    for i, l in enumerate(lens):
+        pcm[i, l:] = 0
+    feats, frames = eng.fbank_batch(torch.from_numpy(pcm).cuda(), torch.from_numpy(lens).cuda())
+    out = {}
+    try:
+        for v in (1, 0, 1):
+            eng.lib.masr_debug_set(eng.h, 23, v)
+            out[v] = eng.encode_full(feats, frames, -1).clone()
+            probs = eng.ctc_probs(out[v])
+            out[('p', v)] = probs.clone()
+    finally:
+        eng.lib.masr_debug_set(eng.h, 23, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1]) and torch.equal(out[('p', 0)], out[('p', 1)])
+    assert float(out[1].abs().max()) > 0
+    eng.close()
