@@ -218,6 +218,7 @@ int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* 
                      int nsplit, hipStream_t s, const FfnPostLn* post = nullptr, const FfnTail* tail = nullptr,
                      const FfnHead* head = nullptr, bool packed = false);
 void launch_pack_ffn_pc(const float* w1, const float* w2, float* p1, float* p2, int dff, hipStream_t s);
+void launch_pack_rows_pc(const float* w, float* p, int N, hipStream_t s);      // tail / head stage weights [N, 256], N % 256 == 0
 
 void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
                        const FfnPostLn* post);

@@ -731,6 +731,30 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         kw1 = it->second.first.as<float>();
         kw2 = it->second.second.as<float>();
     }
+    // ... and so do the row-local stages that ride on the launch (QKV tail, pointwise_conv2 head)
+    FfnTail ptail{};
+    FfnHead phead{};
+    auto packed_rows = [&](const float* W, int N, const float** out) -> int {
+        auto it = e->ffn_packed.find(W);
+        if (it == e->ffn_packed.end()) {
+            std::pair<DevBuf, DevBuf> pk;
+            CHK(pk.first.ensure((size_t)N * d * sizeof(float)));
+            launch_pack_rows_pc(W, pk.first.as<float>(), N, s);
+            it = e->ffn_packed.emplace(W, pk).first;
+        }
+        *out = it->second.first.as<float>();
+        return 0;
+    };
+    if (packed && want_tail && tail->N % 256 == 0) {
+        ptail = *tail;
+        CHK(packed_rows(tail->W, tail->N, &ptail.W));
+        tail = &ptail;
+    }
+    if (packed && want_head) {
+        phead = *head;
+        CHK(packed_rows(head->W, d, &phead.W));
+        head = &phead;
+    }
     const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, kw1, b1, kw2, b2, M, dff, 1e-5f, scale, affine,
                                       nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s, post_y ? &post : nullptr,
                                       want_tail ? tail : nullptr, want_head ? head : nullptr, packed);

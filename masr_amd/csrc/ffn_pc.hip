@@ -131,17 +131,27 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
         }
         // ---- head 3: pointwise_conv2 on all 8 waves (wave w: output channels 32w .. 32w+31, K = 256 in 8 slabs through the
         // wave-private slab pipeline), + bias, pad mask, residual -> x (global) and, raw, back into the xn tile ----------------
+        // (VAR == 2: head.W is the packed copy [wave][slab j][group g][lane][4] -- fragments straight into registers, as in the
+        //  main loops; otherwise the rows go through the wave-private slabs)
         const float* hl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) hl[i] = head.W + (size_t)(wave * 32 + lr8 + 8 * i) * PC_D + lc4;
+        const float* hpk = head.W + (size_t)wave * 8 * 4 * 256 + (size_t)lane * 4;
+        if (VAR == 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(hl[i]);
+            for (int k = 0; k < PC_NSET; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+                for (int g = 0; g < 4; ++g) pre[k][g] = *reinterpret_cast<const f32x4*>(hpk + (size_t)(k * 4 + g) * 256);
+        } else {
 #pragma unroll
-        for (int k = 1; k <= PC_NSET; ++k)
+            for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(hl[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(hl[i] + k * 32);
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+#pragma unroll
+            for (int k = 1; k <= PC_NSET; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(hl[i] + k * 32);
+        }
         __syncthreads();                                  // A tile complete
         {
             const float* xa = xn + frow * PC_XLD + 4 * fh;
@@ -170,18 +180,21 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                 const float* wp = wfrag + (j & 1) * PC_WSLAB;
                 f32x4 a[2], b[2];
                 a[0] = *reinterpret_cast<const f32x4*>(xa + j * 32);
-                b[0] = *reinterpret_cast<const f32x4*>(wp);
+                if (VAR != 2) b[0] = *reinterpret_cast<const f32x4*>(wp);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (g + 1 < 4) {
                         a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(xa + j * 32 + 8 * (g + 1));
-                        b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                        if (VAR != 2) b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], VAR == 2 ? pre[j % PC_NSET][g][q] : b[g & 1][q], acc, 0, 0, 0);
                         const int slot = g * 4 + q, pset = (j + 1) % PC_NSET;
-                        if (slot < 8) {
+                        if (VAR == 2) {
+                            if ((slot & 3) == 3 && j + PC_NSET < 8)
+                                pre[j % PC_NSET][g] = *reinterpret_cast<const f32x4*>(hpk + (size_t)((j + PC_NSET) * 4 + g) * 256);
+                        } else if (slot < 8) {
                             if ((slot & 1) == 0 && j + 1 < 8) *reinterpret_cast<f32x4*>(dst_of(j + 1, slot >> 1)) = pre[pset][slot >> 1];
                         } else if ((slot & 1) == 0 && j + 1 + PC_NSET < 8) {
                             pre[pset][(slot - 8) >> 1] = *reinterpret_cast<const f32x4*>(hl[(slot - 8) >> 1] + (j + 1 + PC_NSET) * 32);
@@ -483,14 +496,26 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     auto tsrc = [&](int t, int j, int i) -> const float* {
         return tl[i] + (size_t)(min(t, ntile - 1) * 256) * PC_D + j * 32;
     };
+    // (VAR == 2: tail.W is the packed copy [tile t][wave][slab j][group g][lane][4])
+    const float* tpk = tail.W + (size_t)wave * 8 * 4 * 256 + (size_t)lane * 4;
+    auto tpsrc = [&](int t, int j, int g) -> const float* {
+        return tpk + ((size_t)min(t, ntile - 1) * 8 * 8 * 4 + (size_t)(j * 4 + g)) * 256;
+    };
+    if (VAR == 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(tsrc(0, 0, i));
+        for (int k = 0; k < PC_NSET; ++k)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+            for (int g = 0; g < 4; ++g) pre[k][g] = *reinterpret_cast<const f32x4*>(tpsrc(0, k, g));
+    } else {
 #pragma unroll
-    for (int k = 1; k <= PC_NSET; ++k)
+        for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(tsrc(0, 0, i));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(tsrc(0, k, i));
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+#pragma unroll
+        for (int k = 1; k <= PC_NSET; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[k % PC_NSET][i] = *reinterpret_cast<const f32x4*>(tsrc(0, k, i));
+    }
     __syncthreads();                                  // normalised tile complete
     {
         const float* xa = xn + frow * PC_XLD + 4 * fh;
@@ -505,18 +530,21 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                 const float* wp = wfrag + (j & 1) * PC_WSLAB;
                 f32x4 a[2], b[2];
                 a[0] = *reinterpret_cast<const f32x4*>(xa + j * 32);
-                b[0] = *reinterpret_cast<const f32x4*>(wp);
+                if (VAR != 2) b[0] = *reinterpret_cast<const f32x4*>(wp);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (g + 1 < 4) {
                         a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(xa + j * 32 + 8 * (g + 1));
-                        b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                        if (VAR != 2) b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], VAR == 2 ? pre[j % PC_NSET][g][q] : b[g & 1][q], acc, 0, 0, 0);
                         const int slot = g * 4 + q, pset = (j + 1) % PC_NSET;
-                        if (slot < 8) {
+                        if (VAR == 2) {
+                            if ((slot & 3) == 3)
+                                pre[j % PC_NSET][g] = *reinterpret_cast<const f32x4*>(tpsrc(t + (j + PC_NSET) / 8, (j + PC_NSET) & 7, g));
+                        } else if (slot < 8) {
                             if ((slot & 1) == 0) *reinterpret_cast<f32x4*>(dst_of(j + 1, slot >> 1)) = pre[pset][slot >> 1];
                         } else if ((slot & 1) == 0) {
                             pre[pset][(slot - 8) >> 1] = *reinterpret_cast<const f32x4*>(
@@ -553,6 +581,19 @@ __global__ __launch_bounds__(256) void pack_ffn_pc_kernel(const float* __restric
     const int frow = lane & 31, fh = lane >> 5;
     if (!second) p1[e] = w1[(size_t)(chunk * PC_CH + 32 * idx + frow) * PC_D + 32 * j + 8 * g + 4 * fh + q];
     else p2[e] = w2[(size_t)(64 * idx + 32 * (j & 1) + frow) * dff + chunk * PC_CH + 32 * (j >> 1) + 8 * g + 4 * fh + q];
+}
+// W [N, 256] (N a multiple of 256: the fused QKV weights, pointwise_conv2) -> [tile t][wave][slab j][group g][lane][4]:
+//   P = W[t*256 + 32 wave + (lane & 31)][32 j + 8 g + 4 (lane >> 5) + q]         (tail / head stages with VAR == 2)
+__global__ __launch_bounds__(256) void pack_rows_pc_kernel(const float* __restrict__ w, float* __restrict__ p, int N) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)N * PC_D) return;
+    const int q = (int)(e & 3), lane = (int)((e >> 2) & 63), g = (int)((e >> 8) & 3), j = (int)((e >> 10) & 7),
+              wave = (int)((e >> 13) & 7), t = (int)(e >> 16);
+    p[e] = w[(size_t)(t * 256 + 32 * wave + (lane & 31)) * PC_D + 32 * j + 8 * g + 4 * (lane >> 5) + q];
+}
+void launch_pack_rows_pc(const float* w, float* p, int N, hipStream_t s) {
+    const size_t n = (size_t)N * PC_D;
+    hipLaunchKernelGGL(pack_rows_pc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, p, N);
 }
 void launch_pack_ffn_pc(const float* w1, const float* w2, float* p1, float* p2, int dff, hipStream_t s) {
     const size_t n = (size_t)2 * dff * PC_D;
