@@ -219,6 +219,14 @@ int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* 
                      const FfnHead* head = nullptr, bool packed = false);
 void launch_pack_ffn_pc(const float* w1, const float* w2, float* p1, float* p2, int dff, hipStream_t s);
 void launch_pack_rows_pc(const float* w, float* p, int N, hipStream_t s);      // tail / head stage weights [N, 256], N % 256 == 0
+// ffn_dual.hip: the same block with two independent accumulator chains per wave (chunks of 256 hidden units); p1 / p2 from
+// launch_pack_ffn_dual, tail->W from launch_pack_rows_dual (N = 768), head->W from launch_pack_rows_pc.
+// Returns 0 / 2 (tail done) / 4 (head done), -1 when the sizes are not covered
+int launch_ffn_dual(float* x, const float* lnw, const float* lnb, const float* p1, const float* b1, const float* p2,
+                    const float* b2, int M, int dff, float eps, float scale, int affine_prologue, hipStream_t s,
+                    const FfnTail* tail, const FfnHead* head);
+void launch_pack_ffn_dual(const float* w1, const float* w2, float* p1, float* p2, int dff, hipStream_t s);
+void launch_pack_rows_dual(const float* w, float* p, hipStream_t s);
 
 void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
                        const FfnPostLn* post);

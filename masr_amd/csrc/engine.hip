@@ -220,6 +220,7 @@ struct masr_engine {
     std::vector<GBeam> gbeams;
     DevBuf beam_pool, beam_state;
     std::map<const float*, std::pair<DevBuf, DevBuf>> ffn_packed;  // fp32 FFN weights in fragment order (ffn_pc.hip VAR == 2), per W1 pointer
+    std::map<const float*, std::pair<DevBuf, DevBuf>> ffn_dual_packed;  // the same in the two-chain order of ffn_dual.hip (and its QKV tail weights)
     std::map<const float*, std::pair<DevBuf, DevBuf>> x3_packed;   // exploratory split-bf16 FFN: packed weights per FFN (W1 pointer)
     long long* beam_prof = nullptr;                                             // debug: phase cycle counters (masr_debug_set key 2)                                               // GPU beam search scratch                               // DeepSpeech2 workspaces
     float *preln_w = nullptr, *preln_b = nullptr, *tr_dw_w = nullptr, *tr_dw_b = nullptr, *tr_pw_w = nullptr,
@@ -305,6 +306,7 @@ struct ProfScope {
     }
 };
 
+static int g_ffn_dual = 0;         // masr_debug_set key 24: 0 = the full FFN launches run ffn_pc.hip (one accumulator chain per wave) instead of ffn_dual.hip (A/B)
 static int g_ffn_packed = 1;       // masr_debug_set key 23: 0 = the full FFN launches stream their weights through the wave-private LDS slabs (A/B)
 // masr_debug_set key 20 -- EXPLORATORY precision mode, never the contract path: the big offline GEMMs (conv2, embed projection,
 // the two FFN GEMMs, unfused) run as split-bf16 products on the bf16 matrix pipe (gemm_bf16x3.hip)
@@ -462,6 +464,10 @@ void masr_destroy(masr_engine* e) {
         kv.second.second.release();
     }
     for (auto& kv : e->ffn_packed) {
+        kv.second.first.release();
+        kv.second.second.release();
+    }
+    for (auto& kv : e->ffn_dual_packed) {
         kv.second.first.release();
         kv.second.second.release();
     }
@@ -745,6 +751,39 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         *out = it->second.first.as<float>();
         return 0;
     };
+    // two accumulator chains per wave (ffn_dual.hip): same arithmetic in the same order, its own packing order
+    if (packed && g_ffn_dual && dff % 256 == 0 && dff >= 512 && !(want_tail && tail->N != 768) && !(affine && (want_tail || want_head))) {
+        auto it = e->ffn_dual_packed.find(w1);
+        if (it == e->ffn_dual_packed.end()) {
+            std::pair<DevBuf, DevBuf> pk;
+            CHK(pk.first.ensure((size_t)dff * d * sizeof(float)));
+            CHK(pk.second.ensure((size_t)dff * d * sizeof(float)));
+            launch_pack_ffn_dual(w1, w2, pk.first.as<float>(), pk.second.as<float>(), dff, s);
+            it = e->ffn_dual_packed.emplace(w1, pk).first;
+        }
+        if (want_tail) {
+            ptail = *tail;
+            auto tw = e->ffn_dual_packed.find(tail->W);
+            if (tw == e->ffn_dual_packed.end()) {
+                std::pair<DevBuf, DevBuf> pk;
+                CHK(pk.first.ensure((size_t)768 * d * sizeof(float)));
+                launch_pack_rows_dual(tail->W, pk.first.as<float>(), s);
+                tw = e->ffn_dual_packed.emplace(tail->W, pk).first;
+            }
+            ptail.W = tw->second.first.as<float>();
+        }
+        if (want_head) {
+            phead = *head;
+            CHK(packed_rows(head->W, d, &phead.W));
+        }
+        const int done = launch_ffn_dual(e->x.as<float>(), lnw, lnb, it->second.first.as<float>(), b1, it->second.second.as<float>(),
+                                         b2, M, dff, 1e-5f, scale, affine, s, want_tail ? &ptail : nullptr, want_head ? &phead : nullptr);
+        if (done < 0) return fail("ffn(): the two-chain FFN kernel rejected the launch");
+        if (want_head && done != 4) return fail("ffn(): head stage was not launched");
+        if (tail_done) *tail_done = done == 2;
+        if (post_y) launch_layernorm(e->x.as<float>(), post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
+        return 0;
+    }
     if (packed && want_tail && tail->N % 256 == 0) {
         ptail = *tail;
         CHK(packed_rows(tail->W, tail->N, &ptail.W));
@@ -2341,6 +2380,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 21) set_gemm_bf16x3_waves(value);
     else if (key == 22) set_ffn_x3_rotation(value);
     else if (key == 23) g_ffn_packed = value;
+    else if (key == 24) g_ffn_dual = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

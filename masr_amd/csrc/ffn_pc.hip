@@ -34,6 +34,17 @@ static constexpr int PC_NSET = 4;
 #define PC_FENCE(var) __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// VAR == 2: the packed fragments are fetched with raw buffer loads -- a descriptor in SGPRs, ONE constant per-lane byte offset
+// (16 * lane) and a wave-uniform scalar offset per fragment: no per-load VALU address arithmetic between the MFMAs and half
+// the address registers of a 64-bit flat address (tools/mfma_study.hip: an MFMA stream that pulls 1 KB per four MFMAs and
+// wave runs at 138 TF with buffer loads, 132 TF with global loads; without any loads 151 TF).  PC_BUFLOAD 0 keeps global loads.
+#ifndef PC_BUFLOAD
+#define PC_BUFLOAD 1
+#endif
+__device__ __forceinline__ f32x4 pc_bufld(__amdgpu_buffer_rsrc_t rs, unsigned lane16, unsigned float_index) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, float_index * 4u, 0));
+}
+
 __device__ __forceinline__ float pc_wsum(float v) {
     return wave_sum_dpp(v);
 }
@@ -137,11 +148,17 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
 #pragma unroll
         for (int i = 0; i < 4; ++i) hl[i] = head.W + (size_t)(wave * 32 + lr8 + 8 * i) * PC_D + lc4;
         const float* hpk = head.W + (size_t)wave * 8 * 4 * 256 + (size_t)lane * 4;
+        const unsigned lane16h = lane * 16;
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(head.W), 0, PC_D * PC_D * 4, 0x00020000);
+        auto hld = [&](int j, int g) -> f32x4 {            // fragment (slab j, group g) of this wave's pointwise_conv2 rows
+            if (PC_BUFLOAD) return pc_bufld(hrs, lane16h, (unsigned)((wave * 8 + j) * 4 + g) * 256u);
+            return *reinterpret_cast<const f32x4*>(hpk + (size_t)(j * 4 + g) * 256);
+        };
         if (VAR == 2) {
 #pragma unroll
             for (int k = 0; k < PC_NSET; ++k)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pre[k][g] = *reinterpret_cast<const f32x4*>(hpk + (size_t)(k * 4 + g) * 256);
+                for (int g = 0; g < 4; ++g) pre[k][g] = hld(k, g);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(hl[i]);
@@ -192,8 +209,7 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], VAR == 2 ? pre[j % PC_NSET][g][q] : b[g & 1][q], acc, 0, 0, 0);
                         const int slot = g * 4 + q, pset = (j + 1) % PC_NSET;
                         if (VAR == 2) {
-                            if ((slot & 3) == 3 && j + PC_NSET < 8)
-                                pre[j % PC_NSET][g] = *reinterpret_cast<const f32x4*>(hpk + (size_t)((j + PC_NSET) * 4 + g) * 256);
+                            if ((slot & 3) == 3 && j + PC_NSET < 8) pre[j % PC_NSET][g] = hld(j + PC_NSET, g);
                         } else if (slot < 8) {
                             if ((slot & 1) == 0 && j + 1 < 8) *reinterpret_cast<f32x4*>(dst_of(j + 1, slot >> 1)) = pre[pset][slot >> 1];
                         } else if ((slot & 1) == 0 && j + 1 + PC_NSET < 8) {
@@ -301,13 +317,18 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     auto psrc = [&](int chunk, int j, int g) -> const float* {
         return pbase + ((((size_t)chunk * 4 + idx) * 8 + j) * 4 + g) * 256;
     };
+    const unsigned lane16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(role == 0 ? w1 : w2), 0, (VAR == 2 ? dff : 0) * PC_D * 4, 0x00020000);
+    auto pld = [&](int chunk, int j, int g) -> f32x4 {
+        if (PC_BUFLOAD) return pc_bufld(wrs, lane16, (unsigned)((((chunk * 4 + idx) * 8 + j) * 4 + g)) * 256u);
+        return *reinterpret_cast<const f32x4*>(psrc(chunk, j, g));
+    };
     // side work in the MFMA issue slots of slab (c, j): store slab s+1 (set (j+1)%NSET) to LDS, refill that set with slab
     // s+1+NSET (chunk index clamped past the end: re-fetches land in buffers nobody reads any more)
     auto side_work = [&](int chunk, int j, int slot) {
         if (VAR == 2) {
-            if ((slot & 3) == 3)
-                pre[j % PC_NSET][slot >> 2] = *reinterpret_cast<const f32x4*>(
-                    psrc(min(chunk + (j + PC_NSET) / 8, nlast), (j + PC_NSET) & 7, slot >> 2));
+            if ((slot & 3) == 3) pre[j % PC_NSET][slot >> 2] = pld(min(chunk + (j + PC_NSET) / 8, nlast), (j + PC_NSET) & 7, slot >> 2);
             return;
         }
         const int p = (j + 1) % PC_NSET;
@@ -323,7 +344,7 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
 #pragma unroll
         for (int k = 0; k < PC_NSET; ++k)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[k][g] = *reinterpret_cast<const f32x4*>(psrc(chunk_lo, k, g));
+            for (int g = 0; g < 4; ++g) pre[k][g] = pld(chunk_lo, k, g);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(chunk_lo, 0, i));
@@ -501,11 +522,17 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
     auto tpsrc = [&](int t, int j, int g) -> const float* {
         return tpk + ((size_t)min(t, ntile - 1) * 8 * 8 * 4 + (size_t)(j * 4 + g)) * 256;
     };
+    const __amdgpu_buffer_rsrc_t trs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tail.W), 0, (VAR == 2 ? ntile : 0) * 256 * PC_D * 4, 0x00020000);
+    auto tld = [&](int t, int j, int g) -> f32x4 {
+        if (PC_BUFLOAD) return pc_bufld(trs, lane16, (unsigned)(((min(t, ntile - 1) * 8 + wave) * 8 + j) * 4 + g) * 256u);
+        return *reinterpret_cast<const f32x4*>(tpsrc(t, j, g));
+    };
     if (VAR == 2) {
 #pragma unroll
         for (int k = 0; k < PC_NSET; ++k)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[k][g] = *reinterpret_cast<const f32x4*>(tpsrc(0, k, g));
+            for (int g = 0; g < 4; ++g) pre[k][g] = tld(0, k, g);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(tsrc(0, 0, i));
@@ -542,8 +569,7 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], VAR == 2 ? pre[j % PC_NSET][g][q] : b[g & 1][q], acc, 0, 0, 0);
                         const int slot = g * 4 + q, pset = (j + 1) % PC_NSET;
                         if (VAR == 2) {
-                            if ((slot & 3) == 3)
-                                pre[j % PC_NSET][g] = *reinterpret_cast<const f32x4*>(tpsrc(t + (j + PC_NSET) / 8, (j + PC_NSET) & 7, g));
+                            if ((slot & 3) == 3) pre[j % PC_NSET][g] = tld(t + (j + PC_NSET) / 8, (j + PC_NSET) & 7, g);
                         } else if (slot < 8) {
                             if ((slot & 1) == 0) *reinterpret_cast<f32x4*>(dst_of(j + 1, slot >> 1)) = pre[pset][slot >> 1];
                         } else if ((slot & 1) == 0) {

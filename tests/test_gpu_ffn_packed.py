@@ -36,3 +36,36 @@ def test_packed_weights_are_bit_identical_to_the_slab_pipeline(kind, streaming):
     assert torch.equal(out[0], out[1]) and torch.equal(out[('p', 0)], out[('p', 1)])
     assert float(out[1].abs().max()) > 0
     eng.close()
+
+
+@pytest.mark.parametrize('kind,streaming', [('conformer', True), ('conformer', False), ('squeezeformer', False),
+                                            ('efficient_conformer', True)])
+def test_two_chain_ffn_is_bit_identical_to_the_single_chain_kernel(kind, streaming):
+    """ffn_dual.hip (two independent accumulator chains per wave over chunks of 256 hidden units, three in the QKV tail stage)
+    sums every accumulator's k in the same ascending order as ffn_pc.hip: encoder output and probabilities BIT-identical with
+    masr_debug_set key 24 on and off; ragged batch with a partial last row block."""
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    V = 512
+    sd = getattr(synthetic, kind + '_state_dict')(0, V)
+    eng = HipEngine(sd, vocab_size=V, use_model=kind, streaming=streaming)
+    rng = np.random.default_rng(5)
+    lens = rng.integers(50000, 160001, 31).astype(np.int32)
+    lens[0] = 160000
+    pcm = synthetic.synthetic_pcm(31, 160000, seed=11)
+    for i, l in enumerate(lens):
+        pcm[i, l:] = 0
+    feats, frames = eng.fbank_batch(torch.from_numpy(pcm).cuda(), torch.from_numpy(lens).cuda())
+    out = {}
+    try:
+        for v in (1, 0, 1):
+            eng.lib.masr_debug_set(eng.h, 24, v)
+            out[v] = eng.encode_full(feats, frames, -1).clone()
+            out[('p', v)] = eng.ctc_probs(out[v]).clone()
+    finally:
+        eng.lib.masr_debug_set(eng.h, 24, 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[1]).all() and float(out[1].abs().max()) > 0
+    assert torch.equal(out[0], out[1]), float((out[0] - out[1]).abs().max())
+    assert torch.equal(out[('p', 0)], out[('p', 1)])
+    eng.close()
