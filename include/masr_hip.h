@@ -283,7 +283,9 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
  *  21  waves per workgroup of the split-bf16 conv2 launch (8 | 4)   22  0 = no per-workgroup chunk rotation in the split-bf16 FFN
  *  23  0 = the full FFN launches stream their weights through the wave-private LDS slabs instead of reading the packed copies
  *      straight into registers (bit-identical either way)
- *  24  0 = the full FFN launches keep one accumulator chain per wave (ffn_pc.hip) instead of two (ffn_dual.hip; bit-identical)
+ *  24  1 = the full FFN launches run two accumulator chains per wave (ffn_dual.hip) instead of one (ffn_pc.hip; bit-identical)
+ *  25  0 = the offline out-proj + pw1 chain kernel and the CTC head stream their weights through LDS slabs instead of reading
+ *      packed copies with buffer loads (bit-identical)
  *  20  1 = EXPLORATORY split-bf16 precision mode (not the reference's fp32 arithmetic, never the contract path): conv2, the embed
  *      projection and the other launches of the generic GEMM in the offline forward as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on
  *      the bf16 matrix pipe, fp32 accumulation (csrc/gemm_bf16x3.hip); 3 = also the FFN, unfused (slower than the fused fp32 FFN) */

@@ -145,6 +145,8 @@ struct RowGemmArgs {
     const float* lnw;     // LayerNorm weight / bias (PRO_LN*)
     const float* lnb;
     const float* W;       // [N, 256]
+    const float* Wp;      // optional: the same weights in fragment order (launch_pack_rows_pc, N rounded up to 256); the offline CHAIN /
+                          // CTC launches then read them with buffer loads straight into MFMA operand registers (no LDS slab staging)
     const float* bias;    // [N]
     float* C;             // output [M, ldc]
     const float* R;       // residual [M, ldr] (EPI_RESID; may alias C)
@@ -218,7 +220,7 @@ int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* 
                      int nsplit, hipStream_t s, const FfnPostLn* post = nullptr, const FfnTail* tail = nullptr,
                      const FfnHead* head = nullptr, bool packed = false);
 void launch_pack_ffn_pc(const float* w1, const float* w2, float* p1, float* p2, int dff, hipStream_t s);
-void launch_pack_rows_pc(const float* w, float* p, int N, hipStream_t s);      // tail / head stage weights [N, 256], N % 256 == 0
+void launch_pack_rows_pc(const float* w, float* p, int N, hipStream_t s, int n_src = -1);   // weights [n_src, 256] -> N % 256 == 0 packed rows (rows >= n_src zero)
 // ffn_dual.hip: the same block with two independent accumulator chains per wave (chunks of 256 hidden units); p1 / p2 from
 // launch_pack_ffn_dual, tail->W from launch_pack_rows_dual (N = 768), head->W from launch_pack_rows_pc.
 // Returns 0 / 2 (tail done) / 4 (head done), -1 when the sizes are not covered

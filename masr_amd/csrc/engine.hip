@@ -324,6 +324,20 @@ void gemm(masr_engine* e, hipStream_t s, const float* A, int lda, const float* W
     launch_gemm(a, A_PLAIN, EPI_STD, s);
 }
 
+static int g_rowgemm_packed = 1;   // masr_debug_set key 25: 0 = the offline out-proj + pw1 chain and the CTC head stream their weights through LDS slabs (A/B)
+// fragment-ordered copy of a [N, 256] weight matrix (rows padded to a multiple of 256 with zeros), built on first use and kept
+const float* packed_rows_of(masr_engine* e, const float* W, int N, hipStream_t s) {
+    auto it = e->ffn_packed.find(W);
+    if (it == e->ffn_packed.end()) {
+        const int Np = (N + 255) / 256 * 256;
+        std::pair<DevBuf, DevBuf> pk;
+        if (pk.first.ensure((size_t)Np * 256 * sizeof(float))) return nullptr;
+        launch_pack_rows_pc(W, pk.first.as<float>(), Np, s, N);
+        it = e->ffn_packed.emplace(W, pk).first;
+    }
+    return it->second.first.as<float>();
+}
+
 void rowgemm(masr_engine* e, hipStream_t s, int pro, int epi, const float* A, int lda, const float* lnw,
              const float* lnb, const float* W, const float* bias, float* C, int ldc, int M, int N, const float* R,
              int ldr, float alpha, const int* lens, int mask_tp, int seq_t, int pad, int* out_idx, float* out_maxp,
@@ -337,6 +351,7 @@ void rowgemm(masr_engine* e, hipStream_t s, int pro, int epi, const float* A, in
     a.out_seq_t = out_seq_t; a.out_pad_l = out_pad_l; a.out_pad_tot = out_pad_tot;
     a.plane_cols = plane_cols; a.plane_stride = plane_stride; a.a_seq_t = a_seq_t; a.a_seq_stride = a_seq_stride;
     a.kv_seqs = kv_seqs; a.kv_tq = kv_tq;
+    if (g_rowgemm_packed && epi == RG_EPI_CTC && pro == RG_PRO_PLAIN && M >= 64 * 32) a.Wp = packed_rows_of(e, W, N, s);
     ProfScope ps(e, s, kind, 2.0 * M * (double)N * 256);
     launch_rowgemm(a, pro, epi, s);
 }
@@ -973,6 +988,7 @@ void mhsa_out_pw1(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCt
     a.C = e->glu.as<float>(); a.ldc = d; a.M = M; a.N = 3 * d; a.R = x; a.R2 = x; a.ldr = d; a.alpha = 1.f;
     a.lens = c.lens; a.seq_t = c.Tq; a.mstride = mstride; a.eps = 1e-5f;
     a.out_seq_t = c.Tq; a.out_pad_l = e->cfg.causal ? pad : pad / 2; a.out_pad_tot = pad;
+    if (g_rowgemm_packed) a.Wp = packed_rows_of(e, w.chain_w, 3 * d, s);
     ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)(3 * d) * d);
     launch_rowgemm(a, RG_PRO_PLAIN, RG_EPI_CHAIN, s);
 }
@@ -2381,6 +2397,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 22) set_ffn_x3_rotation(value);
     else if (key == 23) g_ffn_packed = value;
     else if (key == 24) g_ffn_dual = value;
+    else if (key == 25) g_rowgemm_packed = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

@@ -610,16 +610,18 @@ __global__ __launch_bounds__(256) void pack_ffn_pc_kernel(const float* __restric
 }
 // W [N, 256] (N a multiple of 256: the fused QKV weights, pointwise_conv2) -> [tile t][wave][slab j][group g][lane][4]:
 //   P = W[t*256 + 32 wave + (lane & 31)][32 j + 8 g + 4 (lane >> 5) + q]         (tail / head stages with VAR == 2)
-__global__ __launch_bounds__(256) void pack_rows_pc_kernel(const float* __restrict__ w, float* __restrict__ p, int N) {
+// (rows >= n_src -- the padding of a vocabulary that is no multiple of 256 -- are packed as zeros)
+__global__ __launch_bounds__(256) void pack_rows_pc_kernel(const float* __restrict__ w, float* __restrict__ p, int N, int n_src) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (size_t)N * PC_D) return;
     const int q = (int)(e & 3), lane = (int)((e >> 2) & 63), g = (int)((e >> 8) & 3), j = (int)((e >> 10) & 7),
               wave = (int)((e >> 13) & 7), t = (int)(e >> 16);
-    p[e] = w[(size_t)(t * 256 + 32 * wave + (lane & 31)) * PC_D + 32 * j + 8 * g + 4 * (lane >> 5) + q];
+    const int row = t * 256 + 32 * wave + (lane & 31);
+    p[e] = row < n_src ? w[(size_t)row * PC_D + 32 * j + 8 * g + 4 * (lane >> 5) + q] : 0.f;
 }
-void launch_pack_rows_pc(const float* w, float* p, int N, hipStream_t s) {
+void launch_pack_rows_pc(const float* w, float* p, int N, hipStream_t s, int n_src) {
     const size_t n = (size_t)N * PC_D;
-    hipLaunchKernelGGL(pack_rows_pc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, p, N);
+    hipLaunchKernelGGL(pack_rows_pc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, p, N, n_src < 0 ? N : n_src);
 }
 void launch_pack_ffn_pc(const float* w1, const float* w2, float* p1, float* p2, int dff, hipStream_t s) {
     const size_t n = (size_t)2 * dff * PC_D;

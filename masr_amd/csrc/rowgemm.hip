@@ -38,7 +38,11 @@ __device__ __forceinline__ float rg_wsum(float v) {
 
 // GSPLIT = 1 (few row blocks, streaming chunk steps): blockIdx.y owns ONE column group of 256, so that e.g. the fused
 // QKV projection of 16 streams x 16 frames runs on 8 x 3 workgroups with one MFMA tile (8 weight slabs) per wave
-template <int PRO, int EPI, int GSPLIT>
+// PACKED = 1 (offline CHAIN and CTC launches): p.Wp holds the weights in the order the waves consume them
+// ([tile][wave][slab j][group g][lane][4], pack_rows_pc_kernel) and every B fragment is ONE raw buffer load of 16 bytes per lane
+// straight into operand registers -- descriptor in SGPRs, constant per-lane offset, wave-uniform scalar offset per fragment
+// (the FFN kernels' scheme, ffn_pc.hip): same operand values in the same MFMA order as the slab pipeline, bit-identical.
+template <int PRO, int EPI, int GSPLIT, int PACKED = 0>
 __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
     extern __shared__ __align__(16) float sm[];
     float* at = sm;                               // [32][260] A tile
@@ -144,15 +148,29 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
         return wl[i] + (size_t)trow * RG_K + j * 32;
     };
     auto dst_of = [&](int buf, int i) -> float* { return wmine + buf * RG_WSLAB + (lr8 + 8 * i) * RG_WLD + lc4; };
+    const unsigned lane16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(PACKED ? p.Wp : p.W), 0, PACKED ? ((p.N + 255) / 256) * 256 * RG_K * 4 : 0, 0x00020000);
+    auto pld = [&](int t, int j, int g) -> f32x4 {     // fragment (slab j, group g) of this wave's tile t (clamped past the end)
+        const unsigned fi = (unsigned)((((tbase + min(t, ntiles - 1)) * 8 + wave) * 8 + j) * 4 + g) * 256u;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, lane16, fi * 4u, 0));
+    };
 
+    if (PACKED) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(0, 0, i));
+        for (int k = 0; k < RG_NSET; ++k)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+            for (int g = 0; g < 4; ++g) pre[k][g] = pld(0, k, g);
+    } else {
 #pragma unroll
-    for (int k = 1; k <= RG_NSET; ++k)
+        for (int i = 0; i < 4; ++i) pre[0][i] = *reinterpret_cast<const f32x4*>(src_of(0, 0, i));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pre[k % RG_NSET][i] = *reinterpret_cast<const f32x4*>(src_of(k / 8, k & 7, i));
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst_of(0, i)) = pre[0][i];
+#pragma unroll
+        for (int k = 1; k <= RG_NSET; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[k % RG_NSET][i] = *reinterpret_cast<const f32x4*>(src_of(k / 8, k & 7, i));
+    }
     __syncthreads();                                  // A tile complete
 
     const float* aa = at + frow * RG_ALD + 4 * fh;     // (CHAIN: switched to the second tile after tile 0)
@@ -192,24 +210,26 @@ __global__ __launch_bounds__(512) void rowgemm_kernel(RowGemmArgs p) {
             const float* wp = wfrag + (j & 1) * RG_WSLAB;          // slab index t*8 + j -> buffer j & 1
             f32x4 a[2], b[2];
             a[0] = *reinterpret_cast<const f32x4*>(aa + j * 32);
-            b[0] = *reinterpret_cast<const f32x4*>(wp);
+            if (!PACKED) b[0] = *reinterpret_cast<const f32x4*>(wp);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (g + 1 < 4) {
                     a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(aa + j * 32 + 8 * (g + 1));
-                    b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
+                    if (!PACKED) b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + 8 * (g + 1));
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     // EPI_CTC accumulates the TRANSPOSED tile (A operand = weight rows, B operand = activation
                     // rows): each lane then owns ONE output row and 16 of the tile's 32 columns, so the row-wise
                     // softmax statistics need no cross-lane butterfly (only one lane^32 exchange per tile).
-                    if (EPI == RG_EPI_CTC) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[g & 1][q], a[g & 1][q], acc, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], b[g & 1][q], acc, 0, 0, 0);
+                    if (EPI == RG_EPI_CTC) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(PACKED ? pre[j % RG_NSET][g][q] : b[g & 1][q], a[g & 1][q], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], PACKED ? pre[j % RG_NSET][g][q] : b[g & 1][q], acc, 0, 0, 0);
                     const int slot = g * 4 + q;
                     // slots 0,2,4,6: store piece of slab s+1 (set (j+1)%NSET) into buffer (j+1)&1;
                     // slots 8..14: refill that set with slab s+1+NSET
-                    if (slot < 8) {
+                    if (PACKED) {
+                        if (q == 3) pre[j % RG_NSET][g] = pld(t + (j + RG_NSET) / 8, (j + RG_NSET) & 7, g);
+                    } else if (slot < 8) {
                         if ((slot & 1) == 0)
                             *reinterpret_cast<f32x4*>(dst_of((j + 1) & 1, slot >> 1)) = pre[(j + 1) % RG_NSET][slot >> 1];
                     } else if ((slot & 1) == 0) {
@@ -413,10 +433,16 @@ static void launch_rg(const RowGemmArgs& a, hipStream_t s) {
         fprintf(stderr, "rowgemm: N must be a multiple of 256 for this epilogue\n");
         abort();
     }
-    if (can_split && ngroups > 1 && rowblocks < 64)
+    constexpr bool can_pack = EPI == RG_EPI_CHAIN || (EPI == RG_EPI_CTC && PRO == RG_PRO_PLAIN);
+    if (can_split && ngroups > 1 && rowblocks < 64) {
         hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI, can_split ? 1 : 0>), dim3(rowblocks, ngroups), dim3(512), lds, s, a);
-    else
+    } else if (can_pack && a.Wp) {
+        static LdsAttr attrp;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(rowgemm_kernel<PRO, EPI, 0, can_pack ? 1 : 0>), lds, attrp);
+        hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI, 0, can_pack ? 1 : 0>), dim3(rowblocks), dim3(512), lds, s, a);
+    } else {
         hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI, 0>), dim3(rowblocks), dim3(512), lds, s, a);
+    }
 }
 
 static void launch_rowgemm_big(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
