@@ -307,7 +307,7 @@ struct ProfScope {
 };
 
 static int g_ffn_dual = 0;         // masr_debug_set key 24: 0 = the full FFN launches run ffn_pc.hip (one accumulator chain per wave) instead of ffn_dual.hip (A/B)
-static int g_ffn_packed = 1;       // masr_debug_set key 23: 0 = the full FFN launches stream their weights through the wave-private LDS slabs (A/B)
+static int g_ffn_packed = 2;       // masr_debug_set key 23: 0 = the full FFN launches stream their weights through the wave-private LDS slabs (A/B)
 // masr_debug_set key 20 -- EXPLORATORY precision mode, never the contract path: the big offline GEMMs (conv2, embed projection,
 // the two FFN GEMMs, unfused) run as split-bf16 products on the bf16 matrix pipe (gemm_bf16x3.hip)
 static int g_bf16x3 = 0;
@@ -739,7 +739,7 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
                  4.0 * M * (double)dff * d + (want_tail ? 2.0 * M * (double)tail->N * d : 0.0) + (want_head ? 2.0 * M * (double)d * d : 0.0));
     // full launches stream PACKED weight copies straight into registers (ffn_pc.hip VAR == 2; built on first use, + 4 MB per FFN)
     const float *kw1 = w1, *kw2 = w2;
-    const bool packed = g_ffn_packed && nsplit == 1 && d == 256;
+    const bool packed = g_ffn_packed && (nsplit == 1 || g_ffn_packed >= 2) && d == 256;      // (key 23 = 2: the d_ff-split launches of small M too)
     if (packed) {
         auto it = e->ffn_packed.find(w1);
         if (it == e->ffn_packed.end()) {
@@ -767,7 +767,7 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         return 0;
     };
     // two accumulator chains per wave (ffn_dual.hip): same arithmetic in the same order, its own packing order
-    if (packed && g_ffn_dual && dff % 256 == 0 && dff >= 512 && !(want_tail && tail->N != 768) && !(affine && (want_tail || want_head))) {
+    if (packed && nsplit == 1 && g_ffn_dual && dff % 256 == 0 && dff >= 512 && !(want_tail && tail->N != 768) && !(affine && (want_tail || want_head))) {
         auto it = e->ffn_dual_packed.find(w1);
         if (it == e->ffn_dual_packed.end()) {
             std::pair<DevBuf, DevBuf> pk;

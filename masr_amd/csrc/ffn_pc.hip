@@ -651,10 +651,12 @@ static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float
     ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 0, TV, 1, 0>), lds, attr_tail);
     const int nchunk = dff / PC_CH;
     if (partial && nsplit > 1) {
-        if (VAR == 2) return -1;                          // caller error: packed weights with a split launch
+        constexpr int SV = VAR == 2 ? 2 : 0;              // split launches: slab pipeline or packed weights (never the no-load variant)
+        static LdsAttr attr_split_v;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, SV, 0, 0>), lds, attr_split_v);
         const int cpb = (nchunk + nsplit - 1) / nsplit;
         const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
-        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, 0, 0, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
+        hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, SV, 0, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
                            b1, w2, b2, M, dff, eps, scale, partial, cpb, FfnTail{}, FfnHead{});
         launch_ffn_reduce(x, partial, b2, M, ny, scale, s, post);
         return post && post->y ? 1 : 0;
