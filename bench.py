@@ -93,9 +93,9 @@ def data_tag():
 PROF_STRIDE = 5          # the timed region brackets every 5th launch of the roofline kernel with HIP events
 
 ROOFLINE_KERNELS = [
-    (6, 'ffn_pc_kernel<0, 0, 0, 1, 0>', "ffn_pc_kernel TAIL: LN + [B*T',256]x[256,2048] + SiLU + x[2048,256] + 1/2 residual, then LN + fused "
+    (6, 'ffn_pc_kernel<0, 0, 2, 1, 0>', "ffn_pc_kernel TAIL: LN + [B*T',256]x[256,2048] + SiLU + x[2048,256] + 1/2 residual, then LN + fused "
         "QKV projection [256,768] on the same rows (16.64 + 3.12 GFLOP per launch)"),
-    (7, 'ffn_pc_kernel<0, 0, 0, 0, 15>', 'ffn_pc_kernel HEAD: depthwise conv + LN + SiLU + pointwise_conv2 [256,256] + residual, then '
+    (7, 'ffn_pc_kernel<0, 0, 2, 0, 15>', 'ffn_pc_kernel HEAD: depthwise conv + LN + SiLU + pointwise_conv2 [256,256] + residual, then '
         'LN + FFN + 1/2 residual (1.04 + 16.64 GFLOP per launch)'),
     (3, 'gemm_f32_kernel<128, 128, 2, 4, 1, 0>', 'Conv2d(256,256,3,stride 2) of the subsampling front-end as an implicit GEMM (177.9 GFLOP)'),
     (4, 'attention_kernel', 'rel-pos multi-head self-attention (algorithmic 6 * d * T\'^2 * B = 3.0 GFLOP per launch: the reference\'s '
@@ -110,7 +110,9 @@ def committed_traffic(fragment):
         try:
             k = json.load(open(os.path.join(ROOT, 'profiles', name)))['kernels']
             for key, v in k.items():
-                if fragment in key or (name.startswith('r01') and 'ffn_pc_kernel<0, 0, 0, 1>' in key and 'ffn_pc_kernel<0, 0, 0, 1, 0>' == fragment):
+                # (the third template argument is the weight path of the kernel: 0 LDS slabs until round 3, 2 packed copies since)
+                alt = fragment.replace('<0, 0, 2, ', '<0, 0, 0, ')
+                if fragment in key or alt in key or (name.startswith('r01') and 'ffn_pc_kernel<0, 0, 0, 1>' in key and alt == 'ffn_pc_kernel<0, 0, 0, 1, 0>'):
                     return v['hbm_bytes'], name
         except Exception:
             continue
