@@ -256,9 +256,13 @@ int masr_stream_reset(masr_engine* e, int32_t stream_id);
 int masr_stream_close(masr_engine* e, int32_t stream_id);
 /* required_cache_size of forward_chunk for one stream (conformer/encoder.py:397-410): < 0 (default) every cached key stays
  * visible -- what MASRPredictor.predict_stream passes (predict.py:312-313); >= 0 a chunk attends over at most that many cached
- * keys (Conformer only).  masr_stream_export_cache then returns the last min(required_cache_size, offset) rows. */
+ * keys, in frames of the encoder's input rate (Conformer, Squeezeformer: squeezeformer/encoder.py:292-297,338-347, and
+ * Efficient-Conformer: efficient_conformer/encoder.py:323-336,365-381 -- their half-rate layers follow the reference's
+ * next_cache_start // 2 trimming of the repeat-interleaved cache).  masr_stream_export_cache then returns the kept rows;
+ * masr_stream_cache_len = their number (att_cache.size(2) of the reference after the last step). */
 int masr_stream_set_history(masr_engine* e, int32_t stream_id, int32_t required_cache_size);
 int masr_stream_offset(masr_engine* e, int32_t stream_id, int32_t* offset);
+int masr_stream_cache_len(masr_engine* e, int32_t stream_id, int32_t* cache_len);
 int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, const float* feats_dev, int32_t Tc,
                       float* probs_dev, int32_t* argmax_dev, float* maxprob_dev, void* stream);
 /* Read back a stream's caches in the reference layout (for parity tests):

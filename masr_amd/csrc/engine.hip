@@ -185,6 +185,9 @@ struct Stream {
     int offset_r = 0;   // frames emitted at the reduced rate (Squeezeformer blocks between time reduction and recovery)
     int cap = 0;
     int history = -1;   // required_cache_size of forward_chunk: < 0 keep every key, >= 0 attend over at most that many cached keys
+    int cache_t1 = 0;   // cached keys the next chunk attends over, in input-rate frames (= att_cache.size(2) of the reference)
+    int first_half = 0; // half-rate layers (Squeezeformer between reduction and recovery, Efficient-Conformer behind the stride
+                        // layer): index of their first kept cache entry (advances by next_cache_start // 2 per step)
     DevBuf att;  // [L][cap][2*d]  (k | v per row)
     DevBuf cnn;  // [L][kernel-1][d]   (DeepSpeech2: LSTM state [L][2 (h, c)][rnn_size])
     DevBuf cnn2; // Conformer / Squeezeformer: second half of the double-buffered cnn cache (a chunk step reads `cnn`, writes
@@ -1933,6 +1936,8 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     st.offset = 0;
     st.offset_r = 0;
     st.history = -1;
+    st.cache_t1 = 0;
+    st.first_half = 0;
     st.open = true;
     *stream_id = id;
     return 0;
@@ -1955,6 +1960,8 @@ int masr_stream_reset(masr_engine* e, int32_t stream_id) {
     if (e->cfg.model_kind == 2) HIPCHK(hipMemset(st->att.p, 0, (size_t)L * st->cap * 2 * d * sizeof(float)));
     st->offset = 0;
     st->offset_r = 0;
+    st->cache_t1 = 0;
+    st->first_half = 0;
     return 0;
 }
 
@@ -1973,9 +1980,8 @@ int masr_stream_close(masr_engine* e, int32_t stream_id) {
 int masr_stream_set_history(masr_engine* e, int32_t stream_id, int32_t required_cache_size) {
     Stream* st;
     CHK(stream_of(e, stream_id, &st));
-    if (required_cache_size >= 0 && e->cfg.model_kind != 0)
-        return fail("a bounded attention history (required_cache_size >= 0) is implemented for the Conformer; the Squeezeformer / "
-                    "Efficient-Conformer streams keep all history (required_cache_size < 0, what predict_stream passes)");
+    if (required_cache_size >= 0 && e->cfg.model_kind == 3)
+        return fail("required_cache_size: DeepSpeech2 streams carry an LSTM state, not an attention cache");
     st->history = required_cache_size;
     return 0;
 }
@@ -1987,7 +1993,43 @@ int masr_stream_offset(masr_engine* e, int32_t stream_id, int32_t* offset) {
     return 0;
 }
 
+int masr_stream_cache_len(masr_engine* e, int32_t stream_id, int32_t* cache_len) {
+    Stream* st;
+    CHK(stream_of(e, stream_id, &st));
+    *cache_len = st->cache_t1;
+    return 0;
+}
+
 }  // extern "C"
+
+// forward_chunk's cache bookkeeping (conformer/encoder.py:390-410, squeezeformer/encoder.py:288-297,338-347,
+// efficient_conformer/encoder.py:316-336,365-381), as a window into append-only caches: a chunk of T0 input-rate frames attends
+// over the last cache_t1 cached frames + itself; afterwards the cache is cut at next_cache_start.
+struct ChunkWindow {
+    int cache_t1, first_full;    // cached frames attended over; absolute index of the first of them (= positional index of key 0)
+    int next_cache_t1, ncs;      // after the step
+};
+static ChunkWindow chunk_window(const Stream& st, int T0) {
+    ChunkWindow w;
+    w.cache_t1 = st.cache_t1;
+    w.first_full = st.offset - st.cache_t1;
+    const int key_size = st.cache_t1 + T0;
+    w.ncs = st.history < 0 ? 0 : st.history == 0 ? key_size : std::max(key_size - st.history, 0);
+    w.next_cache_t1 = key_size - w.ncs;
+    return w;
+}
+// half-rate layers: the reference stores their cache repeat-interleaved at the input rate and reads every second entry back, so a
+// step sees `want` entries starting at first_half; they must be exactly the entries appended since (true for chunks of an even
+// number of frames; the reference itself fails or drops the newest entry otherwise)
+static int half_rate_window(const Stream& st, int want, int* first, int* count) {
+    const int avail = st.offset_r - st.first_half;
+    if (want != avail)
+        return fail("bounded attention history: the half-rate cache window is not contiguous with the new frames (odd chunk lengths "
+                    "with required_cache_size >= 0 are not supported)");
+    *first = st.first_half;
+    *count = avail;
+    return 0;
+}
 
 // Squeezeformer chunk step (streaming-trained build), n streams in lock-step: SqueezeformerEncoder.forward_chunk
 // (squeezeformer/encoder.py:240-362) with required_cache_size < 0.  Every layer keeps its key/value cache at its OWN frame
@@ -2010,20 +2052,29 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
     auto reduced = [&](int l) { return e->reduce_idx >= 0 && l >= e->reduce_idx && l < e->recover_idx; };
     std::vector<AttSeq> hs((size_t)n * L);
     std::vector<float*> hp((size_t)n * L * 2);    // cnn cache bases: current (read) | next (written)
+    std::vector<ChunkWindow> win(n);
+    std::vector<int> hfirst(n), hcount(n);
+    for (int i = 0; i < n; ++i) {
+        win[i] = chunk_window(*st[i], T0);
+        // a half-rate layer reads pos_emb[::2] rows minus its queries: ceil((cache_t1 + T0) / 2) - Tr cached entries (encoder.py:338-342)
+        CHK(half_rate_window(*st[i], (win[i].cache_t1 + T0 + 1) / 2 - Tr, &hfirst[i], &hcount[i]));
+    }
     for (int l = 0; l < L; ++l) {
         const int Tl = reduced(l) ? Tr : T0;
         for (int i = 0; i < n; ++i) {
             AttSeq& a = hs[(size_t)l * n + i];
             const int off = reduced(l) ? st[i]->offset_r : st[i]->offset;
+            const int first = reduced(l) ? hfirst[i] : win[i].first_full;       // first cache row attended over
+            const int ncached = reduced(l) ? hcount[i] : win[i].cache_t1;
             float* cache = st[i]->att.as<float>() + (size_t)l * st[i]->cap * 2 * d;
             a.q = e->qkv.as<float>() + (size_t)i * Tl * 3 * d;
-            a.k = cache;
-            a.v = cache + d;
+            a.k = cache + (size_t)first * 2 * d;
+            a.v = a.k + d;
             a.out = e->att.as<float>() + (size_t)i * Tl * d;
             a.nq = Tl;
-            a.nk = off + Tl;
+            a.nk = ncached + Tl;           // (the new rows are appended at k + (nk - nq) rows = cache row `off`)
             a.klen = a.nk;
-            a.pos0 = 0;
+            a.pos0 = win[i].first_full;    // key j of a half-rate layer sits at position first_full + 2 j (pos_emb[:, ::2])
             a.q_abs0 = off;
             a.pad_ = 0;
             hp[(size_t)l * n + i] = st[i]->cnn.as<float>() + (size_t)l * pad * d;
@@ -2090,6 +2141,8 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
     for (int i = 0; i < n; ++i) {
         st[i]->offset += T0;
         st[i]->offset_r += Tr;
+        st[i]->cache_t1 = win[i].next_cache_t1;
+        st[i]->first_half += win[i].ncs / 2;
         std::swap(st[i]->cnn, st[i]->cnn2);
     }
     return 0;
@@ -2121,24 +2174,32 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
     std::vector<AttSeq> hs((size_t)n * L);
     std::vector<PlaneCopy> pcs((size_t)n * e->n_group_layers);
     std::vector<float*> hp((size_t)n * L * 2);   // cnn cache bases: current (read) | next (written)
+    std::vector<ChunkWindow> win(n);
+    std::vector<int> hfirst(n), hcount(n);
+    for (int i = 0; i < n; ++i) {
+        win[i] = chunk_window(*st[i], T0);
+        // layers behind the stride layer read att_cache[:, :, ::2]: ceil(cache_t1 / 2) entries (encoder.py:353)
+        CHK(half_rate_window(*st[i], (win[i].cache_t1 + 1) / 2, &hfirst[i], &hcount[i]));
+    }
     for (int l = 0; l < L; ++l) {
         if (layer_grouped(e, l) && rate(l) != 1) return fail("grouped attention after the stride layer is not supported");
         for (int i = 0; i < n; ++i) {
             AttSeq& a = hs[(size_t)l * n + i];
             float* cache = st[i]->att.as<float>() + (size_t)l * st[i]->cap * 2 * d;
             if (layer_grouped(e, l)) {
+                // the flat regrouping [T, 256] -> [T / 3, 4, 192] runs over (kept cache + chunk): it starts at the first kept row
                 float* kpl = cache;
                 float* vpl = cache + (size_t)st[i]->cap * d;
                 a.q = qp + (size_t)i * Tpad * d;
-                a.k = kpl;
-                a.v = vpl;
+                a.k = kpl + (size_t)win[i].first_full * d;
+                a.v = vpl + (size_t)win[i].first_full * d;
                 a.out = e->attp.as<float>() + (size_t)i * Tpad * d;
                 a.nq = Tg;
-                a.nk = (st[i]->offset + T0 + G - 1) / G;
+                a.nk = (win[i].cache_t1 + T0 + G - 1) / G;
                 a.klen = a.nk;
-                a.pos0 = 0;
+                a.pos0 = win[i].first_full;
                 a.q_abs0 = 0;
-                a.pad_ = st[i]->offset + T0;                   // true number of keys (rows of P behind it read as zero)
+                a.pad_ = win[i].cache_t1 + T0;                 // true number of keys (rows of P behind it read as zero)
                 PlaneCopy& c = pcs[(size_t)l * n + i];
                 c.src_k = qp + plane + (size_t)i * Tpad * d;
                 c.src_v = qp + 2 * plane + (size_t)i * Tpad * d;
@@ -2147,14 +2208,16 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
             } else {
                 const int Tl = rate(l) == 2 ? T2 : T0;
                 const int off = rate(l) == 2 ? st[i]->offset_r : st[i]->offset;
+                const int first = rate(l) == 2 ? hfirst[i] : win[i].first_full;
+                const int ncached = rate(l) == 2 ? hcount[i] : win[i].cache_t1;
                 a.q = e->qkv.as<float>() + (size_t)i * Tl * 3 * d;
-                a.k = cache;
-                a.v = cache + d;
+                a.k = cache + (size_t)first * 2 * d;
+                a.v = a.k + d;
                 a.out = e->att.as<float>() + (size_t)i * Tl * d;
                 a.nq = Tl;
-                a.nk = off + Tl;
+                a.nk = ncached + Tl;
                 a.klen = a.nk;
-                a.pos0 = 0;
+                a.pos0 = win[i].first_full;
                 a.q_abs0 = off;
                 a.pad_ = 0;
             }
@@ -2215,6 +2278,8 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
     for (int i = 0; i < n; ++i) {
         st[i]->offset += T0;
         st[i]->offset_r += T2;
+        st[i]->cache_t1 = win[i].next_cache_t1;
+        st[i]->first_half += win[i].ncs / 2;
         std::swap(st[i]->cnn, st[i]->cnn2);
     }
     return 0;
@@ -2267,7 +2332,7 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
             // keys the chunk attends over: the last cache_t1 cached rows + its own (encoder.py:390-395,397-410: the reference
             // trims its cache tensor to required_cache_size after every step; here the rows stay where they were appended and
             // the window moves).  The positional index of the first key is offset - cache_t1.
-            const int cache_t1 = st[i]->history < 0 ? st[i]->offset : std::min(st[i]->offset, st[i]->history);
+            const int cache_t1 = st[i]->cache_t1;
             const int first = st[i]->offset - cache_t1;
             a.q = e->qkv.as<float>() + (size_t)i * Tq * 3 * d;
             a.k = cache + (size_t)first * 2 * d;
@@ -2308,6 +2373,7 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
     if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
     CHK(ctc_head(e, e->enc.as<float>(), M, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
     for (int i = 0; i < n; ++i) {
+        st[i]->cache_t1 = chunk_window(*st[i], Tq).next_cache_t1;
         st[i]->offset += Tq;
         std::swap(st[i]->cnn, st[i]->cnn2);
     }
@@ -2328,26 +2394,31 @@ int masr_stream_export_cache(masr_engine* e, int32_t stream_id, float* att_dev, 
         }
         return 0;
     }
-    if (att_dev && st->offset > 0) {
-        if (e->cfg.model_kind == 2) {     // planar grouped layers; half-rate layers repeat-interleaved, last t entries (:370,380)
+    // what the reference's (trimmed) cache tensor holds: the last t = cache_t1 input-rate frames [L, H, t, 2 dk]
+    const int t = st->cache_t1;
+    if (att_dev && t > 0) {
+        const int first = st->offset - t;
+        if (e->cfg.model_kind == 2) {     // planar grouped layers; half-rate layers repeat-interleaved, the LAST t entries (:370,380)
             for (int l = 0; l < L; ++l) {
                 const float* base = st->att.as<float>() + (size_t)l * st->cap * 2 * d;
-                float* o = att_dev + (size_t)l * st->offset * 2 * d;
+                float* o = att_dev + (size_t)l * t * 2 * d;
                 if (layer_grouped(e, l))
-                    launch_export_att_planar(base, base + (size_t)st->cap * d, o, H, st->offset, d / H, s);
+                    launch_export_att_planar(base + (size_t)first * d, base + (size_t)st->cap * d + (size_t)first * d, o, H, t, d / H, s);
                 else if (l > e->stride_idx)
-                    launch_export_att(base, o, 1, H, st->cap, st->offset, d / H, s, 2, 2 * st->offset_r - st->offset);
+                    launch_export_att(base, o, 1, H, st->cap, t, d / H, s, 2, 2 * st->offset_r - t);
                 else
-                    launch_export_att(base, o, 1, H, st->cap, st->offset, d / H, s);
+                    launch_export_att(base + (size_t)first * 2 * d, o, 1, H, st->cap, t, d / H, s);
             }
-        } else if (e->cfg.model_kind == 1) {     // half-rate layers: every cache entry twice, like the reference (encoder.py:347)
-            for (int l = 0; l < L; ++l)
-                launch_export_att(st->att.as<float>() + (size_t)l * st->cap * 2 * d, att_dev + (size_t)l * st->offset * 2 * d, 1, H,
-                                  st->cap, st->offset, d / H, s, (l >= e->reduce_idx && l < e->recover_idx) ? 2 : 1);
-        } else {       // the last min(history, offset) rows: what the reference's trimmed cache tensor holds
-            const int t = st->history < 0 ? st->offset : std::min(st->offset, st->history);
-            if (t > 0)
-                launch_export_att(st->att.as<float>() + (size_t)(st->offset - t) * 2 * d, att_dev, L, H, st->cap, t, d / H, s);
+        } else if (e->cfg.model_kind == 1) {     // half-rate layers: every kept entry twice, the FIRST t of them (encoder.py:345-351)
+            for (int l = 0; l < L; ++l) {
+                const float* base = st->att.as<float>() + (size_t)l * st->cap * 2 * d;
+                if (l >= e->reduce_idx && l < e->recover_idx)
+                    launch_export_att(base, att_dev + (size_t)l * t * 2 * d, 1, H, st->cap, t, d / H, s, 2, 2 * st->first_half);
+                else
+                    launch_export_att(base + (size_t)first * 2 * d, att_dev + (size_t)l * t * 2 * d, 1, H, st->cap, t, d / H, s);
+            }
+        } else {
+            launch_export_att(st->att.as<float>() + (size_t)first * 2 * d, att_dev, L, H, st->cap, t, d / H, s);
         }
     }
     if (cnn_dev && e->cfg.model_kind == 2) {       // each layer's own K-1 rows, left-padded with zeros to cnn_module_kernel - 1

@@ -343,7 +343,6 @@ class HipEngine:
     def stream_open(self, max_frames_out=0):
         sid = C.c_int32()
         check(self.lib.masr_stream_open(self.h, int(max_frames_out), C.byref(sid)))
-        self.__dict__.setdefault('_history', {}).pop(sid.value, None)      # a recycled id starts with the default (keep all)
         return sid.value
 
     def stream_reset(self, sid):
@@ -353,9 +352,9 @@ class HipEngine:
         check(self.lib.masr_stream_close(self.h, sid))
 
     def stream_set_history(self, sid, required_cache_size):
-        """forward_chunk's required_cache_size for this stream: < 0 keep all cached keys, >= 0 at most that many (Conformer)"""
+        """forward_chunk's required_cache_size for this stream: < 0 keep all cached keys, >= 0 at most that many (input-rate
+        frames; Conformer, Squeezeformer and Efficient-Conformer)"""
         check(self.lib.masr_stream_set_history(self.h, sid, int(required_cache_size)))
-        self.__dict__.setdefault('_history', {})[sid] = int(required_cache_size)
 
     def stream_offset(self, sid):
         off = C.c_int32()
@@ -379,10 +378,9 @@ class HipEngine:
             c = torch.zeros_like(h)
             check(self.lib.masr_stream_export_cache(self.h, sid, _ptr(h), _ptr(c), _stream()))
             return h, c
-        t = self.stream_offset(sid)
-        hist = self.__dict__.get('_history', {}).get(sid, -1)
-        if hist >= 0:
-            t = min(t, hist)
+        n = C.c_int32(0)
+        check(self.lib.masr_stream_cache_len(self.h, sid, C.byref(n)))       # att_cache.size(2) of the reference after the last step
+        t = n.value
         dk = self.d_model // self.heads
         att = torch.zeros(self.num_blocks, self.heads, t, 2 * dk, dtype=torch.float32, device=self.device)
         cnn = torch.zeros(self.num_blocks, 1, self.d_model, self.cnn_kernel - 1, dtype=torch.float32, device=self.device)

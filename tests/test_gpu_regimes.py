@@ -208,11 +208,55 @@ def test_bounded_attention_history_against_oracle(required):
         eng.close()
 
 
-def test_bounded_history_is_rejected_where_it_is_not_built():
+@pytest.mark.parametrize('which', ['squeezeformer', 'efficient_conformer'])
+@pytest.mark.parametrize('required', [0, 16, 24, 41])
+def test_bounded_attention_history_of_the_sibling_encoders_against_oracle(which, required):
+    """forward_chunk with required_cache_size >= 0 for the Squeezeformer and the Efficient-Conformer (squeezeformer/encoder.py:
+    292-297,338-347; efficient_conformer/encoder.py:323-336,365-381; the oracle's handling is pinned against the live reference
+    in tests/test_oracle_golden.py): probabilities of every chunk step and the exported caches -- the half-rate layers' windows
+    follow the reference's next_cache_start // 2 trimming of the repeat-interleaved cache (even, odd and zero sizes); a second
+    stream of the same lock-step call keeps all history."""
+    from masr_amd.engine import HipEngine
+    from oracle import efficient_conformer as oe, squeezeformer as osq, weights
+    V = 64
+    if which == 'squeezeformer':
+        sd, orc = weights.squeezeformer_state_dict(0, V, streaming=True), osq
+    else:
+        sd, orc = weights.efficient_conformer_state_dict(0, V), oe
+    eng = HipEngine(sd, vocab_size=V, use_model=which, streaming=True)
+    gen = torch.Generator().manual_seed(8)
+    feats = torch.randn(2, 64 * 5 + 67, 80, generator=gen) * 3 + 13
+    try:
+        sids = [eng.stream_open(200), eng.stream_open(200)]
+        eng.stream_set_history(sids[0], required)
+        att0, cnn0 = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0)
+        att1, cnn1 = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0)
+        off, worst = 0, 0.0
+        for cur in range(0, feats.shape[1] - 67 + 1, 64):
+            with torch.no_grad():
+                p0, att0, cnn0 = orc.get_encoder_out_chunk(sd, feats[:1, cur:cur + 67], off, required, att0, cnn0)
+                p1, att1, cnn1 = orc.get_encoder_out_chunk(sd, feats[1:, cur:cur + 67], off, -1, att1, cnn1)
+            off += p0.shape[1]
+            probs, _, _ = eng.encode_chunk(sids, dev(feats[:, cur:cur + 67]))
+            worst = max(worst, (probs[0].cpu() - p0[0]).abs().max().item(), (probs[1].cpu() - p1[0]).abs().max().item())
+            assert worst < 1e-3, (cur, worst)
+            att, cnn = eng.stream_export_cache(sids[0])
+            assert tuple(att.shape) == tuple(att0.shape), (cur, att.shape, att0.shape)
+            if att0.numel():
+                assert (att.cpu() - att0).abs().max() < 1e-3, cur
+            assert (cnn.cpu() - cnn0).abs().max() < 1e-3
+        att, cnn = eng.stream_export_cache(sids[1])                     # the keep-all stream of the same calls
+        assert tuple(att.shape) == tuple(att1.shape) and (att.cpu() - att1).abs().max() < 1e-3
+        print(f'{which}, required_cache_size {required}: max |probs - oracle| = {worst:.2e}, kept cache {tuple(att0.shape)}')
+    finally:
+        eng.close()
+
+
+def test_bounded_history_is_rejected_where_there_is_no_attention_cache():
     from masr_amd._lib import MasrError
     from masr_amd.engine import HipEngine
     from oracle import weights
-    eng = HipEngine(weights.efficient_conformer_state_dict(0, 64), vocab_size=64, streaming=True, use_model='efficient_conformer')
+    eng = HipEngine(weights.deepspeech2_state_dict(0, 64, bidirectional=False), vocab_size=64, streaming=True, use_model='deepspeech2')
     try:
         sid = eng.stream_open(100)
         with pytest.raises(MasrError, match='required_cache_size'):

@@ -293,3 +293,58 @@ def test_chunk_masks_and_nonstreaming_efficient_against_live_reference():
         assert (ref - oe.encoder_full(sd, x, lens, streaming=False)).abs().max() < 2e-5
         ref16, _ = m.encoder(x, lens, 16, -1)                   # use_dynamic_chunk is off in this build: the argument is ignored
         assert torch.equal(ref, ref16)
+
+
+@pytest.mark.skipif(not shims.reference_available(), reason='/root/reference not present')
+@pytest.mark.parametrize('which', ['squeezeformer', 'efficient_conformer'])
+def test_bounded_history_of_the_sibling_encoders_against_live_reference(which):
+    """forward_chunk with required_cache_size >= 0 for the Squeezeformer (squeezeformer/encoder.py:292-297,338-347: the half-rate
+    layers read every second entry of a cache that is trimmed at next_cache_start // 2 and stored repeat-interleaved) and the
+    Efficient-Conformer (efficient_conformer/encoder.py:323-336,365-372): the oracle's probabilities and carried caches follow
+    the live reference chunk by chunk, for even, odd and zero cache sizes, the last chunk short."""
+    import json
+    import tempfile
+    import yaml
+    from oracle import efficient_conformer as oe, squeezeformer as osq
+    shims.install()
+    tmp = tempfile.mkdtemp()
+    if which == 'squeezeformer':
+        from masr.model_utils.squeezeformer.model import SqueezeformerModel as cls
+        sd = weights.squeezeformer_state_dict(0, 64, streaming=True)
+        name, orc = 'squeezeformer.yml', osq
+    else:
+        from masr.model_utils.efficient_conformer.model import EfficientConformerModel as cls
+        sd = weights.efficient_conformer_state_dict(0, 64)
+        name, orc = 'efficient_conformer.yml', oe
+    cfg = yaml.safe_load(open(os.path.join(shims.REFERENCE_ROOT, 'configs', name), encoding='utf-8'))
+    p = os.path.join(tmp, 'cmvn.json')
+    json.dump({'mean': sd['encoder.global_cmvn.mean'].tolist(), 'istd': sd['encoder.global_cmvn.istd'].tolist()}, open(p, 'w'))
+    m = cls(input_dim=80, vocab_size=64, mean_istd_path=p, streaming=True, encoder_conf=cfg['encoder_conf'],
+            decoder_conf=cfg['decoder_conf'], **cfg['model_conf']).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected
+    torch.manual_seed(9)
+    x = torch.randn(1, 64 * 5 + 41, 80) * 3 + 13          # five full chunks and a short one
+    with torch.no_grad():
+        for req in (0, 16, 24, 41, 40):
+            ra, rc = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0)
+            oa, oc_ = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0)
+            off = 0
+            for cur in range(0, x.shape[1], 64):
+                ch = x[:, cur:cur + 67]
+                if ch.shape[1] < 7:
+                    break
+                try:
+                    pr, ra, rc = m.get_encoder_out_chunk(ch, torch.tensor([off]), torch.tensor([req]), ra, rc)
+                except RuntimeError:
+                    # the reference Efficient-Conformer itself fails on a SHORT chunk behind a zero or odd cache size (its stride
+                    # layer / torch.cat see mismatched lengths): nothing to follow there
+                    assert which == 'efficient_conformer' and ch.shape[1] < 67 and (req == 0 or req % 2 == 1), (which, req, cur)
+                    break
+                po, oa, oc_ = orc.get_encoder_out_chunk(sd, ch, off, req, oa, oc_)
+                off += pr.shape[1]
+                assert (pr - po).abs().max() < 2e-5, (which, req, cur)
+                assert ra.shape == oa.shape, (which, req, cur, ra.shape, oa.shape)
+                assert ra.numel() == 0 or (ra - oa).abs().max() < 2e-5
+                assert (rc - oc_).abs().max() < 2e-5
+            assert off >= 5 * (16 if which == 'squeezeformer' else 8)
