@@ -222,6 +222,11 @@ struct masr_engine {
     DevBuf gx, rnn_out, hstate, cstate, ds2_lens;
     std::vector<GBeam> gbeams;
     DevBuf beam_pool, beam_state;
+    // whole-utterance prefix searches launched on OTHER streams than the first one get workspaces of their own: two searches may
+    // run next to each other (predict_batch: the passes' searches on two side streams), launches on one stream are ordered anyway
+    std::map<void*, std::pair<DevBuf, DevBuf>> beam_ws;
+    void* beam_first_stream = nullptr;
+    bool beam_first_set = false;
     std::map<const float*, std::pair<DevBuf, DevBuf>> ffn_packed;  // fp32 FFN weights in fragment order (ffn_pc.hip VAR == 2), per W1 pointer
     std::map<const float*, std::pair<DevBuf, DevBuf>> ffn_dual_packed;  // the same in the two-chain order of ffn_dual.hip (and its QKV tail weights)
     std::map<const float*, std::pair<DevBuf, DevBuf>> x3_packed;   // exploratory split-bf16 FFN: packed weights per FFN (W1 pointer)
@@ -476,6 +481,10 @@ void masr_destroy(masr_engine* e) {
     for (auto& g : e->gbeams) {
         g.pool.release();
         g.state.release();
+    }
+    for (auto& kv : e->beam_ws) {
+        kv.second.first.release();
+        kv.second.second.release();
     }
     for (auto& kv : e->x3_packed) {
         kv.second.first.release();
@@ -1638,11 +1647,20 @@ int masr_beam_search_gpu_lm(masr_engine* e, const int32_t* idx_dev, const float*
     if (K > 64 || beam_size > 512 || beam_size < 1 || beam_gpu_lds_bytes(beam_size, K, lm != nullptr) > 160 * 1024)
         return fail("beam search on the GPU needs cutoff_top_n <= 64, beam_size <= 512 and beam_size*cutoff_top_n*4 B + tables "
                     "within 160 KB of LDS; use masr_beam_search_batch (host threads) beyond that");
-    CHK(e->beam_pool.ensure((size_t)B * a.pool_cap * 2 * sizeof(int)));
-    CHK(e->beam_state.ensure((size_t)B * beam_state_bytes(beam_size)));
-    a.pool_parent = e->beam_pool.as<int>();
+    DevBuf *pool = &e->beam_pool, *state = &e->beam_state;
+    if (!e->beam_first_set) {
+        e->beam_first_set = true;
+        e->beam_first_stream = stream;
+    } else if (stream != e->beam_first_stream) {
+        auto& ws = e->beam_ws[stream];
+        pool = &ws.first;
+        state = &ws.second;
+    }
+    CHK(pool->ensure((size_t)B * a.pool_cap * 2 * sizeof(int)));
+    CHK(state->ensure((size_t)B * beam_state_bytes(beam_size)));
+    a.pool_parent = pool->as<int>();
     a.pool_ch = a.pool_parent + (size_t)B * a.pool_cap;
-    beam_state_carve(e->beam_state.p, B, beam_size, &a.state_h, &a.state_i, &a.state_f);
+    beam_state_carve(state->p, B, beam_size, &a.state_h, &a.state_i, &a.state_f);
     CHK(bind_lm(a, lm, alpha, beta));
     a.init = 1;
     a.prof = e->beam_prof;

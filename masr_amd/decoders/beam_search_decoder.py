@@ -168,7 +168,8 @@ class BeamSearchDecoder:
         """results of a ``_batch(..., defer=True)`` launch (synchronises with the stream it was launched on)"""
         _, toks, lens, scores, _keep, ev = pending
         ev.synchronize()
-        toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
+        eng = runtime.aux_engine()
+        toks, lens, scores = eng.to_host(toks), eng.to_host(lens), eng.to_host(scores)
         if want_tokens:
             return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(len(lens))]
         return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(len(lens))]
@@ -192,7 +193,7 @@ class BeamSearchDecoder:
             # whole search on the device: candidates never leave HBM, one workgroup per utterance
             eng = runtime.aux_engine()
             idx, logp, cnt, blp, K = self._candidates(stacked.reshape(B * Ts, V), to_host=False)
-            fr = torch.from_numpy(frames).to(eng.device)
+            fr = eng.to_device(frames)
             toks = torch.zeros(B, max_len, dtype=torch.int32, device=eng.device)
             lens = torch.zeros(B, dtype=torch.int32, device=eng.device)
             scores = torch.zeros(B, dtype=torch.float32, device=eng.device)

@@ -193,13 +193,34 @@ class HipEngine:
         check(self.lib.masr_mean_square(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max, _ptr(ms), _stream()))
         return ms
 
+    def to_host(self, t):
+        """small device tensor -> numpy through a pinned buffer, waiting for THIS stream only.  (``tensor.cpu()`` copies to
+        pageable memory, which the HIP runtime serialises against every stream of the device: a prefix search running on a side
+        stream then stalls the next pass's features and encoder for its whole duration -- 32 ms per predict_batch call of
+        BASELINE configs[2], tools/beam_batch_profile.py.)"""
+        pin = self.__dict__.setdefault('_pins', {})
+        buf = pin.get(t.dtype)
+        if buf is None or buf.numel() < t.numel():
+            buf = torch.empty(max(int(t.numel()), 256), dtype=t.dtype, pin_memory=True)
+            pin[t.dtype] = buf
+        view = buf[:t.numel()].view(t.shape)
+        view.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return view.numpy().copy()
+
+    def to_device(self, a):
+        """small host array -> device through a pinned tensor of its own (asynchronous, no device-wide serialisation)"""
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        pin.copy_(t)
+        return pin.to(self.device, non_blocking=True)
+
     def host_gains(self, samples, n_samples, target_db, max_gain_db=300.0):
         """The reference's normalisation gain evaluated where the reference evaluates it: the mean square comes from the
         device (bit-identical to numpy's), the scalar float32 expressions of ``rms_db`` / ``normalize`` / ``gain_db``
         (audio.py:256-264,287-304,519-529) run on THIS host's numpy, whose float32 log10 / power are not correctly rounded
         and differ between machines.  Returns linear gains [B] f32 (device); raises like ``normalize`` beyond max_gain_db."""
-        return torch.from_numpy(reference_gains(self.mean_square(samples, n_samples).cpu().numpy(), target_db,
-                                                max_gain_db)).to(self.device)
+        return self.to_device(reference_gains(self.to_host(self.mean_square(samples, n_samples)), target_db, max_gain_db))
 
     def _db_mode(self, use_db_normalization, gain_in, B, return_gain):
         """-> (mode for the C ABI, gain tensor): 0 off / 1 device gains (returned in the tensor when asked) / 2 supplied gains"""

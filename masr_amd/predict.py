@@ -170,7 +170,7 @@ class MASRPredictor:
         for i, s in enumerate(segs):
             buf[i, :n[i]] = s._pcm16 if as_pcm else s._samples
         xs = stage.to(eng.device, non_blocking=True)
-        ns = torch.from_numpy(n).to(eng.device)
+        ns = eng.to_device(n)
         ev = torch.cuda.Event()
         ev.record()
         ring['events'][k] = ev
@@ -209,7 +209,7 @@ class MASRPredictor:
         if self.configs.decoder == 'ctc_beam_search':
             # probabilities stay on the GPU: vocabulary pruning, prefix search and LM scoring run there
             probs = eng.ctc_probs(enc)
-            n_host = [probs.shape[1]] * len(live) if nenc is None else nenc.cpu().tolist()
+            n_host = [probs.shape[1]] * len(live) if nenc is None else eng.to_host(nenc).tolist()
             seqs = [probs[i, :n_host[i]] for i in range(len(live))]
             dec = self.beam_search_decoder
 
@@ -218,11 +218,15 @@ class MASRPredictor:
                     out[i] = r if as_tokens else {'text': r[1], 'score': r[0]}
                 return out
             if defer and dec.use_gpu_search and dec.gpu_search_supported(probs.shape[1], probs.shape[2]):
+                # two side streams take turns: the searches of consecutive passes (one workgroup per utterance each) run next
+                # to each other, not one behind the other
                 main = torch.cuda.current_stream()
-                if getattr(self, '_side', None) is None:
-                    self._side = torch.cuda.Stream()
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
+                if getattr(self, '_sides', None) is None:
+                    self._sides, self._side_turn = [torch.cuda.Stream(), torch.cuda.Stream()], 0
+                side = self._sides[self._side_turn]
+                self._side_turn ^= 1
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
                     pending = dec._batch(seqs, defer=True)
                 return lambda: fill(dec._batch_collect(pending, want_tokens=as_tokens))
             res = fill(dec._batch(seqs, want_tokens=as_tokens))
@@ -287,7 +291,7 @@ class MASRPredictor:
         return [{'text': self._text(tok[i, :nt[i]]), 'score': float(sc[i])} for i in range(len(audio_list))]
 
     def _run_sorted(self, audio_list, sample_rate, hints, which, decode_all_frames, batch_size, as_tokens):
-        """decode ``audio_list[i] for i in which`` in length-sorted device passes (shortest first, ties in input order -- the
+        """decode ``audio_list[i] for i in which`` in length-sorted device passes (cut shortest first, ties in input order -- the
         batches ``evaluate`` forms from a duration-sorted manifest); results in the order of ``which``.  Pipeline depth 2:
         pass k is launched (its prefix search on a side stream), then pass k - 1 is collected and its audio dropped."""
         order = sorted(which, key=lambda i: hints[i]) if batch_size else list(which)
@@ -299,7 +303,13 @@ class MASRPredictor:
             for i, r in zip(idx, fetch()):
                 got[i] = r
 
-        for lo in range(0, len(order), step):
+        # same passes either way; with the GPU prefix search the LONGEST pass goes first: its search (one workgroup per utterance,
+        # the longest utterance is the critical path of the call) then starts right after the first encoder pass and the
+        # shorter passes' encoders and searches run underneath it
+        starts = list(range(0, len(order), step))
+        if self.configs.decoder == 'ctc_beam_search' and getattr(self.beam_search_decoder, 'use_gpu_search', False):
+            starts.reverse()
+        for lo in starts:
             idx = order[lo:lo + step]
             segs = [self._load_audio(audio_list[i], sample_rate) for i in idx]
             # (beam search: the prefix search of this pass runs on a side stream under the encoder of the next pass)
@@ -310,8 +320,8 @@ class MASRPredictor:
             prev = cur
         if prev is not None:
             collect(prev)
-            if getattr(self, '_side', None) is not None:
-                torch.cuda.current_stream().wait_stream(self._side)
+            for side in getattr(self, '_sides', None) or []:
+                torch.cuda.current_stream().wait_stream(side)
         return [got[i] for i in which]
 
     def evaluate(self, manifest, batch_size=32, display_result=False, decode_all_frames=False):

@@ -358,6 +358,31 @@ def test_gpu_search_with_language_model_matches_host_and_oracle(tmp_path, seed, 
 
 
 @pytest.mark.gpu
+def test_two_searches_on_two_streams_do_not_share_workspaces(tmp_path):
+    """predict_batch launches the prefix searches of consecutive passes on two side streams so that they run next to each other
+    (one workgroup per utterance each): searches launched on different streams must work in workspaces of their own -- same
+    transcripts and scores as the searches run one after the other."""
+    import torch
+    V, beam = 600, 300
+    rng = np.random.default_rng(11)
+    sets = [[rng.dirichlet(np.ones(V) * 0.02, size=T).astype(np.float32) for T in Ts] for Ts in ((180, 150, 120, 90), (170, 60, 140))]
+    dec, vocab, _ = _lm_decoder(tmp_path, V, beam, 0.99, 40, order=3)
+    dev_sets = [[torch.from_numpy(p).cuda() for p in ps] for ps in sets]
+    sequential = [dec._batch(ps) for ps in dev_sets]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(3):
+        pending = []
+        for st, ps in zip(streams, dev_sets):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                pending.append(dec._batch(ps, defer=True))
+        both = [dec._batch_collect(h) for h in pending]
+        for seq, con in zip(sequential, both):
+            for (ss, ts), (sc, tc) in zip(seq, con):
+                assert ts == tc and abs(ss - sc) < 1e-4 * max(1.0, abs(ss)), (ts, tc, ss, sc)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('seed,alpha,beta,beam', [(0, 1.0, 0.0, 8), (1, 0.5, 0.3, 300), (2, 1.0, -0.5, 40)])
 def test_gpu_pruning_rule_at_settings_where_it_cuts(tmp_path, seed, alpha, beta, beam):
     """low beta: every candidate less likely than blank is cut for the prefixes at the bottom of a full beam -- GPU == host ==
