@@ -233,7 +233,7 @@ class MASRPredictor:
             return (lambda: res) if defer else res
         idx, mp = eng.ctc_greedy_frames(enc)
         tok, ntok, score = eng.ctc_collapse(idx, mp, nenc)
-        tok, ntok, score = tok.cpu().numpy(), ntok.cpu().numpy(), score.cpu().numpy()
+        tok, ntok, score = eng.to_host(tok), eng.to_host(ntok), eng.to_host(score)
         for j, i in enumerate(ok):
             sc = float(score[j]) * 100.0 if ntok[j] > 0 or score[j] > 0 else 0
             ids = tok[j, :ntok[j]]
