@@ -9,8 +9,10 @@
 // In phase k the producers work on chunk k while the consumers work on chunk k-1: the bias + SiLU + LDS traffic of one
 // wave overlaps with the matrix work of the other wave on the same SIMD, and there is ONE workgroup barrier per chunk
 // (round 1's first version split K of the first GEMM over the waves and exchanged partial sums through LDS, two barriers per
-// chunk; that kernel is gone).  Weights stream through wave-private, double-buffered LDS slabs [32][36] filled by the consuming
-// wave itself with a 4-deep register prefetch rotation; no barrier on the weight path.
+// chunk; that kernel is gone).  Weights (VAR == 2, every launch since round 3): packed copies in the order the waves consume
+// them, fetched with raw buffer loads straight into MFMA operand registers (ring of 16 fragments = 64 MFMAs ahead) -- no LDS and
+// no barrier on the weight path.  VAR == 0 keeps the earlier scheme for A/B runs (masr_debug_set key 23): wave-private,
+// double-buffered LDS slabs [32][36] filled by the consuming wave itself with a 4-deep register prefetch rotation.
 // TAIL = 1 (first macaron FFN of an offline Conformer layer): the 32 finished rows do not leave the CU before the next
 // row-local stage -- they are put back into the LayerNorm tile, normalised with the attention block's LayerNorm, and all 8 waves
 // run the fused QKV projection on them ([768, 256] weights through the same wave-private slab stream, 3 output tiles per
