@@ -563,8 +563,34 @@ def extra_bf16x3(args, rank, world, local):
             'note': 'not the reference arithmetic (fp32): never the headline; tests/test_gpu_bf16x3.py holds it to the 1e-3 bars'}
 
 
-def run_extras(args, rank, world, local):
-    out = {}
+class ExtrasWatchdog:
+    """The secondary workloads run AFTER the contract measurement but before its line is printed.  Under several ranks they use
+    collectives (hypothesis all-gathers); should one of them ever stall (a rank lost, an interconnect fault), this thread prints
+    the already measured contract line -- with whatever extras finished and a note -- and ends the process, on every rank, so
+    that a stalled extra can cost the extras but never the measurement.  (Blocking device synchronisation releases the GIL, so
+    the thread runs while the main thread waits.)  MASR_BENCH_EXTRA_TIMEOUT seconds, default 600; 0 disables."""
+
+    def __init__(self, rank, res, out):
+        import threading
+        self.limit = float(os.environ.get('MASR_BENCH_EXTRA_TIMEOUT', '600'))
+        self.done = threading.Event()
+        self.rank, self.res, self.out = rank, res, out
+        if self.limit > 0:
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def _watch(self):
+        if self.done.wait(self.limit):
+            return
+        log(f'rank {self.rank}: the secondary workloads exceeded {self.limit:.0f} s -- printing the contract line without them')
+        if self.rank == 0:
+            line = dict(self.res)
+            line['extra'] = dict(self.out, _note=f'extras aborted by the watchdog after {self.limit:.0f} s')
+            print(json.dumps(line, ensure_ascii=False), flush=True)
+        os._exit(0)
+
+
+def run_extras(args, rank, world, local, out=None):
+    out = {} if out is None else out
     jobs = [('efficient_b256', extra_efficient_b256), ('stream128', extra_stream128)]
     if world == 1:
         # the per-GPU share of configs[4] on an 8-GPU node (128 streams / 8), measured on this one GPU
@@ -619,7 +645,12 @@ def main():
     else:
         eng, res = run_contract(args, rank, world, local)
         eng.close()
-        extra = None if args.no_extra else run_extras(args, rank, world, local)
+        extra = None
+        if not args.no_extra:
+            partial = {}
+            dog = ExtrasWatchdog(rank, res, partial)
+            extra = run_extras(args, rank, world, local, partial)
+            dog.done.set()
         if rank == 0:
             if extra is not None:
                 res['extra'] = extra

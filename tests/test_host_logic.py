@@ -212,3 +212,21 @@ def test_server_app_on_two_workers():
             assert a.receive_json() == {'code': 0, 'result': 'b5'}
             b.send_bytes(b'end')
         assert len(pools[0].sessions) == 1 and len(pools[1].sessions) == 1      # one session on each worker
+
+
+def test_bench_extras_watchdog_prints_the_contract_line_when_an_extra_stalls():
+    import os
+    """bench.py: a secondary workload that never returns (a stalled collective) must not cost the contract measurement -- the
+    watchdog prints the measured line with the finished extras and a note, and ends the process with status 0"""
+    import json
+    import subprocess
+    import sys
+    code = ("import os, sys, time, json; os.environ['MASR_BENCH_EXTRA_TIMEOUT'] = '0.3'; sys.path.insert(0, %r); import bench; "
+            "res = {'metric': 'm', 'value': 1.0}; part = {'efficient_b256': {'value': 2.0}}; "
+            "dog = bench.ExtrasWatchdog(0, res, part); time.sleep(30); print('not reached')") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and 'not reached' not in p.stdout
+    line = json.loads(lines[0])
+    assert line['value'] == 1.0 and line['extra']['efficient_b256']['value'] == 2.0 and 'watchdog' in line['extra']['_note']
