@@ -29,8 +29,10 @@ import sys
 import tempfile
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime starts (masr_amd/__init__.py says why)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
