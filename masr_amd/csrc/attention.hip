@@ -22,6 +22,40 @@
 namespace masr {
 
 static constexpr int DK = 64;
+
+// ATT_XLANE 1: cross-lane exchanges of attention_kernel on the VALU instead of through the LDS crossbar (__shfl_xor lowers to
+// ds_bpermute_b32, one LDS round trip each): the lane ^ 32 exchange of the online softmax with v_permlane32_swap_b32 (gfx950),
+// the 16-lane sum of the folded score constant with four DPP adds (quad_perm, row_half_mirror, row_mirror -- the same operand
+// pairs as the xor butterfly, so the same bits).  0 keeps the shuffles (A/B builds).
+#ifndef ATT_XLANE
+#define ATT_XLANE 1
+#endif
+__device__ __forceinline__ float att_xor32(float v, int h) {
+#if ATT_XLANE
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0]: lanes 32.. hold lanes 0..31; r[1]: lanes 0..31 hold lanes 32..
+    return __builtin_bit_cast(float, h ? r[0] : r[1]);
+#else
+    return __shfl_xor(v, 32, 64);
+#endif
+}
+__device__ __forceinline__ float att_sum16(float c) {
+#if ATT_XLANE
+#define ATT_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, false))
+    c += ATT_DPP(c, 0xB1);    // quad_perm [1,0,3,2]   (lane ^ 1)
+    c += ATT_DPP(c, 0x4E);    // quad_perm [2,3,0,1]   (lane ^ 2)
+    c += ATT_DPP(c, 0x141);   // row_half_mirror: quad q <-> quad 1 - q of each 8 lanes (all lanes of a quad hold its sum)
+    c += ATT_DPP(c, 0x140);   // row_mirror: half <-> half of the 16 lanes
+#undef ATT_DPP
+    return c;
+#else
+    c += __shfl_xor(c, 1, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 8, 64);
+    return c;
+#endif
+}
 static constexpr int KP_LD = 68;   // padded row of the K / P tiles (floats): 16B slot = (17*row + ..) mod 16
 static constexpr int V_LD = 68;
 
@@ -102,6 +136,32 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
     }
     // register-prefetched staging: pair kp+1 is fetched from global memory while pair kp is multiplied
     f32x4 pk[2], pp[2], pv[2];
+#if ATT_XLANE
+    // raw buffer loads: the sequence's key / value rows and its positional rows behind descriptors in SGPRs, this thread's row and
+    // column as ONE constant byte offset per operand, the tile pair as a scalar offset -- no 64-bit address arithmetic per load
+    // next to the MFMAs; rows past the last key are out of the descriptor's range and read as zero
+    const unsigned kv_row_bytes = (unsigned)kv_stride * 4u, p_row_bytes = (unsigned)pos_stride * 1024u;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sq.k), 0, (unsigned)sq.nk * kv_row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sq.v), 0, (unsigned)sq.nk * kv_row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptab + (size_t)sq.pos0 * 256), 0,
+                                                                         (unsigned)sq.nk * p_row_bytes, 0x00020000);
+    unsigned kvo[2], po[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned jr = (unsigned)(sti * 32 + srow + 16 * i);
+        kvo[i] = jr * kv_row_bytes + (unsigned)(head * DK + sc4) * 4u;
+        po[i] = jr * p_row_bytes + (unsigned)(head * DK + sc4) * 4u;
+    }
+    auto fetch = [&](int kp) {
+        const unsigned skv = (unsigned)kp * 64u * kv_row_bytes, sp = (unsigned)kp * 64u * p_row_bytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvo[i], skv, 0));
+            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, kvo[i], skv, 0));
+            pp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, po[i], sp, 0));
+        }
+    };
+#else
     auto fetch = [&](int kp) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -113,6 +173,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
             if (j >= sq.nk) { pk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[i] = pk[i]; pp[i] = pk[i]; }
         }
     };
+#endif
     fetch(0);
     for (int kp = 0; kp < npair; ++kp) {
         const int j0 = (2 * kp + kh) * 32;     // first key of this wave's tile
@@ -129,10 +190,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
                     c = fmaf(sv[s], pp[i][s], c);
                     kp4[s] = pk[i][s] + pp[i][s];
                 }
-                c += __shfl_xor(c, 1, 64);
-                c += __shfl_xor(c, 2, 64);
-                c += __shfl_xor(c, 4, 64);
-                c += __shfl_xor(c, 8, 64);
+                c = att_sum16(c);
                 *reinterpret_cast<f32x4*>(&Ks[sti * 32 * KP_LD + r * KP_LD + sc4]) = kp4;
                 if ((tid & 15) == 0) Cs[sti * 32 + r] = c;
             } else {
@@ -147,8 +205,17 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
 
         // ---- S^T tile: rows = 32 keys, cols = this wave's 32 queries -------------------------
         f32x16 st;
+        if (FOLD) {            // rows (r & 3) + 8 (r >> 2) + 4 h: four aligned groups of four constants
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = FOLD ? Cs[kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+            for (int rr = 0; rr < 4; ++rr) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(&Cs[kh * 32 + 8 * rr + 4 * h]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st[4 * rr + q] = c4[q];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        }
         const float* kb = &Ks[kh * 32 * KP_LD + (lane & 31) * KP_LD + 4 * h];
         const float* pb = &Ps[kh * 32 * KP_LD + (lane & 31) * KP_LD + 4 * h];
 #pragma unroll
@@ -174,7 +241,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
             if (j >= jlim) st[r] = -INFINITY;
             tmax = fmaxf(tmax, st[r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = fmaxf(tmax, att_xor32(tmax, h));
         const float m_new = fmaxf(m_run, tmax);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float corr = __expf(m_run - m_safe);        // m_run = -inf -> 0
@@ -184,7 +251,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
             st[r] = __expf(st[r] - m_safe);                 // masked (-inf) -> 0
             psum += st[r];
         }
-        psum += __shfl_xor(psum, 32, 64);
+        psum += att_xor32(psum, h);
         l_run = l_run * corr + psum;
         m_run = m_new;
 #pragma unroll
