@@ -357,14 +357,42 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
     if (chunk_size > 0) jlim = min(jlim, (((q_abs * pos_stride) / chunk_size + 1) * chunk_size + pos_stride - 1) / pos_stride);
     const int ntile = (sq.nk + 31) / 32;
 
+#if ATT_XLANE
+    // raw buffer loads (as in attention_kernel): descriptors over this sequence's keys / values / positional rows, ONE constant
+    // per-lane offset per operand, the tile (and, for the value rows, the key of accumulator register r) as a wave-uniform scalar
+    // offset -- no per-load address arithmetic in a kernel whose time is its dependent chain; rows past the last key read as zero
+    // (their keys are masked: probability 0 times 0)
+    const unsigned kv_row_bytes = (unsigned)kv_stride * 4u, p_row_bytes = (unsigned)pos_stride * 1024u;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sq.k), 0, (unsigned)sq.nk * kv_row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sq.v), 0, (unsigned)sq.nk * kv_row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptab + (size_t)sq.pos0 * 256), 0,
+                                                                         (unsigned)sq.nk * p_row_bytes, 0x00020000);
+    const unsigned ko = (unsigned)(lane & 31) * kv_row_bytes + (unsigned)(head * DK + 4 * h) * 4u;
+    const unsigned po = (unsigned)(lane & 31) * p_row_bytes + (unsigned)(head * DK + 4 * h) * 4u;
+    const unsigned vo = (unsigned)(4 * h) * kv_row_bytes + (unsigned)(head * DK + (lane & 31)) * 4u;
+#endif
     for (int t = wave; t < ntile; t += 8) {
         const int j0 = t * 32;
+        f32x4 kf[8], pf[8];
+        float va[16], vb[16];
+#if ATT_XLANE
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            kf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, ko + 32u * g, (unsigned)j0 * kv_row_bytes, 0));
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            pf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, po + 32u * g, (unsigned)j0 * p_row_bytes, 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned so = (unsigned)(j0 + (r & 3) + 8 * (r >> 2)) * kv_row_bytes;
+            va[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrs, vo, so, 0));
+            vb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrs, vo + 128u, so, 0));
+        }
+#else
         // ---- all operand loads of this tile (clamped rows: masked keys get probability 0, times a finite value) ----------
         const int jr = min(j0 + (lane & 31), sq.nk - 1);
         const float* kp = sq.k + (size_t)jr * kv_stride + head * DK + 4 * h;
         const float* pp = ptab + (size_t)(sq.pos0 + jr * pos_stride) * 256 + head * DK + 4 * h;
-        f32x4 kf[8], pf[8];
-        float va[16], vb[16];
 #pragma unroll
         for (int g = 0; g < 8; ++g) kf[g] = *reinterpret_cast<const f32x4*>(kp + 8 * g);
 #pragma unroll
@@ -376,6 +404,7 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
             va[r] = vp[0];
             vb[r] = vp[32];
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 
         f32x16 st;
@@ -397,7 +426,7 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
             if (j >= jlim) st[r] = -INFINITY;
             tmax = fmaxf(tmax, st[r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = fmaxf(tmax, att_xor32(tmax, h));
         const float m_new = fmaxf(m_run, tmax);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float corr = __expf(m_run - m_safe);
@@ -407,7 +436,7 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
             st[r] = __expf(st[r] - m_safe);
             psum += st[r];
         }
-        psum += __shfl_xor(psum, 32, 64);
+        psum += att_xor32(psum, h);
         l_run = l_run * corr + psum;
         m_run = m_new;
 #pragma unroll
