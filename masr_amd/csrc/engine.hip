@@ -359,7 +359,9 @@ void rowgemm(masr_engine* e, hipStream_t s, int pro, int epi, const float* A, in
     a.out_seq_t = out_seq_t; a.out_pad_l = out_pad_l; a.out_pad_tot = out_pad_tot;
     a.plane_cols = plane_cols; a.plane_stride = plane_stride; a.a_seq_t = a_seq_t; a.a_seq_stride = a_seq_stride;
     a.kv_seqs = kv_seqs; a.kv_tq = kv_tq;
-    if (g_rowgemm_packed && epi == RG_EPI_CTC && pro == RG_PRO_PLAIN && M >= 64 * 32) a.Wp = packed_rows_of(e, W, N, s);
+    // full row-block launches (the K-split kernel of few row blocks reads W itself) take the packed copy of their weights
+    if (g_rowgemm_packed && M >= 112 * 32 && pro != RG_PRO_HIST && pro != RG_PRO_DWCONV && (epi == RG_EPI_CTC || N % 256 == 0))
+        a.Wp = packed_rows_of(e, W, N, s);
     ProfScope ps(e, s, kind, 2.0 * M * (double)N * 256);
     launch_rowgemm(a, pro, epi, s);
 }

@@ -433,7 +433,7 @@ static void launch_rg(const RowGemmArgs& a, hipStream_t s) {
         fprintf(stderr, "rowgemm: N must be a multiple of 256 for this epilogue\n");
         abort();
     }
-    constexpr bool can_pack = EPI == RG_EPI_CHAIN || (EPI == RG_EPI_CTC && PRO == RG_PRO_PLAIN);
+    constexpr bool can_pack = true;      // every epilogue of the row-block kernel (the column-group split of few row blocks keeps the slabs)
     if (can_split && ngroups > 1 && rowblocks < 64) {
         hipLaunchKernelGGL((rowgemm_kernel<PRO, EPI, can_split ? 1 : 0>), dim3(rowblocks, ngroups), dim3(512), lds, s, a);
     } else if (can_pack && a.Wp) {

@@ -69,3 +69,38 @@ def test_two_chain_ffn_is_bit_identical_to_the_single_chain_kernel(kind, streami
     assert torch.equal(out[0], out[1]), float((out[0] - out[1]).abs().max())
     assert torch.equal(out[('p', 0)], out[('p', 1)])
     eng.close()
+
+
+@pytest.mark.parametrize('kind,streaming', [('conformer', True), ('conformer', False), ('squeezeformer', False), ('squeezeformer', True),
+                                            ('efficient_conformer', True)])
+def test_packed_row_block_projections_are_bit_identical_to_the_slab_pipeline(kind, streaming):
+    """rowgemm.hip: every full row-block launch (LN -> QKV, out-projection, pointwise convolutions, the out-proj + pw1 chain, the
+    fused CTC head) reads a packed copy of its weights with buffer loads (masr_debug_set key 25, default on) instead of staging
+    them through wave-private LDS slabs: same operands in the same MFMA order, so encoder output, frame argmax and frame
+    probability are BIT-identical with the switch on and off -- for every family, ragged batch, partial last row block."""
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    V = 600                                    # not a multiple of 256: the packed CTC weights are zero-padded to 768 rows
+    sd = getattr(synthetic, kind + '_state_dict')(0, V, **({'streaming': streaming} if kind == 'squeezeformer' else {}))
+    eng = HipEngine(sd, vocab_size=V, use_model=kind, streaming=streaming)
+    rng = np.random.default_rng(7)
+    lens = rng.integers(50000, 160001, 31).astype(np.int32)
+    lens[0] = 160000
+    pcm = synthetic.synthetic_pcm(31, 160000, seed=13)
+    for i, l in enumerate(lens):
+        pcm[i, l:] = 0
+    feats, frames = eng.fbank_batch(torch.from_numpy(pcm).cuda(), torch.from_numpy(lens).cuda())
+    out = {}
+    try:
+        for v in (1, 0, 1):
+            eng.lib.masr_debug_set(eng.h, 25, v)
+            enc = eng.encode_full(feats, frames, -1).clone()
+            idx, mp = eng.ctc_greedy_frames(enc)
+            out[v] = (enc, idx.clone(), mp.clone())
+    finally:
+        eng.lib.masr_debug_set(eng.h, 25, 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[1][0]).all() and float(out[1][0].abs().max()) > 0
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    eng.close()
