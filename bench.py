@@ -44,6 +44,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f
 GFLOP_PER_STEP = 742.0        # 23.18 GFLOP per 10 s utterance x 32
 
 
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio when its first communicator is created; with stdout redirected that buffer
+    is written at process exit -- i.e. BEHIND the JSON line of rank 0.  Flushing the C streams once the collectives are warm
+    (and again just before the line) keeps the contract line the last thing on stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                                   # noqa: BLE001  (cosmetic)
+        pass
+
+
 def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
@@ -335,6 +346,7 @@ def run_contract(args, rank, world, local):
         eng.lib.masr_debug_set(eng.h, 16, 1)
     n_texts, sample_text = cs.n_texts, (cs.texts[0] if cs.texts else '')
     log(f'rank {rank}: timed region done: {dt * 1e3 / args.steps:.3f} ms/step')
+    flush_c_stdio()
     dt_dev = parallel.timed_region(lambda i: cs.step(i, 'device'), args.steps, 1)
     dt_host = parallel.timed_region(lambda i: cs.step(i, 'host'), args.steps, 1, flush=cs.flush)
     others = []
@@ -637,13 +649,14 @@ def main():
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
 
+    line = None
     if args.workload != 'conformer_b32':
         fn = {'efficient_b256': extra_efficient_b256, 'stream128': extra_stream128, 'bf16x3': extra_bf16x3,
               'squeezeformer_b64_beam': extra_squeezeformer_beam,
               'squeezeformer_b64_beam_nolm': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, lm=False)}[args.workload]
         res = fn(args, rank, world, local)
         if rank == 0:
-            print(json.dumps(dict({'dtype': 'f32'}, **res, data=data_tag()), ensure_ascii=False), flush=True)
+            line = json.dumps(dict({'dtype': 'f32'}, **res, data=data_tag()), ensure_ascii=False)
     else:
         eng, res = run_contract(args, rank, world, local)
         eng.close()
@@ -661,9 +674,19 @@ def main():
                     res['cpu_baseline'] = cpu_baseline()
                 except Exception as exc:                                # noqa: BLE001  (the measured line must still print)
                     res['cpu_baseline'] = {'error': f'{type(exc).__name__}: {exc}'}
-            print(json.dumps(res, ensure_ascii=False), flush=True)
+            line = json.dumps(res, ensure_ascii=False)
+    # the JSON line is the LAST thing on stdout: every rank empties its C buffers (RCCL's banner), all ranks meet, rank 0 prints
+    flush_c_stdio()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
+    if line is not None:
+        print(line, flush=True)
+    try:                                     # whatever a library still writes to stdout on its way out goes to stderr
+        sys.stdout.flush()
+        os.dup2(2, 1)
+    except OSError:
+        pass
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
