@@ -19,6 +19,9 @@ rocprofv3 --kernel-trace --stats -d $R/$D/ktx -o x -- python $R/bench.py --workl
 cd $R
 python tools/serve_bench.py > $D/serving.json 2> $D/serving.err
 for o in 0 3 5; do python tools/beam_profile.py 498 4233 300 $o 2>&1 | tail -2; done > $D/beam_profile.txt 2>&1
+python tools/beam_batch_profile.py 2>&1 | grep -v amdgpu > $D/beam_batch_timeline.txt
+python tools/chunk_lat.py build 2>&1 | tail -1 > $D/chunk_lat.txt
+python tools/predict_long_profile.py 2>&1 | grep -v amdgpu | tail -3 > $D/predict_long.txt
 python profiles/summarize_rocpd.py $(find $D/ktx -name "*.db") > $D/x3_kernel_stats.txt
 python profiles/summarize_rocpd.py $(find $D/kt -name "*.db") 44 > $D/kernel_stats.txt
 python profiles/summarize_rocpd.py $(find $D/kts -name "*.db") > $D/stream16_kernel_stats.txt
