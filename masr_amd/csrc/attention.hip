@@ -30,6 +30,9 @@ static constexpr int DK = 64;
 #ifndef ATT_XLANE
 #define ATT_XLANE 1
 #endif
+#ifndef ATT_XCD_MAP
+#define ATT_XCD_MAP 1
+#endif
 __device__ __forceinline__ float att_xor32(float v, int h) {
 #if ATT_XLANE
     const unsigned u = __builtin_bit_cast(unsigned, v);
@@ -74,19 +77,31 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttSeq* __restrict
                                                         const float* __restrict__ ptab,
                                                         const float* __restrict__ bias_u,
                                                         const float* __restrict__ bias_v, int chunk_size,
-                                                        int pos_stride) {
+                                                        int pos_stride, int nqb_1d, int heads_1d, int nseq_1d) {
     __shared__ __align__(16) float lds_att[2 * 32 * KP_LD * 2 + 2 * 32 * V_LD + 64];
     float* Ks = lds_att;                       // [2 tiles][32][68]
     float* Ps = Ks + 2 * 32 * KP_LD;
     float* Vs = Ps + 2 * 32 * KP_LD;
     float* Cs = Vs + 2 * 32 * V_LD;            // FOLD: [2 tiles][32] per-key constants
 
-    const AttSeq sq = seqs[blockIdx.z];
-    const int head = blockIdx.y;
+    // 1-D launch (ATT_XCD_MAP): workgroup ids go round-robin over the 8 XCDs, so id -> (XCD = id % 8, k = id / 8); the query
+    // blocks of one (sequence, head) take consecutive k on the SAME XCD -- its key / value rows are fetched into that XCD's L2
+    // once, not once per query block -- and an XCD serves the (sequence, head) pairs p = XCD + 8 m, i.e. only heads XCD % 4:
+    // the positional rows of a head stay in one L2 as before.  3-D launches (nqb_1d = 0) keep (query block, head, sequence).
+    int qb = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+    if (nqb_1d > 0) {
+        const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
+        qb = k % nqb_1d;
+        const int pr = xcd + 8 * (k / nqb_1d);
+        head = pr % heads_1d;
+        seq = pr / heads_1d;
+        if (seq >= nseq_1d) return;          // padding of the pair count to a multiple of 8 (whole workgroup)
+    }
+    const AttSeq sq = seqs[seq];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qg = wave & 3, kh = wave >> 2;
-    const int q0 = blockIdx.x * 128;
+    const int q0 = qb * 128;
     if (q0 >= sq.nq) return;                 // whole workgroup exits together
     const int qi = q0 + qg * 32 + (lane & 31);
     const int h = lane >> 5;
@@ -494,12 +509,16 @@ void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q
                            bias_v, chunk_size, pos_stride);
         return;
     }
-    if (g_fold)
-        hipLaunchKernelGGL(attention_kernel<1>, dim3((max_nq + 127) / 128, heads, nseq), dim3(512), 0, s, seqs, q_stride,
-                           kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride);
+    const int nqb = (max_nq + 127) / 128;
+    if (g_fold && ATT_XCD_MAP)
+        hipLaunchKernelGGL(attention_kernel<1>, dim3(8 * nqb * ((heads * nseq + 7) / 8)), dim3(512), 0, s, seqs, q_stride,
+                           kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride, nqb, heads, nseq);
+    else if (g_fold)
+        hipLaunchKernelGGL(attention_kernel<1>, dim3(nqb, heads, nseq), dim3(512), 0, s, seqs, q_stride,
+                           kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride, 0, heads, nseq);
     else
-        hipLaunchKernelGGL(attention_kernel<0>, dim3((max_nq + 127) / 128, heads, nseq), dim3(512), 0, s, seqs, q_stride,
-                           kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride);
+        hipLaunchKernelGGL(attention_kernel<0>, dim3(nqb, heads, nseq), dim3(512), 0, s, seqs, q_stride,
+                           kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride, 0, heads, nseq);
 }
 
 // Sequence descriptors for the full-context batch path: q/k/v interleaved in one [B*Tp, 768] buffer
