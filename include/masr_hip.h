@@ -263,6 +263,14 @@ int masr_stream_close(masr_engine* e, int32_t stream_id);
 int masr_stream_set_history(masr_engine* e, int32_t stream_id, int32_t required_cache_size);
 int masr_stream_offset(masr_engine* e, int32_t stream_id, int32_t* offset);
 int masr_stream_cache_len(masr_engine* e, int32_t stream_id, int32_t* cache_len);
+
+/* Host-side resampling of one utterance to the model's rate.  Replaces resampy.resample(samples, sr, target, filter) behind
+ * AudioSegment.resample (masr/data_utils/audio.py:306-317; resampy is third-party: its published band-limited sinc interpolation
+ * is restated, parity unpinned).  x [n_orig] float32 host, ratio = sr_new / sr_orig, win / dwin [nwin] the right wing of the
+ * windowed sinc (already scaled by ratio when ratio < 1) and its first differences, num_table samples per zero crossing,
+ * y [n_out] with n_out = (int)(n_orig * ratio).  No engine, no GPU: an input-format step in front of the hot path. */
+int masr_resample_f32(const float* x, int64_t n_orig, double ratio, const double* win, const double* dwin, int64_t nwin,
+                      int32_t num_table, float* y, int64_t n_out);
 int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, const float* feats_dev, int32_t Tc,
                       float* probs_dev, int32_t* argmax_dev, float* maxprob_dev, void* stream);
 /* Read back a stream's caches in the reference layout (for parity tests):

@@ -87,14 +87,13 @@ class AudioSegment(object):
         self._pcm16 = None
 
     def resample(self, target_sample_rate, filter='kaiser_best'):
-        """The reference uses resampy (absent here); polyphase resampling via scipy instead --
-        NOT bit-compatible with the reference for non-16 kHz input (documented divergence)."""
+        """audio.py:306-317: ``resampy.resample(samples, sample_rate, target, filter=filter)`` in place.  resampy is absent from
+        the image; its published band-limited sinc interpolation and filter parameters are restated in ``data_utils/resample.py``
+        (same output length ``int(n * target / rate)``, same tap order and accumulation; **parity unpinned** -- nothing to
+        compare with here)."""
         if target_sample_rate == self._sample_rate:
             return
-        from math import gcd
-        from scipy.signal import resample_poly
-        g = gcd(int(target_sample_rate), int(self._sample_rate))
-        self._samples = resample_poly(self._samples, int(target_sample_rate) // g,
-                                      int(self._sample_rate) // g).astype(np.float32)
+        from .resample import resample_native
+        self._samples = resample_native(self._samples, self._sample_rate, target_sample_rate, filter)
         self._pcm16 = None
         self._sample_rate = target_sample_rate
