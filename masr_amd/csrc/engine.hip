@@ -507,11 +507,29 @@ void masr_destroy(masr_engine* e) {
     delete e;
 }
 
+// The fragment-ordered weight copies (ffn_packed / ffn_dual_packed / x3_packed) are built on first use and keyed by the device
+// pointer of the weights they were packed from.  A reload (masr_load_tensor on a finalized engine, then masr_finalize) re-uploads
+// into the SAME device buffers when the sizes are unchanged, so the keys would still match while the copies hold the old
+// values: every reload drops them (after the device has drained: launches in flight may still read them).
+static void drop_packed_weights(masr_engine* e) {
+    if (e->ffn_packed.empty() && e->ffn_dual_packed.empty() && e->x3_packed.empty()) return;
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipDeviceSynchronize();
+    for (auto* m : {&e->ffn_packed, &e->ffn_dual_packed, &e->x3_packed}) {
+        for (auto& kv : *m) {
+            kv.second.first.release();
+            kv.second.second.release();
+        }
+        m->clear();
+    }
+}
+
 int masr_load_tensor(masr_engine* e, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
     if (!e || !name || !host) return fail("null argument");
     std::string n(name);
     if (n.rfind("encoder.", 0) != 0 && n.rfind("ctc.", 0) != 0 && n.rfind("decoder.ctc_lo.", 0) != 0 && n != "__pos_table__")
         return 0;
+    drop_packed_weights(e);
     HostTensor t;
     int64_t cnt = 1;
     for (int i = 0; i < ndim; ++i) {

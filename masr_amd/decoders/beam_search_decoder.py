@@ -41,6 +41,7 @@ class BeamSearchDecoder:
         self.blank_id = int(blank_id)
         self.use_gpu_search = True       # False: prefix search on host threads (masr_beam_search_batch)
         self._gstream = None             # device-resident streaming search (masr_gbeam_*), opened on first use
+        self._geng = None                # ... and the (per-device) auxiliary engine that owns it
         self._gout = None
         self.last_tokens = []            # token ids of the last decode_chunk result
         self._lib = _lib.lib()
@@ -80,7 +81,7 @@ class BeamSearchDecoder:
         one per concurrent ``predict_stream`` session (serving.StreamPool)"""
         other = object.__new__(BeamSearchDecoder)
         other.__dict__.update(self.__dict__)
-        other._gstream, other._gout, other.last_tokens = None, None, []
+        other._gstream, other._geng, other._gout, other.last_tokens = None, None, None, []
         h = C.c_void_p()
         if self._lib.masr_beam_create(self.beam_size, self.blank_id, C.byref(h)) != 0:
             raise _lib.MasrError('masr_beam_create failed')
@@ -91,8 +92,8 @@ class BeamSearchDecoder:
     def close(self):
         """release the streaming search state (host trie + device-resident beam)"""
         if getattr(self, '_gstream', None) is not None:
-            check(self._lib.masr_gbeam_close(runtime.aux_engine().h, self._gstream))
-            self._gstream = None
+            check(self._lib.masr_gbeam_close(self._geng.h, self._gstream))
+            self._gstream = self._geng = None
         if getattr(self, '_stream', None):
             self._lib.masr_beam_destroy(self._stream)
             self._stream = None
@@ -107,7 +108,8 @@ class BeamSearchDecoder:
     def _candidates(self, probs, to_host=True):
         """probs np/torch [M, V] -> idx [M,K] int32, logp [M,K] f32, count [M] int32, blank_lp [M] f32 or None, K (host arrays,
         or device tensors).  blank_lp = ln p(blank) per frame, produced when a scorer is bound (the pruning rule's input)."""
-        eng = runtime.aux_engine()
+        # device-resident probabilities are searched on the GPU they live on (one worker thread per GPU, server.WorkerRouter)
+        eng = runtime.aux_engine(probs.device if torch.is_tensor(probs) and probs.is_cuda else None)
         p = torch.as_tensor(np.asarray(probs) if not torch.is_tensor(probs) else probs, dtype=torch.float32)
         p = p.to(eng.device).contiguous()
         M, V = p.shape
@@ -168,7 +170,7 @@ class BeamSearchDecoder:
         """results of a ``_batch(..., defer=True)`` launch (synchronises with the stream it was launched on)"""
         _, toks, lens, scores, _keep, ev = pending
         ev.synchronize()
-        eng = runtime.aux_engine()
+        eng = runtime.aux_engine(toks.device)
         toks, lens, scores = eng.to_host(toks), eng.to_host(lens), eng.to_host(scores)
         if want_tokens:
             return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(len(lens))]
@@ -191,7 +193,7 @@ class BeamSearchDecoder:
         max_len = max(Ts, 1)
         if B and Ts and self.use_gpu_search and self.gpu_search_supported(Ts, V):
             # whole search on the device: candidates never leave HBM, one workgroup per utterance
-            eng = runtime.aux_engine()
+            eng = runtime.aux_engine(stacked.device if torch.is_tensor(stacked) else None)
             idx, logp, cnt, blp, K = self._candidates(stacked.reshape(B * Ts, V), to_host=False)
             fr = eng.to_device(frames)
             toks = torch.zeros(B, max_len, dtype=torch.int32, device=eng.device)
@@ -255,8 +257,9 @@ class BeamSearchDecoder:
 
     def _decode_chunk_gpu(self, p):
         """device-resident search state (masr_gbeam_*): only the best prefix travels back per chunk"""
-        eng = runtime.aux_engine()
+        eng = self._geng if self._gstream is not None else runtime.aux_engine()
         if self._gstream is None:
+            self._geng = eng             # the stream's state lives in THIS device's engine until close()
             h = C.c_int32()
             check(self._lib.masr_gbeam_open(eng.h, self.beam_size, self.blank_id, 5000, C.byref(h)))
             self._gstream = h.value
@@ -282,4 +285,4 @@ class BeamSearchDecoder:
         """beam_search_decoder.py:93-96."""
         self._lib.masr_beam_reset(self._stream)
         if self._gstream is not None:
-            check(self._lib.masr_gbeam_reset(runtime.aux_engine().h, self._gstream))
+            check(self._lib.masr_gbeam_reset(self._geng.h, self._gstream))

@@ -35,7 +35,7 @@ def find_model(path=None):
     for c in cands:
         if c and os.path.exists(c):
             return c
-    raise Exception('Silero VAD model not found: pass path=<silero_vad.onnx> (the file the reference ships in masr/infer_utils/), '
+    raise FileNotFoundError('Silero VAD model not found: pass path=<silero_vad.onnx> (the file the reference ships in masr/infer_utils/), '
                     'set MASR_SILERO_VAD, or copy it next to masr_amd/infer_utils/silero_vad.py')
 
 

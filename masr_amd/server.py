@@ -28,11 +28,14 @@ No static pages, templates or upload archive: the web UI is outside the hot path
 ``wsproto`` package to serve the websocket route; the in-process test client does not.
 """
 import asyncio
+import logging
 import threading
 import time
 from concurrent.futures import Future
 from email.parser import BytesParser
 from email.policy import HTTP
+
+logger = logging.getLogger(__name__)
 
 
 class EngineWorker(object):
@@ -327,7 +330,12 @@ def create_app(predictor=None, max_batch=32, max_wait_ms=10.0, max_frames_out=0,
         try:
             res = await asyncio.wrap_future(worker.recognize_long(await _upload(request)))
             return {'code': 0, 'msg': 'success', 'result': res['text'], 'score': res['score']}
-        except Exception:
+        except FileNotFoundError as exc:
+            # the Silero weights (silero_vad.onnx) are third-party and not shipped: say so instead of blaming the upload
+            logger.error(f'/recognition_long_audio: {exc}')
+            return {'error': 2, 'msg': f'VAD model not found: {exc}'}
+        except Exception as exc:                                        # noqa: BLE001  (same reply as the reference server)
+            logger.exception(f'/recognition_long_audio failed: {exc}')
             return {'error': 1, 'msg': 'audio read fail!'}
 
     @app.websocket('/')
