@@ -42,6 +42,30 @@ N_SAMPLES = 160000          # 10 s @ 16 kHz
 VOCAB = 4233
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 GFLOP_PER_STEP = 742.0        # 23.18 GFLOP per 10 s utterance x 32
+GFLOP_PER_UTT_EFFICIENT = 16.99   # Efficient-Conformer, 10 s utterance, V = 4233
+GFLOP_SQUEEZEFORMER_B64 = 1430.0  # configs[2]'s 64 utterances (727.6 audio-s), useful (unpadded) work
+
+
+def conformer_gflop(T, t2=None, vocab=VOCAB, d=256, dff=2048, layers=12, k=15, pos_per_utt=False):
+    """SURVEY 8(d)'s ALGORITHMIC FLOPs (2 * MAC, GEMM / conv terms only) of one Conformer pass over T feature frames; ``t2`` =
+    attention key length (None: full context T'; streaming chunk step: cache + 16, with the positional projection counted per
+    stream as the survey's 1.45 / 1.90 / 3.31 GFLOP figures do)"""
+    t1 = (T - 1) // 2
+    tp = (t1 - 1) // 2
+    t2 = tp if t2 is None else t2
+    front = 2 * 9 * d * t1 * 39 + 2 * 9 * d * d * tp * 19 + 2 * 19 * d * d * tp
+    layer = (8 * d * dff * tp + 8 * d * d * tp + (2 * d * d * t2 if pos_per_utt else 0) + 4 * d * tp * t2 + 2 * d * tp * t2 +
+             4 * d * d * tp + 2 * k * d * tp + 2 * d * d * tp)
+    return (front + layers * layer + 2 * d * vocab * tp) / 1e9
+
+
+def workload_roofline(gflop, ms, note):
+    """whole-workload roofline block of a secondary config: algorithmic GFLOP of one step / its wall time, against the fp32 MFMA
+    peak (the per-kernel evidence of these workloads is under profiles/r04_*_kernel_stats.txt)"""
+    ach = gflop / ms                                               # GFLOP / ms = TFLOP/s
+    return {'bound': 'mfma', 'scope': 'whole step (wall time, host framing included)', 'achieved': round(ach, 2),
+            'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            'algorithmic_gflop_per_step': round(gflop, 1), 'note': note}
 
 
 def flush_c_stdio():
@@ -156,7 +180,7 @@ def cpu_model():
 
 def cpu_baseline(budget_s=30.0):
     """MASR's own CPU predict path on this node's host cores, on a bounded sample of the contract workload.  Two legs
-    (SURVEY 8(d)): (i) the batched ``get_encoder_out`` path (trainer.py:632) on 4 x 10 s, (ii) the per-utterance
+    (SURVEY 8(d)): (i) the batched ``get_encoder_out`` path (trainer.py:632) on the config's own 32 x 10 s batch, (ii) the per-utterance
     ``MASRPredictor.predict`` loop (featurize + encoder + greedy, B = 1 calls, predict.py:167-192) -- ``value`` is leg (ii),
     the way MASR users run it.  kind = "reference" when /root/reference is importable (the unmodified reference modules via
     oracle/shims), else "port" (oracle/, pinned bit-identical to those modules).  >= 5 timed repetitions per leg, median."""
@@ -166,7 +190,7 @@ def cpu_baseline(budget_s=30.0):
     torch.set_num_threads(cores)
     sd = synthetic.conformer_state_dict(0, VOCAB)
     vocab = synthetic.synthetic_vocab(VOCAB)
-    pcm = synthetic.synthetic_pcm(4, N_SAMPLES, seed=1234)
+    pcm = synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234)       # configs[1]'s batch; leg (ii) takes its first 4 utterances
     kind = 'port'
     encode = lambda f, l: oc.get_encoder_out(sd, f, l)
     if shims.reference_available():
@@ -181,11 +205,11 @@ def cpu_baseline(budget_s=30.0):
     log(f'cpu_baseline: {kind}, {cores} threads, {cpu_model()}')
 
     def leg_batched():
-        feats = np.stack([ofb.featurize_pcm16(pcm[i])[0] for i in range(4)])
+        feats = np.stack([ofb.featurize_pcm16(pcm[i])[0] for i in range(BATCH)])
         with torch.no_grad():
-            probs = encode(torch.from_numpy(feats), torch.full((4,), feats.shape[1])).numpy()
+            probs = encode(torch.from_numpy(feats), torch.full((BATCH,), feats.shape[1])).numpy()
         od.greedy_decoder_batch(list(probs), vocab)
-        return 40.0
+        return BATCH * 10.0
 
     def leg_predict_loop():
         for i in range(4):
@@ -199,7 +223,8 @@ def cpu_baseline(budget_s=30.0):
     for name, leg in (('batched', leg_batched), ('predict_loop', leg_predict_loop)):
         leg()                                                           # warm-up
         times, t_leg = [], time.perf_counter()
-        while len(times) < 5 or (time.perf_counter() - t_leg < budget_s / 2 and len(times) < 9):
+        # (the batched leg is configs[1]'s whole padded batch, ~2.5 s per repetition: 5 repetitions; the B = 1 loop up to 9)
+        while len(times) < 5 or (name != 'batched' and time.perf_counter() - t_leg < budget_s / 2 and len(times) < 9):
             t0 = time.perf_counter()
             audio = leg()
             times.append(time.perf_counter() - t0)
@@ -213,7 +238,8 @@ def cpu_baseline(budget_s=30.0):
             'sample': f'leg (ii) per-utterance predict loop: 4 x 10 s utterances, B = 1 calls (featurize + get_encoder_out + '
                       f'greedy), median of {out["predict_loop"]["reps"]} reps, torch threads = {cores}',
             'batched': {'value': out['batched']['value'], 'reps': out['batched']['reps'],
-                        'sample': 'leg (i) batched get_encoder_out path (trainer.py:632): 4 x 10 s in one padded batch'}}
+                        'sample': f'leg (i) batched get_encoder_out path (trainer.py:632) on configs[1]\'s padded batch: {BATCH} x 10 s '
+                                  '(featurize each utterance, one encoder call, batch greedy decode)'}}
 
 
 # ---- the contract workload ----------------------------------------------------------------------------------------------
@@ -405,7 +431,10 @@ def run_contract(args, rank, world, local):
 
 
 # ---- secondary workloads (BASELINE configs[2,3,4]) ----------------------------------------------------------------------
-def facade(use_model, decoder, device, streaming=True, vocab=VOCAB, beam_conf=None):
+SHARP_HEAD_GAIN = 4.0
+
+
+def facade(use_model, decoder, device, streaming=True, vocab=VOCAB, beam_conf=None, head_gain=None):
     """a MASRPredictor on synthetic weights (the drop-in surface; StreamPool / predict_batch hang off it)"""
     from masr_amd.predict import MASRPredictor
     from masr_amd.utils import synthetic
@@ -416,6 +445,10 @@ def facade(use_model, decoder, device, streaming=True, vocab=VOCAB, beam_conf=No
             f.write(f'{t}\t1\n')
     sd = {'conformer': synthetic.conformer_state_dict, 'efficient_conformer': synthetic.efficient_conformer_state_dict,
           'squeezeformer': synthetic.squeezeformer_state_dict}[use_model](0, vocab)
+    if head_gain:                # a sharper CTC head: the logits of the random-init projection scaled up (weights AND bias)
+        sd = dict(sd)
+        for k in ('ctc.ctc_lo.weight', 'ctc.ctc_lo.bias'):
+            sd[k] = sd[k] * head_gain
     cfg = {'encoder_conf': {}, 'preprocess_conf': {'feature_method': 'fbank', 'n_mels': 80, 'n_mfcc': 40, 'sample_rate': 16000,
                                                    'use_dB_normalization': True, 'target_dB': -20},
            'dataset_conf': {'dataset_vocab': vpath}, 'use_model': use_model, 'streaming': streaming, 'decoder': decoder,
@@ -459,7 +492,9 @@ def extra_efficient_b256(args, rank, world, local):
     return {'workload': f'configs[3]: efficient_conformer.yml streaming fbank, 256 x 10 s utterances sharded over {world} GPU(s) '
                         f'({hi - lo} on rank 0, device passes of 32), ctc_greedy, all-gather of hypotheses, text on host',
             'value': round(total * 10.0 * steps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world, 'steps': steps,
-            'ms_per_step': round(dt * 1e3 / steps, 3), 'scaling': 'strong', 'transcripts': len(texts)}
+            'ms_per_step': round(dt * 1e3 / steps, 3), 'scaling': 'strong', 'transcripts': len(texts),
+            'roofline': workload_roofline(GFLOP_PER_UTT_EFFICIENT * (hi - lo), dt * 1e3 / steps,
+                                          'SURVEY 8(d): 16.99 GFLOP per 10 s utterance x the utterances of rank 0')}
 
 
 def extra_stream128(args, rank, world, local, n_streams=None, reps=None):
@@ -494,16 +529,23 @@ def extra_stream128(args, rank, world, local, n_streams=None, reps=None):
     dt = parallel.timed_region(lambda i: utterance(True), reps, 0)
     lat_all = parallel.gather_floats(lat)
     pred.predictor.engine.close()
+    # algorithmic work of one 10 s stream: its 67-frame windows (stride 64) against a cache that grows by 16 keys per window
+    n_win = ((1 + (chunk * n_chunks - 400) // 160) - 67) // 64 + 1
+    gflop_stream = sum(conformer_gflop(67, t2=16 * (w + 1), pos_per_utt=True) for w in range(n_win))
     return {'workload': f'configs[4]: conformer.yml streaming chunk = 0.5 s online, {n_streams} concurrent synthetic streams over {world} '
                         f'GPU(s) ({len(mine)} per GPU, sticky), real predict_stream framing, ctc_greedy partials every call',
             'value': round(n_streams * n_chunks * 0.5 * reps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world,
             'steps': reps * n_chunks,
             'call_latency_ms': {'p50': round(float(np.percentile(lat_all, 50)) * 1e3, 3),
                                 'p95': round(float(np.percentile(lat_all, 95)) * 1e3, 3), 'calls': len(lat_all),
-                                'note': 'one call = feed + step of all streams of a GPU for one 0.5 s chunk (python framing included)'}}
+                                'note': 'one call = feed + step of all streams of a GPU for one 0.5 s chunk (python framing included)'},
+            'roofline': workload_roofline(gflop_stream * len(mine), dt * 1e3 / reps,
+                                          f'one step = one 10 s utterance of every stream of rank 0 ({n_win} chunk steps of 16 '
+                                          f'encoder frames, {gflop_stream:.1f} GFLOP per stream by SURVEY 8(d)); the chunk step is '
+                                          'latency-, not MFMA-bound (DESIGN 9)')}
 
 
-def extra_squeezeformer_beam(args, rank, world, local, lm=True):
+def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False):
     """configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances of 2-20 s (seed 1234) padded per length bucket,
     ctc_beam_search (beam 300, cutoff_top_n 40, alpha 2.2 / beta 4.3 with a synthetic character n-gram LM when ``lm``)"""
     from masr_amd.utils import synthetic
@@ -519,7 +561,8 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True):
         conf['language_model_path'] = write_synthetic_arpa(os.path.join(d, 'lm.arpa'), synthetic.synthetic_vocab(VOCAB), seed=5)
     else:
         conf['language_model_path'] = None           # explicit scorer-free search (not a reference configuration)
-    pred = facade('squeezeformer', 'ctc_beam_search', local, streaming=False, beam_conf=conf)
+    pred = facade('squeezeformer', 'ctc_beam_search', local, streaming=False, beam_conf=conf,
+                  head_gain=SHARP_HEAD_GAIN if sharp else None)
     steps = 10
     pred.predict_batch(audio, batch_size=32)
     torch.cuda.synchronize()
@@ -529,12 +572,93 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     total = float(lens.sum()) / 16000.0
+    # how many candidates per frame the search really saw (vocabulary pruning at cutoff_prob / cutoff_top_n), on 4 utterances
+    eng = pred.predictor.engine
+    k = [0, 21, 42, 63]
+    nmax = int(max(lens[i] for i in k))
+    x = np.zeros((4, nmax), np.int16)
+    for j, i in enumerate(k):
+        x[j, :lens[i]] = audio[i]
+    feats, frames = eng.fbank_batch(torch.from_numpy(x).to(eng.device), torch.tensor([int(lens[i]) for i in k], dtype=torch.int32,
+                                                                                    device=eng.device))
+    probs = eng.ctc_probs(eng.encode_full(feats, frames, -1))
+    nenc = eng.enc_frames(frames).tolist()
+    cnt = torch.cat([pred.beam_search_decoder._candidates(probs[j, :nenc[j]], to_host=False)[2] for j in range(4)])
+    cand_mean = float(cnt.float().mean())
     pred.predictor.engine.close()
     return {'workload': f'configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s), two '
                         f'length buckets of 32, ctc_beam_search beam 300 / top-n 40, '
                         + ('alpha 2.2 beta 4.3 with a synthetic 3-gram character LM scored on the GPU' if lm else 'LM-free'),
+            'posteriors': ('SHARPENED CTC head (random-init logits x %g: 1-3 candidates survive cutoff_prob 0.99 per frame, what a '
+                           'trained model gives the search)' % SHARP_HEAD_GAIN) if sharp else
+                          'FLAT random-init posteriors: cutoff_top_n = 40 candidates survive in EVERY frame -- the search\'s worst case, '
+                          'which no trained model produces',
+            'candidates_per_frame_mean': round(cand_mean, 2),
             'value': round(total * steps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps,
-            'ms_per_step': round(dt * 1e3 / steps, 3), 'transcripts': len(res)}
+            'ms_per_step': round(dt * 1e3 / steps, 3), 'transcripts': len(res),
+            'roofline': workload_roofline(GFLOP_SQUEEZEFORMER_B64, dt * 1e3 / steps,
+                                          'SURVEY 8(d): 1.43 TFLOP of useful encoder work in the 64 utterances; the call is bound by '
+                                          'the prefix search of its longest utterance, not by the encoder (DESIGN 9)')}
+
+
+def extra_facade(args, rank, world, local):
+    """The drop-in surface itself (the headline is measured one layer below it, on ``masr_transcribe_batch``):
+    ``facade_b32``  MASRPredictor.predict_batch on configs[1]'s batch handed over as 32 host int16 ndarrays -> 32 transcripts
+                    (staging, upload, the bit-exact normalisation route with its mean-square read-back, one device pass, text);
+    ``predict_b1``  MASRPredictor.predict on one test.wav-sized utterance (134 240 samples; masr/predict.py:167-192, the call
+                    docs/infer.md times at 101 ms): p50 / p95 of the call and the GPU time of its device pass."""
+    from masr_amd.utils import synthetic
+    pred = facade('conformer', 'ctc_greedy', local)
+    eng = pred.predictor.engine
+    audio = list(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234 + rank))
+    steps = max(10, args.steps)
+    for _ in range(3):
+        res = pred.predict_batch(audio)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = pred.predict_batch(audio)
+    dt = (time.perf_counter() - t0) / steps
+    out = {'facade_b32': {
+        'workload': 'configs[1] through the facade: MASRPredictor.predict_batch(32 host int16 ndarrays of 10 s) -> 32 transcripts, '
+                    'one call after the other (nothing overlaps between calls); use_dB_normalization on, gains by the bit-exact '
+                    'route (device mean square -> host numpy -> device)',
+        'value': round(BATCH * 10.0 / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps,
+        'ms_per_step': round(dt * 1e3, 3), 'transcripts': len(res),
+        'roofline': workload_roofline(GFLOP_PER_STEP, dt * 1e3, 'SURVEY 8(d): 742 GFLOP per 32 x 10 s')}}
+    golden = os.path.join(ROOT, 'tests', 'golden', 'testwav.npz')
+    wav = np.load(golden)['pcm'] if os.path.exists(golden) else synthetic.synthetic_pcm(1, 134240, seed=7)[0]
+    for _ in range(5):
+        one = pred.predict(wav)
+    lat = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        one = pred.predict(wav)
+        lat.append(time.perf_counter() - t0)
+    # GPU time of the same device pass: the call's kernels enqueued back to back, nothing synchronised in between
+    xs = torch.from_numpy(np.ascontiguousarray(wav[None])).to(eng.device)
+    ns = torch.tensor([len(wav)], dtype=torch.int32, device=eng.device)
+    gain = eng.host_gains(xs, ns, -20.0)
+    for _ in range(3):
+        eng.transcribe_rows(xs, ns, True, -20.0, gain_in=gain)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        eng.transcribe_rows(xs, ns, True, -20.0, gain_in=gain)
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) / 50 * 1e3
+    p50 = float(np.percentile(lat, 50)) * 1e3
+    secs = len(wav) / 16000.0
+    out['predict_b1'] = {
+        'workload': f'MASRPredictor.predict(one {secs:.2f} s utterance as a host int16 ndarray: dataset/test.wav) -> text, 200 calls',
+        'latency_ms': {'p50': round(p50, 3), 'p95': round(float(np.percentile(lat, 95)) * 1e3, 3), 'calls': len(lat)},
+        'gpu_ms_of_the_pass': round(gpu_ms, 3), 'gpu_share_of_p50': round(gpu_ms / p50, 3),
+        'value': round(secs / (p50 * 1e-3), 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'text_chars': len(one['text']),
+        'reference_doc_figure': 'docs/infer.md:93: 101 ms for this file (the reference on its own GPU, not comparable hardware)',
+        'roofline': workload_roofline(conformer_gflop(1 + (len(wav) - 400) // 160), p50,
+                                      'B = 1: 7 row blocks of 32 on 256 CUs -- latency-bound, listed for completeness')}
+    eng.close()
+    return out
 
 
 def extra_bf16x3(args, rank, world, local):
@@ -610,11 +734,17 @@ def run_extras(args, rank, world, local, out=None):
         # the per-GPU share of configs[4] on an 8-GPU node (128 streams / 8), measured on this one GPU
         jobs.append(('stream16', lambda a, r, w, l: extra_stream128(a, r, w, l, n_streams=16)))
         jobs.append(('squeezeformer_b64_beam', extra_squeezeformer_beam))
+        jobs.append(('squeezeformer_b64_beam_sharp', lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True)))
+        jobs.append(('facade', extra_facade))
         jobs.append(('conformer_b32_bf16x3_exploratory', extra_bf16x3))
     for name, fn in jobs:
         try:
             t0 = time.perf_counter()
-            out[name] = fn(args, rank, world, local)
+            res = fn(args, rank, world, local)
+            if name == 'facade':                 # two lines of the drop-in surface from one predictor
+                out.update(res)
+            else:
+                out[name] = res
             log(f'rank {rank}: extra {name} done in {time.perf_counter() - t0:.1f} s')
         except Exception as exc:                                        # noqa: BLE001  (the contract line must still print)
             # the ranks run the same code on the same shapes, so a failure here is a failure on every rank at the same point
@@ -653,7 +783,9 @@ def main():
     if args.workload != 'conformer_b32':
         fn = {'efficient_b256': extra_efficient_b256, 'stream128': extra_stream128, 'bf16x3': extra_bf16x3,
               'squeezeformer_b64_beam': extra_squeezeformer_beam,
-              'squeezeformer_b64_beam_nolm': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, lm=False)}[args.workload]
+              'squeezeformer_b64_beam_nolm': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, lm=False),
+              'squeezeformer_b64_beam_sharp': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True),
+              'facade': extra_facade}[args.workload]
         res = fn(args, rank, world, local)
         if rank == 0:
             line = json.dumps(dict({'dtype': 'f32'}, **res, data=data_tag()), ensure_ascii=False)

@@ -245,6 +245,14 @@ int masr_vad_forward(masr_vad* v, int32_t sample_rate, const float* audio_dev, i
 int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t* n_samples_dev, int32_t B,
                           int32_t n_max, int32_t use_db_normalization, float target_db, int32_t decode_all_frames,
                           int32_t* tokens_dev, int32_t* n_tokens_dev, float* score_dev, void* stream);
+/* The same pass as the facade drives it (MASRPredictor.predict / predict_batch, masr/predict.py:167-192): samples in either
+ * format of masr_fbank_batch, use_db_normalization 0 / 1 / 2 with its meaning there (2: gains SUPPLIED in gain_dev [B], read
+ * only -- the bit-exact int16 route of AudioSegment.normalize, audio.py:287-304), and the hypotheses as ONE packed int32 row per
+ * utterance, rows_dev [B, T' + 2] = token ids (-1 padded) | token count | score bits (f32), so that a caller needs ONE copy
+ * back per pass (T' = encoder frames of n_max samples, halved once more for the Efficient Conformer). */
+int masr_transcribe_rows(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev, int32_t B,
+                         int32_t n_max, int32_t use_db_normalization, float target_db, const float* gain_dev,
+                         int32_t decode_all_frames, int32_t* rows_dev, void* stream);
 
 /* Streaming.  Replaces InferencePredictor.predict_chunk_conformer / reset_stream
  * (inference_predictor.py:80-102) -> ConformerEncoder.forward_chunk (encoder.py:348-420) with

@@ -77,6 +77,7 @@ SIGNATURES = {
     'masr_mfcc_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     'masr_linear_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     'masr_transcribe_batch': [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
+    'masr_transcribe_rows': [_P, _P, _I, _P, _I, _I, _I, _F, _P, _I, _P, _P],
     'masr_stream_open': [_P, _I, C.POINTER(_I)],
     'masr_stream_reset': [_P, _I],
     'masr_stream_close': [_P, _I],

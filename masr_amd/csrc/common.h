@@ -122,6 +122,8 @@ void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs
 // CTC collapse per utterance
 void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank,
                          int* tokens, int* ntok, float* score, hipStream_t s);
+void launch_ctc_collapse_rows(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank, int* rows,
+                              hipStream_t s);
 void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff_prob, int* out_idx, float* out_logp,
                        int* out_cnt, int blank, float* out_blank_lp, hipStream_t s);
 void launch_argmax_rows(const float* probs, int M, int V, int* idx, float* maxp, hipStream_t s);

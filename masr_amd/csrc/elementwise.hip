@@ -427,13 +427,13 @@ void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs
 // fp32 accumulation (lane 0 walks the non-blank max-probs staged in LDS, in frame order).
 __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* __restrict__ idx, const float* __restrict__ maxp,
                                                           const int* __restrict__ nframes, int Tp, int blank,
-                                                          int* tokens, int* ntok, float* score) {
+                                                          int* tokens, int* ntok, float* score, int ldt) {
     extern __shared__ float nbp[];          // [Tp] max-probs of the non-blank frames, compacted in frame order
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = nframes ? min(nframes[b], Tp) : Tp;
     const int* ib = idx + (size_t)b * Tp;
     const float* pb = maxp + (size_t)b * Tp;
-    int* tb = tokens + (size_t)b * Tp;
+    int* tb = tokens + (size_t)b * ldt;     // ldt = Tp, or Tp + 2 for packed rows [tokens | count | score bits] (ntok == nullptr)
     int cnt = 0, nb = 0, carry = -1;
     for (int t0 = 0; t0 < n; t0 += 64) {
         const int t = t0 + lane;
@@ -456,8 +456,14 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* __restrict_
     if (lane == 0) {
         float acc = 0.f;
         for (int i = 0; i < nb; ++i) acc = acc + nbp[i];
-        ntok[b] = cnt;
-        score[b] = nb > 0 ? acc / (float)nb : 0.f;
+        const float sc = nb > 0 ? acc / (float)nb : 0.f;
+        if (ntok) {
+            ntok[b] = cnt;
+            score[b] = sc;
+        } else {
+            tb[Tp] = cnt;
+            tb[Tp + 1] = __float_as_int(sc);
+        }
     }
 }
 
@@ -465,7 +471,15 @@ void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, 
                          int* ntok, float* score, hipStream_t s) {
     if (B <= 0) return;
     hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(64), (size_t)Tp * sizeof(float), s, idx, maxp, nframes, Tp,
-                       blank, tokens, ntok, score);
+                       blank, tokens, ntok, score, Tp);
+}
+
+// the same with ONE packed int32 row per utterance: rows [B, Tp + 2] = tokens (-1 padded) | token count | score bits
+void launch_ctc_collapse_rows(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank, int* rows,
+                              hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(64), (size_t)Tp * sizeof(float), s, idx, maxp, nframes, Tp,
+                       blank, rows, (int*)nullptr, (float*)nullptr, Tp + 2);
 }
 
 // argmax / max over rows of an existing probability matrix (np.argmax semantics: first maximum)

@@ -1905,9 +1905,12 @@ int masr_linear_batch(masr_engine* e, const void* samples_dev, int32_t sample_fo
     return 0;
 }
 
-int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t* n_samples_dev, int32_t B,
-                          int32_t n_max, int32_t use_db_normalization, float target_db, int32_t decode_all_frames,
-                          int32_t* tokens_dev, int32_t* n_tokens_dev, float* score_dev, void* stream) {
+// the offline hot path of one padded batch: samples -> features -> encoder -> CTC greedy -> collapse, either into three
+// arrays (masr_transcribe_batch) or into packed rows (masr_transcribe_rows)
+static int transcribe_impl(masr_engine* e, const void* samples_dev, int32_t fmt, const int32_t* n_samples_dev, int32_t B,
+                           int32_t n_max, int32_t use_db_normalization, float target_db, const float* gain_dev,
+                           int32_t decode_all_frames, int32_t* tokens_dev, int32_t* n_tokens_dev, float* score_dev,
+                           int32_t* rows_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
     ENTER(e);
     if (n_max < 400) return fail("n_max < 400 samples: no frame");
@@ -1924,14 +1927,39 @@ int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t*
     CHK(e->maxp.ensure(sizeof(float) * B * Tq));
     int* nfr = e->nframes.as<int>();
     int* nenc = nfr + B;
-    CHK(masr_fbank_batch(e, pcm_dev, 0, n_samples_dev, B, n_max, use_db_normalization, target_db,
-                         e->feats.as<float>(), nullptr, nullptr, nullptr, stream));
+    // (mode 2 reads the caller's gains: masr_fbank_batch copies them into its own scratch, the caller's array is not written)
+    CHK(masr_fbank_batch(e, samples_dev, fmt, n_samples_dev, B, n_max, use_db_normalization, target_db,
+                         e->feats.as<float>(), nullptr, nullptr, use_db_normalization == 2 ? const_cast<float*>(gain_dev) : nullptr,
+                         stream));
     launch_frame_counts(n_samples_dev, B, nfr, nenc, halved ? 1 : 0, s);
     CHK(masr_encode_full(e, e->feats.as<float>(), nfr, B, T, -1, e->enc.as<float>(), stream));
     CHK(masr_ctc_greedy_frames(e, e->enc.as<float>(), B * Tq, e->idx.as<int>(), e->maxp.as<float>(), stream));
+    if (rows_dev) {
+        launch_ctc_collapse_rows(e->idx.as<int>(), e->maxp.as<float>(), decode_all_frames ? nullptr : nenc, B, Tq, 0, rows_dev, s);
+        LAUNCHCHK();
+        return 0;
+    }
     CHK(masr_ctc_collapse(e, e->idx.as<int>(), e->maxp.as<float>(), decode_all_frames ? nullptr : nenc, B, Tq, 0,
                           tokens_dev, n_tokens_dev, score_dev, stream));
     return 0;
+}
+
+int masr_transcribe_batch(masr_engine* e, const int16_t* pcm_dev, const int32_t* n_samples_dev, int32_t B,
+                          int32_t n_max, int32_t use_db_normalization, float target_db, int32_t decode_all_frames,
+                          int32_t* tokens_dev, int32_t* n_tokens_dev, float* score_dev, void* stream) {
+    if (use_db_normalization == 2) return fail("masr_transcribe_batch: supplied gains go through masr_transcribe_rows");
+    return transcribe_impl(e, pcm_dev, 0, n_samples_dev, B, n_max, use_db_normalization, target_db, nullptr, decode_all_frames,
+                           tokens_dev, n_tokens_dev, score_dev, nullptr, stream);
+}
+
+int masr_transcribe_rows(masr_engine* e, const void* samples_dev, int32_t sample_format, const int32_t* n_samples_dev, int32_t B,
+                         int32_t n_max, int32_t use_db_normalization, float target_db, const float* gain_dev,
+                         int32_t decode_all_frames, int32_t* rows_dev, void* stream) {
+    if (!rows_dev) return fail("null argument");
+    if (sample_format != 0 && sample_format != 1) return fail("sample_format: 0 = int16 PCM, 1 = float32");
+    if (use_db_normalization == 2 && !gain_dev) return fail("use_db_normalization = 2 needs the gains in gain_dev");
+    return transcribe_impl(e, samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, target_db, gain_dev,
+                           decode_all_frames, nullptr, nullptr, nullptr, rows_dev, stream);
 }
 
 // ---- streaming -----------------------------------------------------------------------------------------

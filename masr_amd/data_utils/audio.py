@@ -16,18 +16,33 @@ class AudioSegment(object):
         """Samples are converted to float32, ints scaled to [-1, 1]; multi-channel -> mean
         (audio.py:24-32,532-546)."""
         samples = np.asarray(samples)
+        self._sample_rate = sample_rate
+        # mono int16 input: the batched device front-end takes the PCM as it is (x / 2^15 happens in the kernel, the same
+        # float32 value) -- half the bytes over PCIe -- and the float32 copy is made only when somebody asks for it
+        # (``_samples``).  Dropped as soon as the float samples are modified.
+        self._pcm16 = samples if samples.dtype == np.int16 and samples.ndim == 1 else None
+        self._float = None if self._pcm16 is not None else self._to_float(samples)
+
+    @staticmethod
+    def _to_float(samples):
         f = samples.astype('float32')
         if samples.dtype in (np.int8, np.int16, np.int32, np.int64):
             f *= (1. / 2 ** (np.iinfo(samples.dtype).bits - 1))
         elif samples.dtype not in (np.float16, np.float32, np.float64):
             raise TypeError("Unsupported sample type: %s." % samples.dtype)
-        self._samples = f
-        self._sample_rate = sample_rate
-        if self._samples.ndim >= 2:
-            self._samples = np.mean(self._samples, 1)
-        # mono int16 input: the batched device front-end takes the PCM as it is (x / 2^15 happens in the kernel, the same
-        # float32 value) -- half the bytes over PCIe.  Dropped as soon as the float samples are modified.
-        self._pcm16 = samples if samples.dtype == np.int16 and samples.ndim == 1 else None
+        if f.ndim >= 2:
+            f = np.mean(f, 1)
+        return f
+
+    @property
+    def _samples(self):
+        if self._float is None:
+            self._float = self._to_float(self._pcm16)
+        return self._float
+
+    @_samples.setter
+    def _samples(self, value):
+        self._float = value
 
     # ---- constructors (audio.py:56-152) ---------------------------------------------------------
     @classmethod
@@ -75,15 +90,16 @@ class AudioSegment(object):
 
     @property
     def num_samples(self):
-        return self._samples.shape[0]
+        return (self._pcm16 if self._float is None else self._float).shape[0]
 
     @property
     def duration(self):
-        return self._samples.shape[0] / float(self._sample_rate)
+        return self.num_samples / float(self._sample_rate)
 
     def gain_linear(self, factor):
         """In-place ``samples *= factor`` in float32 (what gain_db does with 10**(gain/20))."""
-        self._samples *= np.float32(factor)
+        x = self._samples
+        x *= np.float32(factor)
         self._pcm16 = None
 
     def resample(self, target_sample_rate, filter='kaiser_best'):

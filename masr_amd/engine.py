@@ -360,6 +360,19 @@ class HipEngine:
                                              _stream()))
         return tokens, ntok, score
 
+    def transcribe_rows(self, samples, n_samples, use_db_normalization=True, target_db=-20.0, gain_in=None,
+                        decode_all_frames=False, out=None):
+        """The same pass with the facade's inputs (int16 PCM or float32 samples, optionally the caller's gains: the bit-exact
+        route of ``host_gains``) and ONE packed int32 row per utterance out: rows [B, T' + 2] = tokens | count | score bits."""
+        B, n_max = samples.shape
+        fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
+        Tp = self.out_frames(1 + (n_max - 400) // 160)
+        rows = out if out is not None else torch.empty(B, Tp + 2, dtype=torch.int32, device=self.device)
+        mode = 0 if not use_db_normalization else (2 if gain_in is not None else 1)
+        check(self.lib.masr_transcribe_rows(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max, mode, float(target_db),
+                                            _ptr(gain_in), 1 if decode_all_frames else 0, _ptr(rows), _stream()))
+        return rows
+
     # ---- streaming ----------------------------------------------------------------------------------
     def stream_open(self, max_frames_out=0):
         sid = C.c_int32()

@@ -148,40 +148,81 @@ class MASRPredictor:
             texts = texts[1:]
         return {'text': texts, 'score': round(sum(scores) / len(scores), 2) if scores else 0}
 
+    def _prep_stream(self):
+        """side stream of the per-pass preparation (upload, mean squares and their read-back, gains): the host waits for THIS
+        stream only, so preparing pass k + 1 never waits for the encoder of pass k on the main stream"""
+        if getattr(self, '_prep', None) is None:
+            self._prep = torch.cuda.Stream(device=self.predictor.engine.device)
+        return self._prep
+
     def _stage_batch(self, segs, n):
         """padded batch through a pinned staging buffer -> device (int16 when every utterance still is the PCM it was
-        loaded from: half the bytes over PCIe, x / 2^15 happens in the kernel).  Two staging buffers per sample type take
+        loaded from: half the bytes over PCIe, x / 2^15 happens in the kernel), on the CURRENT stream.  Staging buffers take
         turns; each carries the event of its last upload, so filling one never waits for the device unless that very
-        buffer's previous copy (two passes ago) is still in flight."""
+        buffer's previous copy (three passes ago) is still in flight."""
         eng = self.predictor.engine
         as_pcm = all(s._pcm16 is not None for s in segs)
         dt = torch.int16 if as_pcm else torch.float32
-        need = len(segs) * int(n.max())
-        ring = self._stage.setdefault(dt, {'bufs': [None, None], 'events': [None, None], 'turn': 0})
+        n_max = int(n.max())
+        need = len(segs) * n_max
+        ring = self._stage.setdefault(dt, {'bufs': [None] * 3, 'events': [None] * 3, 'turn': 0, 'lens': [None] * 3})
         k = ring['turn']
-        ring['turn'] = k ^ 1
+        ring['turn'] = (k + 1) % 3
         if ring['events'][k] is not None:
             ring['events'][k].synchronize()
         if ring['bufs'][k] is None or ring['bufs'][k].numel() < need:
             ring['bufs'][k] = torch.zeros(need + need // 4, dtype=dt, pin_memory=True)
-        stage = ring['bufs'][k][:need].view(len(segs), int(n.max()))
+        if ring['lens'][k] is None or ring['lens'][k].numel() < len(segs):
+            ring['lens'][k] = torch.zeros(max(len(segs), 64), dtype=torch.int32, pin_memory=True)
+        stage = ring['bufs'][k][:need].view(len(segs), n_max)
         buf = stage.numpy()
-        buf[:] = 0
         for i, s in enumerate(segs):
-            buf[i, :n[i]] = s._pcm16 if as_pcm else s._samples
+            m = int(n[i])
+            buf[i, :m] = s._pcm16 if as_pcm else s._samples
+            buf[i, m:] = 0
+        lens = ring['lens'][k][:len(segs)]
+        lens.numpy()[:] = n
         xs = stage.to(eng.device, non_blocking=True)
-        ns = eng.to_device(n)
+        ns = lens.to(eng.device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         ring['events'][k] = ev
         return xs, ns
 
+    def _prepare(self, live, n, use_db, target_db):
+        """upload + (bit-exact normalisation route) the reference's gains: the mean squares come back from the device, the
+        scalar float32 expressions of audio.py:287-304,519-529 run in this host's numpy, the gains go up again -- all on the
+        preparation stream; the main stream then waits for that stream's event, the host for nothing else."""
+        eng = self.predictor.engine
+        main = torch.cuda.current_stream(eng.device)
+        prep = self._prep_stream()
+        with torch.cuda.stream(prep):
+            xs, ns = self._stage_batch(live, n)
+            gain = eng.host_gains(xs, ns, target_db) if use_db else None          # (waits for the preparation stream only)
+            done = torch.cuda.Event()
+            done.record()
+        main.wait_event(done)
+        for t in (xs, ns, gain):
+            if t is not None:
+                t.record_stream(main)
+        return xs, ns, gain
+
+    def _rows_slot(self, B, width):
+        """pinned host buffer for the packed result rows of one pass (a ring of 4: at most two passes are in flight)"""
+        ring = self.__dict__.setdefault('_rows_ring', {'bufs': [None] * 4, 'turn': 0})
+        k = ring['turn']
+        ring['turn'] = (k + 1) % 4
+        if ring['bufs'][k] is None or ring['bufs'][k].numel() < B * width:
+            ring['bufs'][k] = torch.empty(max(B * width, 1 << 14), dtype=torch.int32, pin_memory=True)
+        return ring['bufs'][k][:B * width].view(B, width)
+
     def _predict_local(self, segs, decode_all_frames=False, as_tokens=False, defer=False):
         """AudioSegments -> [{'text','score'}] on THIS rank's engine.  Utterances too short for one feature frame decode to
         the empty transcript (the reference's encoder cannot take them either); a digitally silent utterance (mean square 0) is
-        normalised with gain = target_dB like the reference (audio.py:519-529), only a gain above max_gain_db raises (:300-303).  ``defer=True`` (beam search on the GPU): the prefix search is launched
-        on a side stream and a zero-argument function that returns the results is handed back -- the caller runs the next
-        device pass (features + encoder on the main stream) underneath it."""
+        normalised with gain = target_dB like the reference (audio.py:519-529), only a gain above max_gain_db raises (:300-303).
+        ``defer=True``: nothing is waited for -- a zero-argument function that returns the results is handed back, so the caller
+        prepares and launches the next device pass underneath this one (greedy: the packed hypothesis rows come back in one
+        copy behind an event; beam search on the GPU: the prefix search runs on a side stream)."""
         eng = self.predictor.engine
         pc = self.configs.preprocess_conf
         rate = int(pc.get('sample_rate', 16000))
@@ -193,23 +234,43 @@ class MASRPredictor:
         out = [None] * len(segs)
         # 7 feature frames is the least Conv2dSubsampling4 accepts (subsampling.py:65-112)
         ok = [i for i, s in enumerate(segs) if s.num_samples >= min_samples + 6 * 160]
-        for i in range(len(segs)):
-            if i not in ok:
+        if len(ok) != len(segs):
+            for i in set(range(len(segs))) - set(ok):
                 out[i] = ([], 0) if as_tokens else {'text': '', 'score': 0}
         if not ok:
             return (lambda: out) if defer else out
         live = [segs[i] for i in ok]
         n = np.array([s.num_samples for s in live], np.int32)
-        xs, ns = self._stage_batch(live, n)
-        gain = eng.host_gains(xs, ns, pc.target_dB) if pc.use_dB_normalization else None
+        xs, ns, gain = self._prepare(live, n, pc.use_dB_normalization, pc.target_dB)
+        greedy = self.configs.decoder != 'ctc_beam_search'
+        if greedy and method == 'fbank':
+            # the whole pass is ONE C-ABI call and ONE copy back: rows [B, T' + 2] = tokens | count | score bits
+            rows = eng.transcribe_rows(xs, ns, pc.use_dB_normalization, pc.target_dB, gain_in=gain,
+                                       decode_all_frames=decode_all_frames)
+            host = self._rows_slot(*rows.shape)
+            host.copy_(rows, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+
+            def fetch():
+                ev.synchronize()
+                r = host.numpy()
+                tp = r.shape[1] - 2
+                ntok, score = r[:, tp], r[:, tp + 1].copy().view(np.float32)
+                for j, i in enumerate(ok):
+                    sc = float(score[j]) * 100.0 if ntok[j] > 0 or score[j] > 0 else 0
+                    ids = r[j, :ntok[j]]
+                    out[i] = (ids.tolist(), sc) if as_tokens else {'text': self._text(ids), 'score': sc}
+                return out
+            return fetch if defer else fetch()
         feats, frames = eng.features_batch(method, xs, ns, pc.use_dB_normalization, pc.target_dB, n_mfcc=pc.get('n_mfcc', 40),
                                            gain_in=gain)
         enc = eng.encode_full(feats, frames, -1)
         nenc = None if decode_all_frames else eng.enc_frames(frames).to(torch.int32)
-        if self.configs.decoder == 'ctc_beam_search':
+        if not greedy:
             # probabilities stay on the GPU: vocabulary pruning, prefix search and LM scoring run there
             probs = eng.ctc_probs(enc)
-            n_host = [probs.shape[1]] * len(live) if nenc is None else eng.to_host(nenc).tolist()
+            n_host = [probs.shape[1]] * len(live) if nenc is None else eng.enc_frames((n.astype(np.int64) - min_samples) // 160 + 1).tolist()
             seqs = [probs[i, :n_host[i]] for i in range(len(live))]
             dec = self.beam_search_decoder
 
