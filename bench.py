@@ -467,8 +467,13 @@ def extra_efficient_b256(args, rank, world, local):
     from masr_amd.utils import synthetic
     total = 256
     lo, hi = parallel.shard_range(total, rank, world)
-    passes = [(torch.from_numpy(synthetic.synthetic_pcm(min(BATCH, hi - b0), N_SAMPLES, seed=77 + b0)).to(eng.device),
-               torch.full((min(BATCH, hi - b0),), N_SAMPLES, dtype=torch.int32, device=eng.device)) for b0 in range(lo, hi, BATCH)]
+    # device passes of 64 utterances where the rank's share allows it: behind the stride layer this encoder runs at HALF the frame
+    # rate, and 32 x 10 s are then only 124 row blocks of 32 for 256 CUs; 64 x 10 s fill the chip there (248 row blocks) and are
+    # two full rounds in the full-rate layers (MASR_BENCH_EFFICIENT_PASS overrides; at 8 GPUs the share itself is 32)
+    per_pass = int(os.environ.get('MASR_BENCH_EFFICIENT_PASS', '64'))
+    passes = [(torch.from_numpy(synthetic.synthetic_pcm(min(per_pass, hi - b0), N_SAMPLES, seed=77 + b0)).to(eng.device),
+               torch.full((min(per_pass, hi - b0),), N_SAMPLES, dtype=torch.int32, device=eng.device))
+              for b0 in range(lo, hi, per_pass)]
     per = -(-total // world)
     Tp = eng.out_frames(1 + (N_SAMPLES - 400) // 160)
     tok = torch.full((per, Tp), -1, dtype=torch.int32, device=eng.device)
@@ -490,7 +495,7 @@ def extra_efficient_b256(args, rank, world, local):
     dt = parallel.timed_region(step, steps, 1)
     eng.close()
     return {'workload': f'configs[3]: efficient_conformer.yml streaming fbank, 256 x 10 s utterances sharded over {world} GPU(s) '
-                        f'({hi - lo} on rank 0, device passes of 32), ctc_greedy, all-gather of hypotheses, text on host',
+                        f'({hi - lo} on rank 0, device passes of {min(per_pass, hi - lo)}), ctc_greedy, all-gather of hypotheses, text on host',
             'value': round(total * 10.0 * steps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world, 'steps': steps,
             'ms_per_step': round(dt * 1e3 / steps, 3), 'scaling': 'strong', 'transcripts': len(texts),
             'roofline': workload_roofline(GFLOP_PER_UTT_EFFICIENT * (hi - lo), dt * 1e3 / steps,

@@ -686,9 +686,191 @@ __global__ __launch_bounds__(64 * NW) void attention_grouped_kernel(const AttSeq
     }
 }
 
+// Round 4: the same attention with the positional keys FOLDED into the keys while a tile is staged, like attention_kernel<FOLD = 1>
+// ((q+u).k + (q+v).p = q.(k+p) + (u.k + v.p): ONE 192-wide contraction per key tile instead of two; the per-key constant is
+// reduced over the 16 lanes that stage a key row), and 96 queries x 2 = 6 waves per workgroup, so that a (sequence, head) of a 10 s
+// utterance (83 grouped positions) is ONE workgroup with waves on all four SIMDs.  The two waves of a query group both compute the
+// score tile and its online softmax (96 MFMAs, duplicated) and each accumulates HALF of the 192 output dims (48 MFMAs): 144
+// MFMAs per wave and key tile, no merge at the end, and 96 + 48 instead of 96 + 96 persistent registers -- the even / odd key
+// split of attention_kernel needs q and all of O in both waves, which at d_k' = 192 does not fit the 256 registers of a
+// two-waves-per-SIMD kernel (measured: 46 spilled).  The two-wave kernel above ran 288 MFMAs per wave and key tile on two SIMDs
+// of a CU: 58 us per launch at 32 x 10 s for a third of attention_kernel's work (26 us); masr_debug_set key 26 = 0 keeps it for A/B.
+template <int DKG>
+__global__ __launch_bounds__(384) void attention_grouped_fold_kernel(const AttSeq* __restrict__ seqs, int row_stride,
+                                                                     const float* __restrict__ ptab, int t_true,
+                                                                     const float* __restrict__ bias_u,
+                                                                     const float* __restrict__ bias_v, float scale,
+                                                                     int chunk_size, int group) {
+    constexpr int LD = DKG + 4;
+    constexpr int NG = DKG / 8;       // 8-wide k groups of the contraction
+    constexpr int NT = DKG / 64;      // 32-row output tiles of O^T per wave (half of the DKG / 32)
+    constexpr int SEG = DKG / 16;     // floats of a key row staged by one of its 16 threads (12)
+    static_assert(SEG % 4 == 0 && DKG % 64 == 0, "a staging thread moves whole float4s; the output dims split in two halves");
+    extern __shared__ __align__(16) float smf[];
+    float* Ks = smf;                  // [2 tiles][32][LD]  k + p
+    float* Vs = Ks + 2 * 32 * LD;     // [2 tiles][32][LD]
+    float* Cs = Vs + 2 * 32 * LD;     // [2 tiles][32]      u.k + v.p
+    const AttSeq sq = seqs[blockIdx.z];
+    const int head = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave % 3, oh = wave / 3;      // query group, output half
+    const int q0 = blockIdx.x * 96;
+    if (q0 >= sq.nq) return;                 // whole workgroup exits together
+    const int qi = q0 + qg * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const bool q_ok = qi < sq.nq;
+
+    f32x4 qf[NG];
+    {
+        const float* qrow = sq.q + (size_t)(q_ok ? qi : sq.nq - 1) * row_stride + head * DKG;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qrow + 8 * g + 4 * h);
+    }
+    f32x16 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    int jlim = sq.klen;
+    if (chunk_size > 0) {
+        const int qa = (q_ok ? qi : sq.nq - 1) * group;
+        jlim = min(jlim, ((qa / chunk_size + 1) * chunk_size + group - 1) / group);
+    }
+    const int ntile = (sq.nk + 31) / 32;
+    const int npair = (ntile + 1) / 2;
+    // staging: 16 threads per key row, SEG floats each; 24 rows per pass, three passes cover the 64 rows of a tile pair
+    const int srow = tid >> 4, sseg = (tid & 15) * SEG;
+    const float* ub = bias_u + head * DKG + sseg;
+    const float* vbias = bias_v + head * DKG + sseg;
+    const int t_keys = sq.pad_ > 0 ? sq.pad_ : t_true;      // true key count in frames (per sequence for lock-step streams)
+    for (int kp = 0; kp < npair; ++kp) {
+        __syncthreads();   // previous pair fully consumed
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const int r64 = pass * 24 + srow;          // row of the tile pair
+            if (r64 < 64) {
+                const int j = kp * 64 + r64;
+                f32x4 kk[SEG / 4], pp[SEG / 4], vv[SEG / 4];
+#pragma unroll
+                for (int c = 0; c < SEG / 4; ++c) {
+                    kk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    pp[c] = kk[c];
+                    vv[c] = kk[c];
+                }
+                if (j < sq.nk) {
+                    const size_t e = (size_t)j * row_stride + head * DKG + sseg;      // flat element index in the [T, 256] matrices
+#pragma unroll
+                    for (int c = 0; c < SEG / 4; ++c) {
+                        kk[c] = *reinterpret_cast<const f32x4*>(sq.k + e + 4 * c);
+                        vv[c] = *reinterpret_cast<const f32x4*>(sq.v + e + 4 * c);
+                        // the reference pads P with zeros (not with PE) beyond the true length: frame (e + 4c) / 256
+                        if ((int)((e + 4 * c) / 256) < t_keys) pp[c] = *reinterpret_cast<const f32x4*>(ptab + (size_t)sq.pos0 * 256 + e + 4 * c);
+                    }
+                }
+                float cst = 0.f;
+                float* kd = &Ks[(r64 >> 5) * 32 * LD + (r64 & 31) * LD + sseg];
+                float* vd = &Vs[(r64 >> 5) * 32 * LD + (r64 & 31) * LD + sseg];
+#pragma unroll
+                for (int c = 0; c < SEG / 4; ++c) {
+                    f32x4 kp4;
+                    const f32x4 su = *reinterpret_cast<const f32x4*>(ub + 4 * c), sv = *reinterpret_cast<const f32x4*>(vbias + 4 * c);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        cst = fmaf(su[x], kk[c][x], cst);
+                        cst = fmaf(sv[x], pp[c][x], cst);
+                        kp4[x] = kk[c][x] + pp[c][x];
+                    }
+                    *reinterpret_cast<f32x4*>(kd + 4 * c) = kp4;
+                    *reinterpret_cast<f32x4*>(vd + 4 * c) = vv[c];
+                }
+                cst = att_sum16(cst);
+                if ((tid & 15) == 0) Cs[r64] = cst;
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kt = 0; kt < 2; ++kt) {
+            const int j0 = (2 * kp + kt) * 32;     // first key of this tile
+            if (j0 >= sq.nk) break;                // (uniform) odd tile past the end
+            f32x16 st;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(&Cs[kt * 32 + 8 * rr + 4 * h]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st[4 * rr + q] = c4[q];
+            }
+            const float* kb = &Ks[kt * 32 * LD + (lane & 31) * LD + 4 * h];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kb + 8 * g);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[x], qf[g][x], st, 0, 0, 0);
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                st[r] = j < jlim ? st[r] * scale : -INFINITY;
+                tmax = fmaxf(tmax, st[r]);
+            }
+            tmax = fmaxf(tmax, att_xor32(tmax, h));
+            const float m_new = fmaxf(m_run, tmax);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float corr = __expf(m_run - m_safe);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __expf(st[r] - m_safe);
+                psum += st[r];
+            }
+            psum += att_xor32(psum, h);
+            l_run = l_run * corr + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= corr;
+            const float* vb = &Vs[kt * 32 * LD + (4 * h) * LD + (lane & 31) + oh * 32 * NT];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[krow * LD + 32 * t], st[r], o[t], 0, 0, 0);
+            }
+        }
+    }
+    if (q_ok) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        float* orow = sq.out + (size_t)qi * row_stride + head * DKG + oh * 32 * NT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                f32x4 a;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) a[x] = o[t][rr * 4 + x] * inv;
+                *reinterpret_cast<f32x4*>(orow + 32 * t + 8 * rr + 4 * h) = a;
+            }
+    }
+}
+
+static int g_att_grouped_fold = 1;      // masr_debug_set key 26: 0 = the two-wave, two-term grouped kernel (A/B)
+void set_attention_grouped_fold(int on) { g_att_grouped_fold = on; }
+
 void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int heads, int group, const float* ptab,
                               int t_true, const float* bias_u, const float* bias_v, hipStream_t s, int chunk_size) {
     if (nseq <= 0 || max_nq <= 0 || group != 3) return;
+    if (g_att_grouped_fold) {
+        constexpr int DKG = 192;
+        const size_t lds = (size_t)(2 * 2 * 32 * (DKG + 4) + 64) * sizeof(float);
+        static LdsAttr attr;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(attention_grouped_fold_kernel<DKG>), lds, attr);
+        hipLaunchKernelGGL((attention_grouped_fold_kernel<DKG>), dim3((max_nq + 95) / 96, heads, nseq), dim3(384), lds, s, seqs,
+                           heads * DKG, ptab, t_true, bias_u, bias_v, 1.0f / sqrtf((float)DKG), chunk_size, group);
+        return;
+    }
     constexpr int DKG = 192, NW = 2;
     const size_t lds = (size_t)(3 * 32 * (DKG + 4) + 2 * DKG) * sizeof(float);
     static LdsAttr attr;

@@ -292,6 +292,7 @@ struct AttSeq {            // one per sequence, device memory
 void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q_stride, int kv_stride,
                       const float* ptab /*[max_pos,256]*/, const float* bias_u, const float* bias_v,
                       int chunk_size, int pos_stride, hipStream_t s);
+void set_attention_grouped_fold(int on);   // key 26: 0 = the two-wave two-term grouped attention kernel (A/B)
 void set_attention_fold(int on);     // diagnostics (masr_debug_set key 14): 0 = two-term score contraction in attention_kernel
 void set_attention_fewq(int on);     // diagnostics (masr_debug_set key 7): 0 = always the query-tiled kernel
 void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int heads, int group, const float* ptab,

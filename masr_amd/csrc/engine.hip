@@ -2535,6 +2535,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 23) g_ffn_packed = value;
     else if (key == 24) g_ffn_dual = value;
     else if (key == 25) g_rowgemm_packed = value;
+    else if (key == 26) set_attention_grouped_fold(value);
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

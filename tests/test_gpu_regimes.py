@@ -101,6 +101,33 @@ def test_batch32_10s_against_oracle(family):
     assert agree.all()
 
 
+def test_efficient_conformer_pass_of_64_equals_its_two_halves():
+    """BASELINE configs[3] at N <= 4: device passes of 64 x 10 s (behind the stride layer 64 utterances are the 248 row blocks
+    that fill the chip; 32 are 124).  Size-independent property: an utterance's encoder output does not depend on its batch
+    mates -- the pass of 64 equals the two passes of 32 (which test_batch32_10s_against_oracle holds against the oracle); the
+    half-rate layers of the two run on different kernels (full row-block launches vs the d_ff-split ones), so the bar is the
+    path's 1e-3, measured ~1e-5."""
+    make, _ = _families()['efficient_conformer']
+    eng, sd = make()
+    try:
+        feats, lens = _inputs(64, 998, seed=64, ragged=True)
+        # equal padded length per half (the pad mask keeps one key past an utterance's frames: only the SAME padded length
+        # gives the same function), so the halves see the same [*, 998, 80] inputs
+        enc64 = eng.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
+        enc32 = torch.cat([eng.encode_full(dev(feats[h:h + 32]), dev(lens[h:h + 32], torch.int32), -1).cpu() for h in (0, 32)])
+        n = eng.enc_frames(lens)
+        keep = (torch.arange(enc64.shape[1])[None, :] < n[:, None])[:, :, None]
+        err = ((enc64 - enc32).abs() * keep).max().item()
+        print(f'efficient_conformer 64 x <= 10 s vs 2 x 32: max diff {err:.3e}')
+        assert err < 1e-3
+        tok64 = eng.ctc_greedy_frames(dev(enc64))[0].cpu()
+        tok32 = eng.ctc_greedy_frames(dev(enc32))[0].cpu()
+        same = ((tok64 == tok32) | ~keep[:, :, 0]).float().mean().item()
+        assert same > 0.999, same
+    finally:
+        eng.close()
+
+
 def test_deepspeech2_sizes_against_oracle():
     """bi-directional DeepSpeech2: one 20 s utterance (498 LSTM steps on the per-unit kernel) and 32 ragged utterances of up
     to 3 s (the MFMA recurrence for 5..32 sequences)"""
