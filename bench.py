@@ -517,6 +517,8 @@ def extra_stream128(args, rank, world, local, n_streams=None, reps=None):
     gids = [pool.open() for _ in range(n_streams)]
     mine = pool.local_ids()
     pcm = synthetic.synthetic_pcm(len(mine), chunk * n_chunks, seed=4321 + rank)
+    # the wire format: every 0.5 s chunk of every stream as the bytes object a websocket hands over (sliced before the clock starts)
+    wire = [[pcm[j, c * chunk:(c + 1) * chunk].tobytes() for j in range(len(mine))] for c in range(n_chunks)]
     lat = []
 
     def utterance(record):
@@ -525,7 +527,7 @@ def extra_stream128(args, rank, world, local, n_streams=None, reps=None):
         for c in range(n_chunks):
             t0 = time.perf_counter()
             for j, g in enumerate(mine):
-                pool.feed(g, pcm[j, c * chunk:(c + 1) * chunk].tobytes(), is_end=(c == n_chunks - 1))
+                pool.feed(g, wire[c][j], is_end=(c == n_chunks - 1))
             pool.step()
             if record:
                 lat.append(time.perf_counter() - t0)

@@ -254,6 +254,45 @@ int masr_transcribe_rows(masr_engine* e, const void* samples_dev, int32_t sample
                          int32_t n_max, int32_t use_db_normalization, float target_db, const float* gain_dev,
                          int32_t decode_all_frames, int32_t* rows_dev, void* stream);
 
+/* Serving pool: any number of concurrent predict_stream sessions on one engine, ONE call per step.  Replaces, per session, the
+ * stream framing of MASRPredictor.predict_stream (masr/predict.py:237-343: carried-over samples re-normalised on every call,
+ * :274-281; feature frames cached until a 67-frame decoding window is full, :283-306; 3 overlap frames kept, :329; the greedy
+ * decoder's history, decoders/ctc_greedy_decoder.py:52-89) and, across sessions, the one-predictor-per-websocket loop of
+ * infer_server.py:103-156 -- all sessions fed since the last step share one upload, one feature launch, lock-step chunk steps
+ * (masr_encode_chunk), one collapse launch and one copy back.  Greedy decoding; a handle is the engine's stream id.
+ *   masr_pool_create: feature_method 0 fbank / 1 mfcc (n_mfcc) / 2 linear (audio_featurizer.py:51-69), use_db_normalization and
+ *                     target_db of preprocess_conf, max_frames_out as in masr_stream_open
+ *   masr_pool_step:   the feeds since the last step, in order: feed_handle[k], feed_samples[k] (host memory: int16 PCM, format 0,
+ *                     scaled by 1 / 2^15 like buf_to_float, data_utils/utils.py:382-411; or float32, format 1), feed_n[k] samples,
+ *                     feed_is_end[k] (a session's flags are OR-ed).  gain_fn: evaluator of AudioSegment.normalize's scalar
+ *                     expressions (audio.py:287-304,519-529) on the mean squares the device returns -- the python facade passes
+ *                     its numpy evaluation, which is what makes the normalised samples bit-identical to the reference's on the
+ *                     same host; NULL = libm (log10f / powf).  Returns non-zero to abort the step (gain beyond max_gain_db).
+ *                     Out: the sessions of the step in first-fed order (handles_out[i], state_out[i] = 1 when the session
+ *                     advanced by at least one window, else 0 = the reference returns None), and for the advanced ones, in that
+ *                     order, packed rows [row_width] = token ids (-1 padded) | count | score bits, in pinned host memory
+ *                     (rows_host) and in HBM (rows_dev: what a multi-GPU front-end all-gathers); all out pointers stay valid
+ *                     until the next step of this pool. */
+typedef struct masr_pool masr_pool;
+typedef int (*masr_gain_fn)(const float* mean_square, int32_t n, float target_db, float* gain_out, void* user);
+int masr_pool_create(masr_engine* e, int32_t feature_method, int32_t n_mfcc, int32_t use_db_normalization, float target_db,
+                     int32_t max_frames_out, masr_pool** out);
+void masr_pool_destroy(masr_pool* p);
+int masr_pool_open(masr_pool* p, int32_t* handle);
+int masr_pool_close(masr_pool* p, int32_t handle);
+int masr_pool_reset(masr_pool* p, int32_t handle);      /* MASRPredictor.reset_stream, predict.py:346-353 */
+int masr_pool_step(masr_pool* p, int32_t n_feeds, const int32_t* feed_handle, const void* const* feed_samples,
+                   const int64_t* feed_n, const int32_t* feed_format, const int32_t* feed_is_end, masr_gain_fn gain_fn,
+                   void* gain_user, int32_t* n_sessions, const int32_t** handles_out, const int32_t** state_out,
+                   const int32_t** rows_host, int32_t* row_width, int32_t** rows_dev, void* stream);
+/* diagnostics: host time of masr_pool_step per phase, accumulated over `steps` calls (ms): assemble the samples | upload + mean
+ * squares + wait | gains | features + frame bookkeeping | windows (lock-step chunk steps enqueued) | collapse + copy back + wait */
+int masr_pool_profile(masr_pool* p, double* phase_ms, int64_t* steps, int32_t reset);
+/* encoder frames that T feature frames give (Conv2dSubsampling4, subsampling.py:65-112; halved once more behind the Efficient
+ * Conformer's stride layer) and the engine's geometry -- what a host needs to size the buffers above */
+int masr_encoder_frames(masr_engine* e, int32_t feature_frames, int32_t* encoder_frames);
+int masr_engine_info(masr_engine* e, int32_t* device_id, int32_t* n_mels, int32_t* vocab_size);
+
 /* Streaming.  Replaces InferencePredictor.predict_chunk_conformer / reset_stream
  * (inference_predictor.py:80-102) -> ConformerEncoder.forward_chunk (encoder.py:348-420) with
  * required_cache_size < 0 (keep all history, predict.py:312-313).  Stream state (attention KV

@@ -78,6 +78,16 @@ SIGNATURES = {
     'masr_linear_batch': [_P, _P, _I, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     'masr_transcribe_batch': [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     'masr_transcribe_rows': [_P, _P, _I, _P, _I, _I, _I, _F, _P, _I, _P, _P],
+    'masr_pool_create': [_P, _I, _I, _I, _F, _I, C.POINTER(_P)],
+    'masr_pool_destroy': [_P],
+    'masr_pool_open': [_P, C.POINTER(_I)],
+    'masr_pool_close': [_P, _I],
+    'masr_pool_reset': [_P, _I],
+    'masr_pool_step': [_P, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_I), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                       C.POINTER(_I), C.POINTER(_P), _P],
+    'masr_pool_profile': [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I],
+    'masr_encoder_frames': [_P, _I, C.POINTER(_I)],
+    'masr_engine_info': [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
     'masr_stream_open': [_P, _I, C.POINTER(_I)],
     'masr_stream_reset': [_P, _I],
     'masr_stream_close': [_P, _I],
@@ -94,7 +104,11 @@ SIGNATURES = {
     'masr_profile_read': [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _I],
 }
 _RESTYPE = {'masr_last_error': C.c_char_p, 'masr_destroy': None, 'masr_beam_destroy': None, 'masr_lm_destroy': None,
-            'masr_lm_last_error': C.c_char_p, 'masr_vad_last_error': C.c_char_p, 'masr_vad_destroy': None}
+            'masr_lm_last_error': C.c_char_p, 'masr_vad_last_error': C.c_char_p, 'masr_vad_destroy': None, 'masr_pool_destroy': None}
+
+
+# int gain_fn(const float* mean_square, int32 n, float target_db, float* gain_out, void* user)
+GAIN_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_float), C.c_int32, C.c_float, C.POINTER(C.c_float), C.c_void_p)
 
 
 def lib():

@@ -344,7 +344,9 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
     const int head = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qi = lane & 31, h = lane >> 5;
+    // blockIdx.z = query group of 32 (chunk steps: one; short offline utterances: T' / 32, see launch_attention)
+    if ((int)blockIdx.z * 32 >= sq.nq) return;            // whole workgroup
+    const int qi = (int)blockIdx.z * 32 + (lane & 31), h = lane >> 5;
     const bool q_ok = qi < sq.nq;
     const int qrow_i = q_ok ? qi : sq.nq - 1;
     const int q_abs = sq.q_abs0 + qrow_i;
@@ -497,6 +499,8 @@ __global__ __launch_bounds__(512) void attention_fewq_kernel(const AttSeq* __res
 }
 
 static int g_fewq = 1, g_fold = 1;
+static int g_fewq_wgs = 48;       // masr_debug_set key 28: offline launches with fewer attention_kernel workgroups than this take the key-split kernel
+void set_attention_fewq_wgs(int n) { g_fewq_wgs = n; }
 void set_attention_fewq(int on) { g_fewq = on; }
 void set_attention_fold(int on) { g_fold = on; }
 
@@ -504,12 +508,15 @@ void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q
                       const float* ptab, const float* bias_u, const float* bias_v, int chunk_size, int pos_stride,
                       hipStream_t s) {
     if (nseq <= 0 || max_nq <= 0) return;
-    if (max_nq <= 32 && g_fewq) {
-        hipLaunchKernelGGL(attention_fewq_kernel, dim3(heads, nseq), dim3(512), 0, s, seqs, q_stride, kv_stride, ptab, bias_u,
-                           bias_v, chunk_size, pos_stride);
+    const int nqb = (max_nq + 127) / 128;
+    // the key-split kernel (eight waves share 32 queries and split the key tiles) also takes short offline batches, one
+    // workgroup per (head, sequence, 32 queries): attention_kernel would give such a batch nqb * heads * nseq workgroups that each
+    // walk ALL key tiles in pairs (one 8.4 s utterance: 8 workgroups, 22 us; here 28 workgroups of one tile per wave)
+    if (g_fewq && (max_nq <= 32 || nqb * heads * nseq < g_fewq_wgs)) {
+        hipLaunchKernelGGL(attention_fewq_kernel, dim3(heads, nseq, (max_nq + 31) / 32), dim3(512), 0, s, seqs, q_stride, kv_stride,
+                           ptab, bias_u, bias_v, chunk_size, pos_stride);
         return;
     }
-    const int nqb = (max_nq + 127) / 128;
     if (g_fold && ATT_XCD_MAP)
         hipLaunchKernelGGL(attention_kernel<1>, dim3(8 * nqb * ((heads * nseq + 7) / 8)), dim3(512), 0, s, seqs, q_stride,
                            kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride, nqb, heads, nseq);

@@ -122,6 +122,14 @@ void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs
 // CTC collapse per utterance
 void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank,
                          int* tokens, int* ntok, float* score, hipStream_t s);
+struct PoolSeg {            // masr_pool_step: one contiguous run of rows to copy (rows of `width` floats)
+    long src, dst;
+    int n, pad_;
+};
+void launch_ctc_collapse_hist(const int* idx, const float* maxp, const int* nframes, const int* in_rows, int ld_in, int B, int Tp,
+                              int blank, int* rows, hipStream_t s);
+void launch_copy_segments(const float* src, float* dst, const float* src2, float* dst2, const PoolSeg* seg, int nseg,
+                          int max_rows, int width, hipStream_t s);
 void launch_ctc_collapse_rows(const int* idx, const float* maxp, const int* nframes, int B, int Tp, int blank, int* rows,
                               hipStream_t s);
 void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff_prob, int* out_idx, float* out_logp,
@@ -172,6 +180,8 @@ struct RowGemmArgs {
     int hist_affine;             //           1: new rows = lnw * x + lnb (Squeezeformer, convolution.py:109-110) instead of LayerNorm
     const float* dw_w;           // PRO_DWCONV: depthwise weights [pad + 1][256] and bias [256]; A = GLU rows in the padded layout
     const float* dw_b;           //             [n][pad + seq_t][256], lnw / lnb = the conv module's LayerNorm, M = n * seq_t
+    const float* gconst;         //             offline causal conv: the pad history rows of every sequence are not materialised -- they
+                                 //             all hold this constant row glu(bias) [256] (nullptr: read them like any other row)
     const AttSeq* kv_seqs;       // EPI_STORE, small-M kernel: columns >= 256 (k | v of the fused QKV projection) of row (b, t) =
     int kv_tq;                   //   divmod(row, kv_tq) go to stream b's key/value cache instead of C (replaces launch_kv_append)
 };
@@ -293,6 +303,8 @@ void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q
                       const float* ptab /*[max_pos,256]*/, const float* bias_u, const float* bias_v,
                       int chunk_size, int pos_stride, hipStream_t s);
 void set_attention_grouped_fold(int on);   // key 26: 0 = the two-wave two-term grouped attention kernel (A/B)
+int rowgemm_small_blocks();                // row blocks below which the K-split projection kernel takes a launch
+void set_attention_fewq_wgs(int n);        // key 28
 void set_attention_fold(int on);     // diagnostics (masr_debug_set key 14): 0 = two-term score contraction in attention_kernel
 void set_attention_fewq(int on);     // diagnostics (masr_debug_set key 7): 0 = always the query-tiled kernel
 void launch_attention_grouped(const AttSeq* seqs, int nseq, int max_nq, int heads, int group, const float* ptab,

@@ -1,5 +1,7 @@
 // HBM-bound kernels of the Conformer path: LayerNorm, CMVN+conv1, depthwise-conv+LN+SiLU,
 // CTC softmax/argmax and CTC collapse.  All are written for wave64 and 16-byte coalesced access.
+#include <algorithm>
+
 #include "common.h"
 
 namespace masr {
@@ -427,12 +429,15 @@ void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs
 // fp32 accumulation (lane 0 walks the non-blank max-probs staged in LDS, in frame order).
 __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* __restrict__ idx, const float* __restrict__ maxp,
                                                           const int* __restrict__ nframes, int Tp, int blank,
-                                                          int* tokens, int* ntok, float* score, int ldt) {
+                                                          int* tokens, int* ntok, float* score, int ldt, int ld_in,
+                                                          const int* __restrict__ in_rows) {
     extern __shared__ float nbp[];          // [Tp] max-probs of the non-blank frames, compacted in frame order
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = nframes ? min(nframes[b], Tp) : Tp;
-    const int* ib = idx + (size_t)b * Tp;
-    const float* pb = maxp + (size_t)b * Tp;
+    // in_rows (serving pool): utterance b reads row in_rows[b] of history matrices whose rows are ld_in frames apart
+    const size_t src = (size_t)(in_rows ? in_rows[b] : b) * ld_in;
+    const int* ib = idx + src;
+    const float* pb = maxp + src;
     int* tb = tokens + (size_t)b * ldt;     // ldt = Tp, or Tp + 2 for packed rows [tokens | count | score bits] (ntok == nullptr)
     int cnt = 0, nb = 0, carry = -1;
     for (int t0 = 0; t0 < n; t0 += 64) {
@@ -471,7 +476,7 @@ void launch_ctc_collapse(const int* idx, const float* maxp, const int* nframes, 
                          int* ntok, float* score, hipStream_t s) {
     if (B <= 0) return;
     hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(64), (size_t)Tp * sizeof(float), s, idx, maxp, nframes, Tp,
-                       blank, tokens, ntok, score, Tp);
+                       blank, tokens, ntok, score, Tp, Tp, (const int*)nullptr);
 }
 
 // the same with ONE packed int32 row per utterance: rows [B, Tp + 2] = tokens (-1 padded) | token count | score bits
@@ -479,7 +484,39 @@ void launch_ctc_collapse_rows(const int* idx, const float* maxp, const int* nfra
                               hipStream_t s) {
     if (B <= 0) return;
     hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(64), (size_t)Tp * sizeof(float), s, idx, maxp, nframes, Tp,
-                       blank, rows, (int*)nullptr, (float*)nullptr, Tp + 2);
+                       blank, rows, (int*)nullptr, (float*)nullptr, Tp + 2, Tp, (const int*)nullptr);
+}
+
+// ... and with the (argmax, max prob) frames read from rows in_rows[b] of history matrices [*, ld_in] (masr_pool_step): Tp = the
+// longest history of the call, rows [B, Tp + 2]
+void launch_ctc_collapse_hist(const int* idx, const float* maxp, const int* nframes, const int* in_rows, int ld_in, int B, int Tp,
+                              int blank, int* rows, hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(64), (size_t)Tp * sizeof(float), s, idx, maxp, nframes, Tp,
+                       blank, rows, (int*)nullptr, (float*)nullptr, Tp + 2, ld_in, in_rows);
+}
+
+// Segment copies of the serving pool (masr_pool_step): segment g moves seg[g].n rows of `width` floats from src row seg[g].src to
+// dst row seg[g].dst (feature frames into / out of the sessions' rows of the frame pool; width 1: (argmax, max prob) frames into the
+// histories, both arrays in one launch)
+__global__ __launch_bounds__(256) void copy_segments_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            const float* __restrict__ src2, float* __restrict__ dst2,
+                                                            const PoolSeg* __restrict__ seg, int width) {
+    const PoolSeg g = seg[blockIdx.x];
+    const long total = (long)g.n * width;
+    const float* a = src + (size_t)g.src * width;
+    float* b = dst + (size_t)g.dst * width;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        b[i] = a[i];
+        if (src2) dst2[(size_t)g.dst * width + i] = src2[(size_t)g.src * width + i];
+    }
+}
+void launch_copy_segments(const float* src, float* dst, const float* src2, float* dst2, const PoolSeg* seg, int nseg,
+                          int max_rows, int width, hipStream_t s) {
+    if (nseg <= 0 || max_rows <= 0) return;
+    const long total = (long)max_rows * width;
+    const int gy = (int)std::min<long>(64, (total + 255) / 256);
+    hipLaunchKernelGGL(copy_segments_kernel, dim3(nseg, gy), dim3(256), 0, s, src, dst, src2, dst2, seg, width);
 }
 
 // argmax / max over rows of an existing probability matrix (np.argmax semantics: first maximum)

@@ -24,6 +24,9 @@ static int fail(const std::string& m) {
     g_err = m;
     return 1;
 }
+namespace masr {
+int engine_fail(const std::string& m) { return fail(m); }      // pool.hip reports through the same masr_last_error()
+}
 #define HIPCHK(expr)                                                                                    \
     do {                                                                                                \
         hipError_t _e = (expr);                                                                         \
@@ -76,6 +79,7 @@ static int g_no_ffn_tail = 0;     // masr_debug_set key 8: 1 = the QKV projectio
 // (128 streams: chunk call 5.34 -> 3.16 ms, 256 streams 6.52 -> 4.99 ms; tools/chunk_step_ab.py)
 static int g_ffn_split_blocks = 192;
 static int g_no_ffn_head = 0;     // masr_debug_set key 9: 1 = depthwise conv and pointwise_conv2 as their own launches before the second FFN (A/B)
+static int g_few_rows_path = 1;   // masr_debug_set key 29: 0 = offline Conformer layers of few row blocks keep the row-block chain kernel (A/B)
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
 namespace {
@@ -952,8 +956,19 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
                 M, 2 * d, nullptr, 0, 1.f, c.lens, 0, c.Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, c.Tq,
                 e->cfg.causal ? pad : pad / 2, pad);
     }
+    const float* gconst = (hist || !e->cfg.causal) ? nullptr : w.gconst;
+    {
+        // few row blocks: depthwise conv + LayerNorm + SiLU as the prologue of the K-split pointwise_conv2 launch (the chunk
+        // steps' kernel; the unmaterialised history rows of the offline causal build are substituted there too)
+        RowGemmArgs a{};
+        a.A = e->glu.as<float>(); a.lda = d; a.lnw = w.cln_w; a.lnb = w.cln_b; a.dw_w = w.dw_w; a.dw_b = w.dw_b; a.gconst = gconst;
+        a.W = w.pw2_w; a.bias = w.pw2_b; a.C = x; a.ldc = d; a.R = x; a.ldr = d; a.M = M; a.N = d; a.alpha = 1.f; a.eps = 1e-5f;
+        a.mstride = mstride; a.seq_t = c.Tq; a.pad = pad; a.lens = c.lens; a.mask_tp = c.lens ? c.Tq : 0;
+        ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)d * d);
+        if (g_few_rows_path && launch_rowgemm(a, RG_PRO_DWCONV, RG_EPI_RESID, s)) return 0;
+    }
     launch_dwconv_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), c.nseq, c.Tq, K,
-                          1e-5f, s, (hist || !e->cfg.causal) ? nullptr : w.gconst);
+                          1e-5f, s, gconst);
     rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x, d,
             1.f, c.lens, c.lens ? c.Tq : 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
     return 0;
@@ -1515,6 +1530,7 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
     if (!e->cfg.causal)     // symmetric conv: the (K-1)/2 pad rows on both sides of every sequence stay zero for all layers
         HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + pad) * d * sizeof(float), s));
     const LayerW* prev = nullptr;                 // layer whose norm_final is still pending (it rides on the next FFN launch)
+    const bool few_rows = g_few_rows_path && (M + 31) / 32 < std::min(rowgemm_small_blocks(), g_ffn_split_blocks);
     for (const LayerW& w : e->layers) {
         // first macaron FFN with the attention block's LayerNorm + fused QKV projection as its tail stage (full kernel only)
         const FfnTail tail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, 3 * d,
@@ -1528,7 +1544,16 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
             launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v,
                              (decoding_chunk_size > 0 && e->cfg.causal) ? decoding_chunk_size : 0, 1, s);   // use_dynamic_chunk only in the streaming build
         }
-        if (g_no_chain) {
+        if (few_rows) {
+            // few row blocks (one utterance, a handful of short ones): latency-cut kernels of the chunk steps -- the row-block
+            // chain kernel would put [out-proj -> LN -> pw1] of a row block on ONE workgroup (28.6 us at 7 row blocks against
+            // 7.4 + 7.7 us for the two K-split launches whose columns spread over the chip); norm_final rides on the split
+            // FFN's reduction
+            mhsa_out(e, s, w, M);
+            CHK(conv_module(e, s, w, ctx, false));
+            CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x));
+            continue;                              // (prev stays null: nothing deferred)
+        } else if (g_no_chain) {
             mhsa_out(e, s, w, M);
             CHK(conv_module(e, s, w, ctx, false));
             CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
@@ -1543,12 +1568,13 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
         }
         prev = &w;                                 // norm_final deferred to the next layer's first FFN launch
     }
-    launch_layernorm(x, prev->ln_fin_w, prev->ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
+    if (prev) launch_layernorm(x, prev->ln_fin_w, prev->ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
     launch_layernorm(x, e->after_w, e->after_b, enc_out_dev, M, 1e-5f, 0, 0, nullptr, s);
     LAUNCHCHK();
     return 0;
 }
 
+static int g_ctc_fused_blocks = 160;     // masr_debug_set key 27: row blocks from which the fused CTC head (rowgemm EPI_CTC) runs
 static int ctc_head(masr_engine* e, const float* enc_dev, int M, float* probs_dev, int write_probs, int32_t* argmax_dev,
                     float* maxprob_dev, hipStream_t s) {
     const int d = enc_dim(e), V = e->cfg.vocab_size;
@@ -1578,6 +1604,10 @@ int masr_ctc_greedy_frames(masr_engine* e, const float* enc_dev, int32_t M, int3
     ENTER(e);
     if (e->cfg.model_kind == 3)      // K = 1024 / 2048 rows: generic GEMM + softmax statistics (logits stay in a workspace)
         return ctc_head(e, enc_dev, M, nullptr, 0, argmax_dev, maxprob_dev, (hipStream_t)stream);
+    // few row blocks (one utterance: 7; the Efficient Conformer's half-rate output at 32 x 10 s: 124): the fused head gives a
+    // workgroup 32 rows x the WHOLE vocabulary (165 us whether 7 or 248 row blocks run); below g_ctc_fused_blocks the logits go
+    // through the tiled GEMM (vocabulary spread over the CUs) into a workspace and the softmax statistics are a second launch
+    if ((M + 31) / 32 < g_ctc_fused_blocks) return ctc_head(e, enc_dev, M, nullptr, 0, argmax_dev, maxprob_dev, (hipStream_t)stream);
     // fused: logits GEMM + online softmax statistics + argmax, nothing but (idx, prob) leaves the chip
     rowgemm(e, (hipStream_t)stream, RG_PRO_PLAIN, RG_EPI_CTC, enc_dev, e->cfg.d_model, nullptr, nullptr, e->ctc_w,
             e->ctc_b, nullptr, 0, M, e->cfg.vocab_size, nullptr, 0, 1.f, nullptr, 0, 0, 0, argmax_dev, maxprob_dev);
@@ -2049,6 +2079,22 @@ int masr_stream_set_history(masr_engine* e, int32_t stream_id, int32_t required_
     if (required_cache_size >= 0 && e->cfg.model_kind == 3)
         return fail("required_cache_size: DeepSpeech2 streams carry an LSTM state, not an attention cache");
     st->history = required_cache_size;
+    return 0;
+}
+
+int masr_encoder_frames(masr_engine* e, int32_t feature_frames, int32_t* encoder_frames) {
+    if (!e || !encoder_frames) return fail("null argument");
+    const int T1 = (feature_frames - 1) / 2, Tsub = (T1 - 1) / 2;
+    const bool halved = e->cfg.model_kind == 2 && e->stride_idx >= 0;
+    *encoder_frames = feature_frames < 7 ? 0 : (halved ? (Tsub + 1) / 2 : Tsub);
+    return 0;
+}
+
+int masr_engine_info(masr_engine* e, int32_t* device_id, int32_t* n_mels, int32_t* vocab_size) {
+    if (!e) return fail("null engine");
+    if (device_id) *device_id = e->cfg.device_id;
+    if (n_mels) *n_mels = e->cfg.n_mels;
+    if (vocab_size) *vocab_size = e->cfg.vocab_size;
     return 0;
 }
 
@@ -2536,6 +2582,9 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 24) g_ffn_dual = value;
     else if (key == 25) g_rowgemm_packed = value;
     else if (key == 26) set_attention_grouped_fold(value);
+    else if (key == 27) g_ctc_fused_blocks = value;
+    else if (key == 28) set_attention_fewq_wgs(value);
+    else if (key == 29) g_few_rows_path = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
     f32x4 a[8], b[8];
     // rows for the LayerNorm statistics first: vmcnt retires in order, so their wait leaves the later loads in flight
     f32x4 srow[4];
-    if (PRO == RG_PRO_LN) {
+    constexpr bool LNORM = PRO == RG_PRO_LN || PRO == RG_PRO_LN_PAD;     // LN_PAD (offline pointwise_conv1, pad == 0): LN + pad mask
+    if (LNORM) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = min(row0 + wave * 4 + rr, p.M - 1);
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
 #pragma unroll
     for (int g = 0; g < 8; ++g) b[g] = *reinterpret_cast<const f32x4*>(wp + 8 * g);
     f32x4 gw[8], gb[8];
-    if (PRO == RG_PRO_LN || PRO == RG_PRO_AFFINE) {
+    if (LNORM || PRO == RG_PRO_AFFINE) {
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             gw[g] = *reinterpret_cast<const f32x4*>(p.lnw + kbase + 8 * g);
@@ -110,6 +111,13 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
             kvnq[i] = sq->nq;
             kvnk[i] = sq->nk;
         }
+    }
+    // LN_PAD: frames behind an utterance's own length enter the convolution as zeros (convolution.py:91-92 masked_fill)
+    int a_len = 0x7fffffff, a_t = 0;
+    if (PRO == RG_PRO_LN_PAD && p.lens) {
+        const int bq = arow / p.seq_t;
+        a_t = arow - bq * p.seq_t;
+        a_len = p.lens[bq];
     }
     float bv = 0.f, bg = 0.f;
     if (EPI == RG_EPI_GLU) {
@@ -175,9 +183,15 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
         const int i = row / p.seq_t, t = row - i * p.seq_t;
         const float* gin = p.A + ((size_t)i * (p.pad + p.seq_t) + t) * 256 + lane * 4;
         f32x4 win[KMAX + 3], w[KMAX];
+        f32x4 gc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.gconst) gc = *reinterpret_cast<const f32x4*>(p.gconst + lane * 4);
 #pragma unroll
         for (int j = 0; j < KMAX + 3; ++j)
-            if (j < KT + 3) win[j] = *reinterpret_cast<const f32x4*>(gin + (size_t)j * 256);
+            if (j < KT + 3) {
+                // (offline causal conv: padded rows t + j < pad are the unmaterialised history = the constant glu(bias) row)
+                if (p.gconst && t + j < p.pad) win[j] = gc;
+                else win[j] = *reinterpret_cast<const f32x4*>(gin + (size_t)j * 256);
+            }
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
             if (j < KT) w[j] = *reinterpret_cast<const f32x4*>(p.dw_w + j * 256 + lane * 4);
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
     }
 
     // ---- prologue on the A fragments (registers) ------------------------------------------------------------------
-    if (PRO == RG_PRO_LN) {
+    if (LNORM) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const f32x4 v = srow[rr];
@@ -229,10 +243,11 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
         }
         __syncthreads();
         const float mean = stat[frow * 2], rstd = stat[frow * 2 + 1];
+        const bool dead = PRO == RG_PRO_LN_PAD && p.mstride * a_t >= a_len;
 #pragma unroll
         for (int g = 0; g < 8; ++g)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[g][q] = (a[g][q] - mean) * rstd * gw[g][q] + gb[g][q];
+            for (int q = 0; q < 4; ++q) a[g][q] = dead ? 0.f : (a[g][q] - mean) * rstd * gw[g][q] + gb[g][q];
     } else if (PRO == RG_PRO_AFFINE) {
 #pragma unroll
         for (int g = 0; g < 8; ++g)
@@ -329,6 +344,7 @@ static void launch_rs(const RowGemmArgs& a, hipStream_t s) {
 // tools/efficient_size_ab.py); 93 row blocks are indifferent
 static int g_small_blocks = 112;
 void set_rowgemm_small_blocks(int n) { g_small_blocks = n; }
+int rowgemm_small_blocks() { return g_small_blocks; }
 bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
     if (a.M <= 0 || a.M >= g_small_blocks * 32) return false;
     if (epi == RG_EPI_GLU ? a.N != 512 : (a.N % 64) != 0) return false;
@@ -339,9 +355,16 @@ bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s)
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_RESID) launch_rs<RG_PRO_PLAIN, RG_EPI_RESID>(a, s);
     else if (pro == RG_PRO_PLAIN && epi == RG_EPI_GLU) launch_rs<RG_PRO_PLAIN, RG_EPI_GLU>(a, s);
     else if (pro == RG_PRO_AFFINE && epi == RG_EPI_GLU) launch_rs<RG_PRO_AFFINE, RG_EPI_GLU>(a, s);
+    else if (pro == RG_PRO_LN_PAD && epi == RG_EPI_GLU) {
+        if (a.pad != 0 || a.seq_t <= 0) return false;      // (history rows through the GEMM: row-block kernel only)
+        launch_rs<RG_PRO_LN_PAD, RG_EPI_GLU>(a, s);
+    }
     else if (pro == RG_PRO_HIST && epi == RG_EPI_GLU) launch_rs<RG_PRO_HIST, RG_EPI_GLU>(a, s);
     else if (pro == RG_PRO_DWCONV && epi == RG_EPI_RESID) {
-        if (a.seq_t % 4 || a.M % 4 || a.pad + 1 > 15) return false;
+        // groups of 4 rows share one sequence's window: frames per sequence a multiple of 4 -- or ONE sequence (its last group is
+        // clamped to the last 4 rows and re-writes valid rows)
+        if (a.pad + 1 > 15 || a.M < 4) return false;
+        if ((a.seq_t % 4 || a.M % 4) && a.M != a.seq_t) return false;
         launch_rs<RG_PRO_DWCONV, RG_EPI_RESID>(a, s);
     }
     else return false;

@@ -32,7 +32,7 @@ def subsampled_len(t):
     return ((t - 1) // 2 - 1) // 2
 
 
-def reference_gains(mean_square, target_db, max_gain_db=300.0):
+def reference_gains_scalar(mean_square, target_db, max_gain_db=300.0):
     """float32 mean squares [B] -> linear gains [B] with the reference's own scalar expressions, verbatim in numpy on this host:
     ``rms_db = 10 * np.log10(mean_square)`` (audio.py:524-529), ``gain = target_db - rms_db`` and the max_gain_db check
     (:300-304), ``samples *= 10. ** (gain / 20.)`` (:256-264).  A zero mean square (digital silence) counts as 1, like the
@@ -48,6 +48,28 @@ def reference_gains(mean_square, target_db, max_gain_db=300.0):
         if gain > max_gain_db:
             raise ValueError(f"无法将段规范化到{target_db}dB，音频增益{gain}增益已经超过max_gain_db ({max_gain_db}dB)")
         out[i] = 10. ** (min(max_gain_db, gain) / 20.)
+    return out
+
+
+def reference_gains(mean_square, target_db, max_gain_db=300.0):
+    """``reference_gains_scalar`` for a whole batch: the logarithm, the products and the differences as float32 array operations
+    (numpy evaluates a 0-d and a 1-d float32 operand of these ufuncs in the same inner loops: bit-identical, pinned by
+    tests/test_host_logic.py on 10^5 values), the power ``10. ** (gain / 20.)`` element by element on numpy float32 SCALARS --
+    numpy's scalar power is libm's powf, its float32 ARRAY power is a SIMD routine whose last bit differs on a fifth of the
+    arguments.  128 streams: 0.08 ms instead of 0.3 ms per pool step."""
+    ms = np.asarray(mean_square, np.float32)
+    if not isinstance(target_db, (int, float)) or np.float32(target_db) != target_db:
+        return reference_gains_scalar(ms, target_db, max_gain_db)     # a target that float32 does not hold: the long way
+    silent = ms == 0
+    gain = np.float32(target_db) - np.float32(10) * np.log10(np.where(silent, np.float32(1), ms).astype(np.float32))
+    if (gain > max_gain_db).any():
+        g = gain[gain > max_gain_db][0]
+        raise ValueError(f"无法将段规范化到{target_db}dB，音频增益{g}增益已经超过max_gain_db ({max_gain_db}dB)")
+    out = np.array([10. ** (x / 20.) for x in gain], np.float32)
+    if silent.any():
+        # digital silence: the scalar code sets ``ms = 1`` -- a Python int, so its logarithm, the gain and the power are evaluated in
+        # float64 and rounded once
+        out[silent] = np.float32(10. ** (min(max_gain_db, target_db - 10 * np.log10(1)) / 20.))
     return out
 
 

@@ -19,9 +19,13 @@ pending is done together:
 
 Every session receives exactly the partial results its own reference ``predict_stream`` loop would produce.
 """
+import ctypes as C
+import os
+
 import numpy as np
 import torch
 
+from masr_amd import _lib
 from masr_amd.data_utils.audio import AudioSegment
 from masr_amd.engine import reference_gains
 
@@ -132,6 +136,21 @@ class StreamPool:
         self._feat_cap = 512                                                                   # frames per session row
         self._feat = torch.zeros(0, self._feat_cap, self.feat_dim, dtype=torch.float32, device=self.engine.device)
         self._stage = _HostStage(self.engine.device)
+        # greedy sessions: the whole step is ONE C-ABI call (masr_pool_step, csrc/pool.hip); this class keeps the handles, hands
+        # over the fed buffers and builds the text.  Beam-search sessions (a device-resident prefix search per session) and
+        # MASR_POOL_PY=1 (A/B) keep the python framing below.
+        self._c = None
+        self._feeds = []
+        self._packed = None
+        if not self.beam and not os.environ.get('MASR_POOL_PY'):
+            self._lib = _lib.lib()
+            h = C.c_void_p()
+            method = {'fbank': 0, 'mfcc': 1, 'linear': 2}[self.method]
+            _lib.check(self._lib.masr_pool_create(self.engine.h, method, self.n_mfcc, 1 if self.use_db else 0, float(self.target_db),
+                                                  int(max_frames_out), C.byref(h)))
+            self._c = h
+            self._gain_error = None
+            self._gain_cb = _lib.GAIN_FN(self._gains)          # (kept alive with the pool)
 
     # ---- session life cycle ---------------------------------------------------------------------------------------------
     def _grow(self, rows, frames):
@@ -157,7 +176,30 @@ class StreamPool:
     def _new_decoder(self):
         return self.predictor.beam_search_decoder.fork() if self.beam else None
 
+    def __del__(self):
+        try:
+            if getattr(self, '_c', None) is not None and getattr(self.engine, 'h', None):
+                self._lib.masr_pool_destroy(self._c)
+                self._c = None
+        except Exception:                                      # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def _gains(self, ms_ptr, n, target_db, out_ptr, _user):
+        """masr_gain_fn: the reference's scalar numpy expressions (audio.py:287-304,519-529) on the device's mean squares"""
+        try:
+            ms = np.ctypeslib.as_array(ms_ptr, (n,))
+            np.ctypeslib.as_array(out_ptr, (n,))[:] = reference_gains(ms, self.target_db)
+            return 0
+        except Exception as exc:                               # noqa: BLE001  (re-raised by step() once the C call has returned)
+            self._gain_error = exc
+            return 1
+
     def open(self):
+        if self._c is not None:
+            h = C.c_int32()
+            _lib.check(self._lib.masr_pool_open(self._c, C.byref(h)))
+            self.sessions[h.value] = _Session(h.value, 0, None)
+            return h.value
         sid = self.engine.stream_open(self.max_frames_out)
         used = {s.row for s in self.sessions.values()}
         row = self._free_rows.pop() if self._free_rows else len(used)
@@ -166,6 +208,11 @@ class StreamPool:
         return sid
 
     def close(self, handle):
+        if self._c is not None:
+            _lib.check(self._lib.masr_pool_close(self._c, int(handle)))
+            self.sessions.pop(handle)
+            self._feeds = [f for f in self._feeds if f[0] != handle]
+            return
         self.engine.stream_close(handle)
         s = self.sessions.pop(handle)
         if s.decoder is not None:
@@ -175,6 +222,11 @@ class StreamPool:
 
     def reset(self, handle):
         """start a new utterance on an open session (MASRPredictor.reset_stream, predict.py:346-353)"""
+        if self._c is not None:
+            _lib.check(self._lib.masr_pool_reset(self._c, int(handle)))
+            self.sessions[handle] = _Session(handle, 0, None)
+            self._feeds = [f for f in self._feeds if f[0] != handle]
+            return
         self.engine.stream_reset(handle)
         old = self.sessions[handle]
         if old.decoder is not None:
@@ -186,8 +238,14 @@ class StreamPool:
         """queue raw PCM bytes (or a float / int numpy array) for a session (predict.py:260-272); processed by the next
         ``step()``"""
         s = self.sessions[handle]
-        if isinstance(audio_data, (bytes, bytearray, memoryview)) and samp_width == 2 and channels == 1 and \
-                sample_rate == self.sample_rate:
+        wire = isinstance(audio_data, (bytes, bytearray, memoryview)) and samp_width == 2 and channels == 1 and \
+            sample_rate == self.sample_rate
+        if wire and self._c is not None:
+            # (the buffer is handed to masr_pool_step as it is: the array keeps the caller's bytes alive until the step has run)
+            self._feeds.append((handle, np.frombuffer(bytes(audio_data) if isinstance(audio_data, bytearray) else audio_data, '<i2'),
+                                0, bool(is_end)))
+            return
+        if wire:
             # the common wire format: kept as int16 (a view of the caller's bytes); x / 2^15 -- the float32 value
             # from_pcm_bytes produces -- happens when the step stages the samples for the device
             s.fresh.append(np.frombuffer(bytes(audio_data) if isinstance(audio_data, bytearray) else audio_data, '<i2'))
@@ -201,6 +259,9 @@ class StreamPool:
                 raise Exception(f'不支持该数据类型，当前数据类型为：{type(audio_data)}')
             if seg.sample_rate != self.sample_rate:
                 seg.resample(self.sample_rate)
+            if self._c is not None:
+                self._feeds.append((handle, np.ascontiguousarray(seg.samples, np.float32), 1, bool(is_end)))
+                return
             s.fresh.append(seg.samples)
         self._fed[handle] = bool(is_end) or self._fed.get(handle, False)
 
@@ -263,7 +324,76 @@ class StreamPool:
                                               np.repeat(first, new) + offs]))
             self._feat.view(-1, self.feat_dim)[moves[1]] = feats.view(-1, self.feat_dim)[moves[0]]
 
+    @property
+    def last_packed(self):
+        """(device rows [n, tmax + 2] = tokens | count | score bits, tmax, handles) of the sessions that advanced in the last
+        step -- what a multi-GPU front-end all-gathers (parallel.ShardedStreamPool) -- or None"""
+        pk = self._packed
+        if pk is not None and not torch.is_tensor(pk[0]):
+            ptr, na, width, sids, host = pk
+            try:            # zero-copy view of the pool's device rows (valid until the next step)
+                view = type('_DevRows', (), {'__cuda_array_interface__': {'shape': (na, width), 'typestr': '<i4', 'data': (ptr, False),
+                                                                         'version': 2, 'strides': None}})()
+                rows = torch.as_tensor(view, device=self.engine.device)
+            except Exception:                                  # noqa: BLE001
+                rows = torch.from_numpy(host.copy()).to(self.engine.device)
+            pk = self._packed = (rows, width - 2, sids)
+        return pk
+
+    @last_packed.setter
+    def last_packed(self, value):
+        self._packed = value
+
+    def _step_c(self):
+        """one masr_pool_step call over everything fed since the last step"""
+        feeds, self._feeds = self._feeds, []
+        self._packed = None
+        if not feeds:
+            return {}
+        n = len(feeds)
+        handles = np.fromiter((f[0] for f in feeds), np.int32, n)
+        ptrs = np.fromiter((f[1].__array_interface__['data'][0] for f in feeds), np.uint64, n)
+        counts = np.fromiter((f[1].shape[0] for f in feeds), np.int64, n)
+        fmts = np.fromiter((f[2] for f in feeds), np.int32, n)
+        ends = np.fromiter((f[3] for f in feeds), np.int32, n)
+        ns, width = C.c_int32(), C.c_int32()
+        h_out, st_out, rows_h, rows_d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._gain_error = None
+        rc = self._lib.masr_pool_step(self._c, n, handles.ctypes.data, ptrs.ctypes.data, counts.ctypes.data, fmts.ctypes.data,
+                                      ends.ctypes.data, C.cast(self._gain_cb, C.c_void_p), None, C.byref(ns), C.byref(h_out),
+                                      C.byref(st_out), C.byref(rows_h), C.byref(width), C.byref(rows_d),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if self._gain_error is not None:
+            raise self._gain_error
+        _lib.check(rc)
+        m, w = ns.value, width.value
+        hs = np.ctypeslib.as_array(C.cast(h_out, C.POINTER(C.c_int32)), (m,))
+        st = np.ctypeslib.as_array(C.cast(st_out, C.POINTER(C.c_int32)), (m,))
+        na = int(st.sum())
+        rows = np.ctypeslib.as_array(C.cast(rows_h, C.POINTER(C.c_int32)), (na, w)) if na else None
+        out, j, adv = {}, 0, []
+        vocab = self.vocab
+        for h, ok in zip(hs.tolist(), st.tolist()):
+            s = self.sessions[h]
+            if not ok:
+                s.result = None
+                out[h] = None
+                continue
+            r = rows[j]
+            j += 1
+            nt = int(r[w - 2])
+            s.tokens = r[:nt].tolist()
+            text = ''.join([vocab[t] for t in s.tokens]).replace('<space>', ' ')
+            # the score counts every non-blank frame (repeats included); with none the reference returns 0
+            s.result = out[h] = {'text': text, 'score': float(r[w - 1:w].view(np.float32)[0]) * 100.0 if nt > 0 else 0}
+            adv.append(h)
+        if na:
+            self._packed = (rows_d.value, na, w, adv, rows)
+        return out
+
     def step(self):
+        if self._c is not None:
+            return self._step_c()
         self.last_packed = None
         fed, self._fed = self._fed, {}
         if not fed:

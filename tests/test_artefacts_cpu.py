@@ -113,3 +113,16 @@ def test_committed_bench_line_keeps_the_contract():
     assert set(r['extra']) >= {'efficient_b256', 'stream128', 'stream16', 'squeezeformer_b64_beam', 'conformer_b32_bf16x3_exploratory'}
     assert r['extra']['conformer_b32_bf16x3_exploratory']['dtype'] == 'bf16x3' and 'value_host_to_host' in r
     assert all(r['extra'][k]['steps'] >= 10 for k in ('efficient_b256', 'stream128', 'stream16', 'squeezeformer_b64_beam'))
+
+
+def test_batched_reference_gains_equal_the_scalar_expressions():
+    """engine.reference_gains evaluates a batch with float32 array operations (+ scalar powers): bit-identical to the
+    reference's scalar expressions element by element, digital silence (float64 branch) and several targets included"""
+    from masr_amd.engine import reference_gains, reference_gains_scalar
+    rng = np.random.default_rng(3)
+    ms = (10 ** rng.uniform(-9, 0.5, 100000)).astype(np.float32)
+    ms[::997] = 0
+    for target in (-20, -20.0, -23.5, -17, -3, -20.1):
+        assert np.array_equal(reference_gains(ms, target), reference_gains_scalar(ms, target)), target
+    with pytest.raises(ValueError):
+        reference_gains(np.array([0.5, 1e-38], np.float32), -20)

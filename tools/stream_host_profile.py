@@ -44,6 +44,16 @@ for _ in range(3):
 a = np.array(lat) * 1e3
 print(f'{n} streams: feed p50 {np.percentile(a[:, 0], 50):.3f} ms, step p50 {np.percentile(a[:, 1], 50):.3f} ms, '
       f'call p50 {np.percentile(a.sum(1), 50):.3f} ms')
+if getattr(pool, '_c', None) is not None:
+    import ctypes as C
+    ph, st = (C.c_double * 6)(), C.c_int64()
+    pool._lib.masr_pool_profile(pool._c, ph, C.byref(st), 1)
+    for _ in range(3):
+        utterance()
+    pool._lib.masr_pool_profile(pool._c, ph, C.byref(st), 1)
+    names = ('assemble samples', 'upload + mean squares + wait', 'gains (python evaluator)', 'features + frame bookkeeping',
+             'windows: chunk steps enqueued', 'collapse + copy back + wait')
+    print('masr_pool_step host time per call: ' + ' | '.join(f'{nm} {v / st.value:.3f} ms' for nm, v in zip(names, ph)))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(3):
