@@ -226,6 +226,9 @@ struct FfnHead {
     const float* bias;
     const int* lens;           // feature lengths for the pad mask, or nullptr
     int seq_t, ktaps, mstride;
+    float* xout;               // d_ff-split launches (few rows) only: where the rows updated by the head stage go -- every d_ff
+                               // slice of a row block runs the head on the SAME old rows of x, so x itself must stay untouched
+                               // until the split reduction, which then reads xout and writes x
 };
 int launch_ffn_fused(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                      const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial,
@@ -243,7 +246,7 @@ void launch_pack_ffn_dual(const float* w1, const float* w2, float* p1, float* p2
 void launch_pack_rows_dual(const float* w, float* p, hipStream_t s);
 
 void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
-                       const FfnPostLn* post);
+                       const FfnPostLn* post, const float* xin = nullptr);
 void set_ffn_variant(int v);   // diagnostic ablations of the fused FFN kernel (0 = production)
 
 // ---- CTC prefix beam search on the GPU (beam_gpu.hip) ---------------------------------------------

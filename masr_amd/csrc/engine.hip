@@ -79,6 +79,13 @@ static int g_no_ffn_tail = 0;     // masr_debug_set key 8: 1 = the QKV projectio
 // (128 streams: chunk call 5.34 -> 3.16 ms, 256 streams 6.52 -> 4.99 ms; tools/chunk_step_ab.py)
 static int g_ffn_split_blocks = 192;
 static int g_no_ffn_head = 0;     // masr_debug_set key 9: 1 = depthwise conv and pointwise_conv2 as their own launches before the second FFN (A/B)
+// masr_debug_set key 30: 1 = few rows: [depthwise conv -> LN -> SiLU -> pointwise_conv2 + residual] as the head stage of the d_ff-split
+// FFN launch (every slice repeats it on its row block's rows; slice 0 publishes them).  Built in round 4 because round 3 priced
+// it at -3.4 us per layer; MEASURED (tools/chunk_lat.py, MASR_AB=30:0,30:1,30:0,30:1, one process, one box): 16 streams 1.177 /
+// 1.162 ms per chunk call without it, 1.199 / 1.170 ms with it; 128 streams 3.011 / 3.017 vs 3.037 / 3.042 ms -- the 128
+// dependent MFMAs + the window loads it adds to EVERY slice's critical path cost what the removed 11 us launch (whose columns
+// spread over 32 workgroups) cost.  Off by default; identical frame decisions either way.
+static int g_split_head = 0;
 static int g_few_rows_path = 1;   // masr_debug_set key 29: 0 = offline Conformer layers of few row blocks keep the row-block chain kernel (A/B)
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
@@ -252,7 +259,7 @@ struct masr_engine {
     DevBuf fb_scratch;
     // workspace
     DevBuf x1, x2, x, ln, hid, qkv, att, lnpad, glu, dwo, logits, feats, enc, idx, maxp, attseq, gain, nframes, lens, xsave,
-        xred;
+        xred, xh;      // xh: rows updated by the head stage of a d_ff-split FFN launch (few rows)
     // streams
     std::vector<Stream> streams;
     // profiling
@@ -474,7 +481,7 @@ void masr_destroy(masr_engine* e) {
     if (!e) return;
     for (void* p : e->owned) (void)hipFree(p);
     DevBuf* bufs[] = {&e->x1, &e->x2, &e->x, &e->ln, &e->hid, &e->qkv, &e->att, &e->lnpad, &e->glu, &e->dwo,
-                      &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens, &e->xsave,
+                      &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens, &e->xsave, &e->xh,
                       &e->xred, &e->qplanes, &e->attp, &e->cnnptrs, &e->ffpart, &e->gx, &e->rnn_out, &e->hstate, &e->cstate,
                       &e->ds2_lens, &e->beam_pool, &e->beam_state};
     for (DevBuf* b : bufs) b->release();
@@ -736,8 +743,11 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
     // B = 32 x 10 s: the 65 MB round trip of the hidden tensor ate what the bf16 pipe saved.)
     const bool x3 = (g_bf16x3 & 2) && nsplit == 1 && !affine && d == 256 && dff % 128 == 0;
     const bool want_tail = tail && nsplit == 1 && !g_no_ffn_tail && !x3;
-    const bool want_head = head && head->glu && nsplit == 1 && !want_tail && !g_no_ffn_head && !affine && !x3 &&
-                           (head->ktaps == 15 || head->ktaps == 7);
+    // (few rows: the head stage rides on the d_ff-split launch, every slice repeating it on the row block's rows -- key 30)
+    const bool split_head = head && head->glu && nsplit > 1 && g_split_head && !affine && !x3 && head->ktaps == 15 && d == 256 &&
+                            g_ffn_packed >= 2;
+    const bool want_head = head && head->glu && ((nsplit == 1 && !want_tail && !g_no_ffn_head && !affine && !x3 &&
+                                                  (head->ktaps == 15 || head->ktaps == 7)) || split_head);
     if (head_done) *head_done = want_head;
     if (head && head->glu && !want_head) {
         // the rest of the conv module as its own two launches: depthwise conv + LayerNorm + SiLU, pointwise_conv2 + mask + residual
@@ -843,15 +853,19 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
     if (packed && want_head) {
         phead = *head;
         CHK(packed_rows(head->W, d, &phead.W));
+        if (split_head) {
+            CHK(e->xh.ensure((size_t)M * d * sizeof(float)));
+            phead.xout = e->xh.as<float>();
+        }
         head = &phead;
     }
     const int done = launch_ffn_fused(e->x.as<float>(), lnw, lnb, kw1, b1, kw2, b2, M, dff, 1e-5f, scale, affine,
                                       nsplit > 1 ? e->ffpart.as<float>() : nullptr, nsplit, s, post_y ? &post : nullptr,
                                       want_tail ? tail : nullptr, want_head ? head : nullptr, packed);
     if (done < 0) return fail("ffn(): launch rejected");
-    if (want_head && done != 4) return fail("ffn(): head stage was not launched");
+    if (want_head && !(done & 4)) return fail("ffn(): head stage was not launched");
     if (tail_done) *tail_done = done == 2;
-    if (post_y && done != 1) launch_layernorm(e->x.as<float>(), post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
+    if (post_y && !(done & 1)) launch_layernorm(e->x.as<float>(), post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
     return 0;
 }
 
@@ -936,7 +950,7 @@ int ensure_layer_ws(masr_engine* e, int nseq, int Tq) {
 //  streaming (hist == true): lnpad rows [0,pad) of every sequence already hold the cnn cache; LayerNorm writes
 //                            the new rows behind them (needed for the next cache) and the GEMM reads lnpad.
 int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, bool hist, int K = 0, int mstride = 4,
-                bool pw1_done = false) {
+                bool pw1_done = false, bool pw2_later = false) {
     if (K <= 0) K = e->cfg.cnn_kernel;
     const int d = e->cfg.d_model, pad = K - 1;
     const int M = c.nseq * c.Tq, Mp = c.nseq * (c.Tq + pad);
@@ -956,6 +970,7 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
                 M, 2 * d, nullptr, 0, 1.f, c.lens, 0, c.Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, c.Tq,
                 e->cfg.causal ? pad : pad / 2, pad);
     }
+    if (pw2_later) return 0;       // the rest of the module is the head stage of the FFN launch that follows
     const float* gconst = (hist || !e->cfg.causal) ? nullptr : w.gconst;
     {
         // few row blocks: depthwise conv + LayerNorm + SiLU as the prologue of the K-split pointwise_conv2 launch (the chunk
@@ -980,7 +995,7 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
 // (convolution.py:98-131).  Where the small-M kernel does not apply (>= 2048 rows, frames per chunk not a multiple of 4) the
 // same steps run as separate launches: conv_hist, pointwise_conv1, dwconv_ln_silu, pointwise_conv2.
 int conv_module_stream(masr_engine* e, hipStream_t s, const LayerW& w, int n, int Tq, float* const* cache_rd,
-                       float* const* cache_wr, int K) {
+                       float* const* cache_wr, int K, bool pw2_later = false) {
     const int d = e->cfg.d_model, pad = K - 1, M = n * Tq, Mp = n * (Tq + pad);
     float* x = e->x.as<float>();
     {
@@ -995,6 +1010,7 @@ int conv_module_stream(masr_engine* e, hipStream_t s, const LayerW& w, int n, in
             launch_rowgemm(a, RG_PRO_PLAIN, RG_EPI_GLU, s);
         }
     }
+    if (pw2_later) return 0;       // depthwise conv ... pointwise_conv2: head stage of the FFN launch that follows
     {
         RowGemmArgs a{};
         a.A = e->glu.as<float>(); a.lda = d; a.lnw = w.cln_w; a.lnb = w.cln_b; a.dw_w = w.dw_w; a.dw_b = w.dw_b;
@@ -1550,8 +1566,12 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
             // 7.4 + 7.7 us for the two K-split launches whose columns spread over the chip); norm_final rides on the split
             // FFN's reduction
             mhsa_out(e, s, w, M);
-            CHK(conv_module(e, s, w, ctx, false));
-            CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x));
+            const bool fuse = g_split_head && e->cfg.cnn_kernel == 15 && g_ffn_packed >= 2 && !g_no_ffn_head;
+            CHK(conv_module(e, s, w, ctx, false, 0, 4, false, fuse));
+            const FfnHead head{e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->cfg.causal ? w.gconst : nullptr,
+                               w.pw2_w, w.pw2_b, feat_lens_dev, Tq, e->cfg.cnn_kernel, 4, nullptr};
+            CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x, nullptr,
+                    nullptr, fuse ? &head : nullptr));
             continue;                              // (prev stays null: nothing deferred)
         } else if (g_no_chain) {
             mhsa_out(e, s, w, M);
@@ -1562,7 +1582,7 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
             // (depthwise conv, LayerNorm, SiLU, pointwise_conv2, residual) is the head stage of the second FFN kernel
             mhsa_out_pw1(e, s, w, ctx);
             const FfnHead head{e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->cfg.causal ? w.gconst : nullptr,
-                               w.pw2_w, w.pw2_b, feat_lens_dev, Tq, e->cfg.cnn_kernel, 4};
+                               w.pw2_w, w.pw2_b, feat_lens_dev, Tq, e->cfg.cnn_kernel, 4, nullptr};
             CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, nullptr, nullptr, nullptr, nullptr,
                     nullptr, &head));
         }
@@ -2477,8 +2497,14 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
         launch_attention(e->attseq.as<AttSeq>() + (size_t)l * n, n, Tq, H, 3 * d, 2 * d, w.ptab, w.pos_u, w.pos_v, 0, 1, s);
         mhsa_out(e, s, w, M);
         float* const* cptr = e->cnnptrs.as<float*>() + (size_t)l * n;
-        CHK(conv_module_stream(e, s, w, n, Tq, cptr, cptr + (size_t)L * n, e->cfg.cnn_kernel));
-        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x));
+        // [depthwise conv -> LN -> SiLU -> pointwise_conv2 + residual] rides on the second FFN launch as its head stage (on the
+        // d_ff-split launch of few streams every slice repeats it on the row block's rows; one launch less on the step's chain)
+        const bool fuse = g_split_head && e->cfg.cnn_kernel == 15 && g_ffn_packed >= 2 && !g_no_ffn_head;
+        CHK(conv_module_stream(e, s, w, n, Tq, cptr, cptr + (size_t)L * n, e->cfg.cnn_kernel, fuse));
+        const FfnHead head{e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, nullptr, w.pw2_w, w.pw2_b, nullptr, Tq,
+                           e->cfg.cnn_kernel, 4, nullptr};
+        CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x, nullptr,
+                nullptr, fuse ? &head : nullptr));
     }
     CHK(e->enc.ensure((size_t)M * d * sizeof(float)));
     launch_layernorm(x, e->after_w, e->after_b, e->enc.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
@@ -2585,6 +2611,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 27) g_ctc_fused_blocks = value;
     else if (key == 28) set_attention_fewq_wgs(value);
     else if (key == 29) g_few_rows_path = value;
+    else if (key == 30) g_split_head = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

@@ -229,7 +229,11 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                 float v = acc[r] + bv;
                 if (padded & (1u << r)) v = 0.f;
                 v = res[r] + v;
-                if (row < M) x[(size_t)row * PC_D + col] = v;
+                if (SPLIT) {          // all d_ff slices of the row block computed the same rows from the same old x: slice 0 publishes
+                    if (blockIdx.y == 0 && row < M) head.xout[(size_t)row * PC_D + col] = v;
+                } else if (row < M) {
+                    x[(size_t)row * PC_D + col] = v;
+                }
                 xn[lr * PC_XLD + col] = v;
             }
         }
@@ -658,6 +662,17 @@ static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float
         ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<AFFINE, 1, SV, 0, 0>), lds, attr_split_v);
         const int cpb = (nchunk + nsplit - 1) / nsplit;
         const int ny = (nchunk + cpb - 1) / cpb;          // every blockIdx.y owns at least one chunk
+        // head stage on the split launch (few rows): every slice of a row block runs the conv module's [depthwise conv -> LN ->
+        // SiLU -> pointwise_conv2 + residual] on the block's rows before its share of the FFN; slice 0 writes the updated rows to
+        // head->xout and the reduction continues from there
+        if (head && head->glu && head->xout && head->ktaps == 15 && !AFFINE && SV == 2) {
+            static LdsAttr attr_split_h;
+            ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 1, 2, 0, 15>), lds, attr_split_h);
+            hipLaunchKernelGGL((ffn_pc_kernel<0, 1, 2, 0, 15>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
+                               b1, w2, b2, M, dff, eps, scale, partial, cpb, FfnTail{}, *head);
+            launch_ffn_reduce(x, partial, b2, M, ny, scale, s, post, head->xout);
+            return (post && post->y ? 1 : 0) | 4;
+        }
         hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, SV, 0, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
                            b1, w2, b2, M, dff, eps, scale, partial, cpb, FfnTail{}, FfnHead{});
         launch_ffn_reduce(x, partial, b2, M, ny, scale, s, post);

@@ -19,12 +19,12 @@ template <int POSTLN>
 __global__ __launch_bounds__(256) void ffn_reduce_kernel(float* x, const float* __restrict__ partial,
                                                          const float* __restrict__ b2, int M, int nsplit, float scale,
                                                          const float* __restrict__ lnw, const float* __restrict__ lnb, float* y,
-                                                         float eps) {
+                                                         float eps, const float* xin) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;        // float4 index
     if (i >= (size_t)M * FF_D / 4) return;
     const size_t sstride = (size_t)M * FF_D / 4;
     const f32x4* pp = reinterpret_cast<const f32x4*>(partial) + i;
-    f32x4 xv = reinterpret_cast<f32x4*>(x)[i];
+    f32x4 xv = reinterpret_cast<const f32x4*>(xin ? xin : x)[i];      // xin: the rows a head stage of the split launch updated
     const f32x4 bb = reinterpret_cast<const f32x4*>(b2)[i % (FF_D / 4)];
     f32x4 gw = f32x4{1.f, 1.f, 1.f, 1.f}, gb = f32x4{0.f, 0.f, 0.f, 0.f};
     if (POSTLN) {
@@ -68,14 +68,14 @@ __global__ __launch_bounds__(256) void ffn_reduce_kernel(float* x, const float* 
 }
 
 void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
-                       const FfnPostLn* post) {
+                       const FfnPostLn* post, const float* xin) {
     const dim3 grid((unsigned)(((size_t)M * FF_D / 4 + 255) / 256));
     if (post && post->y)
         hipLaunchKernelGGL(ffn_reduce_kernel<1>, grid, dim3(256), 0, s, x, partial, b2, M, nsplit, scale, post->lnw, post->lnb,
-                           post->y, post->eps);
+                           post->y, post->eps, xin);
     else
         hipLaunchKernelGGL(ffn_reduce_kernel<0>, grid, dim3(256), 0, s, x, partial, b2, M, nsplit, scale, (const float*)nullptr,
-                           (const float*)nullptr, (float*)nullptr, 0.f);
+                           (const float*)nullptr, (float*)nullptr, 0.f, xin);
 }
 int launch_ffn_pc(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
                   const float* b2, int M, int dff, float eps, float scale, int affine_prologue, float* partial, int nsplit,

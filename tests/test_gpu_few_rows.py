@@ -1,0 +1,92 @@
+"""Round 4: offline batches of FEW row blocks (one utterance = 7 row blocks of 32 on 256 CUs) and the chunk steps' optional head
+stage.  Every new launch path is held (a) against the oracle at 1e-3 (measured ~3e-6) and (b) against the kernels it replaces
+(masr_debug_set keys 27: tiled CTC head below N row blocks, 28: key-split attention over query groups, 29: latency-cut layer
+kernels incl. the depthwise conv in the pointwise_conv2 prologue, 30: conv-module head stage on the d_ff-split FFN launch):
+identical greedy decisions, encoder outputs within 2e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+V = 512
+
+
+def _engine(streaming=True):
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    sd = synthetic.conformer_state_dict(0, V)
+    return HipEngine(sd, vocab_size=V, streaming=streaming), sd
+
+
+def _set(eng, conf):
+    for k, v in conf.items():
+        eng.lib.masr_debug_set(eng.h, k, v)
+
+
+OLD = {27: 0, 28: 0, 29: 0, 30: 0}
+NEW = {27: 160, 28: 48, 29: 1, 30: 0}
+
+
+@pytest.mark.parametrize('streaming', [True, False])
+@pytest.mark.parametrize('B,T', [(1, 837), (1, 250), (3, 611), (5, 998)])
+def test_few_row_block_path_against_oracle_and_previous_kernels(streaming, B, T):
+    """B x T feature frames, ragged, frames per utterance NOT a multiple of 4 (the depthwise prologue's clamped last group):
+    streaming-trained (causal conv, unmaterialised history rows) and streaming: False (symmetric conv) builds"""
+    from oracle import conformer as oc
+    eng, sd = _engine(streaming)
+    gen = torch.Generator().manual_seed(B * 1000 + T)
+    feats = torch.randn(B, T, 80, generator=gen) * 3 + 13
+    lens = torch.full((B,), T, dtype=torch.int64)
+    if B > 1:
+        lens[1:] = torch.randint(T // 2, T + 1, (B - 1,), generator=gen)
+    feats = feats * (torch.arange(T)[None, :, None] < lens[:, None, None])
+    with torch.no_grad():
+        ref = oc.encoder_full(sd, feats, lens, -1, streaming=streaming)
+    keep = (torch.arange(ref.shape[1])[None, :] < eng.enc_frames(lens)[:, None])[:, :, None]
+    out = {}
+    try:
+        for name, conf in (('old', OLD), ('new', NEW), ('head', dict(NEW, **{30: 1}))):
+            _set(eng, conf)
+            enc = eng.encode_full(feats.cuda(), lens.to(torch.int32).cuda(), -1)
+            idx, mp = eng.ctc_greedy_frames(enc)
+            out[name] = (enc.cpu(), idx.cpu(), mp.cpu())
+    finally:
+        _set(eng, NEW)
+        eng.close()
+    for name, (enc, idx, mp) in out.items():
+        err = ((enc - ref).abs() * keep).max().item()
+        print(f'{name}: B = {B}, T = {T}, streaming = {streaming}: max |enc - oracle| = {err:.3e}')
+        assert err < 1e-3, (name, err)
+    for name in ('new', 'head'):
+        d = ((out[name][0] - out['old'][0]).abs() * keep).max().item()
+        assert d < 2e-5, (name, d)
+        same = ((out[name][1] == out['old'][1]) | ~keep[:, :, 0])
+        assert same.all(), name
+        assert ((out[name][2] - out['old'][2]).abs() * keep[:, :, 0]).max().item() < 1e-5
+
+
+def test_chunk_steps_with_the_head_stage_on_the_split_ffn_launch():
+    """masr_debug_set key 30 (off by default: measured no faster): the conv module's second half as the head stage of the second
+    FFN's d_ff-split launch -- 3 and 40 lock-step streams over six chunks, frame decisions identical, probabilities within 1e-5"""
+    eng, _ = _engine(True)
+    try:
+        for n in (3, 40):
+            gen = torch.Generator().manual_seed(n)
+            feats = (torch.randn(n, 67 + 5 * 64, 80, generator=gen) * 3 + 13).cuda()
+            res = {}
+            for key30 in (0, 1):
+                eng.lib.masr_debug_set(eng.h, 30, key30)
+                sids = [eng.stream_open(200) for _ in range(n)]
+                outs = []
+                for cur in range(0, feats.shape[1] - 67 + 1, 64):
+                    probs, idx, mp = eng.encode_chunk(sids, feats[:, cur:cur + 67].contiguous(), want_probs=True, want_argmax=True)
+                    outs.append((probs.cpu(), idx.cpu()))
+                for sid in sids:
+                    eng.stream_close(sid)
+                res[key30] = outs
+            for (p0, i0), (p1, i1) in zip(res[0], res[1]):
+                assert torch.equal(i0, i1)
+                assert (p0 - p1).abs().max().item() < 1e-5
+    finally:
+        eng.lib.masr_debug_set(eng.h, 30, 0)
+        eng.close()

@@ -13,7 +13,12 @@ from masr_amd.utils import synthetic  # noqa: E402
 label = sys.argv[1] if len(sys.argv) > 1 else ''
 e = HipEngine(synthetic.conformer_state_dict(0, 4233), vocab_size=4233)
 line = f'{label:8s}'
-for ns in (16, 128):
+# optional A/B inside one process: MASR_AB='30:0,30:1' runs the sizes once per setting of debug key 30
+settings = [tuple(int(v) for v in kv.split(':')) for kv in os.environ.get('MASR_AB', '').split(',') if kv] or [None]
+for ns, ab in [(n, a) for a in settings for n in (16, 128)]:
+    if ab is not None:
+        e.lib.masr_debug_set(e.h, ab[0], ab[1])
+        line += f' | key {ab[0]} = {ab[1]}'
     feats = torch.randn(ns, 998, 80, device='cuda', generator=torch.Generator('cuda').manual_seed(3)) * 3 + 13
     sids = [e.stream_open(300) for _ in range(ns)]
 
