@@ -86,6 +86,7 @@ static int g_no_ffn_head = 0;     // masr_debug_set key 9: 1 = depthwise conv an
 // dependent MFMAs + the window loads it adds to EVERY slice's critical path cost what the removed 11 us launch (whose columns
 // spread over 32 workgroups) cost.  Off by default; identical frame decisions either way.
 static int g_split_head = 0;
+static int g_efficient_fused = 1;   // masr_debug_set key 31: 0 = Efficient-Conformer layers keep separate out-proj / pw1 / dwconv / pw2 launches (A/B)
 static int g_few_rows_path = 1;   // masr_debug_set key 29: 0 = offline Conformer layers of few row blocks keep the row-block chain kernel (A/B)
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
@@ -1043,11 +1044,14 @@ void mhsa_out(masr_engine* e, hipStream_t s, const LayerW& w, int M) {
 
 // offline conformer layer: attention out-projection + residual and the conv module's LayerNorm + pointwise_conv1 + GLU in ONE
 // kernel (rowgemm EPI_CHAIN): the updated rows go to x (global) and, without leaving the CU, through the second GEMM
-void mhsa_out_pw1(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, int mstride = 4) {
-    const int d = e->cfg.d_model, pad = e->cfg.cnn_kernel - 1, M = c.nseq * c.Tq;
+// K: the layer's depthwise kernel size (Efficient Conformer: 15 before, 7 behind the stride layer); att / a_seq_t / a_seq_stride: the
+// attention output when it lives in a per-sequence padded buffer (grouped attention's planes)
+void mhsa_out_pw1(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx& c, int mstride = 4, int K = 0,
+                  const float* att = nullptr, int a_seq_t = 0, int a_seq_stride = 0) {
+    const int d = e->cfg.d_model, pad = (K > 0 ? K : e->cfg.cnn_kernel) - 1, M = c.nseq * c.Tq;
     float* x = e->x.as<float>();
     RowGemmArgs a{};
-    a.A = e->att.as<float>(); a.lda = d; a.lnw = w.ln_conv_w; a.lnb = w.ln_conv_b; a.W = w.chain_w; a.bias = w.chain_b;
+    a.A = att ? att : e->att.as<float>(); a.lda = d; a.a_seq_t = a_seq_t; a.a_seq_stride = a_seq_stride; a.lnw = w.ln_conv_w; a.lnb = w.ln_conv_b; a.W = w.chain_w; a.bias = w.chain_b;
     a.C = e->glu.as<float>(); a.ldc = d; a.M = M; a.N = 3 * d; a.R = x; a.R2 = x; a.ldr = d; a.alpha = 1.f;
     a.lens = c.lens; a.seq_t = c.Tq; a.mstride = mstride; a.eps = 1e-5f;
     a.out_seq_t = c.Tq; a.out_pad_l = e->cfg.causal ? pad : pad / 2; a.out_pad_tot = pad;
@@ -1329,6 +1333,11 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
     for (int i = 0; i < L; ++i) {
         const LayerW& w = e->layers[i];
         int M = B * Tq;
+        const int Ki = layer_kernel(e, i);
+        // enough row blocks for the full (non d_ff-split) FFN launch: the Conformer's fused launches (key 31 = 0: separate ones)
+        const bool fused = g_efficient_fused && !g_no_chain && !g_no_ffn_head && i != e->stride_idx &&
+                           (M + 31) / 32 >= g_ffn_split_blocks && (Ki == 15 || Ki == 7) && d == 256;
+        const EncodeCtx ctx0{B, Tq, lens};
         // regular layers: LayerNorm + fused QKV projection ride on the first FFN kernel (tail stage), like the Conformer
         const FfnTail tail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, 3 * d, nullptr, nullptr};
         bool qkv_done = false;
@@ -1343,17 +1352,30 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
                 ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B / G);
                 launch_attention_grouped(seq_g, B, Tg, H, G, w.ptab, Tq, w.pos_u, w.pos_v, s, chunk);
             }
-            rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->attp.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d,
-                    1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride, 0, 0, 0, 0, 0, Tq, Tpad);
+            if (fused) mhsa_out_pw1(e, s, w, ctx0, mstride, Ki, e->attp.as<float>(), Tq, Tpad);
+            else
+                rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->attp.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d,
+                        1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride, 0, 0, 0, 0, 0, Tq, Tpad);
         } else {
             if (!qkv_done) mhsa(e, s, w, M);
             {
                 ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
                 launch_attention(seq_r, B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v, chunk, pstride, s);
             }
-            mhsa_out(e, s, w, M);
+            if (fused) mhsa_out_pw1(e, s, w, ctx0, mstride, Ki);
+            else mhsa_out(e, s, w, M);
         }
         EncodeCtx ctx{B, Tq, lens};
+        if (fused) {
+            // like the offline Conformer layer: [out-proj + residual -> LN -> pw1 -> GLU] was one kernel; the rest of the conv
+            // module is the head stage of the second FFN launch (15 taps before, 7 behind the stride layer)
+            const FfnHead head{e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, causal ? w.gconst : nullptr,
+                               w.pw2_w, w.pw2_b, lens, Tq, Ki, mstride, nullptr};
+            CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, &head));
+            launch_layernorm(x, w.ln_fin_w, w.ln_fin_b, x, M, 1e-5f, 0, 0, nullptr, s);
+            continue;
+        }
         if (i == e->stride_idx) {
             // StrideConformerEncoderLayer (encoder.py:454-545): x = AvgPool(x) + conv_module_stride2(LN(x))
             const int K = layer_kernel(e, i), pad = K - 1, T2 = (Tq + 1) / 2;
@@ -2612,6 +2634,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 28) set_attention_fewq_wgs(value);
     else if (key == 29) g_few_rows_path = value;
     else if (key == 30) g_split_head = value;
+    else if (key == 31) g_efficient_fused = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

@@ -45,7 +45,7 @@ def test_few_row_block_path_against_oracle_and_previous_kernels(streaming, B, T)
     keep = (torch.arange(ref.shape[1])[None, :] < eng.enc_frames(lens)[:, None])[:, :, None]
     out = {}
     try:
-        for name, conf in (('old', OLD), ('new', NEW), ('head', dict(NEW, **{30: 1}))):
+        for name, conf in (('old', OLD), ('new', NEW), ('head', {**NEW, 30: 1})):
             _set(eng, conf)
             enc = eng.encode_full(feats.cuda(), lens.to(torch.int32).cuda(), -1)
             idx, mp = eng.ctc_greedy_frames(enc)
