@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- writes tests/golden/silero_testwav.npz from the REFERENCE's own artefacts:
 
-* the 16 kHz model of /root/reference/masr/infer_utils/silero_vad.onnx (weights under the names of oracle/silero.py; they are what
+* the 16 kHz AND the 8 kHz model of /root/reference/masr/infer_utils/silero_vad.onnx (weights under the names of oracle/silero.py; they are what
   the GPU tests load into the product network -- /root/reference does not exist on the GPU box),
 * the speech probability of every 512-sample window of /root/reference/dataset/test.wav and the final LSTM state, from the
   operator-by-operator evaluation of that file (oracle/onnx_run.py) driven by the UNMODIFIED reference class
@@ -83,6 +83,20 @@ def main():
     vad4 = reference_vad(graph, window_size_samples=1536)
     vad4.get_speech_timestamps(long_audio[:64000], 16000)
     out['probs_1536'] = np.array(vad4.session.probs, np.float32)
+    # the 8 kHz branch of the same file (vad_predictor.py:51,94-95: sampling_rate 8000, window 256 / 512 / 768): its weights, and the
+    # reference class on every second sample of the same recording (a plain decimation -- the fixture pins arithmetic, not audio
+    # quality): probabilities, segments, final state
+    out.update({'w8.' + k: np.asarray(v, np.float32) for k, v in silero.weights_from_graph(graph, 8000).items()})
+    audio8 = np.ascontiguousarray(long_audio[::2])
+    vad8 = reference_vad(graph, window_size_samples=256)
+    stamps8 = vad8.get_speech_timestamps(audio8, 8000)
+    out['probs_8k'] = np.array(vad8.session.probs, np.float32)
+    out['h_8k'], out['c_8k'] = vad8._h, vad8._c
+    out['stamps_8k'] = np.array([[s['start'], s['end']] for s in stamps8], np.int64).reshape(-1, 2)
+    print('8 kHz:', len(vad8.session.probs), 'windows;', stamps8)
+    vad9 = reference_vad(graph, window_size_samples=768)
+    vad9.get_speech_timestamps(audio8[:32000], 8000)
+    out['probs_8k_768'] = np.array(vad9.session.probs, np.float32)
     np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'silero_testwav.npz'), **out)
     print('written', os.path.getsize(os.path.join(ROOT, 'tests', 'golden', 'silero_testwav.npz')), 'bytes')
 

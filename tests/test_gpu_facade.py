@@ -595,6 +595,33 @@ def test_predict_batch_and_evaluate_through_the_rccl_exchange(predictor, tmp_pat
         dist.destroy_process_group()
 
 
+def test_predict_on_8k_and_44k1_input_goes_through_the_reference_resampler(predictor):
+    """Every request that is not at the model's rate passes AudioSegment.resample (audio_featurizer.py:37-69 ->
+    audio.py:306-317 -> resampy's band-limited sinc interpolation; restated, parity unpinned; its three forms are pinned to each
+    other bit for bit on the CPU, tests/test_host_logic.py).  Through the facade: ``predict(x, sample_rate=r)`` for r = 8000 and
+    44100 (float and int16 samples) returns exactly what ``predict`` returns for the resampled samples handed over at 16 kHz,
+    and the output length is resampy's ``int(n * 16000 / r)``."""
+    from masr_amd.data_utils import resample as rs
+    from masr_amd.data_utils.audio import AudioSegment
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm'][:64000].astype(np.float32) / 32768.0
+    for rate in (8000, 44100):
+        x = rs.resample(pcm, 16000, rate).astype(np.float32)            # an utterance "recorded" at that rate
+        y = rs.resample(x, rate, 16000)
+        assert len(y) == int(len(x) * 16000 / rate)
+        seg = AudioSegment.from_ndarray(x, rate)
+        seg.resample(16000)
+        assert np.array_equal(seg.samples, y)                           # the facade's path (host C++ form) == the numpy form
+        got, want = predictor.predict(x, sample_rate=rate), predictor.predict(y)
+        assert got == want and len(want['text']) > 0, (rate, got, want)
+        xi = np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16)
+        got_i = predictor.predict(xi, sample_rate=rate)
+        want_i = predictor.predict(rs.resample(xi.astype(np.float32) * np.float32(1.0 / 32768.0), rate, 16000))
+        assert got_i == want_i, (rate, got_i, want_i)
+    batch = predictor.predict_batch([rs.resample(pcm, 16000, 8000).astype(np.float32)] * 2, sample_rate=8000)
+    one = predictor.predict(rs.resample(pcm, 16000, 8000).astype(np.float32), sample_rate=8000)
+    assert batch[0] == batch[1] and batch[0]['text'] == one['text'] and abs(batch[0]['score'] - one['score']) < 1e-3
+
+
 def test_stream_pool_feed_forms_are_equivalent(predictor):
     """StreamPool.feed: int16 PCM bytes (kept raw until the step stages them), the same samples as an int16 / float32 ndarray,
     as a bytearray, and a chunk split over two feed calls must give identical partial results; audio at another sample rate
