@@ -552,7 +552,7 @@ def extra_stream128(args, rank, world, local, n_streams=None, reps=None):
                                           'latency-, not MFMA-bound (DESIGN 9)')}
 
 
-def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False):
+def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, word_lm=False):
     """configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances of 2-20 s (seed 1234) padded per length bucket,
     ctc_beam_search (beam 300, cutoff_top_n 40, alpha 2.2 / beta 4.3 with a synthetic character n-gram LM when ``lm``)"""
     from masr_amd.utils import synthetic
@@ -562,7 +562,17 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False):
     audio = [pcm_h[i, :lens[i]] for i in range(64)]
     conf = {'alpha': 2.2 if lm else 0, 'beta': 4.3 if lm else 0, 'beam_size': 300, 'cutoff_prob': 0.99, 'cutoff_top_n': 40,
             'num_processes': 10}
-    if lm:
+    if lm and word_lm:
+        # a WORD-based scorer (an LM word longer than one character: the reference's English configurations,
+        # beam_search_decoder.py:29-30 is_character_based()): spelling dictionary + scoring at <space>; that search runs on host
+        # threads (num_processes), the vocabulary pruning stays on the GPU
+        from masr_amd.decoders.lm_scorer import write_synthetic_word_arpa
+        rng_w = np.random.default_rng(9)
+        chars = [t for t in synthetic.synthetic_vocab(VOCAB) if len(t) == 1][:400]
+        words = sorted({''.join(chars[int(i)] for i in rng_w.integers(0, len(chars), int(rng_w.integers(2, 5)))) for _ in range(3000)})
+        d = tempfile.mkdtemp(prefix='masr_lm_')
+        conf['language_model_path'] = write_synthetic_word_arpa(os.path.join(d, 'wlm.arpa'), words, seed=5)
+    elif lm:
         from masr_amd.decoders.lm_scorer import write_synthetic_arpa
         d = tempfile.mkdtemp(prefix='masr_lm_')
         conf['language_model_path'] = write_synthetic_arpa(os.path.join(d, 'lm.arpa'), synthetic.synthetic_vocab(VOCAB), seed=5)
@@ -570,7 +580,7 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False):
         conf['language_model_path'] = None           # explicit scorer-free search (not a reference configuration)
     pred = facade('squeezeformer', 'ctc_beam_search', local, streaming=False, beam_conf=conf,
                   head_gain=SHARP_HEAD_GAIN if sharp else None)
-    steps = 10
+    steps = 3 if word_lm else 10
     pred.predict_batch(audio, batch_size=32)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -595,7 +605,9 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False):
     pred.predictor.engine.close()
     return {'workload': f'configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s), two '
                         f'length buckets of 32, ctc_beam_search beam 300 / top-n 40, '
-                        + ('alpha 2.2 beta 4.3 with a synthetic 3-gram character LM scored on the GPU' if lm else 'LM-free'),
+                        + ('alpha 2.2 beta 4.3 with a synthetic 3-gram WORD LM: prefix search on %d host threads' % conf['num_processes']
+                           if lm and word_lm else
+                           'alpha 2.2 beta 4.3 with a synthetic 3-gram character LM scored on the GPU' if lm else 'LM-free'),
             'posteriors': ('SHARPENED CTC head (random-init logits x %g: 1-3 candidates survive cutoff_prob 0.99 per frame, what a '
                            'trained model gives the search)' % SHARP_HEAD_GAIN) if sharp else
                           'FLAT random-init posteriors: cutoff_top_n = 40 candidates survive in EVERY frame -- the search\'s worst case, '
@@ -742,6 +754,7 @@ def run_extras(args, rank, world, local, out=None):
         jobs.append(('stream16', lambda a, r, w, l: extra_stream128(a, r, w, l, n_streams=16)))
         jobs.append(('squeezeformer_b64_beam', extra_squeezeformer_beam))
         jobs.append(('squeezeformer_b64_beam_sharp', lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True)))
+        jobs.append(('squeezeformer_b64_beam_wordlm_host', lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True, word_lm=True)))
         jobs.append(('facade', extra_facade))
         jobs.append(('conformer_b32_bf16x3_exploratory', extra_bf16x3))
     for name, fn in jobs:
@@ -792,6 +805,7 @@ def main():
               'squeezeformer_b64_beam': extra_squeezeformer_beam,
               'squeezeformer_b64_beam_nolm': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, lm=False),
               'squeezeformer_b64_beam_sharp': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True),
+              'squeezeformer_b64_beam_wordlm_host': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True, word_lm=True),
               'facade': extra_facade}[args.workload]
         res = fn(args, rank, world, local)
         if rank == 0:
