@@ -143,7 +143,7 @@ ROOFLINE_KERNELS = [
 def committed_traffic(fragment):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this build (profiles/rNN_hbm_traffic.json:
     FETCH_SIZE with the gfx950 correction + WRITE_SIZE); (bytes, file) or (None, None)."""
-    for name in ('r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+    for name in ('r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
         try:
             k = json.load(open(os.path.join(ROOT, 'profiles', name)))['kernels']
             for key, v in k.items():

@@ -159,15 +159,15 @@ class MASRPredictor:
         """padded batch through a pinned staging buffer -> device (int16 when every utterance still is the PCM it was
         loaded from: half the bytes over PCIe, x / 2^15 happens in the kernel), on the CURRENT stream.  Staging buffers take
         turns; each carries the event of its last upload, so filling one never waits for the device unless that very
-        buffer's previous copy (three passes ago) is still in flight."""
+        buffer's previous copy (two passes ago) is still in flight."""
         eng = self.predictor.engine
         as_pcm = all(s._pcm16 is not None for s in segs)
         dt = torch.int16 if as_pcm else torch.float32
         n_max = int(n.max())
         need = len(segs) * n_max
-        ring = self._stage.setdefault(dt, {'bufs': [None] * 3, 'events': [None] * 3, 'turn': 0, 'lens': [None] * 3})
+        ring = self._stage.setdefault(dt, {'bufs': [None] * 2, 'events': [None] * 2, 'turn': 0, 'lens': [None] * 2})
         k = ring['turn']
-        ring['turn'] = (k + 1) % 3
+        ring['turn'] = k ^ 1
         if ring['events'][k] is not None:
             ring['events'][k].synchronize()
         if ring['bufs'][k] is None or ring['bufs'][k].numel() < need:

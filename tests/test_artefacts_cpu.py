@@ -88,12 +88,12 @@ def test_reference_gains_equal_audio_segment_normalize():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r03_bench_line.json -- the line `python bench.py` printed on the GPU box for the final build of the round --
+    """profiles/r04_bench_line.json -- the line `python bench.py` printed on the GPU box for the final build of the round --
     carries every field of the driver's contract, and its numbers are consistent with each other"""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = open(os.path.join(root, 'profiles', 'r03_bench_line.json')).read().strip().splitlines()[-1]
+    line = open(os.path.join(root, 'profiles', 'r04_bench_line.json')).read().strip().splitlines()[-1]
     r = json.loads(line)
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
@@ -113,6 +113,12 @@ def test_committed_bench_line_keeps_the_contract():
     assert set(r['extra']) >= {'efficient_b256', 'stream128', 'stream16', 'squeezeformer_b64_beam', 'conformer_b32_bf16x3_exploratory'}
     assert r['extra']['conformer_b32_bf16x3_exploratory']['dtype'] == 'bf16x3' and 'value_host_to_host' in r
     assert all(r['extra'][k]['steps'] >= 10 for k in ('efficient_b256', 'stream128', 'stream16', 'squeezeformer_b64_beam'))
+    # round 4: the drop-in surface itself and a roofline block per BASELINE config
+    assert set(r['extra']) >= {'facade_b32', 'predict_b1', 'squeezeformer_b64_beam_sharp', 'squeezeformer_b64_beam_wordlm_host'}
+    for k in ('efficient_b256', 'stream128', 'stream16', 'squeezeformer_b64_beam', 'facade_b32', 'predict_b1'):
+        rk = r['extra'][k]['roofline']
+        assert rk['bound'] == 'mfma' and abs(rk['frac'] - rk['achieved'] / rk['peak']) < 1e-3 and 0 < rk['frac'] < 1
+    assert r['extra']['facade_b32']['transcripts'] == 32 and r['extra']['predict_b1']['latency_ms']['p50'] > 0
 
 
 def test_batched_reference_gains_equal_the_scalar_expressions():
