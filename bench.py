@@ -581,11 +581,16 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
     pred = facade('squeezeformer', 'ctc_beam_search', local, streaming=False, beam_conf=conf,
                   head_gain=SHARP_HEAD_GAIN if sharp else None)
     steps = 3 if word_lm else 10
-    pred.predict_batch(audio, batch_size=32)
+    # device passes of 32 utterances, longest first: the prefix search of a pass (one workgroup per utterance, frames in sequence --
+    # the longest utterance is the call's critical path) runs on a side stream under the encoder of the next pass.  Measured with
+    # MASR_BENCH_BEAM_PASS: passes of 16 are faster with the sharpened head (27.2 vs 30.7 ms per call: the longest utterance's search
+    # starts earlier) and slower with flat posteriors (56.6 vs 46.6 ms: four long searches share two side streams); 32 for both lines
+    per_pass = int(os.environ.get('MASR_BENCH_BEAM_PASS', '32'))
+    pred.predict_batch(audio, batch_size=per_pass)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = pred.predict_batch(audio, batch_size=32)
+        res = pred.predict_batch(audio, batch_size=per_pass)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     total = float(lens.sum()) / 16000.0
@@ -603,8 +608,8 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
     cnt = torch.cat([pred.beam_search_decoder._candidates(probs[j, :nenc[j]], to_host=False)[2] for j in range(4)])
     cand_mean = float(cnt.float().mean())
     pred.predictor.engine.close()
-    return {'workload': f'configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s), two '
-                        f'length buckets of 32, ctc_beam_search beam 300 / top-n 40, '
+    return {'workload': f'configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s), '
+                        f'{-(-64 // per_pass)} length buckets of {per_pass}, ctc_beam_search beam 300 / top-n 40, '
                         + ('alpha 2.2 beta 4.3 with a synthetic 3-gram WORD LM: prefix search on %d host threads' % conf['num_processes']
                            if lm and word_lm else
                            'alpha 2.2 beta 4.3 with a synthetic 3-gram character LM scored on the GPU' if lm else 'LM-free'),

@@ -164,13 +164,27 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     float* lv_bo = reinterpret_cast<float*>(lv_ctx + 2 * beam);          // [2][beam][4] backoffs of the context's suffixes
     int* lv_m = reinterpret_cast<int*>(lv_bo + 8 * beam);                // [2][beam] m | oov << 8
     // (the scorer's 14 words per live prefix exist only when a language model is bound: an LM-free beam 500 x 40 fits without them)
-    int* c_idx = use_lm ? lv_m + 2 * beam : reinterpret_cast<int*>(lv_ctx);   // [BS_KMAX]; bit 30 set = unknown to the language model
+    int* pu = lv_m + 2 * beam;                                           // [beam] row of the per-frame scorer table of the prefix's context, or -1
+    int* c_idx = use_lm ? pu + beam + (beam & 1) : reinterpret_cast<int*>(lv_ctx);   // [BS_KMAX]; bit 30 set = unknown to the language model
+                                                                         // (+ beam & 1: the histogram area behind it holds 64-bit keys)
     float* c_lp = reinterpret_cast<float*>(c_idx + BS_KMAX);             // [BS_KMAX]
     float* c_uni = c_lp + BS_KMAX;                                       // [BS_KMAX] ln P_LM(candidate) (unigram), per frame
     int* hist = reinterpret_cast<int*>(c_uni + BS_KMAX);                 // [7][256]: one per radix pass of a step
     int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
     int* misc = wsum + (6 + NPT) * BS_WAVES;                                         // [8]: 0 blank_k, 1 sel_bin, 2 need
     unsigned short* slist = reinterpret_cast<unsigned short*>(misc + 8);  // [beam * K] surviving extension entries
+    // Scorer table of the frame (use_lm): ln P_LM(c | context) depends on the prefix only through its EFFECTIVE context -- the m most
+    // recent words, m = length of the longest suffix that exists in the model -- so the live prefixes' contexts are deduplicated
+    // (LDS hash in the histogram area, which the selection phases only need later and which is cleared again behind the extension
+    // phase) and every (distinct context, candidate) pair is probed ONCE into lmtab (the survivor list's area, idle until the
+    // selection): the 12 000 probes of a frame at beam 300 x 40 candidates become (#contexts x 40).  The values are the ones
+    // lm_cond_desc returns for any prefix of that context: identical scores.  masr_debug key 32 = 0 probes per pair (A/B).
+    unsigned long long* ckey = reinterpret_cast<unsigned long long*>(hist);       // [512] effective-context keys (0 = free)
+    int* cuid = hist + 2 * 512;                                                   // [512] table row of the slot's context
+    int* urep = cuid + 512;                                                       // [<= 256] a live prefix that has the context
+    float* lmtab = reinterpret_cast<float*>(slist);                               // [ucap][cnt]
+    const int ucap = min(256, (beam * K / 2) / max(K, 1));
+    const bool lm_cache = use_lm && a.lm_cache != 0;
 
     int* pool_parent = a.pool_parent + (size_t)u * a.pool_cap;
     int* pool_ch = a.pool_ch + (size_t)u * a.pool_cap;
@@ -251,6 +265,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 misc[0] = bm ? __ffsll((long long)bm) - 1 : -1;
                 misc[3] = (int)0xFFFFFFFFu;                  // min over the live prefixes' score keys (phase 1)
                 misc[4] = __float_as_int(nx_blp);
+                misc[5] = 0;                                 // distinct effective scorer contexts of this frame
             }
         }
         if (t + 1 < T) {
@@ -266,6 +281,29 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
             while (atomicCAS(&hkey[h], 0ull, key) != 0ull) h = (h + 1) & (BS_HASH - 1);
             hval[h] = tid;
+        }
+        unsigned long long my_ek = 0ull;                 // effective scorer context of live prefix tid (0: not cached)
+        if (lm_cache && tid < n) {
+            const int mo = lv_m[o + tid], m = mo & 255;
+            const unsigned long long ctx = lv_ctx[o + tid];
+            if (!(mo >> 8) && m >= 1) {                  // (an OOV context scores a constant, m = 0 the unigram: no probes either way)
+                if (m < 4) my_ek = (ctx & ((1ull << (16 * m)) - 1ull)) | ((unsigned long long)m << 60);
+                else if (!((ctx >> 48) == 0x1000ull || (ctx >> 48) == 0x2000ull || (ctx >> 48) == 0x3000ull)) my_ek = ctx;
+            }
+            if (my_ek != 0ull) {
+                unsigned h = (unsigned)((my_ek * 0x9E3779B97F4A7C15ull) >> 55);        // 9 bits
+                while (true) {
+                    const unsigned long long old = atomicCAS(&ckey[h], 0ull, my_ek);
+                    if (old == 0ull) {                   // first prefix with this context: it owns the table row
+                        const int uid = atomicAdd(&misc[5], 1);
+                        cuid[h] = uid < ucap ? uid : -1;
+                        if (uid < ucap) urep[uid] = tid;
+                        break;
+                    }
+                    if (old == my_ek) break;
+                    h = (h + 1) & 511;
+                }
+            }
         }
         const bool full_beam = cutting && n == beam;
         if (full_beam && tid < ((n + 63) & ~63)) {      // score of the worst live prefix: wave minimum, one LDS atomic per wave
@@ -295,6 +333,34 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             }
             if (par >= 0) next[tid] = atomicExch(&head[par], tid);
         }
+        if (lm_cache) {
+            if (tid < n) {                               // my context's table row
+                int row = -1;
+                if (my_ek != 0ull) {
+                    unsigned h = (unsigned)((my_ek * 0x9E3779B97F4A7C15ull) >> 55);
+                    while (ckey[h] != my_ek) h = (h + 1) & 511;
+                    row = cuid[h];
+                }
+                pu[tid] = row;
+            }
+            const int nu = min(misc[5], ucap);
+            for (int e = tid; e < nu * cnt; e += BS_THREADS) {
+                const int uq = e / cnt, k = e - uq * cnt;
+                const int craw = c_idx[k];
+                float v = LM_OOV_SCORE;
+                if (!(craw >> 30)) {
+                    const int p = urep[uq];
+                    LmState sp;
+                    sp.ctx = lv_ctx[o + p];
+                    sp.m = lv_m[o + p] & 255;
+                    sp.oov = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sp.bo[j] = lv_bo[4 * (o + p) + j];
+                    v = lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, sp, craw, c_uni[k]);
+                }
+                lmtab[e] = v;
+            }
+        }
         __syncthreads();
         BS_TICK(0);
         // ---- 2. extensions (p, c): G threads per prefix, each a strided set of candidates ------------------------
@@ -310,6 +376,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) sp.bo[j] = lv_bo[4 * (o + my_p) + j];
             }
+            const int my_row = lm_cache ? pu[my_p] : -1;
             for (int k = my_g; k < cnt; k += G) {
                 const int craw = c_idx[k];
                 const int c = craw & ~(1 << 30);
@@ -325,6 +392,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                     // the external scorer: every way into the prefix p + c carries the same alpha * ln P_LM + beta
                     if (use_lm && val > -INFINITY) {
                         const float lmp = (sp.oov || (craw >> 30)) ? LM_OOV_SCORE
+                                          : my_row >= 0            ? lmtab[my_row * cnt + k]
                                                                    : lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, sp, c, c_uni[k]);
                         val += a.alpha * lmp + a.beta;
                     }
@@ -338,6 +406,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             }
         }
         __syncthreads();
+        if (lm_cache) {                                  // the context hash lived in the histogram area: clear it for the selection
+            for (int i = tid; i < 7 * 256; i += BS_THREADS) hist[i] = 0;      // (visible behind the block scan's barrier below)
+        }
         BS_TICK(1);
         // ---- 3. the prefixes themselves; this thread's strided sample of the extension keys -------------------------
         unsigned kex = 0;
@@ -560,7 +631,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 }
 
 size_t beam_gpu_lds_bytes(int beam, int K, bool use_lm) {
-    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 14 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 3 * BS_KMAX * 4 + 7 * 256 * 4 +
+    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 15 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 3 * BS_KMAX * 4 + 7 * 256 * 4 +
            (6 + 32) * BS_WAVES * 4 + 8 * 4 + 128;
 }
 

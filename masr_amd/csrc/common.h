@@ -272,6 +272,7 @@ struct BeamGpuArgs {
     int use_lm;
     LmView lm;             // table / known in the memory of the launch device
     float alpha, beta;
+    int lm_cache;          // 1: one scorer probe per (distinct effective context, candidate) and frame; 0: one per (prefix, candidate)
 };
 // per-utterance search state in HBM: [3 * beam] u64 | [2 + 3 * beam] int | [7 * beam] float
 inline size_t beam_state_bytes(int beam) { return (size_t)3 * beam * 8 + (size_t)(2 + 3 * beam) * 4 + (size_t)7 * beam * 4 + 8; }

@@ -1703,8 +1703,10 @@ int masr_ctc_topk_blank(masr_engine* e, const float* probs_dev, int32_t M, int32
     return 0;
 }
 
+static int g_beam_lm_cache = 1;    // masr_debug_set key 32: 0 = the GPU prefix search probes the scorer once per (prefix, candidate) pair (A/B)
 static int bind_lm(BeamGpuArgs& a, masr_lm* lm, float alpha, float beta) {
     a.use_lm = 0;
+    a.lm_cache = g_beam_lm_cache;
     a.alpha = alpha;
     a.beta = beta;
     if (!lm) return 0;
@@ -2635,6 +2637,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 29) g_few_rows_path = value;
     else if (key == 30) g_split_head = value;
     else if (key == 31) g_efficient_fused = value;
+    else if (key == 32) g_beam_lm_cache = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

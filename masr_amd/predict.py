@@ -165,7 +165,7 @@ class MASRPredictor:
         dt = torch.int16 if as_pcm else torch.float32
         n_max = int(n.max())
         need = len(segs) * n_max
-        ring = self._stage.setdefault(dt, {'bufs': [None] * 2, 'events': [None] * 2, 'turn': 0, 'lens': [None] * 2})
+        ring = self._stage.setdefault(dt, {'bufs': [None] * 2, 'events': [None] * 2, 'turn': 0, 'lens': [None] * 2})      # (a buffer's upload is complete long before the pass that staged it ends)
         k = ring['turn']
         ring['turn'] = k ^ 1
         if ring['events'][k] is not None:
@@ -279,13 +279,16 @@ class MASRPredictor:
                     out[i] = r if as_tokens else {'text': r[1], 'score': r[0]}
                 return out
             if defer and dec.use_gpu_search and dec.gpu_search_supported(probs.shape[1], probs.shape[2]):
-                # two side streams take turns: the searches of consecutive passes (one workgroup per utterance each) run next
+                # side streams take turns: the searches of consecutive passes (one workgroup per utterance each) run next
                 # to each other, not one behind the other
                 main = torch.cuda.current_stream()
+                # (two, not one per pass in flight: with four side streams next to the main and the preparation stream the
+                #  streams alias onto hardware queues and an encoder ends up queued behind a 20 ms search -- measured on
+                #  configs[2]: 50.1 vs 46.6 ms per call at passes of 32, 44.2 vs 27.2 ms with a sharpened head at passes of 16)
                 if getattr(self, '_sides', None) is None:
-                    self._sides, self._side_turn = [torch.cuda.Stream(), torch.cuda.Stream()], 0
+                    self._sides, self._side_turn = [torch.cuda.Stream() for _ in range(2)], 0
                 side = self._sides[self._side_turn]
-                self._side_turn ^= 1
+                self._side_turn = (self._side_turn + 1) % len(self._sides)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     pending = dec._batch(seqs, defer=True)
@@ -357,7 +360,7 @@ class MASRPredictor:
         pass k is launched (its prefix search on a side stream), then pass k - 1 is collected and its audio dropped."""
         order = sorted(which, key=lambda i: hints[i]) if batch_size else list(which)
         step = batch_size if batch_size else max(len(order), 1)
-        got, prev = {}, None
+        got, pending = {}, []
 
         def collect(item):
             idx, fetch = item
@@ -368,19 +371,23 @@ class MASRPredictor:
         # the longest utterance is the critical path of the call) then starts right after the first encoder pass and the
         # shorter passes' encoders and searches run underneath it
         starts = list(range(0, len(order), step))
+        depth = 2
         if self.configs.decoder == 'ctc_beam_search' and getattr(self.beam_search_decoder, 'use_gpu_search', False):
             starts.reverse()
+            # a prefix search is a long serial kernel on a few CUs (one workgroup per utterance, frames in sequence): the encoders
+            # of up to three further passes are launched underneath it before its results are waited for
+            depth = 4
         for lo in starts:
             idx = order[lo:lo + step]
             segs = [self._load_audio(audio_list[i], sample_rate) for i in idx]
-            # (beam search: the prefix search of this pass runs on a side stream under the encoder of the next pass)
-            cur = (idx, self._predict_local(segs, decode_all_frames, as_tokens, defer=True))
+            # (beam search: the prefix search of this pass runs on a side stream under the encoders of the next passes)
+            pending.append((idx, self._predict_local(segs, decode_all_frames, as_tokens, defer=True)))
             del segs
-            if prev is not None:
-                collect(prev)
-            prev = cur
-        if prev is not None:
-            collect(prev)
+            if len(pending) >= depth:
+                collect(pending.pop(0))
+        if pending:
+            for item in pending:
+                collect(item)
             for side in getattr(self, '_sides', None) or []:
                 torch.cuda.current_stream().wait_stream(side)
         return [got[i] for i in which]

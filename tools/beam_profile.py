@@ -1,6 +1,6 @@
 """Phase breakdown (cycles of workgroup 0) of the GPU CTC prefix beam search on flat posteriors (worst case: every
 frame keeps cutoff_top_n candidates), without and with the external n-gram scorer.
-usage: python tools/beam_profile.py [T] [V] [beam] [lm_order (0 = no LM)] [prune (1)]"""
+usage: python tools/beam_profile.py [T] [V] [beam] [lm_order (0 = no LM)] [prune (1)] [lm_cache (1: one scorer probe per distinct context and candidate; 0: per pair)]"""
 import os
 import sys
 import tempfile
@@ -30,12 +30,20 @@ if order:
 dec = BeamSearchDecoder(2.2 if order else 0, 4.3 if order else 0, beam, 0.99, 40, vocab, **kw)
 dec.prune_min_cutoff = bool(prune)
 eng = runtime.aux_engine()
-dec._batch([probs[i] for i in range(8)])
+cache = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+eng.lib.masr_debug_set(eng.h, 32, cache)
+ref = dec._batch([probs[i] for i in range(8)])
+if cache and order:                    # the table must not change a score: same transcripts and scores as per-pair probing
+    eng.lib.masr_debug_set(eng.h, 32, 0)
+    base = dec._batch([probs[i] for i in range(8)])
+    eng.lib.masr_debug_set(eng.h, 32, 1)
+    assert base == ref, 'scorer table changed the search result'
+    print('identical transcripts and scores with and without the per-frame scorer table')
 torch.cuda.synchronize()
 eng.lib.masr_debug_set(eng.h, 2, 1)
 t0 = time.perf_counter()
 dec._batch([probs[i] for i in range(8)])
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f'batch of 8 x {T} frames, LM order {order}: {1e3 * dt:.2f} ms  ({1e6 * dt / T:.1f} us per frame step incl. pruning)')
+print(f'batch of 8 x {T} frames, LM order {order}, scorer table {cache}: {1e3 * dt:.2f} ms  ({1e6 * dt / T:.1f} us per frame step incl. pruning)')
 eng.lib.masr_debug_set(eng.h, 2, 0)
