@@ -78,6 +78,7 @@ struct GemmArgs {
 };
 
 void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s);
+void set_conv2_mid_fill(int pct);     // diagnostics (masr_debug_set key 33)
 void set_gemm_waves(int n);          // diagnostics (masr_debug_set key 17): waves per workgroup of the large conv2 launch, 8 (default) or 4
 // deep-K, few-row GEMM: split K over workgroups into `partial` [nsplit][M][N], then reduce + epilogue into a.C
 void launch_gemm_splitk(const GemmArgs& a, float* partial, int nsplit, hipStream_t s, int amode = A_PLAIN);

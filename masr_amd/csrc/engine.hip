@@ -2638,6 +2638,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 30) g_split_head = value;
     else if (key == 31) g_efficient_fused = value;
     else if (key == 32) g_beam_lm_cache = value;
+    else if (key == 33) set_conv2_mid_fill(value);
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

@@ -211,6 +211,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
 // waves per workgroup of the conv2 implicit GEMM on 128x128 tiles: 8 (default) or 4 (masr_debug_set key 17).  In one kernel
 // trace with both shapes alternating (tools/gemm_waves_trace.py): 1 467 vs 1 486 us on average, 1 437 vs 1 480 us at best.
 static int g_gemm_waves = 8;
+static int g_conv2_mid_fill = 50;     // 128 streams: 3.26 -> 3.19 ms per chunk call (tools/chunk_lat.py MASR_AB=33:0,33:50)
+void set_conv2_mid_fill(int pct) { g_conv2_mid_fill = pct; }
 void set_gemm_waves(int n) { g_gemm_waves = n; }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
@@ -246,7 +248,15 @@ void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s) {
     }
     if (amode == A_CONV2) {
         // few output rows (streaming chunk steps): 64x64 tiles so that the grid still covers the chip
-        if ((long)((a.M + 127) / 128) * ((a.N + 127) / 128) < 200) launch_t<64, 64, 2, 2, A_CONV2, EPI_STD>(a, s);
+        const long t128c = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        // mid sizes (the 128-stream chunk step: 608 tiles of 128x128 on 512 resident slots = two rounds, the second at 19 %):
+        // 128x64 tiles (four waves, the tile count doubles) when the last round of the 128x128 grid would be under g_conv2_mid_fill
+        // percent full (masr_debug_set key 33; 0 = never)
+        const long rounds = (t128c + 511) / 512;
+        const bool thin_tail = g_conv2_mid_fill > 0 && t128c >= 200 && t128c <= 1024 &&
+                               (t128c - (rounds - 1) * 512) * 100 < (long)g_conv2_mid_fill * 512;
+        if (t128c < 200) launch_t<64, 64, 2, 2, A_CONV2, EPI_STD>(a, s);
+        else if (thin_tail) launch_t<64, 128, 2, 2, A_CONV2, EPI_STD>(a, s);
         // 8 waves (2 x 4 grid, 64 x 32 per wave) on the 128x128 tile: two workgroups per CU = four waves per SIMD cover each
         // other's slab barriers; 1 494 -> 1 457 us at B = 32 x 10 s by HIP events.  (4 x 2 grid: 1 488 us; 16 waves as a 4 x 4 grid: 1 624 us; 128x256 /
         // 256x128 tiles with 8 waves, one workgroup per CU: 1 540 us.)

@@ -19,6 +19,8 @@
 // Same arithmetic as rowgemm.hip (v_mfma_f32_32x32x2_f32, fp32 throughout); only the order of the K summation differs.
 // References: conformer/attention.py:53-79 (QKV), encoder.py:123-145 (out-projection / residual),
 //             convolution.py:117-119,128 (pointwise_conv1 + GLU, pointwise_conv2), encoder.py:404-419 (cache append).
+#include <algorithm>
+
 #include "common.h"
 
 namespace masr {
@@ -346,7 +348,11 @@ static int g_small_blocks = 112;
 void set_rowgemm_small_blocks(int n) { g_small_blocks = n; }
 int rowgemm_small_blocks() { return g_small_blocks; }
 bool launch_rowgemm_small(const RowGemmArgs& a, int pro, int epi, hipStream_t s) {
-    if (a.M <= 0 || a.M >= g_small_blocks * 32) return false;
+    // (the streaming conv module's fused prologues exist only here: where this kernel declines, the caller runs an extra launch in
+    //  front of the row-block kernel -- 128 streams = 120 padded row blocks of pointwise_conv1: 3.26 -> 3.18 ms per chunk call with
+    //  the limit at 160 for those two prologues, tools/chunk_lat.py MASR_AB=12:112,12:128)
+    const int limit = (pro == RG_PRO_HIST || pro == RG_PRO_DWCONV) ? std::max(g_small_blocks, 160) : g_small_blocks;
+    if (a.M <= 0 || a.M >= limit * 32) return false;
     if (epi == RG_EPI_GLU ? a.N != 512 : (a.N % 64) != 0) return false;
     if (pro == RG_PRO_AFFINE && a.lens && a.seq_t > 0) return false;       // pad masking in the prologue: big kernel only
     if (pro == RG_PRO_LN && epi == RG_EPI_STORE) launch_rs<RG_PRO_LN, RG_EPI_STORE>(a, s);
