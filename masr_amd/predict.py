@@ -320,13 +320,19 @@ class MASRPredictor:
             pass
         return self._load_audio(audio_data, sample_rate).num_samples        # file objects and anything odd: decode
 
+    def pass_size(self):
+        """utterances of ~10 s per device pass that fill the chip for this model family: 32 are 248 row blocks of 32 for 256 CUs;
+        the Efficient-Conformer runs at half the frame rate behind its stride layer, where it takes 64"""
+        return 64 if self.configs.use_model == 'efficient_conformer' else 32
+
     def predict_batch(self, audio_list, sample_rate=16000, decode_all_frames=False, batch_size=0, distributed=None,
                       lengths=None):
         """Batched offline path (an addition; the reference's only batched consumer is MASRTrainer.evaluate,
         trainer.py:592-651): a list of utterances -> [{'text','score'}] in input order.
 
         ``decode_all_frames=True`` reproduces the reference's batch evaluation quirk of decoding padded frames
-        (trainer.py:340).  ``batch_size`` > 0 cuts the (length-sorted) work into device passes of that many utterances; the
+        (trainer.py:340).  ``batch_size`` > 0 cuts the (length-sorted) work into device passes of that many utterances
+        (``batch_size='auto'``: ``pass_size()`` -- 32, or 64 for the Efficient-Conformer); the
         audio of a pass is decoded when the pass is formed and dropped when its results are in, at most two passes are in
         flight (features + encoder of pass k under the prefix search of pass k - 1), so host memory and HBM hold two passes
         whatever the list's length.  ``lengths`` (samples or seconds, any common unit): known durations, e.g. a manifest's,
@@ -335,6 +341,8 @@ class MASRPredictor:
         are dealt out length-balanced over the ranks -- every rank must call with the same list -- each rank decodes ONLY
         its shard on its own GPU and ONE all-gather of the token ids returns all hypotheses to every rank."""
         hints = list(lengths) if lengths is not None else [self._length_hint(a, sample_rate) for a in audio_list]
+        if batch_size == 'auto':
+            batch_size = self.pass_size()
         rank, world = parallel.world_info()
         if distributed is None:
             distributed = world > 1
@@ -392,7 +400,7 @@ class MASRPredictor:
                 torch.cuda.current_stream().wait_stream(side)
         return [got[i] for i in which]
 
-    def evaluate(self, manifest, batch_size=32, display_result=False, decode_all_frames=False):
+    def evaluate(self, manifest, batch_size='auto', display_result=False, decode_all_frames=False):
         """Batched offline evaluation on the engine (the reference's batch > 1 consumer: MASRTrainer.evaluate,
         trainer.py:592-651): ``manifest`` is the reference's txt manifest (one JSON object per line with ``audio_filepath``
         and ``text``, data_utils/reader.py:32-40,55), utterances are sorted by duration, padded per batch and decoded with

@@ -472,6 +472,21 @@ def test_stream_pool_equals_independent_predict_stream(predictor):
         for i, h in enumerate(hs):
             if h in out:
                 got[i].append(out[h])
+        # the device rows a multi-GPU front-end all-gathers (zero-copy view of the C pool's buffer): tokens | count | score bits of
+        # exactly the sessions that advanced, equal to what the step returned on the host
+        packed = pool.last_packed
+        advanced = [h for h in hs if out.get(h) is not None]
+        if advanced:
+            rows_dev, tmax, sids = packed
+            assert rows_dev.is_cuda and list(sids) == advanced and tuple(rows_dev.shape) == (len(advanced), tmax + 2)
+            rows_h = rows_dev.cpu().numpy()
+            for j, h in enumerate(sids):
+                nt = int(rows_h[j, tmax])
+                assert rows_h[j, :nt].tolist() == pool.last_tokens(h)
+                score = float(rows_h[j, tmax + 1:tmax + 2].view(np.float32)[0]) * 100.0 if nt > 0 else 0
+                assert abs(score - out[h]['score']) < 1e-6
+        else:
+            assert packed is None
     for i in range(len(audios)):
         assert len(got[i]) == len(want[i])
         for g_, w_ in zip(got[i], want[i]):
