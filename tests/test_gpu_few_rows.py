@@ -90,3 +90,37 @@ def test_chunk_steps_with_the_head_stage_on_the_split_ffn_launch():
     finally:
         eng.lib.masr_debug_set(eng.h, 30, 0)
         eng.close()
+
+
+@pytest.mark.parametrize('B,Tp', [(8, 444), (8, 448), (8, 452), (16, 318), (16, 320), (16, 322), (16, 382), (16, 384), (16, 386),
+                                  (32, 255), (32, 256), (32, 257)])
+def test_row_block_thresholds_against_oracle(B, Tp):
+    """The launch paths switch on the number of 32-row blocks: 112 (K-split projections / latency-cut layer), 160 (fused CTC
+    head), 192 (d_ff-split FFN, tail / chain / head fusions), 256 (one round of workgroups).  Batches whose row-block count is
+    just below, at and just above each threshold, ragged, against the oracle (encoder output 1e-3, greedy decisions where the
+    oracle's top-2 margin is decided)."""
+    from oracle import conformer as oc
+    eng, sd = _engine(True)
+    T = 4 * Tp + 3
+    gen = torch.Generator().manual_seed(B * 7 + Tp)
+    feats = torch.randn(B, T, 80, generator=gen) * 3 + 13
+    lens = torch.full((B,), T, dtype=torch.int64)
+    lens[1::2] = torch.randint(T // 2, T + 1, (len(lens[1::2]),), generator=gen)
+    feats = feats * (torch.arange(T)[None, :, None] < lens[:, None, None])
+    with torch.no_grad():
+        ref = oc.encoder_full(sd, feats, lens, -1)
+        probs = torch.softmax(torch.nn.functional.linear(ref, sd['ctc.ctc_lo.weight'], sd['ctc.ctc_lo.bias']), dim=-1)
+    try:
+        enc = eng.encode_full(feats.cuda(), lens.to(torch.int32).cuda(), -1)
+        idx, mp = eng.ctc_greedy_frames(enc)
+        enc, idx = enc.cpu(), idx.cpu()
+    finally:
+        eng.close()
+    assert ref.shape[1] == Tp
+    keep = torch.arange(Tp)[None, :] < eng.enc_frames(lens)[:, None]
+    err = ((enc - ref).abs() * keep[:, :, None]).max().item()
+    print(f'B = {B}, T\' = {Tp}: {(B * Tp + 31) // 32} row blocks, max |enc - oracle| = {err:.3e}')
+    assert err < 1e-3
+    top2 = probs.topk(2, dim=-1).values
+    safe = ((top2[..., 0] - top2[..., 1]) > 2e-3) & keep
+    assert (idx == probs.argmax(-1))[safe].all()
