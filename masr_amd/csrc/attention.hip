@@ -528,6 +528,308 @@ void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q
                            kv_stride, ptab, bias_u, bias_v, chunk_size, pos_stride, 0, heads, nseq);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 4: attention + [out-projection + residual -> LayerNorm -> pointwise_conv1 -> GLU] of an offline Conformer layer in ONE
+// kernel (conformer/attention.py:190-251 + encoder.py:123-131 + convolution.py:98-119).  One workgroup = 32 queries of one
+// sequence x ALL FOUR heads, so that the [32, 256] context rows the out-projection contracts over never leave the CU:
+//   attention phase   wave w = (head w & 3, key parity w >> 2): the scheme of attention_kernel<FOLD = 1> per head -- folded
+//                     positional keys, transposed scores, online softmax in registers, even / odd key tiles merged at the end --
+//                     with the K' / V tiles of all four heads staged per tile pair (16 lanes per (key row, head): the same
+//                     partial sums of the folded constant in the same order); the merged, normalised context goes into an LDS
+//                     tile [32][256] instead of HBM;
+//   chain phase       rowgemm EPI_CHAIN's three weight tiles on that tile (packed [Wo; W_pw1] fragments through buffer loads):
+//                     x <- x + ctx . Wo^T + bo (to HBM and into a second LDS tile), LayerNorm + pad mask in place, pointwise_conv1,
+//                     GLU -> the conv module's padded GLU buffer.
+// Same operations in the same order as attention_kernel<1> followed by rowgemm_kernel<PLAIN, CHAIN, 0, 1>: bit-identical
+// (tests/test_gpu_few_rows.py).  Why: both of those are short kernels whose prologue / staging / epilogue cost as much as their
+// matrix work (0.38 and 0.49 matrix-pipe busy at B = 32 x 10 s) and the att [M, 256] round trip sits between them.
+// masr_debug_set key 34 = 0 keeps the two launches.
+// ------------------------------------------------------------------------------------------------------------------
+static constexpr int AC_LD = 68;                      // K' / V tile rows (floats)
+static constexpr int AC_TILE = 4 * 32 * AC_LD;        // one key tile, four heads
+static constexpr int AC_ALD = 256 + 4;                // context / LayerNorm tiles
+static constexpr int AC_LDS_FLOATS = 4 * AC_TILE + 2 * 4 * 32 + 64;
+
+__global__ __launch_bounds__(512) void attn_chain_kernel(AttnChainArgs p) {
+    extern __shared__ __align__(16) float acs[];
+    float* Ks = acs;                         // [2 tiles][4 heads][32][68]
+    float* Vs = Ks + 2 * AC_TILE;            // [2 tiles][4 heads][32][68]
+    float* Cs = Vs + 2 * AC_TILE;            // [2 tiles][4 heads][32] folded per-key constants
+    // workgroup -> (sequence, query block): ids go round-robin over the 8 XCDs; the query blocks of a sequence take consecutive
+    // slots of ONE XCD, whose L2 then serves that sequence's keys / values to all of them
+    const int id = blockIdx.x, xcd = id & 7, kslot = id >> 3;
+    const int qb = kslot % p.nqb, seq = xcd + 8 * (kslot / p.nqb);
+    if (seq >= p.nseq) return;
+    const AttSeq sq = p.seqs[seq];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = wave & 3, kh = wave >> 2;
+    const int q0 = qb * 32;
+    if (q0 >= sq.nq) return;                 // whole workgroup
+    const int qi = q0 + (lane & 31);
+    const int h = lane >> 5;
+    const bool q_ok = qi < sq.nq;
+    const int q_abs = sq.q_abs0 + (q_ok ? qi : sq.nq - 1);
+
+    f32x4 qu[8];
+    {
+        const float* qrow = sq.q + (size_t)(q_ok ? qi : sq.nq - 1) * p.q_stride + head * DK;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(qrow + 8 * g + 4 * h);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) qu[g][x] = q[x] * 0.125f;
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    int jlim = sq.klen;
+    if (p.chunk_size > 0) jlim = min(jlim, (((q_abs * p.pos_stride) / p.chunk_size + 1) * p.chunk_size + p.pos_stride - 1) / p.pos_stride);
+    const int ntile = (sq.nk + 31) / 32;
+    const int npair = (ntile + 1) / 2;
+    // staging: wave w moves key rows w, w + 8, ... of the tile pair; lane = (head lane >> 4, dims 4 (lane & 15) ..)
+    const int shead = lane >> 4, sc4 = (lane & 15) * 4;
+    f32x4 su, sv;
+    {
+        su = *reinterpret_cast<const f32x4*>(p.bias_u + shead * DK + sc4);
+        sv = *reinterpret_cast<const f32x4*>(p.bias_v + shead * DK + sc4);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { su[x] *= 0.125f; sv[x] *= 0.125f; }
+    }
+    const unsigned kv_row_bytes = (unsigned)p.kv_stride * 4u, p_row_bytes = (unsigned)p.pos_stride * 1024u;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sq.k), 0, (unsigned)sq.nk * kv_row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sq.v), 0, (unsigned)sq.nk * kv_row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ptab + (size_t)sq.pos0 * 256), 0,
+                                                                         (unsigned)sq.nk * p_row_bytes, 0x00020000);
+    const unsigned lane_off = (unsigned)lane * 16u;                      // 16 bytes per lane: the 256 floats of a key row
+    f32x4 pk[8], pp[8], pv[8];
+    auto fetch = [&](int kp) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned j = (unsigned)(kp * 64 + wave + 8 * i);       // wave-uniform key row (past the end: reads zero)
+            pk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, lane_off, j * kv_row_bytes, 0));
+            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, lane_off, j * kv_row_bytes, 0));
+            pp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, lane_off, j * p_row_bytes, 0));
+        }
+    };
+    fetch(0);
+    for (int kp = 0; kp < npair; ++kp) {
+        const int j0 = (2 * kp + kh) * 32;     // first key of this wave's tile
+        __syncthreads();   // previous pair fully consumed
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r64 = wave + 8 * i, tl = r64 >> 5, r = r64 & 31;
+            float c = 0.f;
+            f32x4 kp4;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                c = fmaf(su[x], pk[i][x], c);
+                c = fmaf(sv[x], pp[i][x], c);
+                kp4[x] = pk[i][x] + pp[i][x];
+            }
+            c = att_sum16(c);
+            float* base = Ks + tl * AC_TILE + (shead * 32 + r) * AC_LD + sc4;
+            *reinterpret_cast<f32x4*>(base) = kp4;
+            *reinterpret_cast<f32x4*>(base + 2 * AC_TILE) = pv[i];       // Vs = Ks + 2 tiles
+            if ((lane & 15) == 0) Cs[(tl * 4 + shead) * 32 + r] = c;
+        }
+        __syncthreads();
+        if (kp + 1 < npair) fetch(kp + 1);
+        if (j0 >= sq.nk) continue;             // (wave-uniform) odd tile past the end
+
+        f32x16 st;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(&Cs[(kh * 4 + head) * 32 + 8 * rr + 4 * h]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st[4 * rr + q] = c4[q];
+        }
+        const float* kb = Ks + kh * AC_TILE + (head * 32 + (lane & 31)) * AC_LD + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(kb + 8 * g);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[x], qu[g][x], st, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (j >= jlim) st[r] = -INFINITY;
+            tmax = fmaxf(tmax, st[r]);
+        }
+        tmax = fmaxf(tmax, att_xor32(tmax, h));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float corr = __expf(m_run - m_safe);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = __expf(st[r] - m_safe);
+            psum += st[r];
+        }
+        psum += att_xor32(psum, h);
+        l_run = l_run * corr + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+        const float* vb = Vs + kh * AC_TILE + (head * 32 + 4 * h) * AC_LD + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow = (r & 3) + 8 * (r >> 2);
+            const float va = vb[krow * AC_LD];
+            const float vb2 = vb[krow * AC_LD + 32];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va, st[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb2, st[r], o1, 0, 0, 0);
+        }
+    }
+
+    // ---- chain operands that do not depend on the attention: requested now, they land under the merge --------------------
+    const int frow = lane & 31, fh = h;
+    const int row0 = seq * p.seq_t + q0;                    // first row of this block in the flat [B * T', 256] row space
+    const int nrow = min(32, sq.nq - q0);                   // valid rows of the block
+    const unsigned lane16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wp), 0, 3 * 256 * 256 * 4, 0x00020000);
+    auto pld = [&](int t, int j, int g) -> f32x4 {     // fragment (slab j, group g) of this wave's tile t (clamped past the end)
+        const unsigned fi = (unsigned)(((min(t, 2) * 8 + wave) * 8 + j) * 4 + g) * 256u;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, fi * 4u, 0));
+    };
+    f32x4 pre[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[k][g] = pld(0, k, g);
+    const f32x4 cgw = *reinterpret_cast<const f32x4*>(p.lnw + lane * 4);
+    const f32x4 cgb = *reinterpret_cast<const f32x4*>(p.lnb + lane * 4);
+    const float cbo = p.bias[wave * 32 + frow], cba = p.bias[256 + wave * 32 + frow], cbg = p.bias[512 + wave * 32 + frow];
+    float res0[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lr = min((r & 3) + 8 * (r >> 2) + 4 * fh, nrow - 1);
+        res0[r] = p.R[(size_t)(row0 + lr) * 256 + wave * 32 + frow];
+    }
+
+    // ---- merge the odd-tile state into the even-tile wave of the same head; context rows -> LDS tile -------------------------
+    __syncthreads();
+    float* mg = acs;                                         // [4 heads][34][64]  (K tiles: all consumed)
+    float* ctx = acs + 2 * AC_TILE;                          // [32][260]          (V tiles: all consumed)
+    static_assert(4 * 34 * 64 <= 2 * AC_TILE && 32 * AC_ALD <= 2 * AC_TILE, "merge buffer / context tile must fit the K / V tiles");
+    if (kh == 1) {
+        float* d = mg + (size_t)head * 34 * 64 + lane;
+        d[0] = m_run;
+        d[64] = l_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d[(2 + r) * 64] = o0[r]; d[(18 + r) * 64] = o1[r]; }
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const float* d = mg + (size_t)head * 34 * 64 + lane;
+        const float m1 = d[0], l1 = d[64];
+        const float m = fmaxf(m_run, m1);
+        const float ms = (m == -INFINITY) ? 0.f : m;
+        const float c0 = __expf(m_run - ms), c1 = __expf(m1 - ms);     // -inf -> 0
+        l_run = l_run * c0 + l1 * c1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] = o0[r] * c0 + d[(2 + r) * 64] * c1;
+            o1[r] = o1[r] * c0 + d[(18 + r) * 64] * c1;
+        }
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        float* crow = ctx + (lane & 31) * AC_ALD + head * DK;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int dd = 8 * rr + 4 * h;
+            f32x4 a, b;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { a[x] = o0[rr * 4 + x] * inv; b[x] = o1[rr * 4 + x] * inv; }
+            if (!q_ok) { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+            *reinterpret_cast<f32x4*>(crow + dd) = a;
+            *reinterpret_cast<f32x4*>(crow + 32 + dd) = b;
+        }
+    }
+    __syncthreads();                                         // context tile complete; the merge buffer is dead
+
+    // ---- chain phase: rowgemm EPI_CHAIN on the context tile (three weight tiles, wave w = output columns 32 w .. 32 w + 31) ----
+    float* red = acs;                                        // [32][260] second A tile (updated x rows, then their LayerNorm)
+    const float* aa = ctx + frow * AC_ALD + 4 * fh;
+    f32x16 accv;
+    for (int t = 0; t < 3; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x4 a[2];
+            a[0] = *reinterpret_cast<const f32x4*>(aa + j * 32);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(aa + j * 32 + 8 * (g + 1));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q], pre[j % 4][g][q], acc, 0, 0, 0);
+                    if (q == 3) pre[j % 4][g] = pld(t + (j + 4) / 8, (j + 4) & 7, g);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        const int ch = wave * 32 + frow;
+        if (t == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float v = res0[r] + (acc[r] + cbo);
+                if (lr < nrow) p.R2[(size_t)(row0 + lr) * 256 + ch] = v;
+                red[lr * AC_ALD + ch] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int lr = wave * 4 + rr;
+                bool live = lr < nrow;
+                if (live && p.lens) live = p.mstride * (q0 + lr) < p.lens[seq];
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[lr * AC_ALD + lane * 4]);
+                const float mean = wave_sum_dpp(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                const float var = wave_sum_dpp(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + p.eps);
+                f32x4 o;
+                o[0] = d0 * rstd * cgw[0] + cgb[0];
+                o[1] = d1 * rstd * cgw[1] + cgb[1];
+                o[2] = d2 * rstd * cgw[2] + cgb[2];
+                o[3] = d3 * rstd * cgw[3] + cgb[3];
+                if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&red[lr * AC_ALD + lane * 4]) = o;
+            }
+            __syncthreads();
+            aa = red + frow * AC_ALD + 4 * fh;
+        } else if (t == 1) {
+            accv = acc;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (lr >= nrow) continue;
+                const size_t crow = (size_t)seq * (p.seq_t + p.out_pad_tot) + p.out_pad_l + q0 + lr;
+                const float g = acc[r] + cbg;
+                p.C[crow * 256 + ch] = (accv[r] + cba) * __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+            }
+        }
+    }
+}
+
+bool launch_attn_chain(const AttnChainArgs& a, int max_nq, hipStream_t s) {
+    if (a.nseq <= 0 || max_nq <= 0) return false;
+    AttnChainArgs b = a;
+    b.nqb = (max_nq + 31) / 32;
+    const size_t lds = (size_t)AC_LDS_FLOATS * sizeof(float);
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(attn_chain_kernel), lds, attr);
+    hipLaunchKernelGGL(attn_chain_kernel, dim3(8 * b.nqb * ((a.nseq + 7) / 8)), dim3(512), lds, s, b);
+    return true;
+}
+
 // Sequence descriptors for the full-context batch path: q/k/v interleaved in one [B*Tp, 768] buffer
 // (fused QKV projection), keys j valid iff mstride*j < len_b (subsampled pad mask, subsampling.py:112;
 // mstride = 8 between the Squeezeformer time reduction and recovery).

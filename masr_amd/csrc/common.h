@@ -304,6 +304,27 @@ struct AttSeq {            // one per sequence, device memory
     int q_abs0;            // absolute index of query 0 (for the chunk mask)
     int pad_;
 };
+// attention + [out-projection + residual -> LayerNorm -> pointwise_conv1 -> GLU] of an offline Conformer layer as ONE launch
+// (attention.hip attn_chain_kernel; d_model 256, 4 heads of 64): the arguments of launch_attention + those of the EPI_CHAIN rowgemm
+struct AttnChainArgs {
+    const AttSeq* seqs;        // [nseq]; q / k / v rows of sequence b, nq = nk = frames of the padded batch
+    int nseq, nqb;             // nqb (query blocks of 32 per sequence) is filled in by the launcher
+    int q_stride, kv_stride, chunk_size, pos_stride;
+    const float* ptab;         // [max_pos, 256] positional keys of the layer
+    const float* bias_u;       // [4][64]
+    const float* bias_v;
+    const float* Wp;           // [Wo; W_pw1] packed in fragment order (launch_pack_rows_pc, 768 rows)
+    const float* bias;         // [768]  bo | b_pw1 (value | gate)
+    const float* lnw;          // the conv module's LayerNorm
+    const float* lnb;
+    const float* R;            // residual stream in  [nseq * seq_t, 256]
+    float* R2;                 // residual stream out (may alias R)
+    float* C;                  // GLU output, padded layout [nseq][out_pad_tot + seq_t][256], real rows at out_pad_l
+    const int* lens;           // feature lengths for the pad mask, or nullptr
+    int seq_t, mstride, out_pad_l, out_pad_tot;
+    float eps;
+};
+bool launch_attn_chain(const AttnChainArgs& a, int max_nq, hipStream_t s);
 void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q_stride, int kv_stride,
                       const float* ptab /*[max_pos,256]*/, const float* bias_u, const float* bias_v,
                       int chunk_size, int pos_stride, hipStream_t s);

@@ -87,6 +87,13 @@ static int g_no_ffn_head = 0;     // masr_debug_set key 9: 1 = depthwise conv an
 // spread over 32 workgroups) cost.  Off by default; identical frame decisions either way.
 static int g_split_head = 0;
 static int g_efficient_fused = 1;   // masr_debug_set key 31: 0 = Efficient-Conformer layers keep separate out-proj / pw1 / dwconv / pw2 launches (A/B)
+// masr_debug_set key 34: 1 = offline Conformer layers run attention AND the [out-proj -> LN -> pw1 -> GLU] chain as ONE launch
+// (attention.hip attn_chain_kernel: 32 queries x all four heads per workgroup, context rows in LDS).  Built in round 4 (verdict
+// item 6, priced at -0.13 ms per step in round 3), bit-identical to the two launches -- and MEASURED no faster: 58.3 us per launch
+// against 25.9 + 32.7 us (rocprofv3, one trace), 6.428 vs 6.412 ms per 32 x 10 s pass (tools/attn_chain_ab.py): a workgroup that
+// owns 32 queries of all four heads stages four heads' K' / V tiles per 64 MFMAs per wave where attention_kernel's 128 queries of
+// one head stage one -- the saved prologue / epilogue / att round trip is paid back in staging.  Off by default.
+static int g_attn_chain = 0;
 static int g_few_rows_path = 1;   // masr_debug_set key 29: 0 = offline Conformer layers of few row blocks keep the row-block chain kernel (A/B)
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
@@ -1577,7 +1584,20 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2, 0.5f, 0, nullptr, nullptr, nullptr, &tail,
                 &qkv_done));
         if (!qkv_done) mhsa(e, s, w, M);
-        {
+        // attention and the chain kernel behind it as ONE launch (32 queries x all four heads per workgroup; key 34 = 0: two launches)
+        const bool fuse_ac = g_attn_chain && !few_rows && !g_no_chain && H == 4 && d == 256 && g_rowgemm_packed;
+        if (fuse_ac) {
+            AttnChainArgs a{};
+            a.seqs = e->attseq.as<AttSeq>(); a.nseq = B; a.q_stride = 3 * d; a.kv_stride = 3 * d;
+            a.chunk_size = (decoding_chunk_size > 0 && e->cfg.causal) ? decoding_chunk_size : 0; a.pos_stride = 1;
+            a.ptab = w.ptab; a.bias_u = w.pos_u; a.bias_v = w.pos_v;
+            a.Wp = packed_rows_of(e, w.chain_w, 3 * d, s); a.bias = w.chain_b; a.lnw = w.ln_conv_w; a.lnb = w.ln_conv_b;
+            a.R = x; a.R2 = x; a.C = e->glu.as<float>(); a.lens = feat_lens_dev; a.seq_t = Tq; a.mstride = 4;
+            a.out_pad_l = e->cfg.causal ? pad : pad / 2; a.out_pad_tot = pad; a.eps = 1e-5f;
+            if (!a.Wp) return fail("packed chain weights: allocation failed");
+            ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B + 2.0 * M * (double)(3 * d) * d);
+            launch_attn_chain(a, Tq, s);
+        } else {
             ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
             launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v,
                              (decoding_chunk_size > 0 && e->cfg.causal) ? decoding_chunk_size : 0, 1, s);   // use_dynamic_chunk only in the streaming build
@@ -1602,7 +1622,7 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
         } else {
             // out-projection + residual + LayerNorm + pointwise_conv1 + GLU in one kernel; the rest of the conv module
             // (depthwise conv, LayerNorm, SiLU, pointwise_conv2, residual) is the head stage of the second FFN kernel
-            mhsa_out_pw1(e, s, w, ctx);
+            if (!fuse_ac) mhsa_out_pw1(e, s, w, ctx);
             const FfnHead head{e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->cfg.causal ? w.gconst : nullptr,
                                w.pw2_w, w.pw2_b, feat_lens_dev, Tq, e->cfg.cnn_kernel, 4, nullptr};
             CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, nullptr, nullptr, nullptr, nullptr,
@@ -2639,6 +2659,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 31) g_efficient_fused = value;
     else if (key == 32) g_beam_lm_cache = value;
     else if (key == 33) set_conv2_mid_fill(value);
+    else if (key == 34) g_attn_chain = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

@@ -104,3 +104,35 @@ def test_packed_row_block_projections_are_bit_identical_to_the_slab_pipeline(kin
     for a, b in zip(out[0], out[1]):
         assert torch.equal(a, b)
     eng.close()
+
+
+@pytest.mark.parametrize('streaming,chunk', [(True, -1), (False, -1), (True, 16)])
+def test_attention_chain_kernel_is_bit_identical_to_the_two_launches(streaming, chunk):
+    """Round 4: attention + [out-projection + residual -> LN -> pointwise_conv1 -> GLU] as ONE launch (attn_chain_kernel: 32 queries
+    x all four heads per workgroup, the context rows stay in LDS) performs the operations of attention_kernel<1> and of the
+    EPI_CHAIN rowgemm in the same order: encoder output and probabilities BIT-identical with masr_debug_set key 34 on and off --
+    ragged batch (pad masks, a partial last query block per sequence), causal and symmetric conv builds, chunk-masked attention."""
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    V = 512
+    sd = synthetic.conformer_state_dict(0, V)
+    eng = HipEngine(sd, vocab_size=V, streaming=streaming)
+    rng = np.random.default_rng(7)
+    lens = rng.integers(60000, 160001, 32).astype(np.int32)
+    lens[0] = 160000
+    pcm = synthetic.synthetic_pcm(32, 160000, seed=13)
+    for i, l in enumerate(lens):
+        pcm[i, l:] = 0
+    feats, frames = eng.fbank_batch(torch.from_numpy(pcm).cuda(), torch.from_numpy(lens).cuda())
+    out = {}
+    try:
+        for v in (1, 0, 1):
+            eng.lib.masr_debug_set(eng.h, 34, v)
+            out[v] = eng.encode_full(feats, frames, chunk).clone()
+            out[('p', v)] = eng.ctc_probs(out[v]).clone()
+    finally:
+        eng.lib.masr_debug_set(eng.h, 34, 0)               # (the default: measured no faster than the two launches)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1]) and torch.equal(out[('p', 0)], out[('p', 1)])
+    assert float(out[1].abs().max()) > 0 and bool(torch.isfinite(out[1]).all())
+    eng.close()
