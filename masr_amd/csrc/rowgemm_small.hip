@@ -187,13 +187,18 @@ __global__ __launch_bounds__(512) void rowgemm_small_kernel(RowGemmArgs p) {
         f32x4 win[KMAX + 3], w[KMAX];
         f32x4 gc = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.gconst) gc = *reinterpret_cast<const f32x4*>(p.gconst + lane * 4);
+        // every window row is requested unconditionally, all loads in flight before the first use (a branch around a load makes
+        // hipcc wait for it on the spot: the chunk steps' launch went 11.4 -> 17 us with the select written as an if / else)
 #pragma unroll
         for (int j = 0; j < KMAX + 3; ++j)
-            if (j < KT + 3) {
-                // (offline causal conv: padded rows t + j < pad are the unmaterialised history = the constant glu(bias) row)
-                if (p.gconst && t + j < p.pad) win[j] = gc;
-                else win[j] = *reinterpret_cast<const f32x4*>(gin + (size_t)j * 256);
-            }
+            if (j < KT + 3) win[j] = *reinterpret_cast<const f32x4*>(gin + (size_t)j * 256);
+        if (p.gconst) {
+            // offline causal conv: padded rows t + j < pad are the unmaterialised history = the constant glu(bias) row (the
+            // buffer rows exist, whatever they hold is replaced)
+#pragma unroll
+            for (int j = 0; j < KMAX + 3; ++j)
+                if (j < KT + 3 && t + j < p.pad) win[j] = gc;
+        }
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
             if (j < KT) w[j] = *reinterpret_cast<const f32x4*>(p.dw_w + j * 256 + lane * 4);
