@@ -211,6 +211,11 @@ struct FfnTail {
     int N, ldo;
     const float* pre_lnw;      // optional: x <- LayerNorm(x; pre_lnw, pre_lnb) first, written back (the previous layer's norm_final,
     const float* pre_lnb;      // encoder.py:160-161, riding on this launch instead of its own)
+    // planar output (the Efficient Conformer's grouped attention: q | k | v planes [nseq][seq_t + pad_t][256], the time padding
+    // rows stay zero): plane_stride > 0 -> column tile c / 256 goes to plane c / 256, row (b, t) = divmod(row, seq_t) to row
+    // b * (seq_t + pad_t) + t of that plane (ffn_pc.hip only)
+    long plane_stride;
+    int seq_t, pad_t;
 };
 // head: the rest of the conv module in front of the block, on the workgroup's own 32 rows, before the block's LayerNorm:
 //   x <- x + mask(pointwise_conv2(SiLU(LayerNorm(depthwise_conv(glu)))))       (convolution.py:120-131, encoder.py:137-148)

@@ -1348,13 +1348,18 @@ static int encode_full_efficient(masr_engine* e, hipStream_t s, const float* fea
         // regular layers: LayerNorm + fused QKV projection ride on the first FFN kernel (tail stage), like the Conformer
         const FfnTail tail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, 3 * d, nullptr, nullptr};
         bool qkv_done = false;
+        // grouped layers: the same tail stage writes q | k | v PLANAR into the time-padded buffers of the grouped attention
+        // (round 4; ffn_pc.hip only -- the two-chain kernel keeps the separate projection)
+        const FfnTail gtail{w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, qp, 3 * d, d, nullptr, nullptr, (long)plane, Tq, Tpad - Tq};
+        const bool planar_tail = layer_grouped(e, i) && g_efficient_fused && !g_ffn_dual;
         CHK(ffn(e, s, M, w.ln_ffm_w, w.ln_ffm_b, w.ffm_w1, w.ffm_b1, w.ffm_w2, w.ffm_b2, 0.5f, 0, nullptr, nullptr, nullptr,
-                layer_grouped(e, i) ? nullptr : &tail, &qkv_done));
+                layer_grouped(e, i) ? (planar_tail ? &gtail : nullptr) : &tail, &qkv_done));
         if (layer_grouped(e, i)) {
             if (Tq != T0) return fail("grouped attention after the stride layer is not supported");
             // q | k | v -> planar, time-padded buffers; attention over T/3 positions with d_k' = 192
-            rowgemm(e, s, RG_PRO_LN, RG_EPI_STORE, x, d, w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, qp, d, M, 3 * d, nullptr,
-                    0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride, Tq, 0, Tpad - Tq, d, (long)plane);
+            if (!qkv_done)
+                rowgemm(e, s, RG_PRO_LN, RG_EPI_STORE, x, d, w.ln_mha_w, w.ln_mha_b, w.wqkv, w.bqkv, qp, d, M, 3 * d, nullptr,
+                        0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride, Tq, 0, Tpad - Tq, d, (long)plane);
             {
                 ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B / G);
                 launch_attention_grouped(seq_g, B, Tg, H, G, w.ptab, Tq, w.pos_u, w.pos_v, s, chunk);

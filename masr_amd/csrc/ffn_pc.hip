@@ -586,7 +586,17 @@ __global__ __launch_bounds__(512) void ffn_pc_kernel(float* x, const float* __re
                     }
                 }
             }
-            if (col < tail.N) {
+            if (col < tail.N && tail.plane_stride > 0) {
+                // planar q | k | v with per-sequence time padding (grouped attention): tile t IS plane t
+                float* plane = tail.out + (size_t)t * tail.plane_stride + wave * 32 + frow;
+                const int pb0 = row0 / tail.seq_t, pt0 = row0 - pb0 * tail.seq_t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const SeqRow q = seq_row(pb0, pt0, tail.seq_t, lr);
+                    if (row0 + lr < M) plane[((size_t)q.b * (tail.seq_t + tail.pad_t) + q.t) * 256] = acc[r] + bv;
+                }
+            } else if (col < tail.N) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
