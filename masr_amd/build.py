@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, 'csrc')
 LIB_DIR = os.path.join(ROOT, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmasr_hip.so')
-SOURCES = ['gemm_f32.hip', 'gemm_bf16x3.hip', 'ffn_x3.hip', 'ffn_reduce.hip', 'ffn_pc.hip', 'ffn_dual.hip', 'rowgemm.hip', 'rowgemm_small.hip', 'elementwise.hip',
+SOURCES = ['gemm_f32.hip', 'gemm_bf16x3.hip', 'ffn_x3.hip', 'ffn_reduce.hip', 'ffn_coop.hip', 'ffn_pc.hip', 'ffn_dual.hip', 'rowgemm.hip', 'rowgemm_small.hip', 'elementwise.hip',
            'attention.hip', 'lstm.hip', 'beam_gpu.hip', 'lm_scorer.cpp', 'fbank.hip', 'silero.hip', 'engine.hip', 'pool.hip',
            'beam_search.cpp', 'resample.cpp']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'lm_scorer.h'),

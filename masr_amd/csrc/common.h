@@ -251,6 +251,11 @@ int launch_ffn_dual(float* x, const float* lnw, const float* lnb, const float* p
 void launch_pack_ffn_dual(const float* w1, const float* w2, float* p1, float* p2, int dff, hipStream_t s);
 void launch_pack_rows_dual(const float* w, float* p, hipStream_t s);
 
+// one-chunk FFN slices for few rows (ffn_coop.hip): all eight waves on both products; w1p = launch_pack_ffn_coop_w1's copy, w2p =
+// ffn_pc.hip's packed W2, partial [dff / 128][M][256]
+void launch_pack_ffn_coop_w1(const float* w1, float* p, int dff, hipStream_t s);
+void launch_ffn_coop(const float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2, int M,
+                     int dff, float eps, int affine, float* partial, hipStream_t s);
 void launch_ffn_reduce(float* x, const float* partial, const float* b2, int M, int nsplit, float scale, hipStream_t s,
                        const FfnPostLn* post, const float* xin = nullptr);
 void set_ffn_variant(int v);   // diagnostic ablations of the fused FFN kernel (0 = production)

@@ -94,6 +94,14 @@ static int g_efficient_fused = 1;   // masr_debug_set key 31: 0 = Efficient-Conf
 // owns 32 queries of all four heads stages four heads' K' / V tiles per 64 MFMAs per wave where attention_kernel's 128 queries of
 // one head stage one -- the saved prologue / epilogue / att round trip is paid back in staging.  Off by default.
 static int g_attn_chain = 0;
+// masr_debug_set key 35: 1 = one-chunk d_ff slices of few rows (<= 8 row blocks) run ffn_coop.hip -- all eight waves on both products
+// (GEMM 1 as 16 x 16 x 4 tiles without a K split, GEMM 2 as 32 x 32 x 2), every weight fragment from packed copies, all loads in
+// flight before the LayerNorm -- instead of the producer / consumer kernel, whose two roles run one after the other when a
+// workgroup owns ONE chunk.  Built in round 4 on the estimate of 2 x 1.7 us of matrix pipe saved per launch; MEASURED slower:
+// 16 streams 1.167 / 1.195 ms per chunk call against 1.135 / 1.109 ms (tools/chunk_lat.py MASR_AB=35:0,35:1,35:0,35:1; with the
+// weights read from the row-major matrices: 1.33 ms -- 16 / 32 cache lines per load instruction).  The launch is bound by its
+// dependent memory round trips (rows written by another XCD, LayerNorm, LDS exchange, partial store), not by the 256 MFMAs.  Off.
+static int g_ffn_coop = 0;
 static int g_few_rows_path = 1;   // masr_debug_set key 29: 0 = offline Conformer layers of few row blocks keep the row-block chain kernel (A/B)
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
@@ -787,6 +795,31 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
         }
         if (tail_done) *tail_done = false;
         if (post_y) launch_layernorm(x, post_w, post_b, post_y, M, 1e-5f, 0, 0, nullptr, s);
+        return 0;
+    }
+    // few rows, one chunk of 128 hidden units per workgroup: the kernel in which all eight waves work on both products (key 35)
+    if (g_ffn_coop && nsplit > 1 && nsplit == dff / 128 && !want_head && !x3 && d == 256) {
+        // packed copies: ffn_pc.hip's (W2 is shared with it) + the 16 x 16 x 4 fragment order of W1 (its own map: keyed by W1)
+        auto it = e->ffn_packed.find(w1);
+        if (it == e->ffn_packed.end()) {
+            std::pair<DevBuf, DevBuf> pk;
+            CHK(pk.first.ensure((size_t)dff * d * sizeof(float)));
+            CHK(pk.second.ensure((size_t)dff * d * sizeof(float)));
+            launch_pack_ffn_pc(w1, w2, pk.first.as<float>(), pk.second.as<float>(), dff, s);
+            it = e->ffn_packed.emplace(w1, pk).first;
+        }
+        auto ic = e->ffn_dual_packed.find(w1 + 1);            // (+ 1: a key of its own next to ffn_dual.hip's entries for the same W1)
+        if (ic == e->ffn_dual_packed.end()) {
+            std::pair<DevBuf, DevBuf> pk;
+            CHK(pk.first.ensure((size_t)dff * d * sizeof(float)));
+            launch_pack_ffn_coop_w1(w1, pk.first.as<float>(), dff, s);
+            ic = e->ffn_dual_packed.emplace(w1 + 1, pk).first;
+        }
+        ProfScope psc(e, s, PROF_FFN1, 4.0 * M * (double)dff * d);
+        launch_ffn_coop(e->x.as<float>(), lnw, lnb, ic->second.first.as<float>(), b1, it->second.second.as<float>(), M, dff, 1e-5f,
+                        affine, e->ffpart.as<float>(), s);
+        launch_ffn_reduce(e->x.as<float>(), e->ffpart.as<float>(), b2, M, nsplit, scale, s, post_y ? &post : nullptr);
+        if (tail_done) *tail_done = false;
         return 0;
     }
     ProfScope ps(e, s, want_tail ? PROF_FFN_TAIL : want_head ? PROF_FFN_HEAD : PROF_FFN1,
@@ -2665,6 +2698,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 32) g_beam_lm_cache = value;
     else if (key == 33) set_conv2_mid_fill(value);
     else if (key == 34) g_attn_chain = value;
+    else if (key == 35) g_ffn_coop = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }
