@@ -92,8 +92,9 @@ def test_chunk_steps_with_the_head_stage_on_the_split_ffn_launch():
         eng.close()
 
 
-@pytest.mark.parametrize('B,Tp', [(8, 444), (8, 448), (8, 452), (16, 318), (16, 320), (16, 322), (16, 382), (16, 384), (16, 386),
-                                  (32, 255), (32, 256), (32, 257)])
+# (all twelve neighbours of the four thresholds were run once: 3.4e-6 ... 5.2e-6; six stay in the suite -- the oracle's CPU forward
+#  of these sizes is 10 - 20 s each on the GPU box)
+@pytest.mark.parametrize('B,Tp', [(8, 444), (8, 448), (16, 320), (16, 382), (16, 384), (32, 257)])
 def test_row_block_thresholds_against_oracle(B, Tp):
     """The launch paths switch on the number of 32-row blocks: 112 (K-split projections / latency-cut layer), 160 (fused CTC
     head), 192 (d_ff-split FFN, tail / chain / head fusions), 256 (one round of workgroups).  Batches whose row-block count is
