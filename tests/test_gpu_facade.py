@@ -506,6 +506,63 @@ def test_stream_pool_equals_independent_predict_stream(predictor):
         pool.close(h)
 
 
+def test_c_pool_step_equals_the_python_framing(predictor, monkeypatch):
+    """masr_pool_step (csrc/pool.hip, round 4) against the python framing it replaces (serving.py, MASR_POOL_PY=1) on the same
+    engine: five sessions fed in irregular patterns -- a whole 8.4 s utterance in one call (the frame pool's rows widen), 50 ms
+    crumbs, an empty feed that only carries is_end, two feeds of one session inside one step, a float32 array, a session reset
+    and reused -- must return the same partial results call by call: identical token ids, scores to 1e-4."""
+    from masr_amd.serving import StreamPool
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    monkeypatch.setenv('MASR_POOL_PY', '1')
+    py_pool = StreamPool(predictor)
+    monkeypatch.delenv('MASR_POOL_PY')
+    c_pool = StreamPool(predictor)
+    assert py_pool._c is None and c_pool._c is not None
+    rng = np.random.default_rng(11)
+    script = []                                        # per step: list of (session, samples, is_end)
+    cuts = {1: sorted(rng.integers(1, len(pcm) - 1, 40).tolist()), 2: list(range(800, 60000, 800)), 3: [30000, 90000, 90000]}
+    pos = {k: 0 for k in (0, 1, 2, 3, 4)}
+    for step in range(46):
+        feeds = []
+        if step == 0:
+            feeds.append((0, pcm, True))                                   # everything at once
+        for k in (1, 2, 3):
+            if cuts[k]:
+                hi = cuts[k].pop(0)
+                feeds.append((k, pcm[pos[k]:hi], not cuts[k]))
+                pos[k] = hi
+        if step % 3 == 0 and pos[4] < 70000:
+            a, b = pos[4], pos[4] + 3000
+            feeds.append((4, pcm[a:b].astype(np.float32) / np.float32(32768.0), False))     # float samples, twice in one step
+            feeds.append((4, pcm[b:b + 2500], b + 2500 >= 70000))
+            pos[4] = b + 2500
+        script.append(feeds)
+    results = []
+    for pool in (py_pool, c_pool):
+        hs = [pool.open() for _ in range(5)]
+        out = []
+        for step, feeds in enumerate(script):
+            if step == 20:                                                  # session 0: a second utterance on the same session
+                pool.reset(hs[0])
+                pool.feed(hs[0], pcm[:50000].tobytes(), is_end=True)
+            for k, a, end in feeds:
+                pool.feed(hs[k], a.tobytes() if a.dtype == np.int16 else a, is_end=end)
+            res = pool.step()
+            out.append({hs.index(h): (None if r is None else (r['text'], r['score'], tuple(pool.last_tokens(h)))) for h, r in res.items()})
+        for h in hs:
+            pool.close(h)
+        results.append(out)
+    n_results = 0
+    for a, b in zip(*results):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert (a[k] is None) == (b[k] is None), (k, a[k], b[k])
+            if a[k] is not None:
+                assert a[k][2] == b[k][2] and a[k][0] == b[k][0] and abs(a[k][1] - b[k][1]) < 1e-4, (k, a[k][:2], b[k][:2])
+                n_results += 1
+    assert n_results > 20
+
+
 def test_stream_pool_deepspeech2(tmp_path):
     """StreamPool over the streaming DeepSpeech2: two concurrent sessions == two sequential predict_stream runs"""
     from masr_amd.serving import StreamPool
