@@ -765,3 +765,51 @@ def test_config2_bucketed_batch_gpu_search_equals_host_search(tmp_path):
             assert g['text'] == h['text']
             assert abs(g['score'] - h['score']) < 1e-3 * max(1.0, abs(h['score'])), (g['score'], h['score'])
     assert longest[1] > 50, longest
+
+
+def test_auxiliary_engine_is_per_device():
+    """runtime.aux_engine(): one weight-less engine per GPU (the decoders' vocabulary pruning / prefix search / collapse run on the
+    device their inputs live on; round 3's process-wide engine sent the worker thread of GPU k to whichever device came first)"""
+    from masr_amd import runtime
+    a = runtime.aux_engine()
+    assert a is runtime.aux_engine(torch.cuda.current_device()) and a is runtime.aux_engine(torch.device('cuda', torch.cuda.current_device()))
+    assert a.device.index == torch.cuda.current_device()
+    if torch.cuda.device_count() > 1:
+        b = runtime.aux_engine(1)
+        assert b is not a and b.device.index == 1 and runtime.aux_engine(torch.device('cuda', 1)) is b
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (one beam-search predictor per GPU behind the router)')
+def test_two_gpu_server_with_beam_search_predictors(tmp_path):
+    """advisor finding of round 3: create_app(predictors=[one per GPU]) with ctc_beam_search predictors -- every worker thread
+    searches on ITS GPU's auxiliary engine; both workers return what their own predictor returns when called directly"""
+    from concurrent.futures import wait
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.server import EngineWorker, WorkerRouter
+    from masr_amd.utils import synthetic
+    vpath = os.path.join(tmp_path, 'vocabulary.txt')
+    with open(vpath, 'w', encoding='utf-8') as f:
+        for t in synthetic.synthetic_vocab(512):
+            f.write(f'{t}\t1\n')
+    cfg = yaml.safe_load(CONFIG.replace('VOCAB', vpath))
+    cfg['decoder'] = 'ctc_beam_search'
+    cfg['ctc_beam_search_decoder_conf'] = {'alpha': 0, 'beta': 0, 'beam_size': 50, 'cutoff_prob': 0.99, 'cutoff_top_n': 20,
+                                           'num_processes': 2, 'language_model_path': None}
+    preds = []
+    for dev in (0, 1):
+        torch.cuda.set_device(dev)
+        preds.append(MASRPredictor(configs=cfg, use_gpu=True, state_dict=synthetic.conformer_state_dict(0, 512)))
+    torch.cuda.set_device(0)
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    clips = [pcm[:48000], pcm[20000:90000], pcm[60000:120000], pcm[:100000]]
+    router = WorkerRouter([EngineWorker(p, None, max_batch=2, max_wait_ms=2.0) for p in preds])
+    try:
+        futs = [router.recognize(c) for c in clips for _ in range(2)]
+        wait(futs, timeout=120)
+        got = [f.result() for f in futs]
+    finally:
+        router.shutdown()
+    torch.cuda.set_device(0)
+    want = [preds[0].predict(c) for c in clips for _ in range(2)]
+    for g_, w_ in zip(got, want):
+        assert g_['text'] == w_['text'] and abs(g_['score'] - w_['score']) < 1e-2
