@@ -6,6 +6,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_study.hip -o /tmp/mfma_study && /tmp/mfma_study
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <string.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -122,6 +123,66 @@ void run_buf(const char* name, float* out, float* wts) {
     printf("%-52s %6.1f us/launch  (%.1f TF)\n", name, ms * 1e3, 4096.0 * WAVES * 256 * 4096.0 / (ms * 1e-3) / 1e12);
 }
 
+// round 4: what 64-ROW tiles would buy the FFN main loop -- one weight fragment (1 KB per wave) feeds EIGHT MFMAs (two row tiles, two
+// independent accumulator chains, two A fragments from LDS per group) instead of four
+template <int RING, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES) void study_buf_pair(float* out, const float* __restrict__ wts, int iters, unsigned mask) {
+    __shared__ __align__(16) float tile[64 * 260];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 64 * 260; i += 64 * WAVES) tile[i] = (float)(i & 7) * 0.01f;
+    __syncthreads();
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    const float* xa = tile + (lane & 31) * 260 + 4 * (lane >> 5);
+    const float* xb = xa + 32 * 260;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)wts, 0, 8 << 20, 0x00020000);
+    const unsigned wofs = (unsigned)(blockIdx.x & 7) * 16384 + (unsigned)wave * 4096 + lane * 4;
+    f32x4 ring[RING];
+#pragma unroll
+    for (int k = 0; k < RING; ++k)
+        ring[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((wofs + k * 256) & mask) * 4, 0, 0));
+    f32x4 a = *reinterpret_cast<const f32x4*>(xa), b = *reinterpret_cast<const f32x4*>(xb);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < RING; ++g) {
+            const f32x4 an = *reinterpret_cast<const f32x4*>(xa + ((it * RING + g + 1) & 31) * 8);
+            const f32x4 bn = *reinterpret_cast<const f32x4*>(xb + ((it * RING + g + 1) & 31) * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], ring[g][q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q], ring[g][q], acc1, 0, 0, 0);
+                if (q == 3)
+                    ring[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((wofs + (unsigned)((it * RING + g + RING) * 256)) & mask) * 4, 0, 0));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            a = an;
+            b = bn;
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    out[(size_t)blockIdx.x * blockDim.x + tid] = s;
+}
+template <int RING, int WAVES = 8>
+void run_buf_pair(const char* name, float* out, float* wts, int grid = 256) {
+    const int iters = 4096 / (8 * RING);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int k = 0; k < 3; ++k) study_buf_pair<RING, WAVES><<<grid, 64 * WAVES>>>(out, wts, iters, 256 * 1024 - 1);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int k = 0; k < 40; ++k) study_buf_pair<RING, WAVES><<<grid, 64 * WAVES>>>(out, wts, iters, 256 * 1024 - 1);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 40;
+    printf("%-60s %6.1f us/launch  (%.1f TF)\n", name, ms * 1e3, 4096.0 * WAVES * grid * 4096.0 / (ms * 1e-3) / 1e12);
+}
+
 // the same load stream without any MFMA: what a CU can pull through its L1 when all CUs do (8 loads of 1 KB in flight per wave)
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void stream_only(float* out, const float* __restrict__ wts, int nload, unsigned mask) {
@@ -187,13 +248,23 @@ void run(const char* name, int blocks, float* out, float* wts, long long* clk, u
            4096.0 * WAVES * blocks * 4096.0 / (ms * 1e-3) / 1e12);
 }
 
-int main() {
+int main(int argc, char** argv) {
     float *out, *wts;
     long long* clk;
     hipMalloc(&out, sizeof(float) * 512 * 256);
     hipMalloc(&wts, 8 << 20);
     hipMemset(wts, 0, 8 << 20);
     hipMalloc(&clk, 16);
+    if (argc > 1 && !strcmp(argv[1], "pair")) {      // round 4: 32-row against 64-row tiles (weights per MFMA halved)
+        for (int rep = 0; rep < 2; ++rep) {
+            run_buf<0, 8>("32-row tile: 1 KB of weights / 4 MFMAs, ring 8", out, wts);
+            run_buf_pair<8>("64-row tile: 1 KB of weights / 8 MFMAs (2 chains), ring 8", out, wts);
+            run_buf_pair<4>("64-row tile: 1 KB of weights / 8 MFMAs (2 chains), ring 4", out, wts);
+            run_buf_pair<8>("64-row tile, 248 workgroups", out, wts, 248);
+            run<2, 1, 0, 8>("2 chains, ds_read_b128 / 8 MFMAs, no weight stream", 256, out, wts, clk);
+        }
+        return 0;
+    }
     run<1, 0, 0, 8>("1 chain, no side work, 2 waves/SIMD", 256, out, wts, clk);
     run<2, 0, 0, 8>("2 chains, no side work, 2 waves/SIMD", 256, out, wts, clk);
     run<1, 0, 0, 4>("1 chain, no side work, 1 wave/SIMD", 256, out, wts, clk);
