@@ -244,17 +244,27 @@ def cpu_baseline(budget_s=30.0):
 
 # ---- the contract workload ----------------------------------------------------------------------------------------------
 class ContractStep:
-    """one rank's step of configs[1]; ``mode``: 'full' (HBM-resident PCM -> text on host, pipelined), 'device' (-> token ids
-    on the device, nothing synchronised), 'host' (pinned host PCM -> H2D -> ... -> text on host).
+    """one rank's step of configs[1] on the BIT-EXACT normalisation route (``masr_transcribe_rows``, use_db_normalization = 2):
+    the mean squares of a batch come from the device in numpy's summation order, the gain is the reference's own scalar numpy
+    expression evaluated on this host (``engine.reference_gains``; audio.py:287-304,256-264,519-529), so the int16 samples the
+    fbank kernel sees are the reference's, bit for bit.  The round trip (mean squares -> host -> gains) of step k + 1 is issued
+    under step k's kernels on a side stream and is recomputed for every step.
 
-    The exchange of a step -- pack the hypotheses, RCCL all-gather (N > 1), copy to the host -- runs on a side stream behind
+    ``mode``: 'full' (HBM-resident PCM -> text on host, pipelined), 'device' (-> packed hypothesis rows on the device, no
+    per-step wait on the results), 'host' (pinned host PCM -> H2D -> ... -> text on host: SURVEY 8(d)'s metric).
+
+    The exchange of a step -- RCCL all-gather of the packed rows (N > 1), copy to the host -- runs on a side stream behind
     an event of the compute stream, so the next step's kernels start while the collective of this one is in flight; the
     device outputs and the pinned host buffers are double-buffered (slot = step parity)."""
 
+    TARGET_DB = -20.0
+
     def __init__(self, eng, rank, world, vocab):
         from masr_amd import parallel
+        from masr_amd.engine import reference_gains
         from masr_amd.utils import synthetic
         self.parallel, self.eng, self.rank, self.world = parallel, eng, rank, world
+        self.reference_gains = reference_gains
         self.dev = eng.device
         self.vocab = np.array(vocab, dtype=object)
         pcm = torch.from_numpy(synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234 + rank))
@@ -263,21 +273,31 @@ class ContractStep:
         self.pcm = pcm.to(self.dev)
         self.n = torch.full((BATCH,), N_SAMPLES, dtype=torch.int32, device=self.dev)
         self.Tp = eng.out_frames(1 + (N_SAMPLES - 400) // 160)
-        self.out = [(torch.empty(BATCH, self.Tp, dtype=torch.int32, device=self.dev),
-                     torch.empty(BATCH, dtype=torch.int32, device=self.dev),
-                     torch.empty(BATCH, dtype=torch.float32, device=self.dev)) for _ in range(2)]
+        # hypotheses are ONE int32 payload [B, T' + 2] (tokens | count | score bits), written by the collapse kernel itself
+        self.out = [torch.empty(BATCH, self.Tp + 2, dtype=torch.int32, device=self.dev) for _ in range(2)]
         rows = world * BATCH
-        # hypotheses travel as ONE int32 payload [rows, T' + 2] (tokens | count | score bits): one collective, one copy back
         self.host = [torch.empty(rows, self.Tp + 2, dtype=torch.int32, pin_memory=gpu) for _ in range(2)]
         self.side = torch.cuda.Stream(device=self.dev) if gpu else None
         self.computed = [torch.cuda.Event() if gpu else None for _ in range(2)]      # compute stream: outputs of the slot written
         self.events = [torch.cuda.Event() if gpu else None for _ in range(2)]        # side stream: slot gathered (and on the host)
         self.used = [False, False]
+        # the gain round trip: mean squares (device) -> pinned host -> reference_gains -> pinned host -> device, two slots
+        self.prep_stream = torch.cuda.Stream(device=self.dev) if gpu else None
+        self.ms_dev = [torch.empty(BATCH, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.ms_host = [torch.empty(BATCH, dtype=torch.float32, pin_memory=gpu) for _ in range(2)]
+        self.ms_ready = [torch.cuda.Event() if gpu else None for _ in range(2)]
+        self.gain_host = [torch.empty(BATCH, dtype=torch.float32, pin_memory=gpu) for _ in range(2)]
+        self.gain_dev = [torch.empty(BATCH, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.gain_up = [torch.cuda.Event() if gpu else None for _ in range(2)]       # compute stream: the slot's gains were copied up
+        self.gain_used = [False, False]
+        self.prepared = [None, None]                                                  # data_ptr of the PCM the slot's mean squares belong to
+        self.turn = 0
         self.h2d = None
         self.prefetch_pcm_for = None
         self.pending = None
         self.texts = None
         self.n_texts = 0
+        self.last_gains = None
 
     def _finish(self, slot):
         """hypotheses of a finished step as text on the host (rank 0: of all ranks' utterances; others: their own shard)"""
@@ -293,14 +313,59 @@ class ContractStep:
             self._finish(self.pending)
             self.pending = None
 
+    # ---- gains -------------------------------------------------------------------------------------------------------
+    def prepare(self, pcm, stream=None, after_compute=False):
+        """enqueue the mean squares of ``pcm`` (the NEXT step's batch) and their copy to the host on ``stream`` (default: the
+        preparation stream, which does NOT wait for the compute stream: the batch is resident) -- runs under the current
+        step's kernels; ``_gains`` picks the result up"""
+        k = self.turn
+        self.turn ^= 1
+        if self.prep_stream is None:
+            self.eng.mean_square(pcm, self.n, out=self.ms_dev[k])
+            self.ms_host[k].copy_(self.ms_dev[k])
+        else:
+            st = stream if stream is not None else self.prep_stream
+            if after_compute:
+                st.wait_stream(torch.cuda.current_stream())               # a batch nobody announced: it may still be on its way
+            with torch.cuda.stream(st):
+                self.eng.mean_square(pcm, self.n, out=self.ms_dev[k])
+                self.ms_host[k].copy_(self.ms_dev[k], non_blocking=True)
+                self.ms_ready[k].record()
+        self.prepared[k] = pcm.data_ptr()
+
+    def _gains(self, pcm):
+        """linear gains [B] (device) of ``pcm`` for the step about to be enqueued: the prepared mean squares (or, for a batch
+        nobody announced, mean squares computed now) -> this host's numpy -> device"""
+        ptr = pcm.data_ptr()
+        k = next((j for j in (0, 1) if self.prepared[j] == ptr), None)
+        if k is None:
+            self.prepare(pcm, after_compute=True)
+            k = self.turn ^ 1
+        if self.ms_ready[k] is not None:
+            self.ms_ready[k].synchronize()
+        self.prepared[k] = None
+        if self.gain_up[k] is not None and self.gain_used[k]:
+            self.gain_up[k].synchronize()                                   # the slot's previous upload has left the pinned buffer
+        g = self.reference_gains(self.ms_host[k].numpy(), self.TARGET_DB)
+        self.last_gains = g
+        self.gain_host[k].numpy()[:] = g
+        self.gain_dev[k].copy_(self.gain_host[k], non_blocking=True)
+        if self.gain_up[k] is not None:
+            self.gain_up[k].record()
+            self.gain_used[k] = True
+        return self.gain_dev[k]
+
+    # ---- PCM over PCIe ('host' mode) ------------------------------------------------------------------------------------
     def _copy_pcm(self, k):
-        """enqueue the host -> device copy of step k's PCM on the copy stream (buffer k & 1)"""
+        """enqueue the host -> device copy of step k's PCM on the copy stream (buffer k & 1), and behind it, on the same
+        stream, the mean squares of that batch"""
         h = self.h2d
         with torch.cuda.stream(h['stream']):
             if self.used[k & 1]:
                 h['stream'].wait_event(self.computed[k & 1])           # the kernels that read this buffer two steps ago are done
             h['buf'][k & 1].copy_(self.pcm_host, non_blocking=True)
             h['ready'][k & 1].record()
+        self.prepare(h['buf'][k & 1], stream=h['stream'])
         h['issued'] = k
 
     def _pcm_from_host(self, i):
@@ -319,25 +384,52 @@ class ContractStep:
         return self.h2d['buf'][i & 1]
 
     def _exchange(self, slot, mode):
-        rows = self.parallel.gather_hypothesis_rows(*self.out[slot])   # RCCL all-gather of [32, T'+2] int32 per rank (N > 1)
+        rows = self.parallel.gather_rows(self.out[slot])               # RCCL all-gather of [32, T'+2] int32 per rank (N > 1)
         if mode != 'device':
             self.host[slot].copy_(rows, non_blocking=True)
+            self.last_host_slot = slot
 
-    def step(self, i, mode='full'):
+    def ranks_seen(self):
+        """ranks whose hypothesis rows arrived through the LAST step's all-gather: every rank's batch is seeded 1234 + rank, so
+        rank r's block of the gathered payload must equal what rank r alone produces -- here checked the cheap way: each rank
+        all-gathers the checksum of its own rows and compares it with the checksum of the block it received"""
+        if not self.parallel.collectives_on():
+            return [self.rank]
+        import torch.distributed as dist
+        slot = getattr(self, 'last_host_slot', None)
+        if slot is None:
+            return []
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+        got = self.host[slot].numpy().astype(np.int64)
+        mine = torch.tensor([int(got[self.rank * BATCH:(self.rank + 1) * BATCH].sum())], dtype=torch.int64,
+                            device=self.parallel.comm_device())
+        sums = torch.empty(dist.get_world_size(), dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(sums, mine)
+        sums = sums.cpu().numpy()
+        return [r for r in range(len(sums)) if int(got[r * BATCH:(r + 1) * BATCH].sum()) == int(sums[r])]
+
+    def step(self, i, mode='full', next_pcm=None):
+        """``next_pcm``: the HBM-resident batch of the following step when it is not ``self.pcm`` again (tests)"""
         slot = i & 1
         pcm = self.pcm
         if mode == 'host':
             pcm = self._pcm_from_host(i)                                # 10.2 MB over PCIe per step
+        gains = self._gains(pcm)
         if self.side is not None and self.used[slot]:
             torch.cuda.current_stream().wait_event(self.events[slot])   # the slot's previous exchange has read its outputs
-        self.eng.transcribe_batch(pcm, self.n, out=self.out[slot])
+        self.eng.transcribe_rows(pcm, self.n, True, self.TARGET_DB, gain_in=gains, out=self.out[slot])
         if self.side is None:
+            if mode != 'host':
+                self.prepare(next_pcm if next_pcm is not None else self.pcm)
             self._exchange(slot, mode)
         else:
             self.computed[slot].record()
             if self.prefetch_pcm_for is not None:                       # 'host' mode: the next step's PCM starts its way over PCIe
-                self._copy_pcm(self.prefetch_pcm_for)
+                self._copy_pcm(self.prefetch_pcm_for)                   # (+ its mean squares behind the copy)
                 self.prefetch_pcm_for = None
+            elif mode != 'host':
+                self.prepare(next_pcm if next_pcm is not None else self.pcm)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.computed[slot])
                 self._exchange(slot, mode)
@@ -365,7 +457,12 @@ def run_contract(args, rank, world, local):
         eng.profile_select(args.profile_kind)
         eng.profile_read(reset=True)
 
-    dt = parallel.timed_region(lambda i: cs.step(i, 'full'), args.steps, args.warmup, after_warmup=prof_on, flush=cs.flush)
+    dt, dt_local = parallel.timed_region(lambda i: cs.step(i, 'full'), args.steps, args.warmup, after_warmup=prof_on,
+                                         flush=cs.flush, return_local=True)
+    # evidence that the step's exchange really spanned the job: the ranks whose hypothesis rows arrived through the all-gather of
+    # the timed region's last step (ContractStep.ranks_seen), and every rank's own time for the region
+    per_rank_ms = parallel.gather_floats([dt_local * 1e3 / args.steps])
+    ranks_seen = cs.ranks_seen()
     prof_ms, prof_n, prof_flops = eng.profile_read(reset=True)
     eng.profile_select(0)
     if hasattr(eng, 'lib'):
@@ -420,12 +517,21 @@ def run_contract(args, rank, world, local):
                           'global_batch': world * BATCH, 'audio_seconds_per_step': audio_step,
                           'parallelism': f'dp{world}', 'world_size_observed': parallel.world_info()[1],
                           'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else 'none',
+                          'rccl_ranks_seen': ranks_seen,
+                          'ms_per_step_per_rank': {'min': round(min(per_rank_ms), 3), 'max': round(max(per_rank_ms), 3)},
                           'algorithmic_gflop_per_step_per_gpu': GFLOP_PER_STEP,
-                          'timed_region': 'int16 PCM resident in HBM -> token ids -> (all-gather) -> D2H -> text on host; '
+                          'normalisation': 'use_db_normalization = 2 (masr_transcribe_rows): mean squares on the device in numpy\'s '
+                                           'summation order, gain = the reference\'s scalar numpy expressions on this host -- the '
+                                           'int16 samples are the reference\'s bit for bit; the round trip of step k+1 runs under '
+                                           'step k and is recomputed every step',
+                          'timed_region': 'int16 PCM resident in HBM -> mean squares -> host gains -> masr_transcribe_rows (mode 2) '
+                                          '-> packed hypothesis rows -> (all-gather) -> D2H -> text on host; '
                                           f'{n_texts} transcripts built inside it, e.g. {sample_text[:12]!r}'},
+               'value_definition': 'task contract: inputs resident in HBM when the timed region starts; SURVEY 8(d)\'s host-to-host '
+                                   'rate of the same route is value_host_to_host',
                'value_host_to_host': per(dt_host)['value'],
                'roofline': roofline,
-               'timing': {'device_only': dict(per(dt_dev), note='PCM in HBM -> token ids in HBM, nothing synchronised per step'),
+               'timing': {'device_only': dict(per(dt_dev), note='PCM in HBM -> packed hypothesis rows in HBM; the host waits only for the (earlier) mean squares'),
                           'host_to_host': dict(per(dt_host), note='pinned host int16 PCM -> H2D (copy stream, under the previous step) -> ... -> D2H -> text on host')}}
     return eng, res
 

@@ -268,8 +268,12 @@ int masr_transcribe_rows(masr_engine* e, const void* samples_dev, int32_t sample
  *                     expressions (audio.py:287-304,519-529) on the mean squares the device returns -- the python facade passes
  *                     its numpy evaluation, which is what makes the normalised samples bit-identical to the reference's on the
  *                     same host; NULL = libm (log10f / powf).  Returns non-zero to abort the step (gain beyond max_gain_db).
+ *                     All feeds are validated (known handle, format, 0 <= feed_n <= 2^28, non-null samples) before any session
+ *                     state changes: a rejected call commits nothing.
  *                     Out: the sessions of the step in first-fed order (handles_out[i], state_out[i] = 1 when the session
- *                     advanced by at least one window, else 0 = the reference returns None), and for the advanced ones, in that
+ *                     advanced by at least one window, 0 = the reference returns None; then, state -1, the sessions LEFT OUT of
+ *                     the step because their stream has no room for the frames it would emit -- their feeds of this step are
+ *                     dropped, their state is untouched, the other sessions advance), and for the advanced ones, in that
  *                     order, packed rows [row_width] = token ids (-1 padded) | count | score bits, in pinned host memory
  *                     (rows_host) and in HBM (rows_dev: what a multi-GPU front-end all-gathers); all out pointers stay valid
  *                     until the next step of this pool. */
@@ -310,6 +314,10 @@ int masr_stream_close(masr_engine* e, int32_t stream_id);
 int masr_stream_set_history(masr_engine* e, int32_t stream_id, int32_t required_cache_size);
 int masr_stream_offset(masr_engine* e, int32_t stream_id, int32_t* offset);
 int masr_stream_cache_len(masr_engine* e, int32_t stream_id, int32_t* cache_len);
+/* Subsampled frames the stream can still take before masr_encode_chunk refuses it (max_frames_out / the positional table's
+ * max_len, conformer/embedding.py:48-50): lets a caller that advances many streams in one call leave a full one out instead of
+ * failing the call. */
+int masr_stream_room(masr_engine* e, int32_t stream_id, int32_t* frames_left);
 
 /* Host-side resampling of one utterance to the model's rate.  Replaces resampy.resample(samples, sr, target, filter) behind
  * AudioSegment.resample (masr/data_utils/audio.py:306-317; resampy is third-party: its published band-limited sinc interpolation

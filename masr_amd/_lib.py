@@ -93,6 +93,7 @@ SIGNATURES = {
     'masr_stream_close': [_P, _I],
     'masr_stream_offset': [_P, _I, C.POINTER(_I)],
     'masr_stream_cache_len': [_P, _I, C.POINTER(_I)],
+    'masr_stream_room': [_P, _I, C.POINTER(_I)],
     'masr_resample_f32': [_P, C.c_int64, C.c_double, _P, _P, C.c_int64, _I, _P, C.c_int64],
     'masr_stream_set_history': [_P, _I, _I],
     'masr_encode_chunk': [_P, C.POINTER(_I), _I, _P, _I, _P, _P, _P, _P],

@@ -252,6 +252,10 @@ struct masr_engine {
     // whole-utterance prefix searches launched on OTHER streams than the first one get workspaces of their own: two searches may
     // run next to each other (predict_batch: the passes' searches on two side streams), launches on one stream are ordered anyway
     std::map<void*, std::pair<DevBuf, DevBuf>> beam_ws;
+    // masr_mean_square runs on whatever stream prepares the NEXT pass (the facade's side stream, the contract step's copy stream)
+    // while the feature launch of the current pass reads e->gain on the compute stream: its chunk sums and its unused gain slots
+    // live in a scratch of their own, one per calling stream (launches on one stream are ordered anyway)
+    std::map<void*, DevBuf> ms_ws;
     void* beam_first_stream = nullptr;
     bool beam_first_set = false;
     std::map<const float*, std::pair<DevBuf, DevBuf>> ffn_packed;  // fp32 FFN weights in fragment order (ffn_pc.hip VAR == 2), per W1 pointer
@@ -515,6 +519,7 @@ void masr_destroy(masr_engine* e) {
         kv.second.first.release();
         kv.second.second.release();
     }
+    for (auto& kv : e->ms_ws) kv.second.release();
     for (auto& kv : e->x3_packed) {
         kv.second.first.release();
         kv.second.second.release();
@@ -1954,8 +1959,9 @@ int masr_mean_square(masr_engine* e, const void* samples_dev, int32_t sample_for
     if (!e || !mean_square_dev) return fail("null argument");
     ENTER(e);
     if (sample_format != 0 && sample_format != 1) return fail("sample_format must be 0 (int16) or 1 (float32)");
-    CHK(e->gain.ensure(sizeof(float) * fbank_gain_scratch_floats(B)));
-    launch_mean_square(samples_dev, sample_format, n_samples_dev, B, n_max, e->gain.as<float>(), mean_square_dev,
+    DevBuf& ws = e->ms_ws[stream];
+    CHK(ws.ensure(sizeof(float) * fbank_gain_scratch_floats(B)));
+    launch_mean_square(samples_dev, sample_format, n_samples_dev, B, n_max, ws.as<float>(), mean_square_dev,
                        (hipStream_t)stream);
     LAUNCHCHK();
     return 0;
@@ -2204,6 +2210,14 @@ int masr_stream_offset(masr_engine* e, int32_t stream_id, int32_t* offset) {
     Stream* st;
     CHK(stream_of(e, stream_id, &st));
     *offset = st->offset;
+    return 0;
+}
+
+int masr_stream_room(masr_engine* e, int32_t stream_id, int32_t* frames_left) {
+    if (!frames_left) return fail("null argument");
+    Stream* st;
+    CHK(stream_of(e, stream_id, &st));
+    *frames_left = st->cap - st->offset;
     return 0;
 }
 

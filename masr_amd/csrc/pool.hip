@@ -48,6 +48,7 @@ constexpr int kDecodingChunk = 16, kSubsampling = 4, kContext = 7;
 constexpr int kWindow = (kDecodingChunk - 1) * kSubsampling + kContext;      // 67 feature frames per window
 constexpr int kStride = kSubsampling * kDecodingChunk;                       // 64
 constexpr int kOverlap = kContext - kSubsampling;                            // 3 frames carried over
+constexpr int64_t kMaxFeedSamples = (int64_t)1 << 28;                        // per feed (4.6 h at 16 kHz): anything above is a caller bug
 
 struct Dev {                     // grow-only device buffer; `keep` bytes of the old contents survive a growth
     void* p = nullptr;
@@ -291,6 +292,14 @@ int masr_pool_step(masr_pool* p, int32_t n_feeds, const int32_t* feed_handle, co
     p->handles.clear();
     p->state.clear();
     if (n_feeds <= 0) return 0;
+    // ---- validate EVERYTHING before any session state is touched: a bad feed fails the call with nothing committed ----------
+    if (!feed_handle || !feed_samples || !feed_n || !feed_format || !feed_is_end) PFAIL("masr_pool_step: null feed arrays");
+    for (int k = 0; k < n_feeds; ++k) {
+        if (p->sessions.find(feed_handle[k]) == p->sessions.end()) PFAIL("masr_pool_step: unknown handle");
+        if (feed_format[k] != 0 && feed_format[k] != 1) PFAIL("masr_pool_step: sample format 0 = int16 PCM, 1 = float32");
+        if (feed_n[k] < 0 || feed_n[k] > kMaxFeedSamples) PFAIL("masr_pool_step: feed_n out of range (0 .. 2^28 samples)");
+        if (feed_n[k] > 0 && !feed_samples[k]) PFAIL("masr_pool_step: null sample pointer with feed_n > 0");
+    }
     // ---- sessions of this step, in the order they were first fed ------------------------------------------------------
     std::vector<Session*> sess;
     std::vector<int> end_flag;
@@ -298,8 +307,6 @@ int masr_pool_step(masr_pool* p, int32_t n_feeds, const int32_t* feed_handle, co
     std::vector<std::vector<int>> feeds_of;
     for (int k = 0; k < n_feeds; ++k) {
         auto it = p->sessions.find(feed_handle[k]);
-        if (it == p->sessions.end()) PFAIL("masr_pool_step: unknown handle");
-        if (feed_format[k] != 0 && feed_format[k] != 1) PFAIL("masr_pool_step: sample format 0 = int16 PCM, 1 = float32");
         auto q = pos.find(feed_handle[k]);
         if (q == pos.end()) {
             q = pos.emplace(feed_handle[k], (int)sess.size()).first;
@@ -309,6 +316,50 @@ int masr_pool_step(masr_pool* p, int32_t n_feeds, const int32_t* feed_handle, co
         }
         end_flag[q->second] |= feed_is_end[k] ? 1 : 0;
         feeds_of[q->second].push_back(k);
+    }
+    // a session whose stream cannot take the frames this step would emit (masr_encode_chunk would refuse the whole lock-step
+    // call: "stream exceeds its max_frames_out / max_pos") is LEFT OUT, untouched, and reported with state -1: one full
+    // session does not fail the step of the others
+    std::vector<int32_t> refused;
+    {
+        std::vector<Session*> keep_s;
+        std::vector<int> keep_e;
+        std::vector<std::vector<int>> keep_f;
+        for (size_t i = 0; i < sess.size(); ++i) {
+            long tot = (long)sess[i]->remained.size();
+            for (int k : feeds_of[i]) tot += feed_n[k];
+            const int nfr = sess[i]->nf + feature_frames(p, tot);
+            long emit = 0;
+            if (!((nfr < kWindow && !end_flag[i]) || nfr < kContext)) {
+                const int left = end_flag[i] ? kContext : kWindow;
+                for (int cur = 0; cur <= nfr - left; cur += kStride) {
+                    const int len = std::min(cur + kWindow, nfr) - cur;
+                    emit += ((len - 1) / 2 - 1) / 2;
+                }
+            }
+            int32_t room = 0;
+            PCHK(masr_stream_room(p->e, sess[i]->sid, &room));
+            if (emit > 0 && emit + 3 > room) {           // (+ 3: the Efficient-Conformer's grouped layers pad a chunk to a multiple of 3)
+                refused.push_back(sess[i]->sid);
+                continue;
+            }
+            keep_s.push_back(sess[i]);
+            keep_e.push_back(end_flag[i]);
+            keep_f.push_back(std::move(feeds_of[i]));
+        }
+        sess.swap(keep_s);
+        end_flag.swap(keep_e);
+        feeds_of.swap(keep_f);
+    }
+    if (sess.empty()) {
+        for (int32_t h : refused) {
+            p->handles.push_back(h);
+            p->state.push_back(-1);
+        }
+        *n_sessions = (int32_t)refused.size();
+        if (handles_out) *handles_out = p->handles.data();
+        if (state_out) *state_out = p->state.data();
+        return 0;
     }
     const int n = (int)sess.size();
     auto t_last = std::chrono::steady_clock::now();
@@ -549,7 +600,11 @@ int masr_pool_step(masr_pool* p, int32_t n_feeds, const int32_t* feed_handle, co
         p->handles.push_back(q.sid);
         p->state.push_back(plans[i].empty() ? 0 : 1);
     }
-    *n_sessions = n;
+    for (int32_t h : refused) {
+        p->handles.push_back(h);
+        p->state.push_back(-1);
+    }
+    *n_sessions = n + (int32_t)refused.size();
     if (handles_out) *handles_out = p->handles.data();
     if (state_out) *state_out = p->state.data();
     if (rows_host) *rows_host = rows_h;

@@ -197,6 +197,8 @@ class HipEngine:
 
     def close(self):
         if getattr(self, 'h', None):
+            for pool in list(self.__dict__.get('_pools', ())):        # serving pools hold streams of this engine
+                pool.shutdown()
             torch.cuda.synchronize()
             self.lib.masr_destroy(self.h)
             self.h = None
@@ -208,11 +210,13 @@ class HipEngine:
             pass
 
     # ---- features -------------------------------------------------------------------------------
-    def mean_square(self, samples, n_samples):
-        """float32 ``np.mean(samples ** 2)`` per utterance in numpy's summation order (audio.py:524) -> [B] f32 (device)"""
+    def mean_square(self, samples, n_samples, out=None):
+        """float32 ``np.mean(samples ** 2)`` per utterance in numpy's summation order (audio.py:524) -> [B] f32 (device).  The
+        kernels use a scratch of the calling stream's own (not the feature launch's): preparing the next pass on a side
+        stream never touches what the current pass reads."""
         B, n_max = samples.shape
         fmt = {torch.int16: 0, torch.float32: 1}[samples.dtype]
-        ms = torch.empty(B, dtype=torch.float32, device=self.device)
+        ms = out if out is not None else torch.empty(B, dtype=torch.float32, device=self.device)
         check(self.lib.masr_mean_square(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max, _ptr(ms), _stream()))
         return ms
 
@@ -233,18 +237,25 @@ class HipEngine:
 
     def to_device(self, a):
         """small host array -> device through pinned memory (asynchronous, no device-wide serialisation).  A ring of eight pinned
-        slots per dtype: a slot is rewritten eight uploads later, long after its copy has run (callers synchronise a stream at
-        least once per device pass)."""
+        slots per dtype; every slot carries the event of its last copy (recorded on the stream the copy was issued on), which is
+        waited for before the slot is rewritten -- a copy queued on a side stream behind a long prefix search keeps its source
+        however many uploads follow."""
         t = torch.from_numpy(np.ascontiguousarray(a).reshape(-1))
-        slot = self.__dict__.setdefault('_up_ring', {}).setdefault(t.dtype, {'bufs': [None] * 8, 'turn': 0})
+        slot = self.__dict__.setdefault('_up_ring', {}).setdefault(t.dtype, {'bufs': [None] * 8, 'events': [None] * 8, 'turn': 0})
         k = slot['turn']
         slot['turn'] = (k + 1) & 7
+        if slot['events'][k] is not None:
+            slot['events'][k].synchronize()
         buf = slot['bufs'][k]
         if buf is None or buf.numel() < t.numel():
             buf = slot['bufs'][k] = torch.empty(max(t.numel(), 64), dtype=t.dtype, pin_memory=True)
         view = buf[:t.numel()]
         view.copy_(t)
-        return view.view(np.shape(a)).to(self.device, non_blocking=True)
+        out = view.view(np.shape(a)).to(self.device, non_blocking=True)
+        ev = slot['events'][k] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        slot['events'][k] = ev
+        return out
 
     def host_gains(self, samples, n_samples, target_db, max_gain_db=300.0):
         """The reference's normalisation gain evaluated where the reference evaluates it: the mean square comes from the

@@ -88,11 +88,17 @@ def gather_hypothesis_rows(tokens, ntok, scores, group=None):
     ranks -> [world * B, T' + 2] on every rank (world 1: the packed rows themselves).  One tensor means one collective and one
     copy to the host; ``unpack_hypothesis_rows`` splits it again."""
     payload = torch.cat([tokens, ntok.view(-1, 1), scores.view(-1, 1).view(torch.int32)], dim=1).contiguous()
+    return gather_rows(payload, group)
+
+
+def gather_rows(rows, group=None):
+    """packed hypothesis rows [B, T' + 2] int32 of this rank (what ``masr_transcribe_rows`` writes) -> the rows of all ranks
+    [world * B, T' + 2] on every rank: ONE all-gather (world 1: the rows themselves)"""
     if not collectives_on(group):
-        return payload
+        return rows
     w = dist.get_world_size(group)
-    out = torch.empty((w * payload.shape[0], payload.shape[1]), dtype=payload.dtype, device=payload.device)
-    dist.all_gather_into_tensor(out, payload, group=group)
+    out = torch.empty((w * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(out, rows.contiguous(), group=group)
     return out
 
 
@@ -157,10 +163,11 @@ def _sync():
         torch.cuda.synchronize()
 
 
-def timed_region(step, steps, warmup, group=None, after_warmup=None, flush=None):
+def timed_region(step, steps, warmup, group=None, after_warmup=None, flush=None, return_local=False):
     """``warmup`` untimed calls of ``step(i)``, then EXACTLY ``steps`` timed calls bracketed by a barrier + device synchronise
     on both sides; returns the MAX over ranks of the wall time of the timed region in seconds (identical on every rank).
-    ``flush``: called after the last step INSIDE the timed region (a pipelined step finishes its last host-side stage there)."""
+    ``flush``: called after the last step INSIDE the timed region (a pipelined step finishes its last host-side stage there).
+    ``return_local``: -> (max over ranks, this rank's own time up to its device synchronise, before the closing barrier)."""
     rank, world = world_info(group)
     for i in range(warmup):
         step(i)
@@ -179,6 +186,7 @@ def timed_region(step, steps, warmup, group=None, after_warmup=None, flush=None)
     if flush is not None:
         flush()
     _sync()
+    dt_local = time.perf_counter() - t0
     if coll:
         dist.barrier(group=group)
     dt = time.perf_counter() - t0
@@ -186,7 +194,7 @@ def timed_region(step, steps, warmup, group=None, after_warmup=None, flush=None)
         t = torch.tensor([dt], dtype=torch.float64, device=comm_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         dt = float(t.item())
-    return dt
+    return (dt, dt_local) if return_local else dt
 
 
 def gather_floats(values, group=None):

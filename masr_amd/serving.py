@@ -21,6 +21,7 @@ Every session receives exactly the partial results its own reference ``predict_s
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -128,6 +129,7 @@ class StreamPool:
         self.beam = cfg.decoder == 'ctc_beam_search'
         self.max_frames_out = max_frames_out
         self.sessions = {}
+        self.errors = {}              # handle -> message of a session the last step left out (full stream)
         self._fed = {}
         self._free_rows = []
         self._hist_idx = torch.zeros(0, 0, dtype=torch.int32, device=self.engine.device)      # [rows, frames]
@@ -150,7 +152,13 @@ class StreamPool:
                                                   int(max_frames_out), C.byref(h)))
             self._c = h
             self._gain_error = None
-            self._gain_cb = _lib.GAIN_FN(self._gains)          # (kept alive with the pool)
+            me = weakref.ref(self)                             # (no reference cycle through the callback: the pool dies with
+
+            def gain_cb(ms_ptr, n, target_db, out_ptr, user):  #  its last reference, not at some later garbage collection)
+                pool = me()
+                return pool._gains(ms_ptr, n, target_db, out_ptr, user) if pool is not None else 1
+            self._gain_cb = _lib.GAIN_FN(gain_cb)              # (kept alive with the pool)
+            self.engine.__dict__.setdefault('_pools', weakref.WeakSet()).add(self)     # HipEngine.close() shuts its pools down first
 
     # ---- session life cycle ---------------------------------------------------------------------------------------------
     def _grow(self, rows, frames):
@@ -176,11 +184,19 @@ class StreamPool:
     def _new_decoder(self):
         return self.predictor.beam_search_decoder.fork() if self.beam else None
 
-    def __del__(self):
+    def shutdown(self):
+        """destroy the C pool (closes its streams on the engine, synchronises the engine's device).  Idempotent; called by
+        ``HipEngine.close()`` for every pool still alive on it, so a pool never touches a destroyed engine."""
+        c, self._c = getattr(self, '_c', None), None
+        if c is not None and getattr(self.engine, 'h', None):
+            with torch.cuda.device(self.engine.device):
+                self._lib.masr_pool_destroy(c)
+        self.sessions = {}
+        self._feeds = []
+
+    def __del__(self):                                         # fallback only: owners call shutdown()
         try:
-            if getattr(self, '_c', None) is not None and getattr(self.engine, 'h', None):
-                self._lib.masr_pool_destroy(self._c)
-                self._c = None
+            self.shutdown()
         except Exception:                                      # noqa: BLE001  (interpreter shutdown)
             pass
 
@@ -211,6 +227,7 @@ class StreamPool:
         if self._c is not None:
             _lib.check(self._lib.masr_pool_close(self._c, int(handle)))
             self.sessions.pop(handle)
+            self.errors.pop(handle, None)
             self._feeds = [f for f in self._feeds if f[0] != handle]
             return
         self.engine.stream_close(handle)
@@ -225,6 +242,7 @@ class StreamPool:
         if self._c is not None:
             _lib.check(self._lib.masr_pool_reset(self._c, int(handle)))
             self.sessions[handle] = _Session(handle, 0, None)
+            self.errors.pop(handle, None)
             self._feeds = [f for f in self._feeds if f[0] != handle]
             return
         self.engine.stream_reset(handle)
@@ -369,12 +387,19 @@ class StreamPool:
         m, w = ns.value, width.value
         hs = np.ctypeslib.as_array(C.cast(h_out, C.POINTER(C.c_int32)), (m,))
         st = np.ctypeslib.as_array(C.cast(st_out, C.POINTER(C.c_int32)), (m,))
-        na = int(st.sum())
+        na = int((st == 1).sum())
         rows = np.ctypeslib.as_array(C.cast(rows_h, C.POINTER(C.c_int32)), (na, w)) if na else None
         out, j, adv = {}, 0, []
         vocab = self.vocab
         for h, ok in zip(hs.tolist(), st.tolist()):
             s = self.sessions[h]
+            if ok < 0:
+                # left out of the step: its stream is full (max_frames_out / the positional table).  The reference asserts there
+                # (embedding.py:48-50); here the OTHER sessions keep their results and this one carries the error until it is reset
+                s.result = None
+                out[h] = None
+                self.errors[h] = 'stream exceeds max_frames_out / max_pos: reset_stream() or close it'
+                continue
             if not ok:
                 s.result = None
                 out[h] = None

@@ -66,3 +66,24 @@ def cer(ref, hyp):
             cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (r[i - 1] != h[j - 1]))
         prev = cur
     return prev[len(h)] / max(len(r), 1)
+
+
+def acceptable_texts(probs, vocab, margin=2e-3, limit=12):
+    """Transcripts the reference's greedy decoder can give for ``probs`` [T', V] when every frame whose top-2 margin is below
+    the numerical noise of a 1e-3 fp32 path may go either way: the decided frames are FIXED (exact argmax parity), each
+    undecided frame takes its best or its second-best token.  A path whose logits are within tolerance must produce one of
+    these -- with no undecided frame, the one reference transcript."""
+    probs = np.asarray(probs)
+    order = np.argsort(probs, axis=-1)
+    best, second = order[:, -1], order[:, -2]
+    rows = np.arange(len(probs))
+    open_frames = np.nonzero(probs[rows, best] - probs[rows, second] <= margin)[0]
+    assert len(open_frames) <= limit, f'{len(open_frames)} undecided frames: the synthetic head is not sharp enough for this test'
+    out = set()
+    for mask in range(1 << len(open_frames)):
+        p = probs.copy()
+        for bit, t in enumerate(open_frames):
+            if mask >> bit & 1:
+                p[t, best[t]], p[t, second[t]] = probs[t, second[t]], probs[t, best[t]]
+        out.add(greedy_decoder(p, vocab)[1])
+    return out, len(open_frames)

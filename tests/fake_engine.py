@@ -26,6 +26,26 @@ class FakeEngine:
         self.calls += 1
         return out
 
+    def mean_square(self, pcm, n_samples, out=None):
+        ms = (pcm.float() / 32768.0).pow(2).mean(dim=1)
+        if out is not None:
+            out.copy_(ms)
+            return out
+        return ms
+
+    def transcribe_rows(self, pcm, n_samples, use_db_normalization=True, target_db=-20.0, gain_in=None, out=None, **kw):
+        """the packed form [B, T' + 2] = tokens | count | score bits (what masr_transcribe_rows writes)"""
+        assert gain_in is not None and gain_in.shape == (pcm.shape[0],) and bool((gain_in > 0).all())
+        B, n_max = pcm.shape
+        Tp = self.out_frames(1 + (n_max - 400) // 160)
+        trip = (torch.empty(B, Tp, dtype=torch.int32), torch.empty(B, dtype=torch.int32), torch.empty(B, dtype=torch.float32))
+        self.transcribe_batch(pcm, n_samples, out=trip)
+        rows = torch.cat([trip[0], trip[1].view(-1, 1), trip[2].view(-1, 1).view(torch.int32)], dim=1)
+        if out is not None:
+            out.copy_(rows)
+            return out
+        return rows
+
     def profile_select(self, kind):
         pass
 

@@ -255,6 +255,10 @@ def test_bench_cli_launches_ranks_and_rejects_mismatch():
     assert r['n_gpus'] == 2 and r['config']['world_size_observed'] == 2 and r['config']['backend'] == 'gloo'
     assert r['config']['global_batch'] == 64 and r['steps'] == 2 and r['value'] > 0 and 'STAND-IN' in r['data']
     assert set(r['timing']) == {'device_only', 'host_to_host'}
+    # the exchange of the timed region's last step delivered every rank's rows; both ranks report their own time
+    assert r['config']['rccl_ranks_seen'] == [0, 1]
+    assert 0 < r['config']['ms_per_step_per_rank']['min'] <= r['config']['ms_per_step_per_rank']['max'] <= r['ms_per_step'] * 1.001
+    assert 'use_db_normalization = 2' in r['config']['normalisation'] and 'mode 2' in r['config']['timed_region']
     p1 = subprocess.run(cmd + ['--gpus', '1'], env=env, capture_output=True, text=True, timeout=600)
     r1 = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith('{')][0])
     assert r1['n_gpus'] == 1 and r1['config']['global_batch'] == 32

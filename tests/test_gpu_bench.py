@@ -33,25 +33,33 @@ def test_contract_step_texts_are_the_steps_own(force_dist, monkeypatch):
         # a different batch per step: the texts of step k must come from batch k, whatever is in flight
         batches = [torch.from_numpy(synthetic.synthetic_pcm(bench.BATCH, bench.N_SAMPLES, seed=900 + k)).to(eng.device)
                    for k in range(5)]
-        want = []
-        for b in batches:
-            tok, nt, _ = eng.transcribe_batch(b, cs.n)
-            want.append(parallel.tokens_to_text(tok, nt, np.array(vocab, dtype=object)))
+        def direct(b):
+            """the bit-exact route called directly: mean squares -> this host's numpy -> supplied gains -> packed rows"""
+            gains = eng.host_gains(b, cs.n, cs.TARGET_DB)
+            rows = eng.transcribe_rows(b, cs.n, True, cs.TARGET_DB, gain_in=gains)
+            tok, nt, _ = parallel.unpack_hypothesis_rows(rows.cpu().numpy())
+            return parallel.tokens_to_text(tok, nt, np.array(vocab, dtype=object)), gains.cpu().numpy()
+
+        want, want_gains = zip(*[direct(b) for b in batches])
+        want = list(want)
         torch.cuda.synchronize()
         assert len({tuple(w) for w in want}) == 5
-        got = []
-        for k, b in enumerate(batches):
-            cs.pcm = b
-            cs.step(k, 'full')
-            if k:
-                got.append(list(cs.texts))            # step k delivers the text of step k - 1
-        cs.flush()
-        got.append(list(cs.texts))
-        assert got == want
-        assert cs.n_texts == 5 * bench.BATCH
+        for announce in (True, False):                # the next batch announced (its gains prepared under this step) or not
+            got, gains = [], []
+            cs.n_texts = 0
+            for k, b in enumerate(batches):
+                cs.pcm = b
+                cs.step(k, 'full', next_pcm=batches[k + 1] if announce and k + 1 < len(batches) else None)
+                gains.append(cs.last_gains.copy())
+                if k:
+                    got.append(list(cs.texts))        # step k delivers the text of step k - 1
+            cs.flush()
+            got.append(list(cs.texts))
+            assert got == want
+            assert all(np.array_equal(g, w) for g, w in zip(gains, want_gains))     # every step ran on ITS batch's gains
+            assert cs.n_texts == 5 * bench.BATCH
         # 'host' mode: the PCM comes over PCIe on a copy stream, one step ahead; every step must still transcribe that batch
-        tok, nt, _ = eng.transcribe_batch(cs.pcm_host.to(eng.device), cs.n)
-        host_want = parallel.tokens_to_text(tok, nt, np.array(vocab, dtype=object))
+        host_want, _ = direct(cs.pcm_host.to(eng.device))
         for k in range(4):
             cs.step(k, 'host')
             if k:

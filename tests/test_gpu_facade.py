@@ -563,6 +563,71 @@ def test_c_pool_step_equals_the_python_framing(predictor, monkeypatch):
     assert n_results > 20
 
 
+def test_c_pool_step_leaves_a_full_session_out_and_validates_feeds(predictor):
+    """masr_pool_step: (1) a session whose stream has no room for the frames a step would emit is LEFT OUT of the lock-step
+    call (state -1) -- its neighbour's partials are what they are without it, call by call; (2) a malformed feed is rejected
+    before any session state changes: the same step repeated with the feed fixed gives the undisturbed result."""
+    import ctypes as C
+    from masr_amd import _lib
+    from masr_amd.serving import StreamPool
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    chunks = [pcm[i:i + 8000] for i in range(0, 64000, 8000)]          # 4 s: ~100 encoder frames
+    alone = StreamPool(predictor)
+    h = alone.open()
+    want = []
+    for k, c in enumerate(chunks):
+        alone.feed(h, c.tobytes(), is_end=k == len(chunks) - 1)
+        want.append(alone.step()[h])
+    alone.close(h)
+    alone.shutdown()
+    # ONE pool whose limit only the first session reaches: `full` is fed three times as fast as its neighbour
+    pool = StreamPool(predictor, max_frames_out=120)
+    full, ok = pool.open(), pool.open()
+    room = C.c_int32()
+    assert pool.engine.lib.masr_stream_room(pool.engine.h, ok, C.byref(room)) == 0 and room.value == 120
+    got, refused_at = [], None
+    for k, c in enumerate(chunks):
+        pool.feed(ok, c.tobytes(), is_end=k == len(chunks) - 1)
+        pool.feed(full, np.concatenate([c, c, c]).tobytes(), is_end=False)
+        res = pool.step()
+        got.append(res[ok])
+        if full in pool.errors and refused_at is None:
+            refused_at = k
+            assert res[full] is None
+    assert refused_at is not None and refused_at > 0, 'the fast session never reached max_frames_out'
+    for a, b in zip(got, want):
+        assert (a is None) == (b is None) and (a is None or (a['text'] == b['text'] and abs(a['score'] - b['score']) < 1e-4))
+    pool.reset(full)
+    assert full not in pool.errors
+    pool.feed(full, chunks[0].tobytes(), is_end=True)
+    pool.step()                                               # the reset session takes audio again
+    assert full not in pool.errors
+    # (2) validation: a negative sample count is refused, nothing is committed
+    p2 = StreamPool(predictor)
+    a = p2.open()
+    p2.feed(a, chunks[0].tobytes(), is_end=False)
+    first = p2.step()[a]
+    handles = np.array([a], np.int32)
+    arr = np.ascontiguousarray(chunks[1])
+    ptrs = np.array([arr.ctypes.data], np.uint64)
+    ns, width = C.c_int32(), C.c_int32()
+    outs = [C.c_void_p() for _ in range(4)]
+    call = lambda count: p2._lib.masr_pool_step(p2._c, 1, handles.ctypes.data, ptrs.ctypes.data, np.array([count], np.int64).ctypes.data,
+                                                np.array([0], np.int32).ctypes.data, np.array([0], np.int32).ctypes.data,
+                                                C.cast(p2._gain_cb, C.c_void_p), None, C.byref(ns), C.byref(outs[0]), C.byref(outs[1]),
+                                                C.byref(outs[2]), C.byref(width), C.byref(outs[3]),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert call(-5) != 0 and 'feed_n' in _lib.lib().masr_last_error().decode()
+    assert call(1 << 40) != 0
+    p2.feed(a, chunks[1].tobytes(), is_end=False)
+    second = p2.step()[a]
+    assert second == want[1] or (second is not None and want[1] is not None and second['text'] == want[1]['text'])
+    assert (first is None) == (want[0] is None)
+    p2.close(a)
+    p2.shutdown()
+    pool.shutdown()
+
+
 def test_stream_pool_deepspeech2(tmp_path):
     """StreamPool over the streaming DeepSpeech2: two concurrent sessions == two sequential predict_stream runs"""
     from masr_amd.serving import StreamPool

@@ -53,6 +53,10 @@ def dev(x, dtype=None):
     return t.cuda().contiguous()
 
 
+def acceptable_texts(probs, vocab, od, margin=2e-3, limit=12):
+    return od.acceptable_texts(probs, vocab, margin, limit)
+
+
 # ---------------------------------------------------------------------------------------------------
 # single kernels
 # ---------------------------------------------------------------------------------------------------
@@ -331,17 +335,14 @@ def test_transcribe_batch_against_oracle(eng4233, oracle_mods):
         n_enc = oc.subsampled_len(frames[i])
         s_ref, t_ref = od.greedy_decoder(probs[i, :n_enc], vocab)
         text = ''.join(vocab[j] for j in tok[i, :ntok[i]]).replace('<space>', ' ')
-        top2 = np.sort(probs[i, :n_enc], axis=-1)[:, -2:]
-        if (top2[:, 1] - top2[:, 0]).min() > 2e-3:       # argmax is numerically decided
-            assert text == t_ref, (i, text, t_ref)
-        assert od.cer(t_ref, text) <= 0.05, (i, text, t_ref)
+        ok, n_open = acceptable_texts(probs[i, :n_enc], vocab, od)   # decided frames exact; 0 undecided: == t_ref
+        assert text in ok and (n_open or text == t_ref), (i, n_open, text, t_ref)
         assert abs(float(score[i]) * 100.0 - s_ref) < 0.1
     # decode_all_frames reproduces the reference batch quirk (trainer.py:340: padded frames decoded too)
     tok2, ntok2, _ = e.transcribe_batch(dev(pcm), dev(np.array(lens, np.int32)), decode_all_frames=True)
     for i in range(len(lens)):
-        _, t_ref = od.greedy_decoder(probs[i], vocab)
         text = ''.join(vocab[j] for j in tok2[i, :int(ntok2[i])].cpu().numpy()).replace('<space>', ' ')
-        assert od.cer(t_ref, text) <= 0.05, (i, text, t_ref)
+        assert text in acceptable_texts(probs[i], vocab, od)[0], (i, text)
 
 
 def test_baseline_size_properties(eng4233, oracle_mods):
@@ -365,7 +366,43 @@ def test_baseline_size_properties(eng4233, oracle_mods):
     s_ref, t_ref = od.greedy_decoder(probs, weights.synthetic_vocab(4233))
     vocab = weights.synthetic_vocab(4233)
     text = ''.join(vocab[j] for j in t1[5, :int(n1[5])].cpu().numpy()).replace('<space>', ' ')
-    assert od.cer(t_ref, text) <= 0.05 and abs(float(s1[5]) * 100 - s_ref) < 0.1
+    assert text in acceptable_texts(probs, vocab, od)[0] and abs(float(s1[5]) * 100 - s_ref) < 0.1
+
+
+def test_contract_route_is_bit_exact_at_baseline_size(eng4233, oracle_mods):
+    """BASELINE configs[1] on the route bench.py times (masr_transcribe_rows, use_db_normalization = 2): with the gains of
+    ``reference_gains`` (the reference's scalar numpy expressions on the device's numpy-ordered mean squares) the int16
+    samples the fbank kernel consumes are the reference's for ALL 32 utterances, bit for bit (audio.py:287-304,549-574), and
+    every transcript is the reference's wherever its frames are numerically decided (no CER allowance)."""
+    from masr_amd import parallel
+    e, sd = eng4233
+    oc, od, ofb, weights, _ = oracle_mods
+    B, N = 32, 160000
+    pcm = weights.synthetic_pcm(B, N, seed=1234)
+    xs, ns = dev(pcm), dev(np.full(B, N, np.int32))
+    gains = e.host_gains(xs, ns, -20.0)
+    _, _, norm = e.fbank_batch(xs, ns, True, -20.0, return_norm=True, gain_in=gains)
+    norm = norm.cpu().numpy()
+    feats = []
+    for i in range(B):
+        f, i16 = ofb.featurize_pcm16(pcm[i])
+        assert np.array_equal(norm[i], i16), f'utterance {i}: {int((norm[i] != i16).sum())} int16 samples differ'
+        feats.append(f)
+    rows = e.transcribe_rows(xs, ns, True, -20.0, gain_in=gains)
+    tok, nt, score = parallel.unpack_hypothesis_rows(rows.cpu().numpy())
+    with torch.no_grad():
+        probs = oc.get_encoder_out(sd, torch.from_numpy(np.stack(feats)), torch.full((B,), feats[0].shape[0])).numpy()
+    vocab = weights.synthetic_vocab(4233)
+    n_exact = 0
+    for i in range(B):
+        s_ref, t_ref = od.greedy_decoder(probs[i], vocab)
+        text = ''.join(vocab[j] for j in tok[i, :nt[i]]).replace('<space>', ' ')
+        ok, n_open = acceptable_texts(probs[i], vocab, od)
+        assert text in ok and (n_open or text == t_ref), (i, n_open, text, t_ref)
+        n_exact += n_open == 0
+        assert abs(float(score[i]) * 100.0 - s_ref) < 0.1
+    print(f'{n_exact} of {B} utterances fully decided: transcripts identical; the rest identical on every decided frame')
+    assert n_exact >= B // 2
 
 
 # ---------------------------------------------------------------------------------------------------
