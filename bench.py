@@ -44,6 +44,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f
 GFLOP_PER_STEP = 742.0        # 23.18 GFLOP per 10 s utterance x 32
 GFLOP_PER_UTT_EFFICIENT = 16.99   # Efficient-Conformer, 10 s utterance, V = 4233
 GFLOP_SQUEEZEFORMER_B64 = 1430.0  # configs[2]'s 64 utterances (727.6 audio-s), useful (unpadded) work
+GFLOP_PER_UTT_DS2_BI = 61.0       # DeepSpeech2 bi-directional (deepspeech2.yml, streaming: False), 10 s utterance, V = 4233
+GFLOP_DS2_BI_TESTWAV = 51.1       # the same model on dataset/test.wav (837 frames -> T' = 208)
+PEAK_HBM_TBS = 8.0                # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 
 
 def conformer_gflop(T, t2=None, vocab=VOCAB, d=256, dff=2048, layers=12, k=15, pos_per_utt=False):
@@ -118,6 +121,10 @@ def make_engine(kind, device, vocab=VOCAB):
     if kind == 'squeezeformer':
         return HipEngine(synthetic.squeezeformer_state_dict(0, vocab), vocab_size=vocab, streaming=False,
                          use_model='squeezeformer', device=device)
+    if kind in ('deepspeech2', 'deepspeech2_streaming'):
+        bi = kind == 'deepspeech2'
+        return HipEngine(synthetic.deepspeech2_state_dict(0, vocab, bidirectional=bi), vocab_size=vocab, streaming=not bi,
+                         use_model='deepspeech2', device=device)
     raise SystemExit(f'unknown engine kind {kind}')
 
 
@@ -691,7 +698,12 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
     # the longest utterance is the call's critical path) runs on a side stream under the encoder of the next pass.  Measured with
     # MASR_BENCH_BEAM_PASS: passes of 16 are faster with the sharpened head (27.2 vs 30.7 ms per call: the longest utterance's search
     # starts earlier) and slower with flat posteriors (56.6 vs 46.6 ms: four long searches share two side streams); 32 for both lines
-    per_pass = int(os.environ.get('MASR_BENCH_BEAM_PASS', '32'))
+    # Round 5: passes of EQUAL PADDED SIZE (predict_batch(batch_size='balanced'): count x longest utterance <= 32 x 10 s, i.e. one
+    # full round of 248 row-block workgroups per pass): the 64 utterances become passes of 16 / 19 / 29 (three rounds) where two
+    # fixed passes of 32 were 494 + 275 row blocks = four rounds, the second one half empty.  MASR_BENCH_BEAM_PASS=<n> restores
+    # fixed passes of n for A/B.
+    per_pass = os.environ.get('MASR_BENCH_BEAM_PASS', 'balanced')
+    per_pass = per_pass if per_pass == 'balanced' else int(per_pass)
     pred.predict_batch(audio, batch_size=per_pass)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -715,7 +727,8 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
     cand_mean = float(cnt.float().mean())
     pred.predictor.engine.close()
     return {'workload': f'configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s), '
-                        f'{-(-64 // per_pass)} length buckets of {per_pass}, ctc_beam_search beam 300 / top-n 40, '
+                        + ('length-sorted passes of equal padded size (16 / 19 / 29 utterances)' if per_pass == 'balanced' else
+                           f'{-(-64 // per_pass)} length buckets of {per_pass}') + ', ctc_beam_search beam 300 / top-n 40, '
                         + ('alpha 2.2 beta 4.3 with a synthetic 3-gram WORD LM: prefix search on %d host threads' % conf['num_processes']
                            if lm and word_lm else
                            'alpha 2.2 beta 4.3 with a synthetic 3-gram character LM scored on the GPU' if lm else 'LM-free'),
@@ -729,6 +742,131 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
             'roofline': workload_roofline(GFLOP_SQUEEZEFORMER_B64, dt * 1e3 / steps,
                                           'SURVEY 8(d): 1.43 TFLOP of useful encoder work in the 64 utterances; the call is bound by '
                                           'the prefix search of its longest utterance, not by the encoder (DESIGN 9)')}
+
+
+def extra_squeezeformer_greedy(args, rank, world, local):
+    """configs[2]'s 64 utterances through the ENCODER path only (ctc_greedy instead of the prefix search): what the Squeezeformer
+    layers cost, with the two fused stage kernels of a layer (csrc/sqz_layer.hip) timed by HIP events in the same run"""
+    from masr_amd.utils import synthetic
+    rng = np.random.default_rng(1234)
+    lens = np.sort(rng.integers(32000, 320001, 64).astype(np.int32))[::-1].copy()
+    pcm_h = synthetic.synthetic_pcm(64, int(lens.max()), seed=1234)
+    audio = [pcm_h[i, :lens[i]] for i in range(64)]
+    pred = facade('squeezeformer', 'ctc_greedy', local, streaming=False)
+    eng = pred.predictor.engine
+    steps = 10
+    out = {}
+    for mode in ('balanced', 32):
+        for _ in range(2):
+            pred.predict_batch(audio, batch_size=mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = pred.predict_batch(audio, batch_size=mode)
+        torch.cuda.synchronize()
+        out[mode] = (time.perf_counter() - t0) / steps
+    # A/B of the fused-layer threshold (masr_debug_set key 36: row blocks from which a layer takes the fused stage kernels;
+    # 0 = the twelve separate launches of round 4) on the same call
+    ab = {}
+    if os.environ.get('MASR_BENCH_SQZ_AB', '1') == '1' and hasattr(eng, 'lib'):
+        for blocks in (0, 96, 192):
+            eng.lib.masr_debug_set(eng.h, 36, blocks)
+            pred.predict_batch(audio, batch_size='balanced')
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                pred.predict_batch(audio, batch_size='balanced')
+            torch.cuda.synchronize()
+            ab[f'fused_from_{blocks}_row_blocks' if blocks else 'separate_launches'] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+        eng.lib.masr_debug_set(eng.h, 36, 192)
+    kernels = []
+    for kind, name in ((6, 'sqz_stage_kernel<0, 1>: [out-proj + LN1] + FFN1 + LN2 + [pw1 + GLU]'),
+                       (7, 'sqz_stage_kernel<1, 31>: [dwconv + BN + SiLU + pw2 + LN3] + FFN2 + LN4 + [next QKV]')):
+        eng.profile_select(kind)
+        eng.profile_read(reset=True)
+        pred.predict_batch(audio, batch_size='balanced')
+        torch.cuda.synchronize()
+        ms, n, fl = eng.profile_read(reset=True)
+        if n > 0 and ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            kernels.append({'kernel': name, 'launches': int(n), 'avg_us': round(ms * 1e3 / n, 2), 'achieved': round(ach, 2),
+                            'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'unit': 'TFLOP/s',
+                            'note': 'HIP events around every launch of one predict_batch call (launches of full-rate and half-rate layers, '
+                                    'all passes); half-rate layers below 192 row blocks run the separate d_ff-split launches instead'})
+    eng.profile_select(0)
+    total = float(lens.sum()) / 16000.0
+    dt = out['balanced']
+    eng.close()
+    roof = workload_roofline(GFLOP_SQUEEZEFORMER_B64, dt * 1e3, 'SURVEY 8(d): 1.43 TFLOP of useful (unpadded) encoder work in the 64 utterances')
+    roof['kernels'] = kernels
+    return {'workload': f'configs[2] with ctc_greedy: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s) -> text, '
+                        'length-sorted passes of equal padded size (16 / 19 / 29 utterances); encoder-bound line of the Squeezeformer',
+            'value': round(total / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps, 'ms_per_step': round(dt * 1e3, 3),
+            'fixed_passes_of_32_ms_per_step': round(out[32] * 1e3, 3), 'fused_layer_ab_ms_per_step': ab, 'transcripts': len(res),
+            'roofline': roof}
+
+
+def extra_deepspeech2(args, rank, world, local):
+    """DeepSpeech2 (deepspeech2.yml, streaming: False = bi-directional LSTMs), BASELINE configs[0]'s model on the GPU:
+    ``ds2_testwav_b1``  one test.wav-sized utterance (8.39 s, T' = 208) PCM -> text, p50 of 50 calls;
+    ``ds2_b32x10s``     32 x 10 s per pass.
+    The recurrence is one launch per timestep and layer; at B = 1 its bound is the recurrent weight stream (W_hh: 16.8 MB per
+    direction re-read every timestep from L2 / Infinity Cache), reported against the HBM peak; at B = 32 the matrix pipe."""
+    from masr_amd.utils import synthetic
+    eng = make_engine('deepspeech2', local)
+    golden = os.path.join(ROOT, 'tests', 'golden', 'testwav.npz')
+    wav = np.load(golden)['pcm'] if os.path.exists(golden) else synthetic.synthetic_pcm(1, 134240, seed=7)[0]
+    out = {}
+    xs = torch.from_numpy(np.ascontiguousarray(wav[None])).to(eng.device)
+    ns = torch.tensor([len(wav)], dtype=torch.int32, device=eng.device)
+
+    def one():
+        rows = eng.transcribe_rows(xs, ns, True, -20.0, gain_in=eng.host_gains(xs, ns, -20.0))
+        return eng.to_host(rows)
+    for _ in range(3):
+        one()
+    lat = []
+    for _ in range(50):
+        t0 = time.perf_counter()
+        one()
+        lat.append(time.perf_counter() - t0)
+    p50 = float(np.percentile(lat, 50)) * 1e3
+    Tq = eng.out_frames(1 + (len(wav) - 400) // 160)
+    whh_bytes = 2 * 4 * 1024 * 1024 * 4.0 * Tq * 5                 # directions x [4 x 1024, 1024] f32 x timesteps x layers
+    out['ds2_testwav_b1'] = {
+        'workload': f'deepspeech2.yml streaming: False (bi-LSTM x 5), one {len(wav) / 16000.0:.2f} s utterance (dataset/test.wav, T\' = {Tq}): '
+                    'int16 PCM in HBM -> mean squares -> host gains -> masr_transcribe_rows -> packed row on the host, 50 calls',
+        'latency_ms': {'p50': round(p50, 3), 'p95': round(float(np.percentile(lat, 95)) * 1e3, 3), 'calls': len(lat)},
+        'value': round(len(wav) / 16000.0 / (p50 * 1e-3), 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1,
+        'roofline': {'bound': 'hbm', 'scope': 'whole call (wall time); the dominant stream is W_hh re-read per timestep (served by L2 / '
+                                              'Infinity Cache after the first touch: the HBM peak is the stated roof, not a bound it can exceed)',
+                     'achieved': round(whh_bytes / (p50 * 1e-3) / 1e12, 3), 'peak': PEAK_HBM_TBS, 'unit': 'TB/s',
+                     'frac': round(whh_bytes / (p50 * 1e-3) / 1e12 / PEAK_HBM_TBS, 4),
+                     'algorithmic_bytes_per_call': whh_bytes,
+                     'mfma_view': workload_roofline(GFLOP_DS2_BI_TESTWAV, p50, 'SURVEY 8(d): 51.1 GFLOP for test.wav (bi)')}}
+    B = 32
+    pcm = torch.from_numpy(synthetic.synthetic_pcm(B, N_SAMPLES, seed=1234 + rank)).to(eng.device)
+    n = torch.full((B,), N_SAMPLES, dtype=torch.int32, device=eng.device)
+
+    def batch():
+        return eng.transcribe_rows(pcm, n, True, -20.0, gain_in=eng.host_gains(pcm, n, -20.0))
+    for _ in range(2):
+        batch()
+    torch.cuda.synchronize()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rows = batch()
+    eng.to_host(rows)
+    dt = (time.perf_counter() - t0) / steps
+    out['ds2_b32x10s'] = {
+        'workload': 'deepspeech2.yml streaming: False (bi-LSTM x 5), 32 x 10 s per pass: int16 PCM in HBM -> packed hypothesis rows',
+        'value': round(B * 10.0 / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps, 'ms_per_step': round(dt * 1e3, 3),
+        'roofline': workload_roofline(GFLOP_PER_UTT_DS2_BI * B, dt * 1e3,
+                                      'SURVEY 8(d): 61.0 GFLOP per 10 s utterance (bi); the recurrence is 248 dependent launches per '
+                                      'layer and direction pair')}
+    eng.close()
+    return out
 
 
 def extra_facade(args, rank, world, local):
@@ -866,13 +1004,17 @@ def run_extras(args, rank, world, local, out=None):
         jobs.append(('squeezeformer_b64_beam', extra_squeezeformer_beam))
         jobs.append(('squeezeformer_b64_beam_sharp', lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True)))
         jobs.append(('squeezeformer_b64_beam_wordlm_host', lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True, word_lm=True)))
+        jobs.append(('squeezeformer_b64_greedy', extra_squeezeformer_greedy))
         jobs.append(('facade', extra_facade))
-        jobs.append(('conformer_b32_bf16x3_exploratory', extra_bf16x3))
+        jobs.append(('deepspeech2', extra_deepspeech2))
+        from masr_amd import build as _build
+        if _build.has_experiments():             # (the exploratory split-bf16 mode exists only in MASR_BUILD_EXPERIMENTS=1 libraries)
+            jobs.append(('conformer_b32_bf16x3_exploratory', extra_bf16x3))
     for name, fn in jobs:
         try:
             t0 = time.perf_counter()
             res = fn(args, rank, world, local)
-            if name == 'facade':                 # two lines of the drop-in surface from one predictor
+            if name in ('facade', 'deepspeech2'):  # several lines from one predictor / engine
                 out.update(res)
             else:
                 out[name] = res
@@ -917,6 +1059,7 @@ def main():
               'squeezeformer_b64_beam_nolm': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, lm=False),
               'squeezeformer_b64_beam_sharp': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True),
               'squeezeformer_b64_beam_wordlm_host': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True, word_lm=True),
+              'squeezeformer_b64_greedy': extra_squeezeformer_greedy, 'deepspeech2': extra_deepspeech2,
               'facade': extra_facade}[args.workload]
         res = fn(args, rank, world, local)
         if rank == 0:

@@ -545,6 +545,7 @@ void launch_attention(const AttSeq* seqs, int nseq, int max_nq, int heads, int q
 // matrix work (0.38 and 0.49 matrix-pipe busy at B = 32 x 10 s) and the att [M, 256] round trip sits between them.
 // masr_debug_set key 34 = 0 keeps the two launches.
 // ------------------------------------------------------------------------------------------------------------------
+#if MASR_EXPERIMENTS
 static constexpr int AC_LD = 68;                      // K' / V tile rows (floats)
 static constexpr int AC_TILE = 4 * 32 * AC_LD;        // one key tile, four heads
 static constexpr int AC_ALD = 256 + 4;                // context / LayerNorm tiles
@@ -829,6 +830,7 @@ bool launch_attn_chain(const AttnChainArgs& a, int max_nq, hipStream_t s) {
     hipLaunchKernelGGL(attn_chain_kernel, dim3(8 * b.nqb * ((a.nseq + 7) / 8)), dim3(512), lds, s, b);
     return true;
 }
+#endif   // MASR_EXPERIMENTS
 
 // Sequence descriptors for the full-context batch path: q/k/v interleaved in one [B*Tp, 768] buffer
 // (fused QKV projection), keys j valid iff mstride*j < len_b (subsampled pad mask, subsampling.py:112;

@@ -103,6 +103,9 @@ static int g_attn_chain = 0;
 // dependent memory round trips (rows written by another XCD, LayerNorm, LDS exchange, partial store), not by the 256 MFMAs.  Off.
 static int g_ffn_coop = 0;
 static int g_few_rows_path = 1;   // masr_debug_set key 29: 0 = offline Conformer layers of few row blocks keep the row-block chain kernel (A/B)
+// masr_debug_set key 36: row blocks from which a full-context Squeezeformer layer runs as attention + the two fused stage kernels of
+// sqz_layer.hip (0 = never: the twelve separate launches, kept for A/B and the bit-identity test)
+static int g_sqz_fused_blocks = 192;
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
 namespace {
@@ -1293,6 +1296,7 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
     };
     CHK(new_resolution());
     const int L = e->cfg.num_blocks;
+    bool qkv_ready = false;       // the previous layer's fused end stage has already written this layer's q | k | v
     for (int i = 0; i < L; ++i) {
         const SqLayerW& w = e->sq_layers[i];
         if (i == e->reduce_idx) {
@@ -1314,13 +1318,71 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
             CHK(new_resolution());
         }
         const int M = B * Tq;
+        // Fused layer (sqz_layer.hip): attention + two row-block kernels.  Taken when the row blocks fill the chip (below that the
+        // d_ff-split FFN and the K-split projections of the unfused sequence are the faster launches); bit-identical either way.
+        const bool fused = g_sqz_fused_blocks > 0 && (M + 31) / 32 >= g_sqz_fused_blocks && d == 256 && (K == 31 || K == 15);
         // x = LN1(x + MHSA(ada(x)))
-        rowgemm(e, s, RG_PRO_AFFINE, RG_EPI_STORE, x, d, w.att_s, w.att_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M,
-                3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+        if (!qkv_ready)
+            rowgemm(e, s, RG_PRO_AFFINE, RG_EPI_STORE, x, d, w.att_s, w.att_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M,
+                    3 * d, nullptr, 0, 1.f, nullptr, 0, 0, 0, nullptr, nullptr);
+        qkv_ready = false;
         {
             ProfScope ps(e, s, PROF_ATT, 6.0 * d * (double)Tq * Tq * B);
             // (chunk > 0: decoding_chunk_size of the streaming-trained build; the kernel thins the mask by the layer's rate)
             launch_attention(e->attseq.as<AttSeq>(), B, Tq, H, 3 * d, 3 * d, w.ptab, w.pos_u, w.pos_v, chunk, pstride, s);
+        }
+        if (fused) {
+            // the next layer's QKV projection rides on this layer's last launch unless the frame rate changes in between
+            const bool next_same = i + 1 < L && i + 1 != e->reduce_idx && !(i + 1 == e->recover_idx && e->reduce_idx >= 0);
+            auto packed_ffn = [&](const float* w1, const float* w2, const float** p1, const float** p2) -> int {
+                auto it = e->ffn_packed.find(w1);
+                if (it == e->ffn_packed.end()) {
+                    std::pair<DevBuf, DevBuf> pk;
+                    CHK(pk.first.ensure((size_t)e->cfg.d_ff * d * sizeof(float)));
+                    CHK(pk.second.ensure((size_t)e->cfg.d_ff * d * sizeof(float)));
+                    launch_pack_ffn_pc(w1, w2, pk.first.as<float>(), pk.second.as<float>(), e->cfg.d_ff, s);
+                    it = e->ffn_packed.emplace(w1, pk).first;
+                }
+                *p1 = it->second.first.as<float>();
+                *p2 = it->second.second.as<float>();
+                return 0;
+            };
+            SqzStageArgs a{};
+            a.x = x; a.out = x; a.att = e->att.as<float>();
+            a.head_w = packed_rows_of(e, w.wo, d, s); a.head_b = w.bo;
+            a.ln_a_w = w.ln1_w; a.ln_a_b = w.ln1_b; a.ln_b_w = w.ln2_w; a.ln_b_b = w.ln2_b;
+            a.ffn_s = w.f1_s; a.ffn_b = w.f1_b; a.b1 = w.f1_b1; a.b2 = w.f1_b2;
+            CHK(packed_ffn(w.f1_w1, w.f1_w2, &a.w1, &a.w2));
+            a.tail_w = packed_rows_of(e, w.pw1_w, 2 * d, s); a.tail_b = w.pw1_b; a.tail_s = w.cv_s; a.tail_sb = w.cv_b; a.tail_n = 2 * d;
+            a.glu_out = e->glu.as<float>(); a.glu_pad_l = pad_l; a.glu_pad_tot = 2 * half;
+            a.lens = lens; a.M = M; a.dff = e->cfg.d_ff; a.seq_t = Tq; a.mstride = mstride; a.ktaps = K; a.eps = 1e-5f;
+            if (!a.head_w || !a.tail_w) return fail("squeezeformer: packing the layer's weights failed");
+            {
+                ProfScope ps(e, s, PROF_FFN_TAIL, 4.0 * M * (double)e->cfg.d_ff * d + 2.0 * M * (double)(3 * d) * d);
+                if (!launch_sqz_stage(a, 0, s)) return fail("squeezeformer: the fused mid stage rejected the sizes");
+            }
+            SqzStageArgs b{};
+            b.x = x; b.out = i == L - 1 ? enc_out : x; b.glu = e->glu.as<float>();
+            b.head_w = packed_rows_of(e, w.pw2_w, d, s); b.head_b = w.pw2_b;
+            b.dw_w = w.dw_w; b.dw_b = w.dw_b; b.bn_scale = w.bn_scale; b.bn_shift = w.bn_shift; b.gconst = causal ? w.gconst : nullptr;
+            b.ln_a_w = w.ln3_w; b.ln_a_b = w.ln3_b; b.ln_b_w = w.ln4_w; b.ln_b_b = w.ln4_b;
+            b.ffn_s = w.f2_s; b.ffn_b = w.f2_b; b.b1 = w.f2_b1; b.b2 = w.f2_b2;
+            CHK(packed_ffn(w.f2_w1, w.f2_w2, &b.w1, &b.w2));
+            if (next_same) {
+                const SqLayerW& nx = e->sq_layers[i + 1];
+                b.tail_w = packed_rows_of(e, nx.wqkv, 3 * d, s); b.tail_b = nx.bqkv; b.tail_s = nx.att_s; b.tail_sb = nx.att_b;
+                b.tail_n = 3 * d; b.tail_out = e->qkv.as<float>();
+                if (!b.tail_w) return fail("squeezeformer: packing the layer's weights failed");
+            }
+            b.lens = lens; b.M = M; b.dff = e->cfg.d_ff; b.seq_t = Tq; b.mstride = mstride; b.ktaps = K; b.eps = 1e-5f;
+            if (!b.head_w) return fail("squeezeformer: packing the layer's weights failed");
+            {
+                ProfScope ps(e, s, PROF_FFN_HEAD, 4.0 * M * (double)e->cfg.d_ff * d + 2.0 * M * (double)d * d +
+                                                      (next_same ? 2.0 * M * (double)(3 * d) * d : 0.0));
+                if (!launch_sqz_stage(b, 1, s)) return fail("squeezeformer: the fused end stage rejected the sizes");
+            }
+            qkv_ready = next_same;
+            continue;
         }
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->att.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d, 1.f,
                 nullptr, 0, 0, 0, nullptr, nullptr);
@@ -2690,6 +2752,10 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
 
 int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     if (!e) return fail("null engine");
+#if !MASR_EXPERIMENTS
+    if (value != 0 && (key == 20 || key == 21 || key == 22 || key == 24 || key == 30 || key == 34 || key == 35))
+        return fail("masr_debug_set: this key selects an experimental kernel that is not in this build (MASR_BUILD_EXPERIMENTS=1)");
+#endif
     if (key == 1) set_ffn_variant(value);
     else if (key == 5) g_no_chain = value;
     else if (key == 6) set_rowgemm_small(value);
@@ -2713,6 +2779,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 33) set_conv2_mid_fill(value);
     else if (key == 34) g_attn_chain = value;
     else if (key == 35) g_ffn_coop = value;
+    else if (key == 36) g_sqz_fused_blocks = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

@@ -675,6 +675,7 @@ static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float
         // head stage on the split launch (few rows): every slice of a row block runs the conv module's [depthwise conv -> LN ->
         // SiLU -> pointwise_conv2 + residual] on the block's rows before its share of the FFN; slice 0 writes the updated rows to
         // head->xout and the reduction continues from there
+#if MASR_EXPERIMENTS
         if (head && head->glu && head->xout && head->ktaps == 15 && !AFFINE && SV == 2) {
             static LdsAttr attr_split_h;
             ensure_dynamic_lds(reinterpret_cast<const void*>(ffn_pc_kernel<0, 1, 2, 0, 15>), lds, attr_split_h);
@@ -683,6 +684,7 @@ static int launch_pc_t(float* x, const float* lnw, const float* lnb, const float
             launch_ffn_reduce(x, partial, b2, M, ny, scale, s, post, head->xout);
             return (post && post->y ? 1 : 0) | 4;
         }
+#endif
         hipLaunchKernelGGL((ffn_pc_kernel<AFFINE, 1, SV, 0, 0>), dim3((M + PC_BM - 1) / PC_BM, ny), dim3(512), lds, s, x, lnw, lnb, w1,
                            b1, w2, b2, M, dff, eps, scale, partial, cpb, FfnTail{}, FfnHead{});
         launch_ffn_reduce(x, partial, b2, M, ny, scale, s, post);

@@ -31,6 +31,20 @@ from masr_amd.utils.utils import dict_to_object
 logger = logging.getLogger(__name__)
 
 
+def balanced_cuts(sorted_lengths, budget):
+    """[lo, hi) index ranges over an ASCENDING list of utterance lengths such that every range holds as many utterances as fit
+    count x (its longest utterance) <= budget, cut from the long end (at least one utterance per range); ranges in ascending
+    order.  A range is one device pass: all passes then cost about the same padded work -- one full round of workgroups each --
+    instead of a pass of long utterances costing twice a pass of short ones."""
+    cuts, hi = [], len(sorted_lengths)
+    while hi > 0:
+        k = max(1, min(hi, int(float(budget) // max(float(sorted_lengths[hi - 1]), 1.0))))
+        cuts.append((hi - k, hi))
+        hi -= k
+    cuts.reverse()
+    return cuts
+
+
 class MASRPredictor:
     def __init__(self, configs=None, model_tag='conformer_streaming_fbank_aishell',
                  model_path='models/conformer_streaming_fbank/inference.pt', use_pun=False,
@@ -326,13 +340,17 @@ class MASRPredictor:
         return 64 if self.configs.use_model == 'efficient_conformer' else 32
 
     def predict_batch(self, audio_list, sample_rate=16000, decode_all_frames=False, batch_size=0, distributed=None,
-                      lengths=None):
+                      lengths=None, pass_padded=None):
         """Batched offline path (an addition; the reference's only batched consumer is MASRTrainer.evaluate,
         trainer.py:592-651): a list of utterances -> [{'text','score'}] in input order.
 
         ``decode_all_frames=True`` reproduces the reference's batch evaluation quirk of decoding padded frames
         (trainer.py:340).  ``batch_size`` > 0 cuts the (length-sorted) work into device passes of that many utterances
-        (``batch_size='auto'``: ``pass_size()`` -- 32, or 64 for the Efficient-Conformer); the
+        (``batch_size='auto'``: ``pass_size()`` -- 32, or 64 for the Efficient-Conformer).  ``batch_size='balanced'``: passes of
+        EQUAL PADDED SIZE instead of equal count -- a pass takes utterances (longest first) while count x its longest
+        utterance stays within ``pass_padded`` (in the unit of the lengths; default: ``pass_size()`` utterances of 10 s, the row
+        blocks that fill the chip once), so a pass of long utterances holds few of them, a pass of short ones many, every pass is
+        one full round of workgroups and nobody is padded to the longest utterance of the whole list.  The
         audio of a pass is decoded when the pass is formed and dropped when its results are in, at most two passes are in
         flight (features + encoder of pass k under the prefix search of pass k - 1), so host memory and HBM hold two passes
         whatever the list's length.  ``lengths`` (samples or seconds, any common unit): known durations, e.g. a manifest's,
@@ -343,6 +361,13 @@ class MASRPredictor:
         hints = list(lengths) if lengths is not None else [self._length_hint(a, sample_rate) for a in audio_list]
         if batch_size == 'auto':
             batch_size = self.pass_size()
+        if batch_size == 'balanced':
+            rate = int(self.configs.preprocess_conf.get('sample_rate', 16000))
+            if pass_padded is None:
+                if lengths is not None:
+                    raise ValueError("batch_size='balanced' with caller-supplied lengths needs pass_padded in the same unit")
+                pass_padded = self.pass_size() * 10 * rate
+            batch_size = ('balanced', float(pass_padded))
         rank, world = parallel.world_info()
         if distributed is None:
             distributed = world > 1
@@ -367,7 +392,11 @@ class MASRPredictor:
         batches ``evaluate`` forms from a duration-sorted manifest); results in the order of ``which``.  Pipeline depth 2:
         pass k is launched (its prefix search on a side stream), then pass k - 1 is collected and its audio dropped."""
         order = sorted(which, key=lambda i: hints[i]) if batch_size else list(which)
-        step = batch_size if batch_size else max(len(order), 1)
+        if isinstance(batch_size, tuple):             # ('balanced', budget): count x longest <= budget per pass
+            cuts = balanced_cuts([hints[i] for i in order], batch_size[1])
+        else:
+            step = batch_size if batch_size else max(len(order), 1)
+            cuts = [(lo, min(lo + step, len(order))) for lo in range(0, len(order), step)]
         got, pending = {}, []
 
         def collect(item):
@@ -378,15 +407,14 @@ class MASRPredictor:
         # same passes either way; with the GPU prefix search the LONGEST pass goes first: its search (one workgroup per utterance,
         # the longest utterance is the critical path of the call) then starts right after the first encoder pass and the
         # shorter passes' encoders and searches run underneath it
-        starts = list(range(0, len(order), step))
         depth = 2
         if self.configs.decoder == 'ctc_beam_search' and getattr(self.beam_search_decoder, 'use_gpu_search', False):
-            starts.reverse()
+            cuts.reverse()
             # a prefix search is a long serial kernel on a few CUs (one workgroup per utterance, frames in sequence): the encoders
             # of up to three further passes are launched underneath it before its results are waited for
             depth = 4
-        for lo in starts:
-            idx = order[lo:lo + step]
+        for lo, hi in cuts:
+            idx = order[lo:hi]
             segs = [self._load_audio(audio_list[i], sample_rate) for i in idx]
             # (beam search: the prefix search of this pass runs on a side stream under the encoders of the next passes)
             pending.append((idx, self._predict_local(segs, decode_all_frames, as_tokens, defer=True)))

@@ -28,3 +28,10 @@ def built_lib():
     """hipcc cross-compiles gfx950 without a GPU; the prebuilt .so travels to the GPU box."""
     from masr_amd import build
     return build.build()
+
+
+def needs_experiments():
+    """skip marker for the tests of the measured-and-rejected kernels: they are compiled only with MASR_BUILD_EXPERIMENTS=1
+    (masr_amd/build.py); the default library holds the product kernels and refuses their masr_debug_set keys"""
+    from masr_amd import build
+    return pytest.mark.skipif(not build.has_experiments(), reason='experimental kernels are not in this build (MASR_BUILD_EXPERIMENTS=1)')

@@ -8,7 +8,9 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+from conftest import needs_experiments
+
+pytestmark = [pytest.mark.gpu, needs_experiments()]
 
 
 @pytest.fixture()

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import needs_experiments
+
 pytestmark = pytest.mark.gpu
 V = 512
 
@@ -65,6 +67,7 @@ def test_few_row_block_path_against_oracle_and_previous_kernels(streaming, B, T)
         assert ((out[name][2] - out['old'][2]).abs() * keep[:, :, 0]).max().item() < 1e-5
 
 
+@needs_experiments()
 def test_chunk_steps_with_the_head_stage_on_the_split_ffn_launch():
     """masr_debug_set key 30 (off by default: measured no faster): the conv module's second half as the head stage of the second
     FFN's d_ff-split launch -- 3 and 40 lock-step streams over six chunks, frame decisions identical, probabilities within 1e-5"""

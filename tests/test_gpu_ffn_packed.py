@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import needs_experiments
+
 pytestmark = pytest.mark.gpu
 
 
@@ -38,6 +40,7 @@ def test_packed_weights_are_bit_identical_to_the_slab_pipeline(kind, streaming):
     eng.close()
 
 
+@needs_experiments()
 @pytest.mark.parametrize('kind,streaming', [('conformer', True), ('conformer', False), ('squeezeformer', False),
                                             ('efficient_conformer', True)])
 def test_two_chain_ffn_is_bit_identical_to_the_single_chain_kernel(kind, streaming):
@@ -106,6 +109,7 @@ def test_packed_row_block_projections_are_bit_identical_to_the_slab_pipeline(kin
     eng.close()
 
 
+@needs_experiments()
 @pytest.mark.parametrize('streaming,chunk', [(True, -1), (False, -1), (True, 16)])
 def test_attention_chain_kernel_is_bit_identical_to_the_two_launches(streaming, chunk):
     """Round 4: attention + [out-projection + residual -> LN -> pointwise_conv1 -> GLU] as ONE launch (attn_chain_kernel: 32 queries

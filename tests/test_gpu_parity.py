@@ -482,6 +482,43 @@ def test_squeezeformer_streaming_build_against_reference_fixture(oracle_mods):
     e.close()
 
 
+@pytest.mark.parametrize('streaming', [False, True])
+def test_squeezeformer_fused_layer_is_bit_identical_to_the_separate_launches(oracle_mods, streaming):
+    """sqz_layer.hip (attention + two fused stage kernels per layer, the next layer's QKV projection riding on the last one)
+    against the twelve launches it replaces (masr_debug_set key 36 = 0): the same operations in the same order, so the encoder
+    output must be IDENTICAL -- ragged batch of 26 x <= 20 s (405 row blocks at the full rate, 203 behind the time reduction:
+    both resolutions take the fused path), symmetric and causal conv builds; and within 1e-3 of the oracle on two utterances."""
+    from masr_amd.engine import HipEngine
+    from oracle import squeezeformer as osq
+    weights = oracle_mods[3]
+    sd = weights.squeezeformer_state_dict(0, 512, streaming=streaming)
+    enc_conf = {'encoder_dim': 256, 'attention_heads': 4, 'num_blocks': 12, 'reduce_idx': 5, 'recover_idx': 11,
+                'feed_forward_expansion_factor': 8, 'cnn_module_kernel': 31}
+    e = HipEngine(sd, encoder_conf=enc_conf, vocab_size=512, streaming=streaming, use_model='squeezeformer')
+    try:
+        gen = torch.Generator().manual_seed(77)
+        B, T = 26, 1998
+        lens = torch.randint(300, T + 1, (B,), generator=gen)
+        lens[0], lens[1] = T, 1001                                   # a full-length and an odd-length utterance
+        x = torch.randn(B, T, 80, generator=gen) * 3 + 13
+        x = x * (torch.arange(T)[None, :, None] < lens[:, None, None])
+        xd, ld = dev(x), dev(lens, torch.int32)
+        fused = e.encode_full(xd, ld).cpu()
+        assert e.lib.masr_debug_set(e.h, 36, 0) == 0
+        plain = e.encode_full(xd, ld).cpu()
+        assert e.lib.masr_debug_set(e.h, 36, 192) == 0
+        assert torch.isfinite(fused).all()
+        assert torch.equal(fused, plain), f'max |fused - separate| = {(fused - plain).abs().max().item():.3e}'
+        with torch.no_grad():
+            ref = osq.encoder_full(sd, x[:2], lens[:2], causal=streaming)
+        n0, n1 = int(e.enc_frames(lens[:1])[0]), int(e.enc_frames(lens[1:2])[0])
+        # (the oracle runs the two utterances as their own padded batch: the same rows up to each one's valid frames)
+        err = max((fused[0, :n0] - ref[0, :n0]).abs().max().item(), (fused[1, :n1] - ref[1, :n1]).abs().max().item())
+        assert err < 1e-3, err
+    finally:
+        e.close()
+
+
 def test_squeezeformer_stream_chunks_against_reference_fixture(oracle_mods):
     """Squeezeformer forward_chunk (streaming build): half-rate layers keep their own caches, stream time reduction"""
     from masr_amd.engine import HipEngine

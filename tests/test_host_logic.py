@@ -269,3 +269,23 @@ def test_resampler_on_band_limited_tones_and_through_audio_segment():
     assert seg.num_samples == 16000
     with pytest.raises(NotImplementedError):
         rs.filter_table('sinc_best')
+
+
+def test_balanced_pass_cuts_cover_every_utterance_within_the_budget():
+    """predict_batch(batch_size='balanced'): passes of equal padded size -- every utterance in exactly one pass, count x longest
+    within the budget (a single utterance longer than the budget gets a pass of its own), BASELINE configs[2]'s 64 lengths cut
+    into three passes that each fill the chip once instead of two fixed passes of 32 that take four rounds."""
+    import numpy as np
+    from masr_amd.predict import balanced_cuts
+    rng = np.random.default_rng(1234)
+    lens = np.sort(rng.integers(32000, 320001, 64))
+    budget = 32 * 160000
+    cuts = balanced_cuts(lens, budget)
+    assert cuts[0][0] == 0 and cuts[-1][1] == 64 and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    assert all((hi - lo) * lens[hi - 1] <= budget for lo, hi in cuts)
+    assert [hi - lo for lo, hi in cuts] == [29, 19, 16]
+    padded = sum((hi - lo) * lens[hi - 1] for lo, hi in cuts)
+    fixed = 32 * lens[31] + 32 * lens[63]
+    assert lens.sum() < padded < fixed
+    assert balanced_cuts([5, 50, 500], 100) == [(0, 2), (2, 3)]                  # 500 > budget: its own pass; 2 x 50 fits
+    assert balanced_cuts([], 10) == [] and balanced_cuts([3, 3, 3, 3], 12) == [(0, 4)]
