@@ -185,7 +185,7 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(budget_s=30.0):
+def cpu_baseline(budget_s=30.0, force_port=False):
     """MASR's own CPU predict path on this node's host cores, on a bounded sample of the contract workload.  Two legs
     (SURVEY 8(d)): (i) the batched ``get_encoder_out`` path (trainer.py:632) on the config's own 32 x 10 s batch, (ii) the per-utterance
     ``MASRPredictor.predict`` loop (featurize + encoder + greedy, B = 1 calls, predict.py:167-192) -- ``value`` is leg (ii),
@@ -200,7 +200,7 @@ def cpu_baseline(budget_s=30.0):
     pcm = synthetic.synthetic_pcm(BATCH, N_SAMPLES, seed=1234)       # configs[1]'s batch; leg (ii) takes its first 4 utterances
     kind = 'port'
     encode = lambda f, l: oc.get_encoder_out(sd, f, l)
-    if shims.reference_available():
+    if shims.reference_available() and not force_port:
         try:
             from oracle import make_golden
             shims.install()

@@ -272,7 +272,8 @@ struct masr_engine {
     PinnedStage stage;
     DevBuf qplanes, attp, cnnptrs, ffpart;                                      // planar q|k|v and attention output, [B][Tpad][256]
     // fbank tables
-    float *window = nullptr, *melw = nullptr, *tw256 = nullptr, *tw512 = nullptr;
+    float *window = nullptr, *melw = nullptr, *melwt = nullptr, *tw256 = nullptr, *tw512 = nullptr, *twr4 = nullptr;
+    FbankTables fbank_tables() const { return FbankTables{window, melw, melwt, tw256, tw512, twr4, mel_lo, mel_hi}; }
     int *mel_lo = nullptr, *mel_hi = nullptr;
     // mfcc / linear tables (built on first use)
     float *dct = nullptr, *lifter = nullptr;
@@ -441,10 +442,31 @@ int build_fbank_tables(masr_engine* e) {
             }
             if (lo[m] > hi[m]) lo[m] = hi[m] = 0;
         }
+        // transposed weights [tap][filter] for the register-FFT kernel (tap i of filter m = bin lo[m] + i, zero past hi[m])
+        constexpr int TAPS = 16;
+        std::vector<float> melwt((size_t)TAPS * 80, 0.f);
+        for (int m = 0; m < 80; ++m) {
+            if (hi[m] - lo[m] > TAPS) return fail("fbank tables: a mel filter is wider than 16 bins");
+            for (int i = 0; i < hi[m] - lo[m]; ++i) melwt[(size_t)i * 80 + m] = melw[(size_t)m * 257 + lo[m] + i];
+        }
+        // twiddles of the Stockham radix-4 passes Ns = 4, 16, 64 of the 256-point FFT, one row per lane j:
+        // [pass][r - 1][j] = exp(-2 pi i r (j mod Ns) / (4 Ns)), r = 1..3
+        std::vector<float> twr4((size_t)3 * 3 * 64 * 2);
+        for (int p = 0; p < 3; ++p) {
+            const int Ns = p == 0 ? 4 : p == 1 ? 16 : 64;
+            for (int r = 1; r <= 3; ++r)
+                for (int j = 0; j < 64; ++j) {
+                    const double ang = -2.0 * M_PI * (double)(r * (j % Ns)) / (double)(4 * Ns);
+                    twr4[(((size_t)p * 3 + (r - 1)) * 64 + j) * 2] = (float)cos(ang);
+                    twr4[(((size_t)p * 3 + (r - 1)) * 64 + j) * 2 + 1] = (float)sin(ang);
+                }
+        }
         CHK(upload(e, win, &e->window));
         CHK(upload(e, tw256, &e->tw256));
         CHK(upload(e, tw512, &e->tw512));
         CHK(upload(e, melw, &e->melw));
+        CHK(upload(e, melwt, &e->melwt));
+        CHK(upload(e, twr4, &e->twr4));
         CHK(upload(e, lo, &e->mel_lo));
         CHK(upload(e, hi, &e->mel_hi));
     }
@@ -2006,8 +2028,8 @@ int masr_fbank_batch(masr_engine* e, const void* samples_dev, int32_t sample_for
     }
     {
         ProfScope ps(e, s, PROF_FBANK, 0.0);
-        launch_fbank(samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, target_db, e->window,
-                     e->melw, e->mel_lo, e->mel_hi, e->tw256, e->tw512, feats_dev, T_max, gain, norm_pcm_dev, s);
+        launch_fbank(samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, target_db, e->fbank_tables(),
+                     feats_dev, T_max, gain, norm_pcm_dev, s);
     }
     if (gain_dev && use_db_normalization == 1)
         HIPCHK(hipMemcpyAsync(gain_dev, gain, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
@@ -2094,8 +2116,7 @@ int masr_linear_batch(masr_engine* e, const void* samples_dev, int32_t sample_fo
         if (!gain_dev) return fail("use_db_normalization = 2 needs the gains in gain_dev");
         HIPCHK(hipMemcpyAsync(gain, gain_dev, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     } else if (use_db_normalization)          // T_max = 0: only the RMS -> gain kernels of the fbank front-end run
-        launch_fbank(samples_dev, sample_format, n_samples_dev, B, n_max, 1, target_db, e->window, e->melw, e->mel_lo, e->mel_hi,
-                     e->tw256, e->tw512, nullptr, 0, gain, nullptr, s);
+        launch_fbank(samples_dev, sample_format, n_samples_dev, B, n_max, 1, target_db, e->fbank_tables(), nullptr, 0, gain, nullptr, s);
     launch_linear_spec(samples_dev, sample_format, n_samples_dev, B, n_max, use_db_normalization, gain, e->lin_win, e->lin_tw,
                        e->lin_scale, feats_dev, T_max, s);
     if (gain_dev && use_db_normalization == 1)
@@ -2780,6 +2801,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 34) g_attn_chain = value;
     else if (key == 35) g_ffn_coop = value;
     else if (key == 36) g_sqz_fused_blocks = value;
+    else if (key == 37) set_fbank_radix2(value);
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

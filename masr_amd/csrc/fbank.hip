@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void norm_int16_kernel(const ST* __restrict__ 
 
 // ---- fbank ------------------------------------------------------------------------------------------
 static constexpr int WIN = 400, HOP = 160, NFFT = 512, NBIN = 257, NMEL = 80;
+static constexpr int FB_TAPS = 16;        // widest mel filter of the 80-bin 20 Hz - 8 kHz bank (build_fbank_tables checks it)
 
 template <class ST>
 __global__ __launch_bounds__(256) void fbank_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp,
@@ -343,11 +344,171 @@ __global__ __launch_bounds__(256) void fbank_kernel(const ST* __restrict__ pcm, 
     }
 }
 
+// ---- fbank, register FFT (round 5) -------------------------------------------------------------------------------------------
+// Same function as fbank_kernel above, one wave per frame, but the 256-point complex FFT is a Stockham radix-4 transform with FOUR
+// elements per lane in registers: four in-register radix-4 butterflies with three exchanges through a 2 KB per-wave LDS buffer
+// (24 LDS instructions per lane) where the radix-2 kernel walked eight LDS-synchronised stages (128 LDS instructions and 32 table
+// loads per lane).  Lane j holds z[j + 64 r], r = 0..3 (z[n] = y[2n] + i y[2n+1], y = windowed frame zero-padded to 512): the
+// first pass needs no exchange at all and the last one leaves Z[j + 64 q] in the lane's registers.  Complex arithmetic on float2
+// values (packed fp32 instructions).  The left neighbour of the pre-emphasis comes over one DPP wave shift instead of an LDS
+// round trip; the twiddles of the three later passes are one table row per lane (9 coalesced 8-byte loads, issued before the
+// samples arrive); the mel filterbank reads a TRANSPOSED weight table [tap][filter] (coalesced; a filter has at most 16 taps):
+// filters 0..63 one per lane, filters 64..79 four lanes each.
+typedef float f2 __attribute__((ext_vector_type(2)));
+static constexpr int FB_LDS = 272;                  // complex slots per wave: index c lives at c + (c >> 4) (bank-conflict padding)
+__device__ __forceinline__ int fb_slot(int c) { return c + (c >> 4); }
+__device__ __forceinline__ f2 fb_cmul(f2 a, f2 w) {                   // a * w
+    const f2 t = f2{a.x, a.x} * w;
+    return f2{a.y, a.y} * f2{-w.y, w.x} + t;
+}
+__device__ __forceinline__ void fb_radix4(f2 (&v)[4]) {              // forward DFT-4 in place: X_q = sum_r v_r (-i)^(r q)
+    const f2 a0 = v[0] + v[2], a1 = v[0] - v[2], a2 = v[1] + v[3], a3 = v[1] - v[3];
+    const f2 ia3 = f2{a3.y, -a3.x};                                     // -i * a3
+    v[0] = a0 + a2;
+    v[1] = a1 + ia3;
+    v[2] = a0 - a2;
+    v[3] = a1 - ia3;
+}
+
+template <class ST>
+__global__ __launch_bounds__(256) void fbank_r4_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp, int n_max,
+                                                       int use_db, const float* __restrict__ gain, FbankTables tb,
+                                                       float* __restrict__ feats, int T_max) {
+    __shared__ f2 lds[4][FB_LDS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 4 + wv;
+    if (t >= T_max) return;                        // (wave-uniform; only wave barriers below)
+    const int n = nsamp[b];
+    const int T = n >= WIN ? 1 + (n - WIN) / HOP : 0;
+    float* dst = feats + ((size_t)b * T_max + t) * NMEL;
+    if (t >= T) {                                  // frames past the utterance: zeros (collate_fn zero padding)
+        dst[lane] = 0.f;
+        if (lane < NMEL - 64) dst[64 + lane] = 0.f;
+        return;
+    }
+    f2* buf = lds[wv];
+    float* pw = reinterpret_cast<float*>(buf);     // the power spectrum reuses the buffer once the FFT is done
+    const float s = use_db ? gain[b] : 1.f;
+
+    // ---- table rows of this lane (independent of the samples: requested first) ----------------------------------------
+    f2 tw[3][3];                                   // [pass 1..3][r = 1..3]
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) tw[p][r] = *reinterpret_cast<const f2*>(tb.twr4 + ((p * 3 + r) * 64 + lane) * 2);
+    f2 win[4], tws[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int s0 = min(2 * lane + 128 * r, WIN - 2);
+        win[r] = *reinterpret_cast<const f2*>(tb.window + s0);
+        tws[r] = *reinterpret_cast<const f2*>(tb.tw512 + 2 * (lane + 64 * r));
+    }
+
+    // ---- samples 2j + 128 r (+ 1), normalised like AudioSegment (gain, int16 truncation) -----------------------------------
+    const ST* src = pcm + (size_t)b * n_max + (size_t)t * HOP;
+    float x0[4], x1[4];
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int s0 = 2 * lane + 128 * r;
+        const bool in = s0 < WIN;                  // WIN is even: s0 and s0 + 1 are inside or outside together
+        const int sc = in ? s0 : 0;
+        x0[r] = in ? norm_sample(src[sc], s, use_db) : 0.f;
+        x1[r] = in ? norm_sample(src[sc + 1], s, use_db) : 0.f;
+        part += x0[r] + x1[r];
+    }
+    const float mean = wave_sum_dpp(part) / (float)WIN;
+
+    // ---- DC removal, pre-emphasis (left neighbour: replicate at the frame start), povey window -> z[j + 64 r] ---------------
+    f2 v[4];
+    {
+        float d0[4], d1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { d0[r] = x0[r] - mean; d1[r] = x1[r] - mean; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // sample 2j + 128 r - 1 = the second sample of lane j - 1 (same r); lane 0: of lane 63 one r earlier
+            const float edge = r == 0 ? d0[0]
+                                      : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d1[r - 1]), 63));
+            const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                                                     __builtin_bit_cast(int, d1[r]), 0x138, 0xf, 0xf, false));   // wave_shr:1
+            const bool in = 2 * lane + 128 * r < WIN;
+            v[r].x = in ? (d0[r] - 0.97f * prev) * win[r].x : 0.f;
+            v[r].y = in ? (d1[r] - 0.97f * d0[r]) * win[r].y : 0.f;
+        }
+    }
+
+    // ---- 256-point complex FFT: Stockham radix-4, passes Ns = 1, 4, 16, 64 ------------------------------------------------
+    fb_radix4(v);                                  // pass 0 (Ns = 1): no twiddles, inputs already in registers
+#pragma unroll
+    for (int q = 0; q < 4; ++q) buf[fb_slot(4 * lane + q)] = v[q];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 1; p < 4; ++p) {
+        const int Ns = p == 1 ? 4 : p == 2 ? 16 : 64;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = buf[fb_slot(lane + 64 * r)];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) v[r] = fb_cmul(v[r], tw[p - 1][r - 1]);
+        fb_radix4(v);
+        __builtin_amdgcn_wave_barrier();           // (a wave's LDS traffic is in order: every lane has read before anyone writes)
+        if (p < 3) {
+            const int k = lane & (Ns - 1), j0 = (lane - k) * 4 + k;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) buf[fb_slot(j0 + q * Ns)] = v[q];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // v[q] = Z[lane + 64 q]
+
+    // ---- real-split post-pass: X[k] = (Z[k] + conj(Z[256-k]))/2 - i/2 W512^k (Z[k] - conj(Z[256-k])),  power spectrum -------
+#pragma unroll
+    for (int q = 0; q < 4; ++q) buf[fb_slot(lane + 64 * q)] = v[q];
+    __builtin_amdgcn_wave_barrier();
+    f2 zc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) zc[q] = buf[fb_slot((256 - lane - 64 * q) & 255)];
+    const f2 z0 = buf[fb_slot(0)];
+    __builtin_amdgcn_wave_barrier();               // all reads of the complex buffer are done: it becomes the power spectrum
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float zr = v[q].x, zi = v[q].y, yr = zc[q].x, yi = -zc[q].y;
+        const float er = 0.5f * (zr + yr), ei = 0.5f * (zi + yi);
+        const float dr = 0.5f * (zr - yr), di = 0.5f * (zi - yi);
+        const float wr = tws[q].x, wi = tws[q].y;
+        const float pr = wr * dr - wi * di, pi = wr * di + wi * dr;
+        const float xr = er + pi, xi = ei - pr;
+        pw[lane + 64 * q] = xr * xr + xi * xi;
+    }
+    if (lane == 0) pw[256] = (z0.x - z0.y) * (z0.x - z0.y);            // k = 256: X = Re Z[0] - Im Z[0]
+    if (lane < FB_TAPS) pw[257 + lane] = 0.f;                          // taps past a filter's last bin carry weight 0: finite operands
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- mel filterbank + log: filters 0..63 one per lane, filters 64..79 on four lanes each --------------------------------
+    {
+        const int lo = tb.mel_lo[lane];
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < FB_TAPS; ++i) acc = fmaf(tb.melwt[i * NMEL + lane], pw[lo + i], acc);
+        dst[lane] = logf(fmaxf(acc, 1.1920928955078125e-07f));
+        const int m2 = 64 + (lane >> 2), i0 = 4 * (lane & 3);
+        const int lo2 = tb.mel_lo[m2];
+        float a2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a2 = fmaf(tb.melwt[(i0 + u) * NMEL + m2], pw[lo2 + i0 + u], a2);
+        a2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a2), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+        a2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a2), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+        if ((lane & 3) == 0) dst[m2] = logf(fmaxf(a2, 1.1920928955078125e-07f));
+    }
+}
+
+static int g_fbank_r2 = 0;        // masr_debug_set key 37: 1 = the radix-2 LDS kernel of rounds 1-4 (A/B)
+void set_fbank_radix2(int on) { g_fbank_r2 = on; }
+
 template <class ST>
 static void launch_fbank_t(const ST* pcm, const int* nsamp, int B, int n_max, int use_db, float target_db,
-                           const float* window, const float* melw, const int* mel_lo, const int* mel_hi,
-                           const float* tw256, const float* tw512, float* feats, int T_max, float* gain_scratch,
-                           int16_t* norm_out, hipStream_t s) {
+                           const FbankTables& tb, float* feats, int T_max, float* gain_scratch, int16_t* norm_out, hipStream_t s) {
     if (use_db == 1) {       // (use_db == 2: the caller has already put its own gains into gain_scratch[0 .. B))
         // gain_scratch: [B] gains followed by [B][MAX_CHUNKS + 1] chunk sums
         float* chunk_sum = gain_scratch + B;
@@ -359,9 +520,13 @@ static void launch_fbank_t(const ST* pcm, const int* nsamp, int B, int n_max, in
     if (norm_out)
         hipLaunchKernelGGL(norm_int16_kernel<ST>, dim3((n_max + 255) / 256, B), dim3(256), 0, s, pcm, nsamp, n_max,
                            gain_scratch, use_db, norm_out);
-    if (T_max > 0)
+    if (T_max <= 0) return;
+    if (g_fbank_r2)
         hipLaunchKernelGGL(fbank_kernel<ST>, dim3((T_max + 3) / 4, B), dim3(256), 0, s, pcm, nsamp, n_max, use_db,
-                           gain_scratch, window, melw, mel_lo, mel_hi, tw256, tw512, feats, T_max);
+                           gain_scratch, tb.window, tb.melw, tb.mel_lo, tb.mel_hi, tb.tw256, tb.tw512, feats, T_max);
+    else
+        hipLaunchKernelGGL(fbank_r4_kernel<ST>, dim3((T_max + 3) / 4, B), dim3(256), 0, s, pcm, nsamp, n_max, use_db, gain_scratch,
+                           tb, feats, T_max);
 }
 
 // ms_out[b] = float32 np.mean(samples ** 2) of utterance b (numpy's summation order); gain_scratch as in launch_fbank
@@ -378,15 +543,12 @@ void launch_mean_square(const void* pcm, int sample_format, const int* nsamp, in
 }
 
 void launch_fbank(const void* pcm, int sample_format, const int* nsamp, int B, int n_max, int use_db, float target_db,
-                  const float* window, const float* melw, const int* mel_lo, const int* mel_hi, const float* tw256,
-                  const float* tw512, float* feats, int T_max, float* gain_scratch, int16_t* norm_out, hipStream_t s) {
+                  const FbankTables& tb, float* feats, int T_max, float* gain_scratch, int16_t* norm_out, hipStream_t s) {
     if (B <= 0) return;
     if (sample_format == 0)
-        launch_fbank_t((const int16_t*)pcm, nsamp, B, n_max, use_db, target_db, window, melw, mel_lo, mel_hi, tw256,
-                       tw512, feats, T_max, gain_scratch, norm_out, s);
+        launch_fbank_t((const int16_t*)pcm, nsamp, B, n_max, use_db, target_db, tb, feats, T_max, gain_scratch, norm_out, s);
     else
-        launch_fbank_t((const float*)pcm, nsamp, B, n_max, use_db, target_db, window, melw, mel_lo, mel_hi, tw256,
-                       tw512, feats, T_max, gain_scratch, norm_out, s);
+        launch_fbank_t((const float*)pcm, nsamp, B, n_max, use_db, target_db, tb, feats, T_max, gain_scratch, norm_out, s);
 }
 
 

@@ -300,7 +300,7 @@ class MASRPredictor:
                 #  streams alias onto hardware queues and an encoder ends up queued behind a 20 ms search -- measured on
                 #  configs[2]: 50.1 vs 46.6 ms per call at passes of 32, 44.2 vs 27.2 ms with a sharpened head at passes of 16)
                 if getattr(self, '_sides', None) is None:
-                    self._sides, self._side_turn = [torch.cuda.Stream() for _ in range(2)], 0
+                    self._sides, self._side_turn = [torch.cuda.Stream() for _ in range(int(os.environ.get('MASR_BEAM_SIDES', '2')))], 0
                 side = self._sides[self._side_turn]
                 self._side_turn = (self._side_turn + 1) % len(self._sides)
                 side.wait_stream(main)

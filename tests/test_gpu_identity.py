@@ -176,3 +176,16 @@ def test_ragged_efficient_conformer_batch_equals_per_utterance(tmp_path):
         assert abs(got[i]['score'] - s_ref) < 0.1
         assert len(got[i]['text']) <= n_enc               # nothing decoded from the padding behind the utterance
     p.predictor.engine.close()
+
+
+def test_batched_reference_gains_equal_the_scalar_expressions_on_this_host():
+    """engine.reference_gains against reference_gains_scalar (the reference's own expressions, one numpy scalar at a time) ON THE
+    GPU BOX'S HOST: numpy's float32 array loops of log10 / power are SIMD routines on AVX-512 hosts and differ from the scalar
+    libm path in the last bit of some arguments (round 5: 1 of 32 gains on an EPYC 9575F with the array logarithm) -- the batch
+    form must take the scalar route for both, whatever the host."""
+    from masr_amd.engine import reference_gains, reference_gains_scalar
+    rng = np.random.default_rng(3)
+    for target in (-20, -20.0, -23.5, -3):
+        ms = (10.0 ** rng.uniform(-9, 0, 20000)).astype(np.float32)
+        ms[::997] = 0
+        assert np.array_equal(reference_gains(ms, target), reference_gains_scalar(ms, target)), target

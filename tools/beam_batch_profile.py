@@ -20,7 +20,11 @@ audio = [pcm_h[i, :lens[i]] for i in range(64)]
 d = tempfile.mkdtemp(prefix='masr_lm_')
 conf = {'alpha': 2.2, 'beta': 4.3, 'beam_size': 300, 'cutoff_prob': 0.99, 'cutoff_top_n': 40, 'num_processes': 10,
         'language_model_path': write_synthetic_arpa(os.path.join(d, 'lm.arpa'), synthetic.synthetic_vocab(bench.VOCAB), seed=5)}
-pred = bench.facade('squeezeformer', 'ctc_beam_search', 0, streaming=False, beam_conf=conf)
+SHARP = os.environ.get('MASR_PROFILE_SHARP') == '1'
+PASS = os.environ.get('MASR_BENCH_BEAM_PASS', 'balanced')
+PASS = PASS if PASS == 'balanced' else int(PASS)
+pred = bench.facade('squeezeformer', 'ctc_beam_search', 0, streaming=False, beam_conf=conf, head_gain=bench.SHARP_HEAD_GAIN if SHARP else None)
+print(f'passes: {PASS}, sharp head: {SHARP}, side streams: {os.environ.get("MASR_BEAM_SIDES", "2")}')
 marks = []
 orig_local = pred._predict_local
 
@@ -40,12 +44,12 @@ def local(segs, *a, **k):
 
 pred._predict_local = local
 for rep in range(3):
-    pred.predict_batch(audio, batch_size=32)
+    pred.predict_batch(audio, batch_size=PASS)
 for rep in range(2):
     marks.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pred.predict_batch(audio, batch_size=32)
+    pred.predict_batch(audio, batch_size=PASS)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     print(f'call {rep}: {1e3 * (t1 - t0):.1f} ms')
