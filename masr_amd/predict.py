@@ -230,7 +230,7 @@ class MASRPredictor:
             ring['bufs'][k] = torch.empty(max(B * width, 1 << 14), dtype=torch.int32, pin_memory=True)
         return ring['bufs'][k][:B * width].view(B, width)
 
-    def _predict_local(self, segs, decode_all_frames=False, as_tokens=False, defer=False):
+    def _predict_local(self, segs, decode_all_frames=False, as_tokens=False, defer=False, hold_search=False):
         """AudioSegments -> [{'text','score'}] on THIS rank's engine.  Utterances too short for one feature frame decode to
         the empty transcript (the reference's encoder cannot take them either); a digitally silent utterance (mean square 0) is
         normalised with gain = target_dB like the reference (audio.py:519-529), only a gain above max_gain_db raises (:300-303).
@@ -293,20 +293,26 @@ class MASRPredictor:
                     out[i] = r if as_tokens else {'text': r[1], 'score': r[0]}
                 return out
             if defer and dec.use_gpu_search and dec.gpu_search_supported(probs.shape[1], probs.shape[2]):
-                # side streams take turns: the searches of consecutive passes (one workgroup per utterance each) run next
-                # to each other, not one behind the other
+                # The prefix search of a pass (one workgroup per utterance, frames in sequence) runs on a side stream.  Round 5:
+                # it is LAUNCHED only once the encoders of the whole group of passes have been enqueued (``launch_search``,
+                # called by _run_sorted): a search that shares the chip with an encoder pass shares CUs with its 248
+                # workgroups and runs 2-3 x slower (tools/beam_batch_profile.py: the longest utterance's search, 13.6 ms
+                # alone, ended 35 ms after its own encoder) -- and it IS the call's critical path.  Searches of different
+                # passes run next to each other on their own side streams (64 workgroups on 64 CUs: no sharing).
                 main = torch.cuda.current_stream()
-                # (two, not one per pass in flight: with four side streams next to the main and the preparation stream the
-                #  streams alias onto hardware queues and an encoder ends up queued behind a 20 ms search -- measured on
-                #  configs[2]: 50.1 vs 46.6 ms per call at passes of 32, 44.2 vs 27.2 ms with a sharpened head at passes of 16)
                 if getattr(self, '_sides', None) is None:
-                    self._sides, self._side_turn = [torch.cuda.Stream() for _ in range(int(os.environ.get('MASR_BEAM_SIDES', '2')))], 0
-                side = self._sides[self._side_turn]
-                self._side_turn = (self._side_turn + 1) % len(self._sides)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    pending = dec._batch(seqs, defer=True)
-                return lambda: fill(dec._batch_collect(pending, want_tokens=as_tokens))
+                    self._sides, self._side_turn = [torch.cuda.Stream() for _ in range(int(os.environ.get('MASR_BEAM_SIDES', '3')))], 0
+
+                def launch_search():
+                    side = self._sides[self._side_turn]
+                    self._side_turn = (self._side_turn + 1) % len(self._sides)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        pending = dec._batch(seqs, defer=True)
+                    return lambda: fill(dec._batch_collect(pending, want_tokens=as_tokens))
+                if hold_search:
+                    return ('held', launch_search)
+                return launch_search()
             res = fill(dec._batch(seqs, want_tokens=as_tokens))
             return (lambda: res) if defer else res
         idx, mp = eng.ctc_greedy_frames(enc)
@@ -408,19 +414,39 @@ class MASRPredictor:
         # the longest utterance is the critical path of the call) then starts right after the first encoder pass and the
         # shorter passes' encoders and searches run underneath it
         depth = 2
-        if self.configs.decoder == 'ctc_beam_search' and getattr(self.beam_search_decoder, 'use_gpu_search', False):
+        gpu_search = self.configs.decoder == 'ctc_beam_search' and getattr(self.beam_search_decoder, 'use_gpu_search', False)
+        if gpu_search:
             cuts.reverse()
-            # a prefix search is a long serial kernel on a few CUs (one workgroup per utterance, frames in sequence): the encoders
-            # of up to three further passes are launched underneath it before its results are waited for
-            depth = 4
+            # groups of up to `depth` passes: the encoders of a group first, back to back (they fill the chip), THEN the group's
+            # prefix searches side by side on side streams (a search must not share CUs with an encoder pass, see
+            # _predict_local); the next group's encoders start behind them.  The probabilities of a group stay in HBM until
+            # its searches are done (4 passes of 32 x 20 s: 1.1 GB).
+            depth = int(os.environ.get('MASR_BEAM_GROUP', '4'))
+        held = []
+
+        def release_group():
+            for idx_h, launch in held:
+                pending.append((idx_h, launch()))
+            held.clear()
+            while pending:
+                collect(pending.pop(0))
+            for side in getattr(self, '_sides', None) or []:
+                torch.cuda.current_stream().wait_stream(side)
         for lo, hi in cuts:
             idx = order[lo:hi]
             segs = [self._load_audio(audio_list[i], sample_rate) for i in idx]
-            # (beam search: the prefix search of this pass runs on a side stream under the encoders of the next passes)
-            pending.append((idx, self._predict_local(segs, decode_all_frames, as_tokens, defer=True)))
+            res = self._predict_local(segs, decode_all_frames, as_tokens, defer=True, hold_search=gpu_search)
             del segs
+            if isinstance(res, tuple) and res[0] == 'held':
+                held.append((idx, res[1]))
+                if len(held) >= depth:
+                    release_group()
+                continue
+            pending.append((idx, res))
             if len(pending) >= depth:
                 collect(pending.pop(0))
+        if held:
+            release_group()
         if pending:
             for item in pending:
                 collect(item)

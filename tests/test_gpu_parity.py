@@ -381,6 +381,15 @@ def test_contract_route_is_bit_exact_at_baseline_size(eng4233, oracle_mods):
     pcm = weights.synthetic_pcm(B, N, seed=1234)
     xs, ns = dev(pcm), dev(np.full(B, N, np.int32))
     gains = e.host_gains(xs, ns, -20.0)
+    # step by step against the reference's expressions on this host (audio.py:519-529,287-304): the device's mean squares ARE
+    # numpy's, the batch gains ARE the scalar expressions' -- then the int16 samples must be
+    ms_dev = e.mean_square(xs, ns).cpu().numpy()
+    fl = [ofb.pcm16_to_float32(pcm[i]) for i in range(B)]
+    ms_np = np.array([np.mean(f ** 2) for f in fl], np.float32)
+    assert np.array_equal(ms_dev, ms_np), f'mean squares differ for utterances {np.nonzero(ms_dev != ms_np)[0].tolist()}'
+    g_np = np.array([10. ** (min(300.0, -20 - ofb.rms_db(f)) / 20.) for f in fl], np.float32)
+    g_dev = gains.cpu().numpy()
+    assert np.array_equal(g_dev, g_np), f'gains differ for utterances {np.nonzero(g_dev != g_np)[0].tolist()}: {g_dev[g_dev != g_np]} vs {g_np[g_dev != g_np]}'
     _, _, norm = e.fbank_batch(xs, ns, True, -20.0, return_norm=True, gain_in=gains)
     norm = norm.cpu().numpy()
     feats = []

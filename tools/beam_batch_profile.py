@@ -24,7 +24,7 @@ SHARP = os.environ.get('MASR_PROFILE_SHARP') == '1'
 PASS = os.environ.get('MASR_BENCH_BEAM_PASS', 'balanced')
 PASS = PASS if PASS == 'balanced' else int(PASS)
 pred = bench.facade('squeezeformer', 'ctc_beam_search', 0, streaming=False, beam_conf=conf, head_gain=bench.SHARP_HEAD_GAIN if SHARP else None)
-print(f'passes: {PASS}, sharp head: {SHARP}, side streams: {os.environ.get("MASR_BEAM_SIDES", "2")}')
+print(f'passes: {PASS}, sharp head: {SHARP}, side streams: {os.environ.get("MASR_BEAM_SIDES", "3")}, group: {os.environ.get("MASR_BEAM_GROUP", "4")}')
 marks = []
 orig_local = pred._predict_local
 
@@ -32,14 +32,24 @@ orig_local = pred._predict_local
 def local(segs, *a, **k):
     t0 = time.perf_counter()
     fetch = orig_local(segs, *a, **k)
-    marks.append(('launched pass of %d (longest %.1f s)' % (len(segs), max(s.num_samples for s in segs) / 16000), t0, time.perf_counter()))
+    tag = 'pass of %d (longest %.1f s)' % (len(segs), max(s.num_samples for s in segs) / 16000)
+    marks.append(('encoder enqueued: ' + tag, t0, time.perf_counter()))
 
-    def timed_fetch():
-        t1 = time.perf_counter()
-        r = fetch()
-        marks.append(('collected pass of %d' % len(segs), t1, time.perf_counter()))
-        return r
-    return timed_fetch
+    def timed(f):
+        def timed_fetch():
+            t1 = time.perf_counter()
+            r = f()
+            marks.append(('collected ' + tag, t1, time.perf_counter()))
+            return r
+        return timed_fetch
+    if isinstance(fetch, tuple) and fetch[0] == 'held':          # round 5: the search is launched later, per group of passes
+        def launch():
+            t1 = time.perf_counter()
+            f = fetch[1]()
+            marks.append(('search launched: ' + tag, t1, time.perf_counter()))
+            return timed(f)
+        return ('held', launch)
+    return timed(fetch)
 
 
 pred._predict_local = local
