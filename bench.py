@@ -698,11 +698,14 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
     # the longest utterance is the call's critical path) runs on a side stream under the encoder of the next pass.  Measured with
     # MASR_BENCH_BEAM_PASS: passes of 16 are faster with the sharpened head (27.2 vs 30.7 ms per call: the longest utterance's search
     # starts earlier) and slower with flat posteriors (56.6 vs 46.6 ms: four long searches share two side streams); 32 for both lines
-    # Round 5: passes of EQUAL PADDED SIZE (predict_batch(batch_size='balanced'): count x longest utterance <= 32 x 10 s, i.e. one
-    # full round of 248 row-block workgroups per pass): the 64 utterances become passes of 16 / 19 / 29 (three rounds) where two
-    # fixed passes of 32 were 494 + 275 row blocks = four rounds, the second one half empty.  MASR_BENCH_BEAM_PASS=<n> restores
-    # fixed passes of n for A/B.
-    per_pass = os.environ.get('MASR_BENCH_BEAM_PASS', 'balanced')
+    # Passes: with the prefix search on the GPU, fixed passes of 32 (the longest utterance's search -- ~30 us per frame x 494 frames,
+    # the call's critical path -- starts behind ONE encoder pass and the second pass runs underneath it; round 5 timelines,
+    # tools/beam_batch_profile.py: 45.7 ms flat / 29.1 ms sharp against 55 / 39 ms with three passes of equal padded size).  With
+    # the search on host threads (word LM) the encoder is what counts and passes of EQUAL PADDED SIZE win
+    # (predict_batch(batch_size='balanced'): count x longest utterance <= 32 x 10 s, one full round of 248 row-block workgroups
+    # per pass: 16 / 19 / 29 utterances in three rounds where 2 x 32 take four, the second half empty).  MASR_BENCH_BEAM_PASS
+    # overrides (a number, or 'balanced').
+    per_pass = os.environ.get('MASR_BENCH_BEAM_PASS', 'balanced' if (lm and word_lm) else '32')
     per_pass = per_pass if per_pass == 'balanced' else int(per_pass)
     pred.predict_batch(audio, batch_size=per_pass)
     torch.cuda.synchronize()

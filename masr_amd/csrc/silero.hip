@@ -422,7 +422,10 @@ int masr_vad_forward(masr_vad* v, int32_t sample_rate, const float* audio_dev, i
     const int m = sample_rate == 16000 ? 0 : 1;
     if (!v->ready[m]) return vfail("masr_vad_forward: the model of this sample rate was not loaded / finalized");
     if (B <= 0 || n_win <= 0) return 0;
-    if (window % 64 != 0 || window < 256 || window > WMAX) return vfail("window_size_samples must be a multiple of 64 in [256, 1536]");
+    // any chunk length from sr / 31.25 samples (the graph's own lower bound: 512 at 16 kHz, 256 at 8 kHz) up to 1536; the STFT takes
+    // floor(window / 64) frames, the samples behind the last full hop only enter through the right reflection, like the ONNX graph
+    if (window < (sample_rate == 16000 ? 512 : 256) || window > WMAX)
+        return vfail("window_size_samples must lie in [sample_rate / 31.25, 1536]");
     VHIP(hipSetDevice(v->device));
     const Net& n = v->net[m];
     int F = window / 64;

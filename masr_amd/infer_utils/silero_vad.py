@@ -134,9 +134,9 @@ class SileroVAD:
 
     def run(self, _names, feeds):
         """onnxruntime's ``session.run(None, {'input': [B, N], 'h', 'c': [2, B, 64], 'sr'})`` -> [prob [B, 1], h, c].
-        N (the window) must be a multiple of 64 in [256, 1536] -- the sizes the reference class itself asks for (512 / 1024 / 1536 at
-        16 kHz, 256 / 512 / 768 at 8 kHz, vad_predictor.py:23,31) and everything between; the ONNX graph under onnxruntime also takes
-        longer or odd chunks, this network refuses them with that message (masr_vad_forward)."""
+        N (the window): any length from sr / 31.25 samples (512 at 16 kHz, 256 at 8 kHz -- the ONNX graph's own lower bound) up to
+        1536, which covers the sizes the reference class asks for (512 / 1024 / 1536 at 16 kHz, 256 / 512 / 768 at 8 kHz,
+        vad_predictor.py:23,31) and every odd length between; longer chunks are refused with that message (masr_vad_forward)."""
         x = torch.as_tensor(np.ascontiguousarray(feeds['input'], np.float32)).to(self.device)
         h = torch.as_tensor(np.ascontiguousarray(feeds['h'], np.float32)).to(self.device)
         c = torch.as_tensor(np.ascontiguousarray(feeds['c'], np.float32)).to(self.device)

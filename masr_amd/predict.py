@@ -293,15 +293,17 @@ class MASRPredictor:
                     out[i] = r if as_tokens else {'text': r[1], 'score': r[0]}
                 return out
             if defer and dec.use_gpu_search and dec.gpu_search_supported(probs.shape[1], probs.shape[2]):
-                # The prefix search of a pass (one workgroup per utterance, frames in sequence) runs on a side stream.  Round 5:
-                # it is LAUNCHED only once the encoders of the whole group of passes have been enqueued (``launch_search``,
-                # called by _run_sorted): a search that shares the chip with an encoder pass shares CUs with its 248
-                # workgroups and runs 2-3 x slower (tools/beam_batch_profile.py: the longest utterance's search, 13.6 ms
-                # alone, ended 35 ms after its own encoder) -- and it IS the call's critical path.  Searches of different
-                # passes run next to each other on their own side streams (64 workgroups on 64 CUs: no sharing).
+                # The prefix search of a pass (one workgroup per utterance, frames in sequence) runs on a side stream; side streams
+                # take turns, so the searches of consecutive passes run next to each other, not one behind the other.  Two of
+                # them: with four side streams next to the main and the preparation stream the streams alias onto hardware
+                # queues (round 4: 50.1 vs 46.6 ms per configs[2] call).  Round 5 measured the alternative of HOLDING the
+                # searches of a group of passes until the group's encoders are enqueued (MASR_BEAM_GROUP=n, ``hold_search``):
+                # slower (flat posteriors 58.2 vs 45.7 ms, sharpened head 38.2 vs 29.1 ms per call, gpurun_out r05c) -- the
+                # call is bound by the longest utterance's ~30 us per frame x 494 frames, and starting that search late costs
+                # more than sharing CUs with the next encoder pass.  Default: launch at once.
                 main = torch.cuda.current_stream()
                 if getattr(self, '_sides', None) is None:
-                    self._sides, self._side_turn = [torch.cuda.Stream() for _ in range(int(os.environ.get('MASR_BEAM_SIDES', '3')))], 0
+                    self._sides, self._side_turn = [torch.cuda.Stream() for _ in range(int(os.environ.get('MASR_BEAM_SIDES', '2')))], 0
 
                 def launch_search():
                     side = self._sides[self._side_turn]
@@ -417,11 +419,11 @@ class MASRPredictor:
         gpu_search = self.configs.decoder == 'ctc_beam_search' and getattr(self.beam_search_decoder, 'use_gpu_search', False)
         if gpu_search:
             cuts.reverse()
-            # groups of up to `depth` passes: the encoders of a group first, back to back (they fill the chip), THEN the group's
-            # prefix searches side by side on side streams (a search must not share CUs with an encoder pass, see
-            # _predict_local); the next group's encoders start behind them.  The probabilities of a group stay in HBM until
-            # its searches are done (4 passes of 32 x 20 s: 1.1 GB).
-            depth = int(os.environ.get('MASR_BEAM_GROUP', '4'))
+            # a prefix search is a long serial kernel on a few CUs (one workgroup per utterance, frames in sequence): the encoders
+            # of up to three further passes are launched underneath it before its results are waited for
+            depth = 4
+        # MASR_BEAM_GROUP=n (A/B, off by default): hold the searches of n passes until their encoders are enqueued
+        group = int(os.environ.get('MASR_BEAM_GROUP', '0')) if gpu_search else 0
         held = []
 
         def release_group():
@@ -435,11 +437,11 @@ class MASRPredictor:
         for lo, hi in cuts:
             idx = order[lo:hi]
             segs = [self._load_audio(audio_list[i], sample_rate) for i in idx]
-            res = self._predict_local(segs, decode_all_frames, as_tokens, defer=True, hold_search=gpu_search)
+            res = self._predict_local(segs, decode_all_frames, as_tokens, defer=True, hold_search=group > 0)
             del segs
             if isinstance(res, tuple) and res[0] == 'held':
                 held.append((idx, res[1]))
-                if len(held) >= depth:
+                if len(held) >= group:
                     release_group()
                 continue
             pending.append((idx, res))
