@@ -31,17 +31,35 @@ __device__ __forceinline__ float to_unit(float v) { return v; }
 // combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), split point n/2 rounded down to a multiple of 8).
 // Reproducing that order makes the gain -- and with it the int16 normalisation -- bit-identical
 // to the reference (pinned by oracle/fbank.py against numpy itself, tests/test_oracle_golden.py).
+// one rounding per operation, whatever the compiler's contraction mode: the product and the sum below carry no `contract` flag, so
+// LLVM cannot fuse them with a neighbour (HIP's own mul_rn / add_rn intrinsics -- spelled with the two leading underscores and an
+// f -- are plain ``*`` / ``+`` compiled in contract-fast mode unless OCML_BASIC_ROUNDED_OPERATIONS is defined: they DO fuse)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
+// NO FLOATING-POINT CONTRACTION in anything that feeds the mean square: hipcc's default (-ffp-contract=fast) turns
+// ``r + f * f`` into one fused multiply-add -- a single rounding where numpy rounds the square and the sum separately.  Rounds 1-4
+// shipped 96 v_pk_fma_f32 in rms_partial_kernel: the mean squares of ~10 % of utterances were one ulp off numpy's (found by the
+// B = 32 route test of round 5; tools/mean_square_locate.py, tools/mean_square_probe.py).
 template <class ST>
 __device__ __forceinline__ float sq_unit(const ST* x, int i) {
+#pragma clang fp contract(off)
     const float f = to_unit(x[i]);
-    return __fmul_rn(f, f);               // samples ** 2: rounded to float32 before any add
+    return mul_rn(f, f);               // samples ** 2: rounded to float32 before any add
 }
 
 template <class ST>
 __device__ float pw_leaf(const ST* x, int off, int len) {
+#pragma clang fp contract(off)
     if (len < 8) {
         float r = 0.f;
-        for (int i = 0; i < len; ++i) r = __fadd_rn(r, sq_unit(x, off + i));
+        for (int i = 0; i < len; ++i) r = add_rn(r, sq_unit(x, off + i));
         return r;
     }
     float r[8];
@@ -52,11 +70,11 @@ __device__ float pw_leaf(const ST* x, int off, int len) {
 #pragma unroll 4
     for (; i < m; i += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], sq_unit(x, off + i + j));
+        for (int j = 0; j < 8; ++j) r[j] = add_rn(r[j], sq_unit(x, off + i + j));
     }
-    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
-                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
-    for (; i < len; ++i) res = __fadd_rn(res, sq_unit(x, off + i));
+    float res = add_rn(add_rn(add_rn(r[0], r[1]), add_rn(r[2], r[3])),
+                          add_rn(add_rn(r[4], r[5]), add_rn(r[6], r[7])));
+    for (; i < len; ++i) res = add_rn(res, sq_unit(x, off + i));
     return res;
 }
 
@@ -64,6 +82,7 @@ __device__ float pw_leaf(const ST* x, int off, int len) {
 // 16-byte (int16) / two 16-byte (float) vector loads per step instead of 8 scalar loads (leaf starts are 256-B aligned
 // relative to the utterance, and utterance rows are 16-B aligned when n_max is a multiple of 8 -- checked by the caller)
 __device__ __forceinline__ float pw_leaf128(const int16_t* x, int off) {
+#pragma clang fp contract(off)
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8* p = reinterpret_cast<const s16x8*>(x + off);
     s16x8 v[16];                           // all 16 loads in flight before the (ordered) add chain starts
@@ -71,33 +90,34 @@ __device__ __forceinline__ float pw_leaf128(const int16_t* x, int off) {
     for (int i = 0; i < 16; ++i) v[i] = p[i];
     float r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float f = (float)v[0][j] * (1.0f / 32768.0f); r[j] = __fmul_rn(f, f); }
+    for (int j = 0; j < 8; ++j) { const float f = (float)v[0][j] * (1.0f / 32768.0f); r[j] = mul_rn(f, f); }
 #pragma unroll
     for (int i = 1; i < 16; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = (float)v[i][j] * (1.0f / 32768.0f); r[j] = __fadd_rn(r[j], __fmul_rn(f, f)); }
-    return __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
-                     __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (int j = 0; j < 8; ++j) { const float f = (float)v[i][j] * (1.0f / 32768.0f); r[j] = add_rn(r[j], mul_rn(f, f)); }
+    return add_rn(add_rn(add_rn(r[0], r[1]), add_rn(r[2], r[3])),
+                     add_rn(add_rn(r[4], r[5]), add_rn(r[6], r[7])));
 }
 __device__ __forceinline__ float pw_leaf128(const float* x, int off) {
+#pragma clang fp contract(off)
     const f32x4* p = reinterpret_cast<const f32x4*>(x + off);
     float r[8];
     {
         const f32x4 a = p[0], b = p[1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { r[j] = __fmul_rn(a[j], a[j]); r[4 + j] = __fmul_rn(b[j], b[j]); }
+        for (int j = 0; j < 4; ++j) { r[j] = mul_rn(a[j], a[j]); r[4 + j] = mul_rn(b[j], b[j]); }
     }
 #pragma unroll 5
     for (int i = 1; i < 16; ++i) {
         const f32x4 a = p[2 * i], b = p[2 * i + 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            r[j] = __fadd_rn(r[j], __fmul_rn(a[j], a[j]));
-            r[4 + j] = __fadd_rn(r[4 + j], __fmul_rn(b[j], b[j]));
+            r[j] = add_rn(r[j], mul_rn(a[j], a[j]));
+            r[4 + j] = add_rn(r[4 + j], mul_rn(b[j], b[j]));
         }
     }
-    return __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
-                     __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+    return add_rn(add_rn(add_rn(r[0], r[1]), add_rn(r[2], r[3])),
+                     add_rn(add_rn(r[4], r[5]), add_rn(r[6], r[7])));
 }
 
 static constexpr int NP_BUF = 8192;       // numpy's default ufunc buffer size (elements)
@@ -108,6 +128,7 @@ static constexpr int MAX_CHUNKS = 2048;   // 16.7 M samples (17 min @ 16 kHz) pe
 template <class ST>
 __global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp,
                                                           int n_max, float* __restrict__ chunk_sum /*[B][MAX_CHUNKS+1]*/) {
+#pragma clang fp contract(off)
     __shared__ int lvl_child[8][64], lvl_split[8][64], tmp_off[64], tmp_len[64];
     __shared__ float tmp_val[64];
     const int b = blockIdx.y;
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__
     if (c < nc) {
         float v = (n_max & 7) == 0 ? pw_leaf128(x, c * NP_BUF + lane * 128) : pw_leaf(x, c * NP_BUF + lane * 128, 128);
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) v = __fadd_rn(v, __shfl_xor(v, o, 64));
+        for (int o = 1; o < 64; o <<= 1) v = add_rn(v, __shfl_xor(v, o, 64));
         if (lane == 0) out[c] = v;
     }
     if (blockIdx.x != gridDim.x - 1 || wave != 0) return;
@@ -172,7 +193,7 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__
         tmp_val[lane] = val;
         __builtin_amdgcn_wave_barrier();
         const int ch = lvl_child[d][lane];
-        val = lvl_split[d][lane] ? __fadd_rn(tmp_val[min(ch, 63)], tmp_val[min(ch + 1, 63)]) : tmp_val[min(ch, 63)];
+        val = lvl_split[d][lane] ? add_rn(tmp_val[min(ch, 63)], tmp_val[min(ch + 1, 63)]) : tmp_val[min(ch, 63)];
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) out[MAX_CHUNKS] = val;
@@ -184,15 +205,18 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__
 // on its own numpy and hand the gain back (use_db == 2)
 __global__ void rms_final_kernel(const int* __restrict__ nsamp, int B, float target_db,
                                  const float* __restrict__ chunk_sum, float* __restrict__ gain, float* __restrict__ ms_out) {
+#pragma clang fp contract(off)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int n = min(nsamp[b], NP_BUF * MAX_CHUNKS);
     const int nc = n / NP_BUF, tail = n - nc * NP_BUF;
     const float* cs = chunk_sum + (size_t)b * (MAX_CHUNKS + 1);
     float tot = 0.f;
-    for (int c = 0; c < nc; ++c) tot = __fadd_rn(tot, cs[c]);
-    if (tail > 0) tot = __fadd_rn(tot, cs[MAX_CHUNKS]);
-    float ms = n > 0 ? __fdiv_rn(tot, (float)n) : 0.f;
+    for (int c = 0; c < nc; ++c) tot = add_rn(tot, cs[c]);
+    if (tail > 0) tot = add_rn(tot, cs[MAX_CHUNKS]);
+    // numpy's mean divides the float32 sum by an np.intp count: evaluated in float64 and rounded to float32 (core/_methods.py
+    // _mean: ``ret.dtype.type(ret / rcount)``) -- the correctly rounded float32 quotient
+    float ms = n > 0 ? (float)((double)tot / (double)n) : 0.f;
     if (ms_out) ms_out[b] = ms;
     if (ms == 0.f || !(ms == ms)) ms = 1.f;
     // float32 scalar arithmetic of rms_db / normalize / gain_db (numpy >= 2 promotion): each
@@ -206,8 +230,9 @@ __global__ void rms_final_kernel(const int* __restrict__ nsamp, int B, float tar
 
 template <class ST>
 __device__ __forceinline__ float norm_sample(ST v, float s, int use_db) {
+#pragma clang fp contract(off)
     float f = to_unit(v);
-    if (use_db) f = __fmul_rn(f, s);
+    if (use_db) f = mul_rn(f, s);
     f = f * 32768.0f;
     f = fminf(fmaxf(f, -32768.0f), 32767.0f);
     return truncf(f);

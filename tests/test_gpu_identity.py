@@ -189,3 +189,30 @@ def test_batched_reference_gains_equal_the_scalar_expressions_on_this_host():
         ms = (10.0 ** rng.uniform(-9, 0, 20000)).astype(np.float32)
         ms[::997] = 0
         assert np.array_equal(reference_gains(ms, target), reference_gains_scalar(ms, target)), target
+
+
+def test_device_mean_square_is_numpys_for_many_utterances():
+    """masr_mean_square == ``np.mean(samples ** 2)`` (audio.py:524) BIT FOR BIT on this host's numpy: 96 utterances of random
+    lengths (whole 8192-chunks, tails, lengths below one leaf, odd lengths), int16 PCM and float32 samples, row strides that take
+    the 16-byte vector leaves and strides that take the scalar ones.  Rounds 1-4 held only test.wav to this; the kernel fused
+    ``r + f * f`` into FMAs and was one ulp off for ~10 % of utterances."""
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    eng = HipEngine(None)
+    rng = np.random.default_rng(42)
+    lens = np.concatenate([rng.integers(1, 200000, 72), [100, 128, 129, 1000, 8191, 8192, 8193, 16384, 40960, 131072, 159992, 159999,
+                                                          160000, 65536, 4352, 12544, 7, 8, 9, 1, 127, 255, 256, 257]]).astype(np.int32)
+    scale = rng.uniform(200, 9000, len(lens))
+    for n_max in (200000, 200003):                       # rows 16-byte aligned (vector leaves) / not (scalar leaves)
+        pcm = np.zeros((len(lens), n_max), np.int16)
+        for i, n in enumerate(lens):
+            pcm[i, :n] = np.clip(np.rint(rng.normal(0, scale[i], n)), -32768, 32767).astype(np.int16)
+        want = np.array([np.mean((pcm[i, :n].astype('float32') * np.float32(1. / 2 ** 15)) ** 2) for i, n in enumerate(lens)], np.float32)
+        got = eng.mean_square(torch.from_numpy(pcm).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy()
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, f'n_max {n_max}: int16 mean squares differ for lengths {lens[bad].tolist()}'
+        fl = pcm.astype(np.float32) * np.float32(1. / 2 ** 15)
+        got = eng.mean_square(torch.from_numpy(fl).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy()
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, f'n_max {n_max}: float32 mean squares differ for lengths {lens[bad].tolist()}'
+    eng.close()
