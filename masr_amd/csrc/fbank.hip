@@ -147,54 +147,70 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(const ST* __restrict__
     }
     if (blockIdx.x != gridDim.x - 1 || wave != 0) return;
     // tail chunk (< 8192 samples) on wave 0: numpy's pairwise recursion (split at n/2 rounded down to a multiple of 8, leaves of
-    // <= 128 elements) unrolled level by level -- at most 64 nodes per level, one per lane: a node that splits gets two slots
-    // in the next level, a leaf is carried down unchanged; the sums then fold back up level by level in the same tree order.
+    // <= 128 elements) unrolled level by level -- one node per lane: a node that splits gets two slots in the next level, a leaf
+    // is carried down unchanged; the sums then fold back up level by level in the same tree order.  A subtree of <= 4103 elements
+    // has at most 33 nodes per level, a whole tail up to 65 (441 of the 8191 tail lengths: rounds 1-4 overflowed the 64 lanes
+    // there), so the tail's two top-level halves are walked one after the other and added.
     if (tail == 0) {
         if (lane == 0) out[MAX_CHUNKS] = 0.f;
         return;
     }
-    int off = nc * NP_BUF, len = tail;
-    bool have = lane == 0;
-    int depth = 0;
-    while (true) {
-        const bool split = have && len > 128;
-        lvl_child[depth][lane] = 0;
-        lvl_split[depth][lane] = split ? 1 : 0;
-        if (!__ballot(split)) break;
-        const int width = have ? (split ? 2 : 1) : 0;
-        int incl = width;
+    auto subtree = [&](int off0, int len0) -> float {
+        int off = off0, len = len0;
+        bool have = lane == 0;
+        int depth = 0;
+        while (true) {
+            const bool split = have && len > 128;
+            lvl_child[depth][lane] = 0;
+            lvl_split[depth][lane] = split ? 1 : 0;
+            if (!__ballot(split)) break;
+            const int width = have ? (split ? 2 : 1) : 0;
+            int incl = width;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
-        const int pos = incl - width;
-        const int total = __shfl(incl, 63, 64);
-        lvl_child[depth][lane] = pos;
-        if (have) {
-            if (split) {
-                int n2 = len / 2;
-                n2 -= n2 % 8;
-                tmp_off[pos] = off; tmp_len[pos] = n2;
-                tmp_off[pos + 1] = off + n2; tmp_len[pos + 1] = len - n2;
-            } else {
-                tmp_off[pos] = off; tmp_len[pos] = len;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
             }
+            const int pos = incl - width;
+            const int total = __shfl(incl, 63, 64);
+            lvl_child[depth][lane] = pos;
+            if (have) {
+                if (split) {
+                    int n2 = len / 2;
+                    n2 -= n2 % 8;
+                    tmp_off[pos] = off; tmp_len[pos] = n2;
+                    tmp_off[pos + 1] = off + n2; tmp_len[pos + 1] = len - n2;
+                } else {
+                    tmp_off[pos] = off; tmp_len[pos] = len;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            have = lane < total;
+            off = have ? tmp_off[lane] : 0;
+            len = have ? tmp_len[lane] : 0;
+            __builtin_amdgcn_wave_barrier();
+            ++depth;
         }
+        float val = have ? pw_leaf(x, off, len) : 0.f;
+        for (int d = depth - 1; d >= 0; --d) {
+            tmp_val[lane] = val;
+            __builtin_amdgcn_wave_barrier();
+            const int ch = lvl_child[d][lane];
+            val = lvl_split[d][lane] ? add_rn(tmp_val[min(ch, 63)], tmp_val[min(ch + 1, 63)]) : tmp_val[min(ch, 63)];
+            __builtin_amdgcn_wave_barrier();
+        }
+        return val;                                 // lane 0 holds the subtree's sum
+    };
+    float val;
+    if (tail <= 128) {
+        val = subtree(nc * NP_BUF, tail);
+    } else {
+        int n2 = tail / 2;
+        n2 -= n2 % 8;
+        const float left = subtree(nc * NP_BUF, n2);
         __builtin_amdgcn_wave_barrier();
-        have = lane < total;
-        off = have ? tmp_off[lane] : 0;
-        len = have ? tmp_len[lane] : 0;
-        __builtin_amdgcn_wave_barrier();
-        ++depth;
-    }
-    float val = have ? pw_leaf(x, off, len) : 0.f;
-    for (int d = depth - 1; d >= 0; --d) {
-        tmp_val[lane] = val;
-        __builtin_amdgcn_wave_barrier();
-        const int ch = lvl_child[d][lane];
-        val = lvl_split[d][lane] ? add_rn(tmp_val[min(ch, 63)], tmp_val[min(ch + 1, 63)]) : tmp_val[min(ch, 63)];
-        __builtin_amdgcn_wave_barrier();
+        const float right = subtree(nc * NP_BUF + n2, tail - n2);
+        val = add_rn(left, right);
     }
     if (lane == 0) out[MAX_CHUNKS] = val;
 }

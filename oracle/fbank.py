@@ -17,8 +17,8 @@ Restates, in numpy:
 torchaudio (third-party; the reference pins no version, docs/install.md:7
 recommends torchaudio==2.0.2) is NOT vendored in the reference and NOT
 installed in the build container, and the reference ships no fbank vectors:
-**parity unpinned** at the reference level.  ``tests/test_oracle_fbank.py``
-cross-checks this restatement against ``transformers.audio_utils`` (an
+**parity unpinned** at the reference level.  ``tests/test_oracle_golden.py``
+(``test_fbank_cross_check_transformers``) cross-checks this restatement against ``transformers.audio_utils`` (an
 independent numpy Kaldi mimic).
 * ``torchaudio.compliance.kaldi.mfcc`` as called by ``audio_featurizer.py:98-117`` (``num_mel_bins=n_mels=80,
   num_ceps=n_mfcc``; torchaudio defaults ``cepstral_lifter=22, use_energy=False``): the fbank above times torchaudio's
