@@ -216,3 +216,27 @@ def test_device_mean_square_is_numpys_for_many_utterances():
         bad = np.nonzero(got != want)[0]
         assert len(bad) == 0, f'n_max {n_max}: float32 mean squares differ for lengths {lens[bad].tolist()}'
     eng.close()
+
+
+def test_feature_kernel_normalises_exactly_like_the_int16_round_trip():
+    """the fbank kernel applies gain -> int16 truncation to the samples it reads (AudioSegment.normalize + to('int16'),
+    audio.py:287-304,549-574) with a shorter operation sequence than norm_int16_kernel (power-of-two scalings dropped): the
+    features of (PCM, gain) must EQUAL the features of the materialised normalised int16 samples with normalisation off -- bit
+    for bit, loud and quiet utterances, gains from 0.1 to 3000"""
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    eng = HipEngine(None)
+    rng = np.random.default_rng(8)
+    B, N = 12, 48000
+    pcm = np.zeros((B, N), np.int16)
+    lens = rng.integers(4000, N + 1, B).astype(np.int32)
+    for i in range(B):
+        pcm[i, :lens[i]] = np.clip(np.rint(rng.normal(0, 10.0 ** rng.uniform(0.5, 4.2), lens[i])), -32768, 32767)
+    xs, ns = torch.from_numpy(pcm).cuda(), torch.from_numpy(lens).cuda()
+    gains = eng.host_gains(xs, ns, -20.0)
+    feats, frames, norm = eng.fbank_batch(xs, ns, True, -20.0, return_norm=True, gain_in=gains)
+    again, frames2 = eng.fbank_batch(norm, ns, use_db_normalization=False)
+    assert torch.equal(frames, frames2) and torch.equal(feats, again)
+    g = gains.cpu().numpy()
+    assert g.min() < 0.5 and g.max() > 100                       # the case list really spans attenuation and amplification
+    eng.close()
