@@ -416,14 +416,13 @@ void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* l
 // ---- features ------------------------------------------------------------------------------
 size_t fbank_gain_scratch_floats(int B);   // size of gain_scratch ([B] gains + partial sums)
 // use_db: 0 = no dB normalisation, 1 = gains computed on the device, 2 = gains supplied in gain_scratch[0 .. B)
-// tables of the fbank front-end (engine.hip build_fbank_tables): povey window [400]; mel weights [80][257] with the non-zero
-// range [mel_lo, mel_hi) per filter, and transposed [16 taps][80] (tap i of filter m = bin mel_lo[m] + i); W256^k (k < 128) and
-// W512^k (k <= 256); twr4 [3 passes][3][64]: the twiddles of the radix-4 passes Ns = 4, 16, 64 per lane
+// tables of the fbank front-end (engine.hip build_fbank_tables): povey window [400]; mel weights transposed [16 taps][80] (tap i of
+// filter m = bin mel_lo[m] + i, zero past the filter's last bin); W512^k (k <= 256) for the real-split pass; twr4 [3 passes][3][64]:
+// the twiddles of the radix-4 passes Ns = 4, 16, 64 per lane
 struct FbankTables {
-    const float *window, *melw, *melwt, *tw256, *tw512, *twr4;
-    const int *mel_lo, *mel_hi;
+    const float *window, *melwt, *tw512, *twr4;
+    const int* mel_lo;
 };
-void set_fbank_radix2(int on);       // diagnostics (masr_debug_set key 37): 1 = the radix-2 LDS kernel of rounds 1-4
 void launch_fbank(const void* pcm, int sample_format /*0 int16, 1 float32*/, const int* nsamp, int B, int n_max,
                   int use_db, float target_db, const FbankTables& tb, float* feats, int T_max, float* gain_scratch,
                   int16_t* norm_out, hipStream_t s);

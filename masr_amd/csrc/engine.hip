@@ -272,9 +272,9 @@ struct masr_engine {
     PinnedStage stage;
     DevBuf qplanes, attp, cnnptrs, ffpart;                                      // planar q|k|v and attention output, [B][Tpad][256]
     // fbank tables
-    float *window = nullptr, *melw = nullptr, *melwt = nullptr, *tw256 = nullptr, *tw512 = nullptr, *twr4 = nullptr;
-    FbankTables fbank_tables() const { return FbankTables{window, melw, melwt, tw256, tw512, twr4, mel_lo, mel_hi}; }
-    int *mel_lo = nullptr, *mel_hi = nullptr;
+    float *window = nullptr, *melwt = nullptr, *tw512 = nullptr, *twr4 = nullptr;
+    FbankTables fbank_tables() const { return FbankTables{window, melwt, tw512, twr4, mel_lo}; }
+    int* mel_lo = nullptr;
     // mfcc / linear tables (built on first use)
     float *dct = nullptr, *lifter = nullptr;
     int dct_ceps = 0;
@@ -408,15 +408,11 @@ namespace {
 // depend on the model, so a weight-less engine can already run the feature front-end.
 int build_fbank_tables(masr_engine* e) {
     {
-        std::vector<float> win(400), tw256(256), tw512(2 * 257), melw((size_t)80 * 257, 0.f);
+        std::vector<float> win(400), tw512(2 * 257), melw((size_t)80 * 257, 0.f);
         std::vector<int> lo(80), hi(80);
         for (int i = 0; i < 400; ++i) {
             const double hann = 0.5 - 0.5 * cos(2.0 * M_PI * i / 399.0);
             win[i] = (float)pow(hann, 0.85);
-        }
-        for (int k = 0; k < 128; ++k) {
-            tw256[2 * k] = (float)cos(-2.0 * M_PI * k / 256.0);
-            tw256[2 * k + 1] = (float)sin(-2.0 * M_PI * k / 256.0);
         }
         for (int k = 0; k <= 256; ++k) {
             tw512[2 * k] = (float)cos(-2.0 * M_PI * k / 512.0);
@@ -462,13 +458,11 @@ int build_fbank_tables(masr_engine* e) {
                 }
         }
         CHK(upload(e, win, &e->window));
-        CHK(upload(e, tw256, &e->tw256));
         CHK(upload(e, tw512, &e->tw512));
-        CHK(upload(e, melw, &e->melw));
         CHK(upload(e, melwt, &e->melwt));
         CHK(upload(e, twr4, &e->twr4));
         CHK(upload(e, lo, &e->mel_lo));
-        CHK(upload(e, hi, &e->mel_hi));
+
     }
     return 0;
 }
@@ -2801,7 +2795,6 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 34) g_attn_chain = value;
     else if (key == 35) g_ffn_coop = value;
     else if (key == 36) g_sqz_fused_blocks = value;
-    else if (key == 37) set_fbank_radix2(value);
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

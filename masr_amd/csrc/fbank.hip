@@ -10,8 +10,9 @@
 //
 // MI355X mapping: one wave64 per frame, 4 frames per workgroup.  The 400 samples of a frame are read
 // coalesced (int16), windowed in registers, and the 512-point real FFT is done as a 256-point complex
-// radix-2 FFT in LDS (2 butterflies per lane per stage) plus the real-split post-pass.  The mel
-// filterbank is applied from the LDS-resident power spectrum with per-bin [lo,hi) ranges.
+// radix-4 Stockham FFT with four elements per lane in registers (three LDS exchanges) plus the real-split
+// post-pass.  The mel filterbank is applied from the LDS-resident power spectrum with a transposed
+// [tap][filter] weight table.
 // Frames past an utterance's length are written as zeros (collate_fn zero padding, collate_fn.py:8-42).
 #include <algorithm>
 
@@ -280,127 +281,12 @@ __global__ __launch_bounds__(256) void norm_int16_kernel(const ST* __restrict__ 
 static constexpr int WIN = 400, HOP = 160, NFFT = 512, NBIN = 257, NMEL = 80;
 static constexpr int FB_TAPS = 16;        // widest mel filter of the 80-bin 20 Hz - 8 kHz bank (build_fbank_tables checks it)
 
-template <class ST>
-__global__ __launch_bounds__(256) void fbank_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp,
-                                                    int n_max, int use_db, const float* __restrict__ gain,
-                                                    const float* __restrict__ window, const float* __restrict__ melw,
-                                                    const int* __restrict__ mel_lo, const int* __restrict__ mel_hi,
-                                                    const float* __restrict__ tw256, const float* __restrict__ tw512,
-                                                    float* __restrict__ feats, int T_max) {
-    __shared__ float re[4][256 + 4];
-    __shared__ float im[4][256 + 4];
-    __shared__ float pw[4][NBIN + 3];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * 4 + wv;
-    const int n = nsamp[b];
-    const int T = n >= WIN ? 1 + (n - WIN) / HOP : 0;
-    const bool live = t < T;               // wave-uniform
-    float* R = re[wv];
-    float* I = im[wv];
-    float* P = pw[wv];
-    const float s = use_db ? gain[b] : 1.f;
-
-    // ---- load 400 samples (lane handles j = lane + 64*i), DC removal, pre-emphasis, window -----------
-    float x[7];
-    float part = 0.f;
-    const ST* src = pcm + (size_t)b * n_max + (size_t)t * HOP;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int j = lane + 64 * i;
-        x[i] = (live && j < WIN) ? norm_sample(src[j], s, use_db) : 0.f;
-        part += x[i];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    const float mean = part / (float)WIN;
-    // stash DC-removed samples in LDS to fetch the left neighbour for pre-emphasis
-    __shared__ float tmp[4][WIN + 8];
-    float* Tm = tmp[wv];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int j = lane + 64 * i;
-        if (j < WIN) Tm[j] = x[i] - mean;
-    }
-    __builtin_amdgcn_wave_barrier();   // the four waves of a workgroup work on four independent frames: LDS traffic of a wave is in order
-    // z[n] = y[2n] + i*y[2n+1], written at bit-reversed n for the in-place DIT FFT
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int j = lane + 64 * i;               // 0..511
-        float y = 0.f;
-        if (j < WIN) {
-            const float cur = Tm[j];
-            const float prev = Tm[j > 0 ? j - 1 : 0];
-            y = (cur - 0.97f * prev) * window[j];
-        }
-        const int nn = j >> 1;
-        const int br = __brev((unsigned)nn) >> 24;  // 8-bit reversal
-        if (j & 1) I[br] = y; else R[br] = y;
-    }
-    __builtin_amdgcn_wave_barrier();   // the four waves of a workgroup work on four independent frames: LDS traffic of a wave is in order
-
-    // ---- 256-point complex FFT, radix-2 DIT, 8 stages, 2 butterflies per lane per stage ---------------
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-        const int half = 1 << st;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int bf = lane + 64 * q;            // 0..127
-            const int grp = bf >> st;
-            const int pos = bf & (half - 1);
-            const int i0 = (grp << (st + 1)) + pos;
-            const int i1 = i0 + half;
-            const int tw = pos << (7 - st);          // pos * 256 / len, len = 2*half
-            const float wr = tw256[2 * tw], wi = tw256[2 * tw + 1];
-            const float ar = R[i0], ai = I[i0], br_ = R[i1], bi = I[i1];
-            const float tr = wr * br_ - wi * bi;
-            const float ti = wr * bi + wi * br_;
-            R[i0] = ar + tr; I[i0] = ai + ti;
-            R[i1] = ar - tr; I[i1] = ai - ti;
-        }
-        __builtin_amdgcn_wave_barrier();   // the four waves of a workgroup work on four independent frames: LDS traffic of a wave is in order
-    }
-
-    // ---- real-split post-pass: X[k] = (Z[k] + conj(Z[N-k]))/2 - i/2 * W^k * (Z[k] - conj(Z[N-k])), N = 256 ---
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int k = lane + 64 * i;                 // 0..256
-        if (k <= 256) {
-            const int ka = k & 255, kb = (256 - k) & 255;
-            const float zr = R[ka], zi = I[ka], yr = R[kb], yi = -I[kb];   // y = conj(Z[N-k])
-            const float er = 0.5f * (zr + yr), ei = 0.5f * (zi + yi);     // even part
-            const float dr = 0.5f * (zr - yr), di = 0.5f * (zi - yi);     // (Z - conj)/2
-            // odd part = -i * W512^k * d
-            const float wr = tw512[2 * k], wi = tw512[2 * k + 1];
-            const float pr = wr * dr - wi * di, pi = wr * di + wi * dr;   // W * d
-            const float xr = er + pi, xi = ei - pr;                        // e + (-i)*(pr + i pi) = e + pi - i pr
-            P[k] = xr * xr + xi * xi;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();   // the four waves of a workgroup work on four independent frames: LDS traffic of a wave is in order
-
-    // ---- mel filterbank + log --------------------------------------------------------------------------
-    float* dst = feats + ((size_t)b * T_max + t) * NMEL;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = lane + 64 * i;
-        if (m < NMEL && t < T_max) {
-            float acc = 0.f;
-            if (live) {
-                const int lo = mel_lo[m], hi = mel_hi[m];
-                for (int k = lo; k < hi; ++k) acc = fmaf(melw[m * NBIN + k], P[k], acc);
-                acc = logf(fmaxf(acc, 1.1920928955078125e-07f));
-            }
-            dst[m] = acc;
-        }
-    }
-}
-
-// ---- fbank, register FFT (round 5) -------------------------------------------------------------------------------------------
-// Same function as fbank_kernel above, one wave per frame, but the 256-point complex FFT is a Stockham radix-4 transform with FOUR
-// elements per lane in registers: four in-register radix-4 butterflies with three exchanges through a 2 KB per-wave LDS buffer
-// (24 LDS instructions per lane) where the radix-2 kernel walked eight LDS-synchronised stages (128 LDS instructions and 32 table
-// loads per lane).  Lane j holds z[j + 64 r], r = 0..3 (z[n] = y[2n] + i y[2n+1], y = windowed frame zero-padded to 512): the
+// ---- fbank kernel --------------------------------------------------------------------------------------------------------------
+// One wave per frame.  The 256-point complex FFT is a Stockham radix-4 transform with FOUR elements per lane in registers: four
+// in-register radix-4 butterflies with three exchanges through a 2 KB per-wave LDS buffer (24 LDS instructions per lane).  Rounds
+// 1-4 ran a radix-2 FFT entirely in LDS (eight LDS-synchronised stages, 128 LDS instructions and 32 table loads per lane): 57.6 us
+// per 32 x 10 s launch against 30.5-34.8 us for this kernel on the same box (profiles/r05_fbank_ab.txt; the old kernel is in the
+// history, commit 'fbank: register radix-4 Stockham FFT kernel').  Lane j holds z[j + 64 r], r = 0..3 (z[n] = y[2n] + i y[2n+1], y = windowed frame zero-padded to 512): the
 // first pass needs no exchange at all and the last one leaves Z[j + 64 q] in the lane's registers.  Complex arithmetic on float2
 // values (packed fp32 instructions).  The left neighbour of the pre-emphasis comes over one DPP wave shift instead of an LDS
 // round trip; the twiddles of the three later passes are one table row per lane (9 coalesced 8-byte loads, issued before the
@@ -423,7 +309,7 @@ __device__ __forceinline__ void fb_radix4(f2 (&v)[4]) {              // forward 
 }
 
 template <class ST>
-__global__ __launch_bounds__(256) void fbank_r4_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp, int n_max,
+__global__ __launch_bounds__(256) void fbank_kernel(const ST* __restrict__ pcm, const int* __restrict__ nsamp, int n_max,
                                                        int use_db, const float* __restrict__ gain, FbankTables tb,
                                                        float* __restrict__ feats, int T_max) {
     __shared__ f2 lds[4][FB_LDS];
@@ -555,9 +441,6 @@ __global__ __launch_bounds__(256) void fbank_r4_kernel(const ST* __restrict__ pc
     }
 }
 
-static int g_fbank_r2 = 0;        // masr_debug_set key 37: 1 = the radix-2 LDS kernel of rounds 1-4 (A/B)
-void set_fbank_radix2(int on) { g_fbank_r2 = on; }
-
 template <class ST>
 static void launch_fbank_t(const ST* pcm, const int* nsamp, int B, int n_max, int use_db, float target_db,
                            const FbankTables& tb, float* feats, int T_max, float* gain_scratch, int16_t* norm_out, hipStream_t s) {
@@ -573,12 +456,8 @@ static void launch_fbank_t(const ST* pcm, const int* nsamp, int B, int n_max, in
         hipLaunchKernelGGL(norm_int16_kernel<ST>, dim3((n_max + 255) / 256, B), dim3(256), 0, s, pcm, nsamp, n_max,
                            gain_scratch, use_db, norm_out);
     if (T_max <= 0) return;
-    if (g_fbank_r2)
-        hipLaunchKernelGGL(fbank_kernel<ST>, dim3((T_max + 3) / 4, B), dim3(256), 0, s, pcm, nsamp, n_max, use_db,
-                           gain_scratch, tb.window, tb.melw, tb.mel_lo, tb.mel_hi, tb.tw256, tb.tw512, feats, T_max);
-    else
-        hipLaunchKernelGGL(fbank_r4_kernel<ST>, dim3((T_max + 3) / 4, B), dim3(256), 0, s, pcm, nsamp, n_max, use_db, gain_scratch,
-                           tb, feats, T_max);
+    hipLaunchKernelGGL(fbank_kernel<ST>, dim3((T_max + 3) / 4, B), dim3(256), 0, s, pcm, nsamp, n_max, use_db, gain_scratch, tb, feats,
+                       T_max);
 }
 
 // ms_out[b] = float32 np.mean(samples ** 2) of utterance b (numpy's summation order); gain_scratch as in launch_fbank
