@@ -7,7 +7,7 @@ import json
 import sqlite3
 import sys
 
-WIDE = ('gemm_f32_kernel', 'ffn_pc_kernel', 'ffn_fused_kernel', 'rowgemm_kernel', 'attention_kernel', 'dwconv_ln_silu_kernel',
+WIDE = ('gemm_f32_kernel', 'ffn_pc_kernel', 'sqz_stage_kernel', 'ffn_fused_kernel', 'rowgemm_kernel', 'attention_kernel', 'dwconv_ln_silu_kernel',
         'layernorm256_kernel')
 
 
