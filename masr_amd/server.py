@@ -203,8 +203,12 @@ class EngineWorker(object):
                 self.stats['chunks'] += len(live)
                 try:
                     out = self.pool.step()
+                    errors = getattr(self.pool, 'errors', {})
                     for handle, fut in live:
-                        fut.set_result(out.get(handle))
+                        if handle in errors:        # the step left this session out (its stream is full): only ITS request fails
+                            fut.set_exception(Exception(errors[handle]))
+                        else:
+                            fut.set_result(out.get(handle))
                 except BaseException as e:
                     for _, fut in live:
                         fut.set_exception(e)
