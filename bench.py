@@ -64,7 +64,7 @@ def conformer_gflop(T, t2=None, vocab=VOCAB, d=256, dff=2048, layers=12, k=15, p
 
 def workload_roofline(gflop, ms, note):
     """whole-workload roofline block of a secondary config: algorithmic GFLOP of one step / its wall time, against the fp32 MFMA
-    peak (the per-kernel evidence of these workloads is under profiles/r04_*_kernel_stats.txt)"""
+    peak (the per-kernel evidence of these workloads is under profiles/r05_*_kernel_stats.txt)"""
     ach = gflop / ms                                               # GFLOP / ms = TFLOP/s
     return {'bound': 'mfma', 'scope': 'whole step (wall time, host framing included)', 'achieved': round(ach, 2),
             'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
@@ -150,7 +150,7 @@ ROOFLINE_KERNELS = [
 def committed_traffic(fragment):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this build (profiles/rNN_hbm_traffic.json:
     FETCH_SIZE with the gfx950 correction + WRITE_SIZE); (bytes, file) or (None, None)."""
-    for name in ('r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+    for name in ('r05_hbm_traffic.json', 'r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
         try:
             k = json.load(open(os.path.join(ROOT, 'profiles', name)))['kernels']
             for key, v in k.items():
