@@ -29,7 +29,7 @@ import sys
 import tempfile
 import time
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime starts (masr_amd/__init__.py says why)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # before the HIP runtime starts (masr_amd/__init__.py says why)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
