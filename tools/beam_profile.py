@@ -1,6 +1,7 @@
 """Phase breakdown (cycles of workgroup 0) of the GPU CTC prefix beam search on flat posteriors (worst case: every
 frame keeps cutoff_top_n candidates), without and with the external n-gram scorer.
-usage: python tools/beam_profile.py [T] [V] [beam] [lm_order (0 = no LM)] [prune (1)] [lm_cache (1: one scorer probe per distinct context and candidate; 0: per pair)]"""
+usage: python tools/beam_profile.py [T] [V] [beam] [lm_order (0 = no LM)] [prune (1)] [lm_cache (1: one scorer probe per distinct context and candidate; 0: per pair)]
+       [logit scale (1: flat posteriors, 40 candidates in every frame; 8: ~12; 14: ~3 -- what a trained model gives the search)]"""
 import os
 import sys
 import tempfile
@@ -20,7 +21,8 @@ V = int(sys.argv[2]) if len(sys.argv) > 2 else 4233
 beam = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 order = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 rng = np.random.default_rng(0)
-logits = rng.normal(0, 1.0, (8, T, V)).astype(np.float32)
+scale = float(sys.argv[7]) if len(sys.argv) > 7 else 1.0
+logits = (rng.normal(0, 1.0, (8, T, V)) * scale).astype(np.float32)
 probs = torch.softmax(torch.from_numpy(logits), -1).cuda()
 vocab = ['<blank>', '<unk>', '<space>'] + [chr(0x4e00 + i) for i in range(V - 3)]
 kw = {'language_model_path': None}
@@ -32,6 +34,8 @@ dec.prune_min_cutoff = bool(prune)
 eng = runtime.aux_engine()
 cache = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 eng.lib.masr_debug_set(eng.h, 32, cache)
+cand = dec._candidates(probs[0], to_host=False)[2].float().mean().item()
+print(f'logit scale {scale}: {cand:.1f} candidates per frame')
 ref = dec._batch([probs[i] for i in range(8)])
 if cache and order:                    # the table must not change a score: same transcripts and scores as per-pair probing
     eng.lib.masr_debug_set(eng.h, 32, 0)
