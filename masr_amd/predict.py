@@ -354,7 +354,8 @@ class MASRPredictor:
 
         ``decode_all_frames=True`` reproduces the reference's batch evaluation quirk of decoding padded frames
         (trainer.py:340).  ``batch_size`` > 0 cuts the (length-sorted) work into device passes of that many utterances
-        (``batch_size='auto'``: ``pass_size()`` -- 32, or 64 for the Efficient-Conformer).  ``batch_size='balanced'``: passes of
+        (``batch_size='auto'``: ``pass_size()`` -- 32, or 64 for the Efficient-Conformer; a LIST gives the pass sizes explicitly,
+        counted from the longest utterance down, the last size repeating).  ``batch_size='balanced'``: passes of
         EQUAL PADDED SIZE instead of equal count -- a pass takes utterances (longest first) while count x its longest
         utterance stays within ``pass_padded`` (in the unit of the lengths; default: ``pass_size()`` utterances of 10 s, the row
         blocks that fill the chip once), so a pass of long utterances holds few of them, a pass of short ones many, every pass is
@@ -399,9 +400,17 @@ class MASRPredictor:
         """decode ``audio_list[i] for i in which`` in length-sorted device passes (cut shortest first, ties in input order -- the
         batches ``evaluate`` forms from a duration-sorted manifest); results in the order of ``which``.  Pipeline depth 2:
         pass k is launched (its prefix search on a side stream), then pass k - 1 is collected and its audio dropped."""
-        order = sorted(which, key=lambda i: hints[i]) if batch_size else list(which)
+        order = sorted(which, key=lambda i: hints[i]) if batch_size else list(which)      # (a list / tuple / number: sorted)
         if isinstance(batch_size, tuple):             # ('balanced', budget): count x longest <= budget per pass
             cuts = balanced_cuts([hints[i] for i in order], batch_size[1])
+        elif isinstance(batch_size, list):            # explicit pass sizes, counted from the LONGEST utterance down (the last size repeats)
+            cuts, hi, k = [], len(order), 0
+            while hi > 0:
+                step = max(1, int(batch_size[min(k, len(batch_size) - 1)]))
+                cuts.append((max(0, hi - step), hi))
+                hi -= step
+                k += 1
+            cuts.reverse()
         else:
             step = batch_size if batch_size else max(len(order), 1)
             cuts = [(lo, min(lo + step, len(order))) for lo in range(0, len(order), step)]

@@ -22,7 +22,7 @@ conf = {'alpha': 2.2, 'beta': 4.3, 'beam_size': 300, 'cutoff_prob': 0.99, 'cutof
         'language_model_path': write_synthetic_arpa(os.path.join(d, 'lm.arpa'), synthetic.synthetic_vocab(bench.VOCAB), seed=5)}
 SHARP = os.environ.get('MASR_PROFILE_SHARP') == '1'
 PASS = os.environ.get('MASR_BENCH_BEAM_PASS', 'balanced')
-PASS = PASS if PASS == 'balanced' else int(PASS)
+PASS = PASS if PASS == 'balanced' else ([int(v) for v in PASS.split(',')] if ',' in PASS else int(PASS))
 pred = bench.facade('squeezeformer', 'ctc_beam_search', 0, streaming=False, beam_conf=conf, head_gain=bench.SHARP_HEAD_GAIN if SHARP else None)
 print(f'passes: {PASS}, sharp head: {SHARP}, side streams: {os.environ.get("MASR_BEAM_SIDES", "3")}, group: {os.environ.get("MASR_BEAM_GROUP", "4")}')
 marks = []
