@@ -434,9 +434,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         // ---- 4a. lower bound of the beam-th best key: the beam-th best of the per-thread maxima, to 24 bits ---------------
         unsigned low = NEG + 1;                                         // every finite entry
         const bool overflow = tot > beam;
-        // (frames with at most one extension entry per thread -- what a sharp posterior gives: 1-3 candidates x 300 prefixes -- skip
-        //  the bound: all their finite entries fit the one re-dealt row of the exact select below; same threshold, same result)
-        if (overflow && nq > BS_THREADS) {
+        // (round 5 measured skipping the bound for frames of <= 1 024 / <= 4 096 extension entries -- what a sharp posterior gives:
+        //  no gain / slower, 19.6 -> 19.6 / 21.0 us per frame at 3.7 candidates: the survivors' rows cost the compaction what the
+        //  three bound passes cost the selection)
+        if (overflow) {
             unsigned prefix = 0, mask = 0;
             int need = beam;
             for (int pass = 0; pass < 3; ++pass) {
