@@ -301,9 +301,9 @@ class MASRPredictor:
                 # slower (flat posteriors 58.2 vs 45.7 ms, sharpened head 38.2 vs 29.1 ms per call, gpurun_out r05c) -- the
                 # call is bound by the longest utterance's ~30 us per frame x 494 frames, and starting that search late costs
                 # more than sharing CUs with the next encoder pass.  Default: launch at once.
-                main = torch.cuda.current_stream()
+                main = torch.cuda.current_stream(eng.device)          # (explicit device: a server runs one worker thread per GPU)
                 if getattr(self, '_sides', None) is None:
-                    self._sides, self._side_turn = [torch.cuda.Stream() for _ in range(int(os.environ.get('MASR_BEAM_SIDES', '2')))], 0
+                    self._sides, self._side_turn = [torch.cuda.Stream(device=eng.device) for _ in range(int(os.environ.get('MASR_BEAM_SIDES', '2')))], 0
 
                 def launch_search():
                     side = self._sides[self._side_turn]
@@ -442,7 +442,7 @@ class MASRPredictor:
             while pending:
                 collect(pending.pop(0))
             for side in getattr(self, '_sides', None) or []:
-                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.current_stream(self.predictor.engine.device).wait_stream(side)
         for lo, hi in cuts:
             idx = order[lo:hi]
             segs = [self._load_audio(audio_list[i], sample_rate) for i in idx]
@@ -462,7 +462,7 @@ class MASRPredictor:
             for item in pending:
                 collect(item)
             for side in getattr(self, '_sides', None) or []:
-                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.current_stream(self.predictor.engine.device).wait_stream(side)
         return [got[i] for i in which]
 
     def evaluate(self, manifest, batch_size='auto', display_result=False, decode_all_frames=False):
