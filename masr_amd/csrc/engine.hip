@@ -1403,9 +1403,9 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
         rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->att.as<float>(), d, nullptr, nullptr, w.wo, w.bo, x, d, M, d, x, d, 1.f,
                 nullptr, 0, 0, 0, nullptr, nullptr);
         launch_layernorm(x, w.ln1_w, w.ln1_b, x, M, 1e-5f, 0, 0, nullptr, s);
-        // x = LN2(x + FFN1(ada(x)))
-        CHK(ffn(e, s, M, w.f1_s, w.f1_b, w.f1_w1, w.f1_b1, w.f1_w2, w.f1_b2, 1.0f, 1));
-        launch_layernorm(x, w.ln2_w, w.ln2_b, x, M, 1e-5f, 0, 0, nullptr, s);
+        // x = LN2(x + FFN1(ada(x)))   (the post-LayerNorm rides on the d_ff-split reduction where the block runs split: few row
+        // blocks, i.e. exactly the launches that take this branch by default; otherwise ffn() launches it)
+        CHK(ffn(e, s, M, w.f1_s, w.f1_b, w.f1_w1, w.f1_b1, w.f1_w2, w.f1_b2, 1.0f, 1, w.ln2_w, w.ln2_b, x));
         // x = LN3(x + Conv(ada(x)))   symmetric depthwise conv: (K-1)/2 zero rows on both sides of the GLU output
         rowgemm(e, s, RG_PRO_AFFINE, RG_EPI_GLU, x, d, w.cv_s, w.cv_b, w.pw1_w, w.pw1_b, e->glu.as<float>(), d, M, 2 * d,
                 nullptr, 0, 1.f, lens, 0, Tq, 0, nullptr, nullptr, PROF_GEMM, mstride, Tq, pad_l, 2 * half);
@@ -1415,8 +1415,7 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
                 d, 1.f, lens, Tq, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
         launch_layernorm(x, w.ln3_w, w.ln3_b, x, M, 1e-5f, 0, 0, nullptr, s);
         // x = LN4(x + FFN2(ada(x)))
-        CHK(ffn(e, s, M, w.f2_s, w.f2_b, w.f2_w1, w.f2_b1, w.f2_w2, w.f2_b2, 1.0f, 1));
-        launch_layernorm(x, w.ln4_w, w.ln4_b, i == L - 1 ? enc_out : x, M, 1e-5f, 0, 0, nullptr, s);
+        CHK(ffn(e, s, M, w.f2_s, w.f2_b, w.f2_w1, w.f2_b1, w.f2_w2, w.f2_b2, 1.0f, 1, w.ln4_w, w.ln4_b, i == L - 1 ? enc_out : x));
     }
     LAUNCHCHK();
     return 0;
