@@ -42,7 +42,7 @@ python profiles/summarize_rocpd.py $(find $D/ktg -name "*.db") > $D/squeezeforme
 python profiles/summarize_rocpd.py $(find $D/ktd -name "*.db") > $D/deepspeech2_kernel_stats.txt
 python profiles/summarize_mfma.py $(find $D/pmg -name "*.db") $D/squeezeformer_greedy_mfma_util.json > $D/squeezeformer_greedy_mfma.txt 2>&1
 python profiles/summarize_pmc.py $(find $D/pfg -name "*.db") $(find $D/pwg -name "*.db") $D/squeezeformer_greedy_hbm_traffic.json > $D/squeezeformer_greedy_hbm.txt 2>&1
-python profiles/summarize_rocpd.py $(find $D/kt -name "*.db") 44 > $D/kernel_stats.txt
+python profiles/summarize_rocpd.py $(find $D/kt -name "*.db") 48 > $D/kernel_stats.txt
 python profiles/summarize_rocpd.py $(find $D/kte -name "*.db") > $D/efficient_kernel_stats.txt
 python profiles/summarize_rocpd.py $(find $D/ktq -name "*.db") > $D/squeezeformer_beam_kernel_stats.txt
 python profiles/summarize_rocpd.py $(find $D/kts -name "*.db") > $D/stream16_kernel_stats.txt
