@@ -134,6 +134,56 @@ __device__ __forceinline__ void pick_bin(const int* hist, int need, int& bin, in
     rem = __builtin_amdgcn_readlane(r, leader);
 }
 
+// as pick_bin, and the number of keys in the histogram (its 256 bins together)
+__device__ __forceinline__ void pick_bin_tot(const int* hist, int need, int& bin, int& rem, int& total, int& binc) {
+    const int lane = threadIdx.x & 63;
+    int c4[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c4[j] = hist[255 - (4 * lane + j)];
+        s += c4[j];
+    }
+    const int incl = wave_scan_incl(s);
+    const int excl = incl - s;
+    const bool mine = excl < need && need <= incl;
+    int b = 0, r = 0, bc = 0, acc = excl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (acc < need && need <= acc + c4[j]) {
+            b = 255 - (4 * lane + j);
+            r = need - acc;
+            bc = c4[j];
+        }
+        acc += c4[j];
+    }
+    const unsigned long long m = __ballot(mine);
+    const int leader = m ? __ffsll((long long)m) - 1 : 0;
+    bin = __builtin_amdgcn_readlane(b, leader);
+    rem = __builtin_amdgcn_readlane(r, leader);
+    binc = __builtin_amdgcn_readlane(bc, leader);
+    total = __builtin_amdgcn_readlane(incl, 63);
+}
+
+// ---- narrow frames ------------------------------------------------------------------------------------------------------------
+// A frame whose extension table has at most NW_ENT entries (live prefixes x candidates of the frame: every frame in which a trained
+// model's posterior leaves 1-3 candidates) is a few hundred items of work, and the 1024-thread step above spends its time on what
+// every one of its 16 waves executes regardless of the entry count -- scans, bin picks, loop control: ~2 500 instructions per wave
+// and frame at four waves per SIMD.  Such a frame is run by the first NW_WAVES waves only (one per SIMD), each thread owning a BLOCK
+// of consecutive prefixes / entries (so that index order = thread order and the ordered compaction needs one scan), its keys in
+// registers from the extension phase to the compaction (no entry table, no survivor list, no bound stage: one exact 4-pass radix
+// select whose first pass also counts the finite keys); the other waves wait at the frame's NW_BARRIERS barriers.  Same arithmetic
+// per (prefix, candidate) pair, same selection rule and the same order of the new live set as the wide step: identical transcripts
+// and scores (masr_debug_set key 37 = 0 runs every frame on the wide step; tests/test_beam_search.py compares the two).
+#ifndef BS_NARROW_WAVES
+#define BS_NARROW_WAVES 8
+#endif
+static constexpr int NW_WAVES = BS_NARROW_WAVES;
+static constexpr int NW_T = 64 * NW_WAVES;
+static constexpr int NW_EPT = 8;                                    // entries per thread, consecutive
+static constexpr int NW_ENT = NW_EPT * NW_T;
+static constexpr int NW_PPT = (512 + NW_T - 1) / NW_T;              // live prefixes per thread, consecutive (beam <= 512)
+static constexpr int NW_BARRIERS = 11;
+
 // NPT = extension entries per thread in the selection phase, strided (beam * K <= 1024 * NPT)
 // ORD = 0: no external scorer; 3 | 5: a language model of order <= ORD is bound (bounds the probes per scored extension, which
 //       live in registers while a batch of extensions is in flight)
@@ -141,7 +191,7 @@ template <int NPT, int ORD>
 __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     constexpr bool use_lm = ORD > 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // (shadowed inside the frame loop, see there)
     const int u = blockIdx.x;
     const int beam = a.beam, K = a.K;
     // ---- LDS carve-up --------------------------------------------------------------------------------
@@ -169,10 +219,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                                                                          // (+ beam & 1: the histogram area behind it holds 64-bit keys)
     float* c_lp = reinterpret_cast<float*>(c_idx + BS_KMAX);             // [BS_KMAX]
     float* c_uni = c_lp + BS_KMAX;                                       // [BS_KMAX] ln P_LM(candidate) (unigram), per frame
-    int* hist = reinterpret_cast<int*>(c_uni + BS_KMAX);                 // [7][256]: one per radix pass of a step
+    float* c_ubo = c_uni + BS_KMAX;                                      // [BS_KMAX] ln backoff of the candidate's unigram
+    int* hist = reinterpret_cast<int*>(c_ubo + BS_KMAX);                 // [7][256]: one per radix pass of a step
     int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
     int* misc = wsum + (6 + NPT) * BS_WAVES;                                         // [8]: 0 blank_k, 1 sel_bin, 2 need
-    unsigned short* slist = reinterpret_cast<unsigned short*>(misc + 8);  // [beam * K] surviving extension entries
+    unsigned short* slist = reinterpret_cast<unsigned short*>(misc + 8 + 32);  // [beam * K] surviving extension entries
     // Scorer table of the frame (use_lm): ln P_LM(c | context) depends on the prefix only through its EFFECTIVE context -- the m most
     // recent words, m = length of the longest suffix that exists in the model -- so the live prefixes' contexts are deduplicated
     // (LDS hash in the histogram area, which the selection phases only need later and which is cleared again behind the extension
@@ -222,57 +273,458 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     const unsigned NEG = okey(-INFINITY);
     const int T = a.frames ? min(a.frames[u], a.T_stride) : a.T_stride;
     const int G = BS_THREADS / beam;                  // threads per prefix in the extension phase (>= 2)
-    const int my_p = tid / G, my_g = tid - my_p * G;
-    // candidates of the next frame are fetched one step ahead (registers of threads 0..K-1)
+    const int my_p0 = tid / G, my_g0 = tid - my_p0 * G;
+    // Candidates are fetched TWO frames ahead (nx2_*: registers of threads 0..K-1; the count in every thread), and the scorer's view
+    // of a frame's candidates -- known-word flag, unigram entry -- ONE frame ahead (nx_kn, nx_u*: the first probe of the unigram;
+    // a collision walks on when the frame is staged), so that no frame starts with a chain of dependent global loads.  The counts
+    // come through the VECTOR memory path (vz: a zero the compiler cannot see): a scalar load would be drained by the
+    // lgkmcnt(0) in front of every barrier.
     const size_t row0 = (size_t)u * a.T_stride;
-    int nx_cnt = 0, nx_c = 0;
-    float nx_lp = 0.f, nx_blp = 0.f;
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    int nx_cnt = 0, nx_c = 0, nx2_cnt = 0, nx2_c = 0, nx_kn = 0;
+    float nx_lp = 0.f, nx_blp = 0.f, nx2_lp = 0.f, nx2_blp = 0.f, nx_up0 = 0.f, nx_ub0 = 0.f;
+    unsigned long long nx_uk0 = 0ull;
     const bool cutting = use_lm && a.blank_lp != nullptr;       // the decoder's min_cutoff rule (needs ln p(blank) per frame)
+    // frame f of this utterance -> (count, candidate of this lane, ln p(blank))
+#define BS_LOAD_FRAME(f, cnt_, c_, lp_, blp_) do {                                                              \
+        cnt_ = min(a.ccount[row0 + (f) + vz], K);                                                                \
+        if (tid < K) { c_ = a.cidx[(row0 + (f)) * K + tid]; lp_ = a.clp[(row0 + (f)) * K + tid]; }              \
+        if (cutting && tid == 0) blp_ = a.blank_lp[row0 + (f)];                                                 \
+    } while (0)
+    // first probe of the unigram of the candidate in nx_c and its known-word flag (wave 0; results are used one frame later)
+#define BS_PROBE_UNIGRAM() do {                                                                                  \
+        if (use_lm && wave == 0 && lane < nx_cnt && nx_c >= 0 && nx_c < a.lm.n_words) {                          \
+            nx_kn = a.lm.known[nx_c];                                                                            \
+            lm_load_entry(a.lm, lm_key(0ull, 0, nx_c) & a.lm.mask, &nx_uk0, &nx_up0, &nx_ub0);                   \
+        }                                                                                                        \
+    } while (0)
+    // stage the frame in nx_* (wave 0): candidates, blank index, scorer flags / unigrams -> LDS; then advance the pipeline
+#define BS_STAGE_FRAME() do {                                                                                    \
+        if (wave == 0) {                                                                                         \
+            const bool isb = lane < cnt && nx_c == a.blank;                                                      \
+            const unsigned long long bm = __ballot(isb);                                                         \
+            if (lane < cnt) {                                                                                    \
+                /* the scorer's known-word flag of this candidate rides in bit 30 of its index: one lookup per frame and */ \
+                /* candidate instead of one per (prefix, candidate) pair */                                      \
+                const bool unk = use_lm && !(nx_c >= 0 && nx_c < a.lm.n_words && nx_kn);                         \
+                c_idx[lane] = nx_c | (unk ? (1 << 30) : 0);                                                      \
+                c_lp[lane] = nx_lp;                                                                              \
+                if (use_lm) {                             /* the candidate's unigram: one lookup per frame and candidate */ \
+                    float up = LM_OOV_SCORE, ub = 0.f;                                                           \
+                    if (!unk) {                                                                                  \
+                        const unsigned long long key = lm_key(0ull, 0, nx_c);                                    \
+                        if (nx_uk0 == key) { up = nx_up0; ub = nx_ub0; }                                         \
+                        else if (nx_uk0 != 0ull) lm_find(a.lm, key, &up, &ub);                                   \
+                    }                                                                                            \
+                    c_uni[lane] = up;                                                                            \
+                    c_ubo[lane] = ub;                                                                            \
+                }                                                                                                \
+            }                                                                                                    \
+            if (lane == 0) {                                                                                     \
+                misc[0] = bm ? __ffsll((long long)bm) - 1 : -1;                                                  \
+                misc[3] = (int)0xFFFFFFFFu;                  /* min over the live prefixes' score keys */         \
+                misc[4] = __float_as_int(nx_blp);                                                                \
+                misc[5] = 0;                                 /* distinct effective scorer contexts of this frame */ \
+            }                                                                                                    \
+        }                                                                                                        \
+        nx_cnt = nx2_cnt; nx_c = nx2_c; nx_lp = nx2_lp; nx_blp = nx2_blp;                                        \
+        if (t + 1 < T) BS_PROBE_UNIGRAM();                                                                       \
+        if (t + 2 < T) BS_LOAD_FRAME(t + 2, nx2_cnt, nx2_c, nx2_lp, nx2_blp);                                    \
+    } while (0)
     if (T > 0) {
-        nx_cnt = min(a.ccount[row0], K);
-        if (tid < K) { nx_c = a.cidx[row0 * K + tid]; nx_lp = a.clp[row0 * K + tid]; }
-        if (cutting && tid == 0) nx_blp = a.blank_lp[row0];
+        BS_LOAD_FRAME(0, nx_cnt, nx_c, nx_lp, nx_blp);
+        BS_PROBE_UNIGRAM();
+        if (T > 1) BS_LOAD_FRAME(1, nx2_cnt, nx2_c, nx2_lp, nx2_blp);
     }
-    long long pc[6] = {0, 0, 0, 0, 0, 0};
     const bool prof = a.prof && u == 0 && tid == 0;
-#define BS_TICK(i) do { if (prof) { const long long now_ = clock64(); pc[i] += now_ - tick_; tick_ = now_; } } while (0)
+    // phase counters of workgroup 0 live in LDS (16 x 64 bit behind misc): 0-4 wide step, 5 narrow frames, 6-13 narrow step
+    unsigned long long* pcl = reinterpret_cast<unsigned long long*>(misc + 8);
+    if (tid < 16) pcl[tid] = 0ull;
+#define BS_TICK(i) do { if (prof) { const long long now_ = clock64(); pcl[i] += (unsigned long long)(now_ - tick_); tick_ = now_; } } while (0)
     long long tick_ = prof ? clock64() : 0;
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
+        // The thread's indices are made opaque once per frame: every LDS address of the step is then recomputed from them (one or
+        // two VALU instructions) instead of being hoisted out of the frame loop, kept alive across all its phases and SPILLED -- a
+        // scratch reload waits with vmcnt(0), i.e. for every prefetch in flight as well (18-40 spilled VGPRs before this).
+        int tid_ = (int)threadIdx.x, my_p_ = my_p0, my_g_ = my_g0;
+        asm volatile("" : "+v"(tid_), "+v"(my_p_), "+v"(my_g_));
+        const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int my_p = my_p_, my_g = my_g_;
         const int cnt = nx_cnt;
         const int o = cur * beam, o2 = (cur ^ 1) * beam;
+        if (a.narrow && n * cnt <= NW_ENT) {
+            // ================= narrow frame: waves 0 .. NW_WAVES-1 work, the others wait ======================================
+            if (wave >= NW_WAVES) {
+                nx_cnt = nx2_cnt;
+                if (t + 2 < T) nx2_cnt = min(a.ccount[row0 + t + 2 + vz], K);
+                for (int b = 0; b < NW_BARRIERS; ++b) __syncthreads();
+                n = misc[6];
+                pool_count = misc[7];
+                cur ^= 1;
+                continue;
+            }
+            if (prof) ++pcl[5];
+            // ---- N0. tables, candidates, prefetch ------------------------------------------------------------------------
+            for (int i = tid; i < BS_HASH; i += NW_T) hkey[i] = 0ull;
+            if (lm_cache)
+                for (int i = tid; i < 512; i += NW_T) ckey[i] = 0ull;
+            for (int i = tid; i < n; i += NW_T) { rep[i] = -INFINITY; ext[i] = -INFINITY; head[i] = -1; }
+            BS_STAGE_FRAME();
+            __syncthreads();                                                                                  // (1)
+            BS_TICK(6);
+            // ---- N1. string identities -> hash, scorer contexts -> rows, worst live score ------------------------------------
+            const int blank_k = misc[0];
+            // scorer-state table of the frame: next to ln P_LM(c | context) the table fill records m and the backoffs of the context
+            // EXTENDED by c (lm_cond_next: they come out of the same probes), so a surviving extension takes its scorer state from
+            // LDS instead of probing the model again (lm_state_of: 2 - 4 more dependent loads per new prefix, at the end of the
+            // frame's critical path).  STW words per (context, candidate) in the wide step's entry-key area, idle in narrow frames.
+            constexpr int STW = ORD > 1 ? ORD - 1 : 1;
+            float* lmst = reinterpret_cast<float*>(ekeys);
+            const int ucap_n = min(ucap, (beam * K) / (STW * max(cnt, 1)));
+            const int i0 = NW_PPT * tid;                  // this thread's live prefixes: i0 .. i0 + NW_PPT - 1
+            unsigned long long my_ek[NW_PPT];
+            unsigned kmin = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < NW_PPT; ++j) {
+                const int i = i0 + j;
+                my_ek[j] = 0ull;
+                if (i < n) {
+                    const unsigned long long key = lv_hid[o + i];
+                    unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
+                    while (atomicCAS(&hkey[h], 0ull, key) != 0ull) h = (h + 1) & (BS_HASH - 1);
+                    hval[h] = i;
+                    kmin = min(kmin, okey(lv_sc[o + i]));
+                    if (lm_cache) {
+                        const int mo = lv_m[o + i], m = mo & 255;
+                        const unsigned long long ctx = lv_ctx[o + i];
+                        unsigned long long ek = 0ull;
+                        if (!(mo >> 8) && m >= 1) {
+                            if (m < 4) ek = (ctx & ((1ull << (16 * m)) - 1ull)) | ((unsigned long long)m << 60);
+                            else if (!((ctx >> 48) == 0x1000ull || (ctx >> 48) == 0x2000ull || (ctx >> 48) == 0x3000ull)) ek = ctx;
+                        }
+                        my_ek[j] = ek;
+                        if (ek != 0ull) {
+                            unsigned hc = (unsigned)((ek * 0x9E3779B97F4A7C15ull) >> 55);        // 9 bits
+                            while (true) {
+                                const unsigned long long old = atomicCAS(&ckey[hc], 0ull, ek);
+                                if (old == 0ull) {
+                                    const int uid = atomicAdd(&misc[5], 1);
+                                    cuid[hc] = uid < ucap_n ? uid : -1;
+                                    if (uid < ucap_n) urep[uid] = i;
+                                    break;
+                                }
+                                if (old == ek) break;
+                                hc = (hc + 1) & 511;
+                            }
+                        }
+                    }
+                }
+            }
+            const bool full_beam = cutting && n == beam;
+            if (full_beam) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, off, 64));
+                if (lane == 0) atomicMin(reinterpret_cast<unsigned*>(&misc[3]), kmin);
+            }
+            __syncthreads();                                                                                  // (2)
+            BS_TICK(7);
+            // ---- N2. blank term, children lists, scorer table ------------------------------------------------------------------
+            const float min_cut = full_beam ? (float)((double)ikey((unsigned)misc[3]) + (double)__int_as_float(misc[4]) -
+                                                      fmax(0.0, (double)a.beta))
+                                            : -INFINITY;
+#pragma unroll
+            for (int j = 0; j < NW_PPT; ++j) {
+                const int i = i0 + j;
+                if (i < n) {
+                    {
+                        const float lpb = blank_k >= 0 ? c_lp[blank_k] : -INFINITY, scb = lv_sc[o + i];
+                        bcur[i] = blank_k >= 0 && !(lpb + scb < min_cut) ? lpb + scb : -INFINITY;
+                    }
+                    const unsigned long long key = lv_phid[o + i];
+                    unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
+                    int par = -1;
+                    while (key != 0ull) {
+                        const unsigned long long hk = hkey[h];
+                        if (hk == key) { par = hval[h]; break; }
+                        if (hk == 0ull) break;
+                        h = (h + 1) & (BS_HASH - 1);
+                    }
+                    if (par >= 0) next[i] = atomicExch(&head[par], i);
+                    if (lm_cache) {
+                        int row = -1;
+                        if (my_ek[j] != 0ull) {
+                            unsigned hc = (unsigned)((my_ek[j] * 0x9E3779B97F4A7C15ull) >> 55);
+                            while (ckey[hc] != my_ek[j]) hc = (hc + 1) & 511;
+                            row = cuid[hc];
+                        }
+                        pu[i] = row;
+                    }
+                }
+            }
+            if (lm_cache) {
+                const int nu = min(misc[5], ucap_n);
+                for (int e = tid; e < nu * cnt; e += NW_T) {
+                    const int uq = e / cnt, k = e - uq * cnt;
+                    const int craw = c_idx[k];
+                    float v = LM_OOV_SCORE;
+                    if (!(craw >> 30)) {
+                        const int p = urep[uq];
+                        LmState sp;
+                        sp.ctx = lv_ctx[o + p];
+                        sp.m = lv_m[o + p] & 255;
+                        sp.oov = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sp.bo[q] = lv_bo[4 * (o + p) + q];
+                        int m2;
+                        float bo2[STW];
+                        v = lm_cond_next<(ORD > 0 ? ORD : 1)>(a.lm, sp, craw, c_uni[k], c_ubo[k], &m2, bo2);
+                        lmst[e * STW] = __int_as_float(m2);
+#pragma unroll
+                        for (int q = 1; q < STW; ++q) lmst[e * STW + q] = bo2[q];
+                    }
+                    lmtab[e] = v;
+                }
+            }
+            __syncthreads();                                                                                  // (3)
+            BS_TICK(8);
+            // ---- N3. extensions: NW_EPT consecutive entries e = p * cnt + k per thread, keys stay in registers ---------------
+            const int nq = n * cnt;
+            const int eptf = (nq + NW_T - 1) / NW_T;      // block of consecutive entries per thread in THIS frame: 1 .. NW_EPT
+            unsigned keyE[NW_EPT];
+            int peE[NW_EPT];                              // p | k << 16 of the entry
+            {
+                const int e0 = eptf * tid;
+                int p = 0, k = 0;
+                if (e0 < nq) {
+                    p = (int)(((float)e0 + 0.5f) * (1.0f / (float)cnt));      // e0 / cnt (exact: e0 < 4096, cnt <= 64)
+                    k = e0 - p * cnt;
+                }
+#pragma unroll
+                for (int j = 0; j < NW_EPT; ++j) {
+                    keyE[j] = 0u;
+                    peE[j] = p | (k << 16);
+                    if (j < eptf && e0 + j < nq) {
+                        const float sc = lv_sc[o + p];
+                        const int craw = c_idx[k];
+                        const int c = craw & ~(1 << 30);
+                        const float lp = c_lp[k];
+                        float val = -INFINITY;
+                        if (c != a.blank && !(lp + sc < min_cut)) {
+                            const float pb = lv_b[o + p];
+                            if (c == lv_ch[o + p]) {
+                                rep[p] = lp + lv_nb[o + p];
+                                val = pb > -INFINITY ? lp + pb : -INFINITY;
+                            } else {
+                                val = lp + sc;
+                            }
+                            if (use_lm && val > -INFINITY) {
+                                const int mo = lv_m[o + p];
+                                const int my_row = lm_cache ? pu[p] : -1;
+                                float lmp;
+                                if ((mo >> 8) || (craw >> 30)) lmp = LM_OOV_SCORE;
+                                else if (my_row >= 0) lmp = lmtab[my_row * cnt + k];
+                                else {
+                                    LmState sp;
+                                    sp.ctx = lv_ctx[o + p];
+                                    sp.m = mo & 255; sp.oov = 0;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) sp.bo[q] = lv_bo[4 * (o + p) + q];
+                                    lmp = lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, sp, c, c_uni[k]);
+                                }
+                                val += a.alpha * lmp + a.beta;
+                            }
+                            for (int q = head[p]; q >= 0; q = next[q])
+                                if (lv_ch[o + q] == c) {
+                                    ext[q] = val;
+                                    val = -INFINITY;
+                                }
+                        }
+                        const unsigned kk = okey(val);
+                        keyE[j] = kk > NEG ? kk : 0u;             // 0: no entry / -inf
+                        if (++k == cnt) { k = 0; ++p; }
+                    }
+                }
+            }
+            for (int i = tid; i < 512; i += NW_T) reinterpret_cast<int2*>(hist)[i] = make_int2(0, 0);   // 4 tables for the select
+            __syncthreads();                                                                                  // (4)
+            BS_TICK(9);
+            // ---- N4. the prefixes themselves -------------------------------------------------------------------------------------
+            unsigned kxP[NW_PPT];
+            float nbP[NW_PPT], scP[NW_PPT];
+#pragma unroll
+            for (int j = 0; j < NW_PPT; ++j) {
+                const int i = i0 + j;
+                kxP[j] = 0u; nbP[j] = -INFINITY; scP[j] = -INFINITY;
+                if (i < n) {
+                    nbP[j] = lse2(rep[i], ext[i]);
+                    scP[j] = lse2(bcur[i], nbP[j]);
+                    const unsigned kk = okey(scP[j]);
+                    kxP[j] = kk > NEG ? kk : 0u;
+                }
+            }
+            // ---- N5. exact radix select over the finite keys; pass 0 also counts them ------------------------------------------
+            unsigned thr = NEG;
+            int need_eq = 0;
+            {
+                // a pass whose picked bin is needed WHOLE ends the selection: every key at or above the bin stays, no tie to break
+                // (the later passes are then bare barriers; with scores ~1e-2 apart that is the third pass, often the second)
+                unsigned prefix = 0, mask = 0;
+                int need = beam;
+                bool open = true, exact = true;
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int shift = 24 - 8 * pass;
+                    int* hp = hist + pass * 256;
+                    if (open) {
+#pragma unroll
+                        for (int j = 0; j < NW_PPT; ++j) hist_add(hp, kxP[j] != 0 && (kxP[j] & mask) == prefix, (kxP[j] >> shift) & 255);
+#pragma unroll
+                        for (int j = 0; j < NW_EPT; ++j)
+                            if (j < eptf) hist_add(hp, keyE[j] != 0 && (keyE[j] & mask) == prefix, (keyE[j] >> shift) & 255);
+                    }
+                    __syncthreads();                                                                          // (5) .. (8)
+                    if (open) {
+                        int bin, rem, total, binc;
+                        pick_bin_tot(hp, need, bin, rem, total, binc);
+                        if (pass == 0 && total <= beam) {             // nothing to drop: every finite key stays (thr = NEG)
+                            open = false;
+                            exact = false;
+                        } else {
+                            prefix |= (unsigned)bin << shift;
+                            mask |= 255u << shift;
+                            need = rem;
+                            if (rem == binc && pass < 3) {
+                                thr = prefix - 1u;
+                                open = false;
+                                exact = false;
+                            }
+                        }
+                    }
+                }
+                if (exact) { thr = prefix; need_eq = need; }
+            }
+            BS_TICK(10);
+            // ---- N6. ordered compaction: live prefixes first (by index), then the extensions (by entry index) ---------------
+            int vP = 0, vE = 0;
+#pragma unroll
+            for (int j = 0; j < NW_PPT; ++j) vP += (kxP[j] > thr) | ((kxP[j] == thr && kxP[j] != 0) << 16);
+#pragma unroll
+            for (int j = 0; j < NW_EPT; ++j) vE += (keyE[j] > thr) | ((keyE[j] == thr && keyE[j] != 0) << 16);
+            int exP, exE, totP = 0, totE = 0;
+            {
+                const int inP = wave_scan_incl(vP), inE = wave_scan_incl(vE);
+                if (lane == 63) { wsum[wave] = inP; wsum[BS_WAVES + wave] = inE; }
+                __syncthreads();                                                                              // (9)
+                BS_TICK(11);
+                int bP = 0, bE = 0;
+#pragma unroll
+                for (int w = 0; w < NW_WAVES; ++w) {
+                    const int xp = wsum[w], xe = wsum[BS_WAVES + w];
+                    if (w < wave) { bP += xp; bE += xe; }
+                    totP += xp; totE += xe;
+                }
+                exP = bP + inP - vP;
+                exE = bE + inE - vE;
+            }
+            const int eq_take_P = min(totP >> 16, need_eq);
+            const int n_exist = (totP & 0xffff) + eq_take_P;
+            const int need_eq_new = need_eq - eq_take_P;
+            const int n_new = (totE & 0xffff) + min(totE >> 16, need_eq_new);
+            {
+                int gb = exP & 0xffff, eb = exP >> 16;
+#pragma unroll
+                for (int j = 0; j < NW_PPT; ++j) {
+                    const unsigned kk = kxP[j];
+                    const int i = i0 + j;
+                    const bool gt = kk > thr, eq = kk == thr && kk != 0;
+                    if (gt || (eq && eb < need_eq)) {
+                        const int slot = gb + min(eb, need_eq);
+                        lv_node[o2 + slot] = lv_node[o + i];
+                        lv_hid[o2 + slot] = lv_hid[o + i];
+                        lv_phid[o2 + slot] = lv_phid[o + i];
+                        lv_ch[o2 + slot] = lv_ch[o + i];
+                        lv_b[o2 + slot] = bcur[i];
+                        lv_nb[o2 + slot] = nbP[j];
+                        lv_sc[o2 + slot] = scP[j];
+                        if (use_lm) {
+                            lv_ctx[o2 + slot] = lv_ctx[o + i]; lv_m[o2 + slot] = lv_m[o + i];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) lv_bo[4 * (o2 + slot) + q] = lv_bo[4 * (o + i) + q];
+                        }
+                    }
+                    gb += gt; eb += eq;
+                }
+            }
+            {
+                // the selected extensions, in entry order, as a dense list (the select's histogram area is free behind the scan's
+                // barrier): the new prefixes are then built one per thread instead of one divergent pass per block position
+                int* sel_pe = hist;
+                unsigned* sel_key = reinterpret_cast<unsigned*>(hist + 512);
+                int gb = exE & 0xffff, eb = exE >> 16;
+#pragma unroll
+                for (int j = 0; j < NW_EPT; ++j) {
+                    const unsigned kk = keyE[j];
+                    const bool gt = kk > thr, eq = kk == thr && kk != 0;
+                    if (gt || (eq && eb < need_eq_new)) {
+                        const int r = gb + min(eb, need_eq_new);            // rank among the selected extensions
+                        sel_pe[r] = peE[j];
+                        sel_key[r] = kk;
+                    }
+                    gb += gt; eb += eq;
+                }
+                __syncthreads();                                                                              // (10)
+                BS_TICK(12);
+                for (int r = tid; r < n_new; r += NW_T) {
+                    const unsigned kk = sel_key[r];
+                    const int slot = n_exist + r, node = pool_count + r;
+                    const int p = sel_pe[r] & 0xffff, k = sel_pe[r] >> 16;
+                    const int c = c_idx[k] & ~(1 << 30);
+                    const float add = ikey(kk);           // the entry's own score (acoustic term + scorer term), as ranked
+                    if (node < a.pool_cap) {
+                        pool_parent[node] = lv_node[o + p];
+                        pool_ch[node] = c;
+                    }
+                    lv_node[o2 + slot] = node;
+                    lv_hid[o2 + slot] = str_hash(lv_hid[o + p], c);
+                    lv_phid[o2 + slot] = lv_hid[o + p];
+                    lv_ch[o2 + slot] = c;
+                    lv_b[o2 + slot] = -INFINITY;
+                    lv_nb[o2 + slot] = add;
+                    lv_sc[o2 + slot] = add;
+                    if (use_lm) {
+                        const int row = lm_cache ? pu[p] : -1;
+                        if (row >= 0 && !(c_idx[k] >> 30)) {      // (a row: the parent's context has no unknown word)
+                            const float* st = lmst + (row * cnt + k) * STW;
+                            lv_ctx[o2 + slot] = lm_push(lv_ctx[o + p], c);
+                            lv_m[o2 + slot] = __float_as_int(st[0]);
+                            lv_bo[4 * (o2 + slot)] = c_ubo[k];
+#pragma unroll
+                            for (int q = 1; q < 4; ++q) lv_bo[4 * (o2 + slot) + q] = q < STW ? st[q] : 0.f;
+                        } else {
+                            const LmState sn = lm_state_of(a.lm, lm_push(lv_ctx[o + p], c));
+                            lv_ctx[o2 + slot] = sn.ctx; lv_m[o2 + slot] = sn.m | (sn.oov << 8);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) lv_bo[4 * (o2 + slot) + q] = sn.bo[q];
+                        }
+                    }
+                }
+            }
+            pool_count += n_new;
+            n = n_exist + n_new;
+            cur ^= 1;
+            if (tid == 0) { misc[6] = n; misc[7] = pool_count; }
+            __syncthreads();                                                                                  // (11)
+            BS_TICK(13);
+            continue;
+        }
         // ---- 0. candidates -> LDS, clear tables; prefetch the next frame -------------------------------------
         for (int i = tid; i < 7 * 256; i += BS_THREADS) hist[i] = 0;
         if (tid < n) { rep[tid] = -INFINITY; ext[tid] = -INFINITY; head[tid] = -1; }
         if (tid < BS_HASH) hkey[tid] = 0ull;
-        if (wave == 0) {
-            const bool isb = lane < cnt && nx_c == a.blank;
-            const unsigned long long bm = __ballot(isb);
-            if (lane < cnt) {
-                // the scorer's known-word flag of this candidate rides in bit 30 of its index: one lookup per frame and
-                // candidate instead of one per (prefix, candidate) pair
-                const bool unk = use_lm && !(nx_c >= 0 && nx_c < a.lm.n_words && a.lm.known[nx_c]);
-                c_idx[lane] = nx_c | (unk ? (1 << 30) : 0);
-                c_lp[lane] = nx_lp;
-                if (use_lm) {                             // the candidate's unigram: one lookup per frame and candidate
-                    float up = LM_OOV_SCORE, ub;
-                    if (!unk) lm_find(a.lm, lm_key(0ull, 0, nx_c), &up, &ub);
-                    c_uni[lane] = up;
-                }
-            }
-            if (lane == 0) {
-                misc[0] = bm ? __ffsll((long long)bm) - 1 : -1;
-                misc[3] = (int)0xFFFFFFFFu;                  // min over the live prefixes' score keys (phase 1)
-                misc[4] = __float_as_int(nx_blp);
-                misc[5] = 0;                                 // distinct effective scorer contexts of this frame
-            }
-        }
-        if (t + 1 < T) {
-            nx_cnt = min(a.ccount[row0 + t + 1], K);
-            if (tid < K) { nx_c = a.cidx[(row0 + t + 1) * K + tid]; nx_lp = a.clp[(row0 + t + 1) * K + tid]; }
-            if (cutting && tid == 0) nx_blp = a.blank_lp[row0 + t + 1];
-        }
+        BS_STAGE_FRAME();
         __syncthreads();
         // ---- 1. live children lists; blank term ------------------------------------------------------------------
         const int blank_k = misc[0];
@@ -578,7 +1030,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         BS_TICK(4);
     }
     if (prof)
-        for (int i = 0; i < 5; ++i) a.prof[i] = pc[i];
+        for (int i = 0; i < 16; ++i) a.prof[i] = (long long)pcl[i];
 
     // ---- persist the live set (streams), pick the best prefix, walk the parent pointers ----------------------
     const int o = cur * beam;
@@ -634,8 +1086,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 }
 
 size_t beam_gpu_lds_bytes(int beam, int K, bool use_lm) {
-    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 15 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 3 * BS_KMAX * 4 + 7 * 256 * 4 +
-           (6 + 32) * BS_WAVES * 4 + 8 * 4 + 128;
+    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 15 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 4 * BS_KMAX * 4 + 7 * 256 * 4 +
+           (6 + 32) * BS_WAVES * 4 + (8 + 32) * 4 + 128;
 }
 
 template <int NPT, int ORD>

@@ -338,6 +338,7 @@ struct BeamGpuArgs {
     LmView lm;             // table / known in the memory of the launch device
     float alpha, beta;
     int lm_cache;          // 1: one scorer probe per (distinct effective context, candidate) and frame; 0: one per (prefix, candidate)
+    int narrow;            // 1: frames of <= 1024 extension entries run on the narrow step (beam_gpu.hip); 0: every frame on the wide step
 };
 // per-utterance search state in HBM: [3 * beam] u64 | [2 + 3 * beam] int | [7 * beam] float
 inline size_t beam_state_bytes(int beam) { return (size_t)3 * beam * 8 + (size_t)(2 + 3 * beam) * 4 + (size_t)7 * beam * 4 + 8; }

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -468,6 +469,37 @@ int build_fbank_tables(masr_engine* e) {
 }
 }  // namespace
 
+// ---- side streams (masr_side_stream) ------------------------------------------------------------------------------------------
+// The library owns the streams its callers run beside the main stream: two for the prefix searches of consecutive passes, one for
+// the per-pass preparation, one for copies.  ONE SET PER DEVICE, created with the first engine on that device and shared by every
+// engine there.  They are created non-blocking at the device's HIGHEST stream priority: the HIP runtime keeps one pool of hardware
+// queues per priority and deals the streams of a pool onto at most GPU_MAX_HW_QUEUES (default 4) queues, so these four have
+// hardware queues of their own whatever else the process has created or will create at normal priority (torch's pools, a server's
+// copy streams, other engines) -- rounds 3-5 borrowed torch.cuda.Stream()s of normal priority, and a search stream that shared a
+// queue with the main stream ran BEHIND the next encoder pass (BASELINE configs[2]: 63 vs 46 ms per call by process history).  The
+// priority also lets a search's 32-64 long-running workgroups take the first compute units that drain instead of queueing behind
+// the rest of an encoder launch.  (hipExtStreamCreateWithCUMask would give a dedicated queue AND a CU reservation, but it can
+// only create streams that synchronise with the NULL stream, which is torch's default stream: every search would serialise with
+// the encoder it is meant to run beside.)
+struct SideStreams {
+    hipStream_t s[MASR_SIDE_STREAMS] = {};
+    bool made = false;
+};
+static std::mutex g_side_mu;
+static std::map<int, SideStreams> g_side;
+static int side_streams_of(int dev, SideStreams** out) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStreams& ss = g_side[dev];
+    if (!ss.made) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        for (int k = 0; k < MASR_SIDE_STREAMS; ++k) HIPCHK(hipStreamCreateWithPriority(&ss.s[k], hipStreamNonBlocking, greatest));
+        ss.made = true;
+    }
+    *out = &ss;
+    return 0;
+}
+
 extern "C" {
 
 const char* masr_last_error(void) { return g_err.c_str(); }
@@ -497,6 +529,10 @@ int masr_create(const masr_config* cfg, masr_engine** out) {
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail("no HIP device");
     HIPCHK(hipSetDevice(cfg->device_id));
+    {
+        SideStreams* ss = nullptr;                   // (created with the first engine of the device: a fixed place in the process's history)
+        if (side_streams_of(cfg->device_id, &ss)) return 1;
+    }
     masr_engine* e = new masr_engine();
     e->cfg = *cfg;
     if (e->cfg.max_pos <= 0) e->cfg.max_pos = 5000;
@@ -1843,10 +1879,12 @@ int masr_ctc_topk_blank(masr_engine* e, const float* probs_dev, int32_t M, int32
     return 0;
 }
 
+static int g_beam_narrow = 1;      // masr_debug_set key 37: 0 = every frame of the GPU prefix search on the wide (1024-thread) step (A/B, tests)
 static int g_beam_lm_cache = 1;    // masr_debug_set key 32: 0 = the GPU prefix search probes the scorer once per (prefix, candidate) pair (A/B)
 static int bind_lm(BeamGpuArgs& a, masr_lm* lm, float alpha, float beta) {
     a.use_lm = 0;
     a.lm_cache = g_beam_lm_cache;
+    a.narrow = g_beam_narrow;
     a.alpha = alpha;
     a.beta = beta;
     if (!lm) return 0;
@@ -2764,6 +2802,15 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
     return 0;
 }
 
+int masr_side_stream(masr_engine* e, int32_t kind, void** stream_out) {
+    if (!e || !stream_out) return fail("null argument");
+    if (kind < 0 || kind >= MASR_SIDE_STREAMS) return fail("masr_side_stream: kind must be 0 / 1 (prefix search), 2 (preparation) or 3 (copy)");
+    SideStreams* ss = nullptr;
+    if (side_streams_of(e->cfg.device_id, &ss)) return 1;
+    *stream_out = (void*)ss->s[kind];
+    return 0;
+}
+
 int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     if (!e) return fail("null engine");
 #if !MASR_EXPERIMENTS
@@ -2794,6 +2841,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 34) g_attn_chain = value;
     else if (key == 35) g_ffn_coop = value;
     else if (key == 36) g_sqz_fused_blocks = value;
+    else if (key == 37) g_beam_narrow = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }
@@ -2805,15 +2853,17 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
         if (value) {
             if (!e->beam_prof) {
                 void* p = nullptr;
-                HIPCHK(hipMalloc(&p, 8 * sizeof(long long)));
+                HIPCHK(hipMalloc(&p, 16 * sizeof(long long)));
                 e->owned.push_back(p);
                 e->beam_prof = (long long*)p;
             }
         } else if (e->beam_prof) {
-            long long h[8];
+            long long h[16];
             HIPCHK(hipMemcpy(h, e->beam_prof, sizeof(h), hipMemcpyDeviceToHost));
             fprintf(stderr, "beam phases (cycles, wg 0): setup+hash %lld  extensions %lld  prefixes+count %lld  select %lld  compact %lld\n",
                     h[0], h[1], h[2], h[3], h[4]);
+            fprintf(stderr, "  narrow step (%lld frames): tables+candidates %lld  hash+contexts %lld  children+scorer table %lld  extensions %lld  "
+                    "prefixes+select %lld  scan %lld  survivors %lld  new prefixes %lld\n", h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13]);
             e->beam_prof = nullptr;
         }
     }

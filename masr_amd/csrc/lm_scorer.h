@@ -211,4 +211,72 @@ LM_HD float lm_cond_desc(const LmView& lm, const LmState& s, int w, float uni) {
     return acc + uni;
 }
 
+// ln P(w | the state's words) exactly as lm_cond_desc returns it AND the scorer state of the prefix extended by w, i.e. m and bo[] of
+// lm_state_of(lm, lm_push(s.ctx, w)), for a KNOWN word w behind a context without unknown words: the n-grams (j most recent words
+// of the context, w), j = 1 .. s.m, are the ones the backoff recursion reads and -- for j <= max_order - 2 -- the (j + 1)-word
+// suffixes of the new context (the one-word suffix is w's unigram: `uni` / `ubo` = its ln P and ln backoff, looked up by the caller
+// once per frame and candidate; no longer suffix can exist because ARPA models are prefix-closed).  The first probes of all lengths
+// are in flight together: one memory round trip for the score and the state, where lm_cond_desc + lm_state_of make 2 - 5.
+// m_next: matched suffix length of the new context; bo_next[0 .. ORD-2]: its backoffs (bo_next[0] = ubo), 0 beyond m_next.
+template <int ORD>
+LM_HD float lm_cond_next(const LmView& lm, const LmState& s, int w, float uni, float ubo, int* m_next, float* bo_next) {
+    constexpr int NK = ORD > 1 ? ORD - 1 : 1;
+    unsigned long long key[NK], k0[NK];
+    float p0[NK], b0[NK];
+    bool hit[NK];
+    unsigned long long h = lm_mix(LM_SEED, (unsigned long long)w);
+#pragma unroll
+    for (int len = 1; len < ORD; ++len) {
+        key[len - 1] = 0ull; k0[len - 1] = 0ull; p0[len - 1] = 0.f; b0[len - 1] = 0.f;
+        if (len <= s.m) {
+            h = lm_mix(h, (s.ctx >> (16 * (len - 1))) & 0xFFFFull);
+            key[len - 1] = lm_fin(h, len + 1);
+        }
+    }
+#pragma unroll
+    for (int len = 1; len < ORD; ++len)
+        if (len <= s.m) lm_load_entry(lm, key[len - 1] & lm.mask, &k0[len - 1], &p0[len - 1], &b0[len - 1]);
+#pragma unroll
+    for (int len = 1; len < ORD; ++len) {
+        hit[len - 1] = false;
+        if (len <= s.m) {
+            hit[len - 1] = k0[len - 1] == key[len - 1];
+            if (!hit[len - 1] && k0[len - 1] != 0ull) hit[len - 1] = lm_find(lm, key[len - 1], &p0[len - 1], &b0[len - 1]);
+        }
+    }
+    float acc = 0.f, val = 0.f;
+    bool done = false;
+#pragma unroll
+    for (int len = ORD - 1; len >= 1; --len) {
+        if (len > s.m || done) continue;
+        if (hit[len - 1]) {
+            val = acc + p0[len - 1];
+            done = true;
+        } else {
+            acc += s.bo[len - 1];
+        }
+    }
+    if (!done) val = acc + uni;
+    const int kk = lm.max_order - 1;
+    int m2 = 0;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) bo_next[j] = 0.f;
+    if (kk >= 1) {
+        m2 = 1;
+        bo_next[0] = ubo;
+        bool open = true;
+#pragma unroll
+        for (int len = 1; len < ORD - 1; ++len) {
+            if (open && len + 1 <= kk && len <= s.m && hit[len - 1]) {
+                m2 = len + 1;
+                bo_next[len] = b0[len - 1];
+            } else {
+                open = false;
+            }
+        }
+    }
+    *m_next = m2;
+    return val;
+}
+
 }  // namespace masr

@@ -357,6 +357,57 @@ def test_gpu_search_with_language_model_matches_host_and_oracle(tmp_path, seed, 
     assert any(tp != tg or abs(sp - sg) > 1e-2 for (sp, tp), (sg, tg) in zip(plain, gpu))
 
 
+def _mixed_posteriors(rng, V, T, sharp_every=3):
+    """frames of a trained model's kind (1-3 candidates pass cutoff_prob) with flat frames (cutoff_top_n candidates) in between:
+    the GPU search switches between its narrow and its wide step inside one utterance"""
+    logits = rng.normal(0, 1.0, (T, V))
+    for t in range(T):
+        if t % sharp_every:
+            logits[t] *= 14.0
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    return (e / e.sum(-1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lm_order,beam,V,prune', [(0, 300, 4233, True), (3, 300, 4233, True), (3, 300, 4233, False), (5, 120, 900, True),
+                                                   (0, 20, 300, True), (3, 500, 600, True), (3, 16, 50, True)])
+def test_gpu_narrow_step_equals_wide_step_on_the_same_frames(tmp_path, lm_order, beam, V, prune):
+    """masr_debug_set key 37: 1 (default) runs frames of <= 1024 extension entries on the narrow step of beam_gpu.hip, 0 runs every
+    frame on the wide step.  Same candidates, same frames: transcripts AND scores must be identical (not close), offline and
+    through the streaming state; both equal the host search."""
+    from masr_amd import runtime
+    from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    rng = np.random.default_rng(77 + beam)
+    probs = [_mixed_posteriors(rng, V, T, sharp_every=se) for T, se in ((90, 3), (61, 1000), (40, 2), (17, 1))]
+    if lm_order:
+        dec, vocab, _ = _lm_decoder(tmp_path, V, beam, 0.99, 40, order=lm_order)
+        dec.prune_min_cutoff = prune
+    else:
+        vocab = ['<blank>'] + [chr(0x4e00 + i) for i in range(V - 1)]
+        dec = BeamSearchDecoder(0, 0, beam, 0.99, 40, vocab, num_processes=4, language_model_path=None)
+    eng = runtime.aux_engine()
+    out = {}
+    try:
+        for mode in (1, 0):
+            assert eng.lib.masr_debug_set(eng.h, 37, mode) == 0
+            dec.use_gpu_search = True
+            off = dec._batch(probs)
+            dec.reset_decoder()
+            chunks = []
+            for lo in range(0, 90, 16):
+                chunks.append(dec.decode_chunk(probs[0][None, lo:lo + 16], [min(16, 90 - lo)]))
+            dec.reset_decoder()
+            out[mode] = (off, chunks)
+    finally:
+        eng.lib.masr_debug_set(eng.h, 37, 1)
+    assert out[1] == out[0]
+    assert out[1][1][-1][1] == out[1][0][0][1] and abs(out[1][1][-1][0] - out[1][0][0][0]) < 1e-3 * max(1.0, abs(out[1][0][0][0]))
+    dec.use_gpu_search = False
+    host = dec._batch(probs)
+    for (sg, tg), (sh, th) in zip(out[1][0], host):
+        assert tg == th and abs(sg - sh) < 2e-3 * max(1.0, abs(sh))
+
+
 @pytest.mark.gpu
 def test_two_searches_on_two_streams_do_not_share_workspaces(tmp_path):
     """predict_batch launches the prefix searches of consecutive passes on two side streams so that they run next to each other
