@@ -29,8 +29,6 @@ import sys
 import tempfile
 import time
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # before the HIP runtime starts (masr_amd/__init__.py says why)
-
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -709,17 +707,18 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
     # overrides (a number, or 'balanced').
     per_pass = os.environ.get('MASR_BENCH_BEAM_PASS', 'balanced' if (lm and word_lm) else '32')
     per_pass = per_pass if per_pass == 'balanced' else int(per_pass)
+    pass_padded = float(os.environ['MASR_BENCH_BEAM_PADDED']) * 160000 if os.environ.get('MASR_BENCH_BEAM_PADDED') else None      # (x 10 s of audio)
     # three untimed calls: the caching allocator's per-stream pools (probabilities of a pass: 134 MB, allocated on the main
     # stream, restacked on a side stream) reach their steady state only with the third call -- with one warm-up call the first
     # timed calls still paid device allocations (round 5: 62.7 ms mean against 45.8 ms per call in the steady state, same box)
     for _ in range(3):
-        pred.predict_batch(audio, batch_size=per_pass)
+        pred.predict_batch(audio, batch_size=per_pass, pass_padded=pass_padded)
     torch.cuda.synchronize()
     calls = []
     t0 = time.perf_counter()
     for _ in range(steps):
         t1 = time.perf_counter()
-        res = pred.predict_batch(audio, batch_size=per_pass)        # (synchronous: returns with the transcripts on the host)
+        res = pred.predict_batch(audio, batch_size=per_pass, pass_padded=pass_padded)        # (synchronous: returns with the transcripts on the host)
         calls.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

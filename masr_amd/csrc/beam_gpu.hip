@@ -808,7 +808,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                     sp.oov = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) sp.bo[j] = lv_bo[4 * (o + p) + j];
-                    v = lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, sp, craw, c_uni[k]);
+                    // (all suffix lengths probed at once: one memory round trip per table entry instead of up to ORD - 1 -- the
+                    //  table fill is a chain of dependent loads in front of the frame's extension phase)
+                    int m2;
+                    float bo2[ORD > 1 ? ORD - 1 : 1];
+                    v = lm_cond_next<(ORD > 0 ? ORD : 1)>(a.lm, sp, craw, c_uni[k], 0.f, &m2, bo2);
                 }
                 lmtab[e] = v;
             }

@@ -166,30 +166,62 @@ class BeamSearchDecoder:
         """list of [T_i, V] -> list of texts (beam_search_decoder.py:59-73), num_processes host threads."""
         return [t for _, t in self._batch([np.asarray(p) for p in probs_split])]
 
-    def _batch_collect(self, pending, want_tokens=False):
-        """results of a ``_batch(..., defer=True)`` launch (synchronises with the stream it was launched on)"""
-        _, toks, lens, scores, _keep, ev = pending
-        ev.synchronize()
-        eng = runtime.aux_engine(toks.device)
-        toks, lens, scores = eng.to_host(toks), eng.to_host(lens), eng.to_host(scores)
-        if want_tokens:
-            return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(len(lens))]
-        return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(len(lens))]
+    def _pinned_out(self, n):
+        """a pinned host buffer of >= n int32 for the results of one deferred search, from a small free list"""
+        pool = self.__dict__.setdefault('_pin_free', [])
+        for i, b in enumerate(pool):
+            if b.numel() >= n:
+                return pool.pop(i)
+        return torch.empty(max(n, 1 << 15), dtype=torch.int32, pin_memory=True)
 
-    def _batch(self, probs_list, defer=False, want_tokens=False):
+    def _batch_collect(self, pending, want_tokens=False):
+        """results of a ``_batch(..., defer=True)`` launch.  The host waits for the EVENT behind this pass's search, then copies
+        the packed rows (tokens | length | score bits, int32) back on the library's copy stream and waits for that copy only.
+        Round 6 measured the three simpler ways and why they stall: through the current (main) stream the first of three passes
+        came back at 35 instead of 15 ms (the encoders of the later passes are queued there); an asynchronous copy enqueued right
+        behind the search kernel is a DMA-engine command that waits 6 ms and holds up the next pass's upload on the same engine
+        (the host sat 17 ms in the next pass's preparation); a copy enqueued on the search's stream at collection time queues
+        behind the search of pass k + 2, which shares that stream."""
+        _, B, max_len, packed, _keep, done = pending
+        host = self._pinned_out(B * (max_len + 2))
+        done.synchronize()                           # the search (and the packing behind it) of THIS pass
+        with torch.cuda.stream(runtime.aux_engine(packed.device).side_stream(3)):          # the library's copy stream: idle
+            host[:B * (max_len + 2)].copy_(packed.view(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        ev.synchronize()
+        r = host[:B * (max_len + 2)].view(B, max_len + 2).numpy()
+        toks, lens, scores = r[:, :max_len], r[:, max_len].copy(), r[:, max_len + 1].copy().view(np.float32)
+        res_tok = [toks[i, :lens[i]].tolist() for i in range(B)]
+        self._pin_free.append(host)
+        if want_tokens:
+            return [(res_tok[i], float(scores[i])) for i in range(B)]
+        return [(float(scores[i]), self._text(res_tok[i])) for i in range(B)]
+
+    def _batch(self, probs_list, defer=False, want_tokens=False, frames=None):
         """``defer=True`` (device-resident probabilities, GPU search): launch pruning + search on the current torch stream and
         return a handle for ``_batch_collect`` without synchronising -- lets the caller run the search of one sub-batch on a
-        side stream while the encoder works on the next one (the search occupies one workgroup per utterance)."""
-        B = len(probs_list)
-        frames = np.array([p.shape[0] for p in probs_list], np.int32)
-        Ts = int(frames.max()) if B else 0
-        V = probs_list[0].shape[1]
-        if torch.is_tensor(probs_list[0]):          # device-resident probabilities: no host round trip
-            stacked = torch.zeros(B, Ts, V, dtype=torch.float32, device=probs_list[0].device)
+        side stream while the encoder works on the next one (the search occupies one workgroup per utterance).
+        ``frames`` given: ``probs_list`` is ONE padded [B, Ts, V] array / device tensor (what the CTC head of a device pass
+        leaves behind) with ``frames[i]`` valid rows per utterance -- searched in place, no restacking (round 6: the 32 slice
+        copies + the fill of a 134 MB buffer were 3 ms on the critical path of every BASELINE configs[2] pass)."""
+        if frames is not None:
+            stacked = probs_list
+            B, Ts, V = stacked.shape
+            frames = np.asarray(frames, np.int32)
+            assert frames.shape == (B,) and (B == 0 or int(frames.max()) <= Ts)
+            probs_list = stacked
         else:
-            stacked = np.zeros((B, Ts, V), np.float32)
-        for i, p in enumerate(probs_list):
-            stacked[i, :p.shape[0]] = p
+            B = len(probs_list)
+            frames = np.array([p.shape[0] for p in probs_list], np.int32)
+            Ts = int(frames.max()) if B else 0
+            V = probs_list[0].shape[1]
+            if torch.is_tensor(probs_list[0]):          # device-resident probabilities: no host round trip
+                stacked = torch.zeros(B, Ts, V, dtype=torch.float32, device=probs_list[0].device)
+            else:
+                stacked = np.zeros((B, Ts, V), np.float32)
+            for i, p in enumerate(probs_list):
+                stacked[i, :p.shape[0]] = p
         max_len = max(Ts, 1)
         if B and Ts and self.use_gpu_search and self.gpu_search_supported(Ts, V):
             # whole search on the device: candidates never leave HBM, one workgroup per utterance
@@ -206,9 +238,10 @@ class BeamSearchDecoder:
                                                     C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             if defer:                      # nothing has been synchronised: _batch_collect() fetches the result later
-                ev = torch.cuda.Event()
-                ev.record()
-                return ('gpu', toks, lens, scores, (stacked, idx, logp, cnt, blp, fr, probs_list), ev)
+                packed = torch.cat([toks, lens[:, None], scores.view(torch.int32)[:, None]], 1)       # one contiguous copy back
+                done = torch.cuda.Event()
+                done.record()
+                return ('gpu', B, max_len, packed, (stacked, idx, logp, cnt, blp, fr, probs_list, toks, lens, scores), done)
             toks, lens, scores = toks.cpu().numpy(), lens.cpu().numpy(), scores.cpu().numpy()
             if want_tokens:          # (token ids, score): what a multi-GPU caller gathers instead of text
                 return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(B)]
@@ -237,6 +270,57 @@ class BeamSearchDecoder:
         if want_tokens:
             return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(B)]
         return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(B)]
+
+    # ---- one search for the utterances of several device passes ---------------------------------------------------------------
+    def prune_padded(self, probs, frames):
+        """vocabulary pruning of ONE device pass (padded probabilities [B, Ts, V] on the device, ``frames[i]`` valid rows) on the
+        current stream; the probabilities are not needed afterwards.  -> a part for ``search_pruned``."""
+        B, Ts, V = probs.shape
+        idx, logp, cnt, blp, K = self._candidates(probs.reshape(B * Ts, V), to_host=False)
+        return {'idx': idx.view(B, Ts, K), 'logp': logp.view(B, Ts, K), 'cnt': cnt.view(B, Ts), 'blp': None if blp is None else blp.view(B, Ts),
+                'frames': np.asarray(frames, np.int32), 'B': B, 'Ts': Ts, 'K': K}
+
+    def search_pruned(self, parts):
+        """ONE prefix-search launch over the utterances of every part (one workgroup per utterance): the candidates of the passes
+        are gathered into common [B_total, T_max, K] arrays (a few MB) and searched together, on the current stream.  Returns a
+        handle for ``_batch_collect``; results come back in the order of the parts.  (Round 6: a search that runs BESIDE an
+        encoder pass holds 32 compute units for milliseconds, and every row-block launch of that encoder pass -- sized for one
+        round of 256 -- then takes two rounds; searched together behind the encoders of the group, all utterances advance at the
+        kernel's stand-alone rate and the call is encoders + the longest utterance's search.)"""
+        eng = runtime.aux_engine(parts[0]['idx'].device)
+        Bt, Tm, K = sum(p['B'] for p in parts), max(p['Ts'] for p in parts), parts[0]['K']
+        if len(parts) == 1:
+            p = parts[0]
+            idx, logp, cnt, blp = p['idx'], p['logp'], p['cnt'], p['blp']
+        else:
+            idx = torch.zeros(Bt, Tm, K, dtype=torch.int32, device=eng.device)
+            logp = torch.zeros(Bt, Tm, K, dtype=torch.float32, device=eng.device)
+            cnt = torch.zeros(Bt, Tm, dtype=torch.int32, device=eng.device)
+            blp = None if parts[0]['blp'] is None else torch.zeros(Bt, Tm, dtype=torch.float32, device=eng.device)
+            lo = 0
+            for p in parts:
+                idx[lo:lo + p['B'], :p['Ts']] = p['idx']
+                logp[lo:lo + p['B'], :p['Ts']] = p['logp']
+                cnt[lo:lo + p['B'], :p['Ts']] = p['cnt']
+                if blp is not None:
+                    blp[lo:lo + p['B'], :p['Ts']] = p['blp']
+                lo += p['B']
+        frames = np.concatenate([p['frames'] for p in parts]).astype(np.int32)
+        fr = eng.to_device(frames)
+        max_len = max(Tm, 1)
+        toks = torch.zeros(Bt, max_len, dtype=torch.int32, device=eng.device)
+        lens = torch.zeros(Bt, dtype=torch.int32, device=eng.device)
+        scores = torch.zeros(Bt, dtype=torch.float32, device=eng.device)
+        check(self._lib.masr_beam_search_gpu_lm(eng.h, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                                C.c_void_p(cnt.data_ptr()), C.c_void_p(fr.data_ptr()), Bt, Tm, K,
+                                                self.beam_size, self.blank_id, *self._lm_args(), self._ptr(blp),
+                                                C.c_void_p(toks.data_ptr()), max_len,
+                                                C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        packed = torch.cat([toks, lens[:, None], scores.view(torch.int32)[:, None]], 1)
+        done = torch.cuda.Event()
+        done.record()
+        return ('gpu', Bt, max_len, packed, (idx, logp, cnt, blp, fr, toks, lens, scores, parts), done)
 
     def decode_chunk(self, probs, logits_lens):
         """streaming: feed a chunk probs [1, T, V]; returns (score, text) of the best prefix so far

@@ -222,6 +222,19 @@ class HipEngine:
         check(self.lib.masr_mean_square(self.h, _ptr(samples), fmt, _ptr(n_samples), B, n_max, _ptr(ms), _stream()))
         return ms
 
+    def side_stream(self, kind):
+        """a side stream of THIS DEVICE owned by libmasr_hip.so (masr_side_stream; kind 0 / 1: prefix searches of consecutive
+        passes, 2: per-pass preparation, 3: copies), as a torch stream.  One set per device, created with the device's first
+        engine at the highest stream priority -- hardware queues of their own, whatever streams the process creates before or
+        after (include/masr_hip.h); borrowed, never destroyed."""
+        cache = self.__dict__.setdefault('_side', {})
+        st = cache.get(kind)
+        if st is None:
+            ptr = C.c_void_p()
+            check(self.lib.masr_side_stream(self.h, int(kind), C.byref(ptr)))
+            st = cache[kind] = torch.cuda.ExternalStream(ptr.value, device=self.device)
+        return st
+
     def to_host(self, t):
         """small device tensor -> numpy through a pinned buffer, waiting for THIS stream only.  (``tensor.cpu()`` copies to
         pageable memory, which the HIP runtime serialises against every stream of the device: a prefix search running on a side

@@ -166,7 +166,7 @@ class MASRPredictor:
         """side stream of the per-pass preparation (upload, mean squares and their read-back, gains): the host waits for THIS
         stream only, so preparing pass k + 1 never waits for the encoder of pass k on the main stream"""
         if getattr(self, '_prep', None) is None:
-            self._prep = torch.cuda.Stream(device=self.predictor.engine.device)
+            self._prep = self.predictor.engine.side_stream(2)
         return self._prep
 
     def _stage_batch(self, segs, n):
@@ -285,7 +285,7 @@ class MASRPredictor:
             # probabilities stay on the GPU: vocabulary pruning, prefix search and LM scoring run there
             probs = eng.ctc_probs(enc)
             n_host = [probs.shape[1]] * len(live) if nenc is None else eng.enc_frames((n.astype(np.int64) - min_samples) // 160 + 1).tolist()
-            seqs = [probs[i, :n_host[i]] for i in range(len(live))]
+            seqs = probs                       # searched in place: padded [B, T', V] + the valid frames per utterance
             dec = self.beam_search_decoder
 
             def fill(res):
@@ -303,19 +303,22 @@ class MASRPredictor:
                 # more than sharing CUs with the next encoder pass.  Default: launch at once.
                 main = torch.cuda.current_stream(eng.device)          # (explicit device: a server runs one worker thread per GPU)
                 if getattr(self, '_sides', None) is None:
-                    self._sides, self._side_turn = [torch.cuda.Stream(device=eng.device) for _ in range(int(os.environ.get('MASR_BEAM_SIDES', '2')))], 0
+                    # the library's two search streams of this device (masr_side_stream: queues of their own, highest priority)
+                    self._sides, self._side_turn = [eng.side_stream(k) for k in range(max(1, min(2, int(os.environ.get('MASR_BEAM_SIDES', '2')))))], 0
 
                 def launch_search():
                     side = self._sides[self._side_turn]
                     self._side_turn = (self._side_turn + 1) % len(self._sides)
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        pending = dec._batch(seqs, defer=True)
+                        pending = dec._batch(seqs, defer=True, frames=n_host)
                     return lambda: fill(dec._batch_collect(pending, want_tokens=as_tokens))
                 if hold_search:
-                    return ('held', launch_search)
+                    # the pass's candidates are pruned here, on the main stream right behind its CTC head (the 134 MB of
+                    # probabilities are then dead); the search itself is launched ONCE for the passes of a group (_run_sorted)
+                    return ('held', dec.prune_padded(seqs, n_host), fill)
                 return launch_search()
-            res = fill(dec._batch(seqs, want_tokens=as_tokens))
+            res = fill(dec._batch(seqs, want_tokens=as_tokens, frames=n_host))
             return (lambda: res) if defer else res
         idx, mp = eng.ctc_greedy_frames(enc)
         tok, ntok, score = eng.ctc_collapse(idx, mp, nenc)
@@ -431,27 +434,49 @@ class MASRPredictor:
             # a prefix search is a long serial kernel on a few CUs (one workgroup per utterance, frames in sequence): the encoders
             # of up to three further passes are launched underneath it before its results are waited for
             depth = 4
-        # MASR_BEAM_GROUP=n (A/B, off by default): hold the searches of n passes until their encoders are enqueued
-        group = int(os.environ.get('MASR_BEAM_GROUP', '0')) if gpu_search else 0
+        # MASR_BEAM_GROUP=n (A/B, off by default): the prefix searches of a GROUP of passes as ONE launch behind the group's last
+        # encoder pass (one workgroup per utterance; a group closes at n utterances or with the list), on a library side stream,
+        # so that nothing runs beside an encoder pass inside a group.  Round 6, BASELINE configs[2] (sharpened head / flat): 33.0 /
+        # 55.7 ms per call against 30.2 / 48.5 ms with each pass's search launched behind its own encoder -- 64 searches side by
+        # side advance at 19 us per frame where 32 do at 16 (tools/beam_profile.py, BEAM_PROFILE_B), and the first pass's search
+        # no longer hides under the second encoder.  Default: per-pass launches.
+        group_utts = int(os.environ.get('MASR_BEAM_GROUP', '0')) if gpu_search else 0
         held = []
 
         def release_group():
-            for idx_h, launch in held:
-                pending.append((idx_h, launch()))
+            eng = self.predictor.engine
+            dec = self.beam_search_decoder
+            main = torch.cuda.current_stream(eng.device)
+            if getattr(self, '_sides', None) is None:
+                self._sides, self._side_turn = [eng.side_stream(k) for k in range(2)], 0
+            side = self._sides[self._side_turn]
+            self._side_turn = (self._side_turn + 1) % len(self._sides)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                handle = dec.search_pruned([part for _, part, _ in held])
+            group = list(held)
             held.clear()
-            while pending:
-                collect(pending.pop(0))
-            for side in getattr(self, '_sides', None) or []:
-                torch.cuda.current_stream(self.predictor.engine.device).wait_stream(side)
+
+            def fetch():
+                res = dec._batch_collect(handle, want_tokens=as_tokens)
+                lo = 0
+                for idx_h, part, fill in group:
+                    for i, r in zip(idx_h, fill(res[lo:lo + part['B']])):
+                        got[i] = r
+                    lo += part['B']
+                return []
+            pending.append(([], fetch))
         for lo, hi in cuts:
             idx = order[lo:hi]
             segs = [self._load_audio(audio_list[i], sample_rate) for i in idx]
-            res = self._predict_local(segs, decode_all_frames, as_tokens, defer=True, hold_search=group > 0)
+            res = self._predict_local(segs, decode_all_frames, as_tokens, defer=True, hold_search=group_utts > 0)
             del segs
             if isinstance(res, tuple) and res[0] == 'held':
-                held.append((idx, res[1]))
-                if len(held) >= group:
+                held.append((idx, res[1], res[2]))
+                if sum(part['B'] for _, part, _ in held) >= group_utts:
                     release_group()
+                    while len(pending) > 1:           # (the previous group's results: its search ran beside this group's encoders)
+                        collect(pending.pop(0))
                 continue
             pending.append((idx, res))
             if len(pending) >= depth:

@@ -42,13 +42,8 @@ def local(segs, *a, **k):
             marks.append(('collected ' + tag, t1, time.perf_counter()))
             return r
         return timed_fetch
-    if isinstance(fetch, tuple) and fetch[0] == 'held':          # round 5: the search is launched later, per group of passes
-        def launch():
-            t1 = time.perf_counter()
-            f = fetch[1]()
-            marks.append(('search launched: ' + tag, t1, time.perf_counter()))
-            return timed(f)
-        return ('held', launch)
+    if isinstance(fetch, tuple) and fetch[0] == 'held':          # round 6: pruned here, searched per group of passes (MASR_BEAM_GROUP)
+        return fetch
     return timed(fetch)
 
 

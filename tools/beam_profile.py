@@ -22,7 +22,8 @@ beam = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 order = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 rng = np.random.default_rng(0)
 scale = float(sys.argv[7]) if len(sys.argv) > 7 else 1.0
-logits = (rng.normal(0, 1.0, (8, T, V)) * scale).astype(np.float32)
+NB = int(os.environ.get("BEAM_PROFILE_B", "8"))
+logits = (rng.normal(0, 1.0, (NB, T, V)) * scale).astype(np.float32)
 probs = torch.softmax(torch.from_numpy(logits), -1).cuda()
 vocab = ['<blank>', '<unk>', '<space>'] + [chr(0x4e00 + i) for i in range(V - 3)]
 kw = {'language_model_path': None}
@@ -36,18 +37,18 @@ cache = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 eng.lib.masr_debug_set(eng.h, 32, cache)
 cand = dec._candidates(probs[0], to_host=False)[2].float().mean().item()
 print(f'logit scale {scale}: {cand:.1f} candidates per frame')
-ref = dec._batch([probs[i] for i in range(8)])
+ref = dec._batch([probs[i] for i in range(NB)])
 if cache and order:                    # the table must not change a score: same transcripts and scores as per-pair probing
     eng.lib.masr_debug_set(eng.h, 32, 0)
-    base = dec._batch([probs[i] for i in range(8)])
+    base = dec._batch([probs[i] for i in range(NB)])
     eng.lib.masr_debug_set(eng.h, 32, 1)
     assert base == ref, 'scorer table changed the search result'
     print('identical transcripts and scores with and without the per-frame scorer table')
 torch.cuda.synchronize()
 eng.lib.masr_debug_set(eng.h, 2, 1)
 t0 = time.perf_counter()
-dec._batch([probs[i] for i in range(8)])
+dec._batch([probs[i] for i in range(NB)])
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f'batch of 8 x {T} frames, LM order {order}, scorer table {cache}: {1e3 * dt:.2f} ms  ({1e6 * dt / T:.1f} us per frame step incl. pruning)')
+print(f'batch of {NB} x {T} frames, LM order {order}, scorer table {cache}: {1e3 * dt:.2f} ms  ({1e6 * dt / T:.1f} us per frame step incl. pruning)')
 eng.lib.masr_debug_set(eng.h, 2, 0)
