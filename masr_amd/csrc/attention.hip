@@ -836,7 +836,7 @@ bool launch_attn_chain(const AttnChainArgs& a, int max_nq, hipStream_t s) {
 // (fused QKV projection), keys j valid iff mstride*j < len_b (subsampled pad mask, subsampling.py:112;
 // mstride = 8 between the Squeezeformer time reduction and recovery).
 __global__ void attseq_full_kernel(AttSeq* seqs, const float* qkv, float* out, const int* __restrict__ lens, int B,
-                                   int Tp, int mstride) {
+                                   int Tp, int mstride, int valid_only) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     AttSeq s;
@@ -847,6 +847,7 @@ __global__ void attseq_full_kernel(AttSeq* seqs, const float* qkv, float* out, c
     s.nq = Tp;
     s.nk = Tp;
     s.klen = min(Tp, (lens[b] + mstride - 1) / mstride);
+    if (valid_only) s.nq = s.nk = s.klen;      // padded queries are not computed, padded keys not even read (they are masked anyway)
     s.pos0 = 0;
     s.q_abs0 = 0;
     s.pad_ = 0;
@@ -854,8 +855,8 @@ __global__ void attseq_full_kernel(AttSeq* seqs, const float* qkv, float* out, c
 }
 
 void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, int mstride,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(attseq_full_kernel, dim3((B + 63) / 64), dim3(64), 0, s, seqs, qkv, out, lens, B, Tp, mstride);
+                        hipStream_t s, int valid_only) {
+    hipLaunchKernelGGL(attseq_full_kernel, dim3((B + 63) / 64), dim3(64), 0, s, seqs, qkv, out, lens, B, Tp, mstride, valid_only);
 }
 
 

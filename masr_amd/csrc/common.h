@@ -82,6 +82,9 @@ struct GemmArgs {
     // A_CONV2 geometry: row m -> (b, t2, f2) with m = (b*T2 + t2)*F2 + f2 ; k -> (kh, kw*C + c)
     int T1, F1, T2, F2, Cc;
     int nsplit, ksplit;  // EPI_SPLITK: number of K ranges (gridDim.y) and BK-slabs per range
+    // skip_rps > 0 (with lens): row r belongs to sequence r / skip_rps at frame (r % skip_rps) / skip_div; a tile whose rows all lie in
+    // ONE sequence at frames with 4 * frame >= lens[sequence] (padding) is not computed -- its output rows keep what they held
+    int skip_rps, skip_div;
 };
 
 void launch_gemm(const GemmArgs& a, int amode, int epi, hipStream_t s);
@@ -278,9 +281,11 @@ struct SqzStageArgs {
     float* glu_out;            // stage 0: [nseq][glu_pad_tot + seq_t][256], real rows at glu_pad_l
     const float* glu;          // stage 1: the same buffer
     const float *dw_w, *dw_b, *bn_scale, *bn_shift, *gconst;
+    const float* gpad;         // stage 1 with skip_pad, symmetric conv: glu(pointwise_conv1 bias) [256], the GLU row of a padded frame
     const int* lens;           // feature lengths for the pad mask, or nullptr
     int M, dff, seq_t, mstride, ktaps, tail_n, glu_pad_l, glu_pad_tot;
     float eps;
+    int skip_pad;              // 1 (with lens): a row block of padded frames only is not computed (x, glu, qkv rows keep what they held)
 };
 bool launch_sqz_stage(const SqzStageArgs& a, int stage, hipStream_t s);
 // ffn_dual.hip: the same block with two independent accumulator chains per wave (chunks of 256 hidden units); p1 / p2 from
@@ -412,7 +417,7 @@ void launch_cnn_cache_move(float* const* caches, float* lnpad, int n, int Tq, in
 void launch_conv_hist(const float* x, const float* w, const float* b, float* const* cache_rd, float* const* cache_wr,
                       float* lnpad, int n, int Tq, int pad, int affine, float eps, hipStream_t s);
 void launch_attseq_full(AttSeq* seqs, const float* qkv, float* out, const int* lens, int B, int Tp, int mstride,
-                        hipStream_t s);
+                        hipStream_t s, int valid_only = 0);     // valid_only: nq = nk = klen (padded queries / keys are not touched)
 
 // ---- features ------------------------------------------------------------------------------
 size_t fbank_gain_scratch_floats(int B);   // size of gain_scratch ([B] gains + partial sums)

@@ -121,6 +121,9 @@ struct DevBuf {
         bytes = 0;
         size_t want = n + n / 8 + 256;
         HIPCHK(hipMalloc(&p, want));
+        // zero once: kernels that skip the padded row blocks of a batch (masr_debug_set key 38) leave those rows as they are, and
+        // what is there must at least be finite -- a later 0 * stale product must not see the NaN patterns of fresh memory
+        HIPCHK(hipMemset(p, 0, want));
         bytes = want;
         return 0;
     }
@@ -260,6 +263,7 @@ struct masr_engine {
     // while the feature launch of the current pass reads e->gain on the compute stream: its chunk sums and its unused gain slots
     // live in a scratch of their own, one per calling stream (launches on one stream are ordered anyway)
     std::map<void*, DevBuf> ms_ws;
+    int skip_padding = 7;            // masr_debug_set key 38: the offline Squeezeformer launches skip the all-padding row blocks of a batch
     void* beam_first_stream = nullptr;
     bool beam_first_set = false;
     std::map<const float*, std::pair<DevBuf, DevBuf>> ffn_packed;  // fp32 FFN weights in fragment order (ffn_pc.hip VAR == 2), per W1 pointer
@@ -973,7 +977,7 @@ int ffn(masr_engine* e, hipStream_t s, int M, const float* lnw, const float* lnb
 static int g_hot_weights = 0;      // masr_debug_set key 19 (timing experiment only): every chunk-step layer runs on layer 0's weights
 static int g_embed_split = 1;      // masr_debug_set key 15: 0 = the offline embed projection never splits K
 // feats [nseq, T, 80] -> x [nseq*Tq, d] (embed incl. x*sqrt(d))
-int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, int* Tq_out) {
+int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, int* Tq_out, const int* skip_lens = nullptr) {
     const int d = e->cfg.d_model, F = e->cfg.n_mels, F1 = (F - 1) / 2, F2 = (F1 - 1) / 2;
     const int T1 = (T - 1) / 2, Tq = (T1 - 1) / 2;
     if (T < 7 || Tq <= 0) return fail("input too short for Conv2dSubsampling4 (need >= 7 frames)");
@@ -987,6 +991,7 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
         a.A = e->x1.as<float>(); a.W = e->conv2_w; a.bias = e->conv2_b; a.C = e->x2.as<float>();
         a.M = M * F2; a.N = d; a.K = 9 * d; a.ldc = d; a.act = ACT_RELU; a.alpha = 1.f;
         a.T1 = T1; a.F1 = F1; a.T2 = Tq; a.F2 = F2; a.Cc = d;
+        if (skip_lens) { a.lens = skip_lens; a.skip_rps = Tq * F2; a.skip_div = F2; }      // tiles of padded frames only: not computed
         ProfScope ps(e, s, PROF_CONV2, 2.0 * a.M * (double)a.N * a.K);
         const int tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
         if (g_bf16x3 && tiles >= 640 && launch_gemm_bf16x3(a, A_CONV2, s)) {
@@ -1006,6 +1011,7 @@ int embed(masr_engine* e, hipStream_t s, const float* feats, int nseq, int T, in
         a.A = e->x2.as<float>(); a.lda = F2 * d; a.W = e->embed_w; a.bias = e->embed_b; a.C = e->x.as<float>(); a.ldc = d;
         a.M = M; a.N = d; a.K = F2 * d; a.act = ACT_NONE; a.alpha = sqrtf((float)d);
         a.bias_after_alpha = e->cfg.model_kind == 1 ? 1 : 0;
+        if (skip_lens) { a.lens = skip_lens; a.skip_rps = Tq; a.skip_div = 1; }
         ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)d * F2 * d);
         const int tiles = ((M + 63) / 64) * ((d + 63) / 64);
         const long wide = (long)((M + 63) / 64) * ((d + 127) / 128);      // 64x128 tiles of the unsplit launch
@@ -1330,7 +1336,13 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
                                      float* enc_out, int chunk) {
     const int d = e->cfg.d_model, H = e->cfg.heads, K = e->cfg.cnn_kernel, half = (K - 1) / 2;
     int T0 = 0;
-    CHK(embed(e, s, feats, B, T, &T0));
+    // Row blocks / tiles that hold padded frames only are not computed (the valid frames' results do not depend on them: pad masks,
+    // klen; reference encoder.py:168-216 computes and masks them): conv2, the input projection, attention (queries and keys stop at the
+    // valid length) and the fused stage kernels -- a length-sorted batch padded to its longest utterance costs its VALID frames, so
+    // one pass can take utterances of any lengths.  Off (masr_debug_set key 38 = 0) when the caller decodes the padded frames too.
+    const bool skip = e->skip_padding != 0 && lens != nullptr;
+    const int skm = skip ? e->skip_padding : 0;        // (bits, for A/B: 1 stage kernels, 2 conv2 + input projection, 4 attention)
+    CHK(embed(e, s, feats, B, T, &T0, (skm & 2) ? lens : nullptr));
     if (T0 >= e->cfg.max_pos) return fail("sequence longer than max_pos");
     CHK(ensure_layer_ws(e, B, T0));
     CHK(e->attseq.ensure(sizeof(AttSeq) * B));
@@ -1343,7 +1355,7 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
     const int pad_l = causal ? K - 1 : half;
     auto new_resolution = [&]() -> int {     // zero the symmetric pad rows of the GLU buffer, rebuild the descriptors
         if (!causal) HIPCHK(hipMemsetAsync(e->glu.p, 0, (size_t)B * (Tq + 2 * half) * d * sizeof(float), s));
-        launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), lens, B, Tq, mstride, s);
+        launch_attseq_full(e->attseq.as<AttSeq>(), e->qkv.as<float>(), e->att.as<float>(), lens, B, Tq, mstride, s, (skm & 4) ? 1 : 0);
         return 0;
     };
     CHK(new_resolution());
@@ -1407,7 +1419,7 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
             CHK(packed_ffn(w.f1_w1, w.f1_w2, &a.w1, &a.w2));
             a.tail_w = packed_rows_of(e, w.pw1_w, 2 * d, s); a.tail_b = w.pw1_b; a.tail_s = w.cv_s; a.tail_sb = w.cv_b; a.tail_n = 2 * d;
             a.glu_out = e->glu.as<float>(); a.glu_pad_l = pad_l; a.glu_pad_tot = 2 * half;
-            a.lens = lens; a.M = M; a.dff = e->cfg.d_ff; a.seq_t = Tq; a.mstride = mstride; a.ktaps = K; a.eps = 1e-5f;
+            a.lens = lens; a.M = M; a.dff = e->cfg.d_ff; a.seq_t = Tq; a.mstride = mstride; a.ktaps = K; a.eps = 1e-5f; a.skip_pad = skm & 1;
             if (!a.head_w || !a.tail_w) return fail("squeezeformer: packing the layer's weights failed");
             {
                 ProfScope ps(e, s, PROF_FFN_TAIL, 4.0 * M * (double)e->cfg.d_ff * d + 2.0 * M * (double)(3 * d) * d);
@@ -1417,6 +1429,7 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
             b.x = x; b.out = i == L - 1 ? enc_out : x; b.glu = e->glu.as<float>();
             b.head_w = packed_rows_of(e, w.pw2_w, d, s); b.head_b = w.pw2_b;
             b.dw_w = w.dw_w; b.dw_b = w.dw_b; b.bn_scale = w.bn_scale; b.bn_shift = w.bn_shift; b.gconst = causal ? w.gconst : nullptr;
+            b.gpad = causal ? nullptr : w.gconst; b.glu_pad_l = pad_l;
             b.ln_a_w = w.ln3_w; b.ln_a_b = w.ln3_b; b.ln_b_w = w.ln4_w; b.ln_b_b = w.ln4_b;
             b.ffn_s = w.f2_s; b.ffn_b = w.f2_b; b.b1 = w.f2_b1; b.b2 = w.f2_b2;
             CHK(packed_ffn(w.f2_w1, w.f2_w2, &b.w1, &b.w2));
@@ -1426,7 +1439,7 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
                 b.tail_n = 3 * d; b.tail_out = e->qkv.as<float>();
                 if (!b.tail_w) return fail("squeezeformer: packing the layer's weights failed");
             }
-            b.lens = lens; b.M = M; b.dff = e->cfg.d_ff; b.seq_t = Tq; b.mstride = mstride; b.ktaps = K; b.eps = 1e-5f;
+            b.lens = lens; b.M = M; b.dff = e->cfg.d_ff; b.seq_t = Tq; b.mstride = mstride; b.ktaps = K; b.eps = 1e-5f; b.skip_pad = skm & 1;
             if (!b.head_w) return fail("squeezeformer: packing the layer's weights failed");
             {
                 ProfScope ps(e, s, PROF_FFN_HEAD, 4.0 * M * (double)e->cfg.d_ff * d + 2.0 * M * (double)d * d +
@@ -2184,7 +2197,15 @@ static int transcribe_impl(masr_engine* e, const void* samples_dev, int32_t fmt,
                          e->feats.as<float>(), nullptr, nullptr, use_db_normalization == 2 ? const_cast<float*>(gain_dev) : nullptr,
                          stream));
     launch_frame_counts(n_samples_dev, B, nfr, nenc, halved ? 1 : 0, s);
-    CHK(masr_encode_full(e, e->feats.as<float>(), nfr, B, T, -1, e->enc.as<float>(), stream));
+    {
+        // decode_all_frames: the padded frames are decoded too (the reference's batch evaluation, trainer.py:340) -- then they
+        // must be computed, whatever masr_debug_set key 38 says
+        const int keep = e->skip_padding;
+        if (decode_all_frames) e->skip_padding = 0;
+        const int rc = masr_encode_full(e, e->feats.as<float>(), nfr, B, T, -1, e->enc.as<float>(), stream);
+        e->skip_padding = keep;
+        if (rc) return rc;
+    }
     CHK(masr_ctc_greedy_frames(e, e->enc.as<float>(), B * Tq, e->idx.as<int>(), e->maxp.as<float>(), stream));
     if (rows_dev) {
         launch_ctc_collapse_rows(e->idx.as<int>(), e->maxp.as<float>(), decode_all_frames ? nullptr : nenc, B, Tq, 0, rows_dev, s);
@@ -2842,6 +2863,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
     else if (key == 35) g_ffn_coop = value;
     else if (key == 36) g_sqz_fused_blocks = value;
     else if (key == 37) g_beam_narrow = value;
+    else if (key == 38) e->skip_padding = value;
     else if (key == 17) set_gemm_waves(value);
     else if (key == 18) set_conv1_nt(value);
     else if (key == 16) { e->prof_stride = value > 1 ? value : 1; e->prof_seen = 0; }

@@ -50,12 +50,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs p) {
     const int nbn = (p.N + BN - 1) / BN;
     const int nblk = nbm * nbn;
     int bid = blockIdx.x;
-    {
+    if (p.skip_rps <= 0) {          // (tiles are skipped by sequence length: contiguous per-XCD ranges would leave the XCDs of the
+                                    //  short sequences idle -- plain order then, every XCD sees every sequence)
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int bm = (bid / nbn) * BM;
     const int bn = (bid % nbn) * BN;
+    if (p.skip_rps > 0 && p.lens) {         // a tile of padded frames only (whole workgroup, before any barrier)
+        const int span = min(bm + BM, p.M) - 1 - bm;
+        const int b0 = bm / p.skip_rps, r0 = bm - b0 * p.skip_rps;
+        if (r0 + span < p.skip_rps && 4 * (r0 / p.skip_div) >= p.lens[b0]) return;
+    }
 
     // ---- per-thread global source pointers ------------------------------------------------
     const int lrow = tid >> 3;          // 0..RPP-1

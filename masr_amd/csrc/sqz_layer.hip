@@ -98,6 +98,17 @@ __global__ __launch_bounds__(512) void sqz_stage_kernel(SqzStageArgs p) {
     const unsigned lane16 = lane * 16;
     const float* xa = xn + frow * SQ_XLD + 4 * fh;
     const int sb0 = row0 / p.seq_t, st0 = row0 - sb0 * p.seq_t;       // (sequence, frame) of the block's first row
+    // a block of padded frames only: nothing a valid frame reads comes from it (its GLU rows stay zero from the per-resolution
+    // memset, attention stops at the valid length) -- whole workgroup, before any barrier
+    // (the encoder OUTPUT is the exception: its padded frames are written as zeros, by skipped and computed blocks alike, so that
+    //  what a caller sees there does not depend on what the buffer held)
+    const bool zero_pad_out = STAGE == 1 && p.skip_pad && p.lens && p.out != p.x;
+    if (p.skip_pad && p.lens && st0 + (min(row0 + SQ_BM, M) - 1 - row0) < p.seq_t && p.mstride * st0 >= p.lens[sb0]) {
+        if (zero_pad_out)
+            for (int i = tid; i < SQ_BM * 64; i += 512)
+                if (row0 + (i >> 6) < M) *reinterpret_cast<f32x4*>(p.out + (size_t)(row0 + (i >> 6)) * SQ_D + (i & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     f32x4 pre[SQ_NSET][4];
 
     // =========================================================================================================================
@@ -137,11 +148,21 @@ __global__ __launch_bounds__(512) void sqz_stage_kernel(SqzStageArgs p) {
             const float bsc = p.bn_scale[c], bsh = p.bn_shift[c];
             const float gc = p.gconst ? p.gconst[c] : 0.f;
             const bool has_gc = p.gconst != nullptr;
+            // skip_pad: the row blocks of padded frames only never wrote their GLU rows; a padded frame inside the batch's padded
+            // length holds glu(pointwise_conv1 bias) in the reference (its input is masked to zero BEFORE pointwise_conv1,
+            // convolution.py:105-119) and the symmetric window of the last valid frames reaches it: substituted here (gpad =
+            // the constant glu_const_kernel computes with the mid stage's own epilogue arithmetic: identical bits)
+            const bool sub = p.skip_pad && p.gpad != nullptr && p.lens != nullptr;
+            const float gp = sub ? p.gpad[c] : 0.f;
             const int lr_last = M - 1 - row0;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {              // the newest window element of every row, all 16 loads in flight
                 const SeqRow q = seq_row(sb0, st0, p.seq_t, min(half * 16 + rr, lr_last));
                 nw[rr] = p.glu[((size_t)q.b * (pad + p.seq_t) + q.t + pad) * 256 + c];
+                if (sub) {
+                    const int f = q.t + pad - p.glu_pad_l;
+                    if (f < p.seq_t && p.mstride * f >= p.lens[q.b]) nw[rr] = gp;
+                }
             }
 #pragma unroll
             for (int j = 0; j < KT; ++j) win[j] = 0.f;
@@ -152,7 +173,13 @@ __global__ __launch_bounds__(512) void sqz_stage_kernel(SqzStageArgs p) {
                 if (rr == 0 || q.t == 0 || row0 + lr >= M) {
                     const float* gin = p.glu + ((size_t)q.b * (pad + p.seq_t) + q.t) * 256 + c;     // padded rows t .. t + pad
 #pragma unroll
-                    for (int j = 0; j < pad; ++j) win[j + 1] = (has_gc && q.t + j < pad) ? gc : gin[(size_t)j * 256];
+                    for (int j = 0; j < pad; ++j) {
+                        win[j + 1] = (has_gc && q.t + j < pad) ? gc : gin[(size_t)j * 256];
+                        if (sub) {
+                            const int f = q.t + j - p.glu_pad_l;
+                            if (f >= 0 && f < p.seq_t && p.mstride * f >= p.lens[q.b]) win[j + 1] = gp;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < pad; ++j) win[j] = win[j + 1];
@@ -350,7 +377,11 @@ __global__ __launch_bounds__(512) void sqz_stage_kernel(SqzStageArgs p) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int lr = wave * 4 + rr, row = row0 + lr;
-            const f32x4 y = sq_layernorm(*reinterpret_cast<const f32x4*>(&xn[lr * SQ_XLD + lane * 4]), lw, lb, eps);
+            f32x4 y = sq_layernorm(*reinterpret_cast<const f32x4*>(&xn[lr * SQ_XLD + lane * 4]), lw, lb, eps);
+            if (zero_pad_out && row < M) {
+                const SeqRow q = seq_row(sb0, st0, p.seq_t, lr);
+                if (p.mstride * q.t >= p.lens[q.b]) y = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             if (row < M) *reinterpret_cast<f32x4*>(p.out + (size_t)row * SQ_D + lane * 4) = y;
             if (has_tail) {
                 bool live = row < M;

@@ -21,6 +21,7 @@ import torch
 import yaml
 
 from masr_amd import SUPPORT_MODEL, parallel
+from masr_amd._lib import check
 from masr_amd.data_utils.audio import AudioSegment
 from masr_amd.data_utils.featurizer.audio_featurizer import AudioFeaturizer
 from masr_amd.data_utils.featurizer.text_featurizer import TextFeaturizer
@@ -279,7 +280,13 @@ class MASRPredictor:
             return fetch if defer else fetch()
         feats, frames = eng.features_batch(method, xs, ns, pc.use_dB_normalization, pc.target_dB, n_mfcc=pc.get('n_mfcc', 40),
                                            gain_in=gain)
-        enc = eng.encode_full(feats, frames, -1)
+        if decode_all_frames:        # the padded frames are decoded too: the engine must compute them (masr_debug_set key 38)
+            check(eng.lib.masr_debug_set(eng.h, 38, 0))
+        try:
+            enc = eng.encode_full(feats, frames, -1)
+        finally:
+            if decode_all_frames:
+                check(eng.lib.masr_debug_set(eng.h, 38, 7))
         nenc = None if decode_all_frames else eng.enc_frames(frames).to(torch.int32)
         if not greedy:
             # probabilities stay on the GPU: vocabulary pruning, prefix search and LM scoring run there

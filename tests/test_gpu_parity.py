@@ -53,6 +53,28 @@ def dev(x, dtype=None):
     return t.cuda().contiguous()
 
 
+def valid_frames(a, lens, rate=4):
+    """[B, T', ...] array / tensor with the PADDED encoder frames (rate * t >= feature length) set to zero -- the Squeezeformer engine
+    does not compute the row blocks of padded frames (masr_debug_set key 38) and returns zeros there"""
+    a = np.array(a.cpu().numpy() if torch.is_tensor(a) else a, copy=True)
+    for b in range(a.shape[0]):
+        a[b, min(a.shape[1], -(-int(lens[b]) // rate)):] = 0
+    return a
+
+
+class computing_padded_frames:
+    """with computing_padded_frames(engine): the padded frames are computed like the reference computes them (key 38 = 0)"""
+    def __init__(self, e):
+        self.e = e
+
+    def __enter__(self):
+        assert self.e.lib.masr_debug_set(self.e.h, 38, 0) == 0
+
+    def __exit__(self, *exc):
+        self.e.lib.masr_debug_set(self.e.h, 38, 7)
+
+
+
 def acceptable_texts(probs, vocab, od, margin=2e-3, limit=12):
     return od.acceptable_texts(probs, vocab, margin, limit)
 
@@ -434,9 +456,25 @@ def test_squeezeformer_against_reference_fixture(sq512, oracle_mods):
     _, _, _, _, golden_inputs = oracle_mods
     z = g('squeezeformer_v512.npz')
     feats, lens = golden_inputs()
+    # default: the row blocks of padded frames are not computed (masr_debug_set key 38) -- the VALID frames must match the reference;
+    # key 38 = 0 computes the padded frames as the reference does: then every row must
     enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1)
-    err = np.abs(enc.cpu().numpy() - z['enc']).max()
+    got = enc.cpu().numpy()
+    for b in range(got.shape[0]):
+        v = min(got.shape[1], -(-int(lens[b]) // 4))
+        err = np.abs(got[b, :v] - z['enc'][b, :v]).max()
+        assert err < 1e-3, f'squeezeformer encoder_out max err {err} on the valid frames of utterance {b}'
+    assert e.lib.masr_debug_set(e.h, 38, 0) == 0
+    try:
+        full = e.encode_full(dev(feats), dev(lens, torch.int32), -1)
+    finally:
+        e.lib.masr_debug_set(e.h, 38, 7)
+    err = np.abs(full.cpu().numpy() - z['enc']).max()
     assert err < 1e-3, f'squeezeformer encoder_out max err {err}'
+    for b in range(got.shape[0]):       # skipping changes nothing on a valid frame: identical bits
+        v = min(got.shape[1], -(-int(lens[b]) // 4))
+        assert np.array_equal(got[b, :v], full.cpu().numpy()[b, :v])
+    enc = full
     probs = e.ctc_probs(enc).cpu().numpy()
     assert np.abs(probs - z['probs']).max() < 1e-3
     idx, mp = e.ctc_greedy_frames(enc)
@@ -476,9 +514,12 @@ def test_squeezeformer_streaming_build_against_reference_fixture(oracle_mods):
     z = g('squeezeformer_streaming_v512.npz')
     feats, lens = golden_inputs()
     enc = e.encode_full(dev(feats), dev(lens, torch.int32))
-    assert np.abs(enc.cpu().numpy() - z['enc']).max() < 1e-3
-    probs = e.ctc_probs(enc).cpu().numpy()
-    assert np.abs(probs - z['probs']).max() < 1e-3
+    assert np.abs(valid_frames(enc, lens) - valid_frames(z['enc'], lens)).max() < 1e-3
+    with computing_padded_frames(e):
+        enc = e.encode_full(dev(feats), dev(lens, torch.int32))
+        assert np.abs(enc.cpu().numpy() - z['enc']).max() < 1e-3
+        probs = e.ctc_probs(enc).cpu().numpy()
+        assert np.abs(probs - z['probs']).max() < 1e-3
     # odd frame counts (time reduction / recovery edge) against the oracle
     torch.manual_seed(4)
     x = torch.randn(2, 203, 80) * 3 + 13
@@ -487,6 +528,9 @@ def test_squeezeformer_streaming_build_against_reference_fixture(oracle_mods):
     with torch.no_grad():
         ref = osq.encoder_full(sd, x, l2, causal=True).numpy()
     got = e.encode_full(dev(x), dev(l2, torch.int32)).cpu().numpy()
+    assert np.abs(valid_frames(got, l2) - valid_frames(ref, l2)).max() < 1e-3
+    with computing_padded_frames(e):
+        got = e.encode_full(dev(x), dev(l2, torch.int32)).cpu().numpy()
     assert np.abs(got - ref).max() < 1e-3
     e.close()
 
@@ -512,12 +556,16 @@ def test_squeezeformer_fused_layer_is_bit_identical_to_the_separate_launches(ora
         x = torch.randn(B, T, 80, generator=gen) * 3 + 13
         x = x * (torch.arange(T)[None, :, None] < lens[:, None, None])
         xd, ld = dev(x), dev(lens, torch.int32)
-        fused = e.encode_full(xd, ld).cpu()
-        assert e.lib.masr_debug_set(e.h, 36, 0) == 0
-        plain = e.encode_full(xd, ld).cpu()
-        assert e.lib.masr_debug_set(e.h, 36, 192) == 0
-        assert torch.isfinite(fused).all()
+        skipping = e.encode_full(xd, ld).cpu()                      # default: row blocks of padded frames are not computed
+        with computing_padded_frames(e):
+            fused = e.encode_full(xd, ld).cpu()
+            assert e.lib.masr_debug_set(e.h, 36, 0) == 0
+            plain = e.encode_full(xd, ld).cpu()
+            assert e.lib.masr_debug_set(e.h, 36, 192) == 0
+        assert torch.isfinite(fused).all() and torch.isfinite(skipping).all()
         assert torch.equal(fused, plain), f'max |fused - separate| = {(fused - plain).abs().max().item():.3e}'
+        # skipping the padded row blocks changes no bit of a valid frame, and the padded frames of the output read zero
+        assert np.array_equal(skipping.numpy(), valid_frames(fused, lens))
         with torch.no_grad():
             ref = osq.encoder_full(sd, x[:2], lens[:2], causal=streaming)
         n0, n1 = int(e.enc_frames(lens[:1])[0]), int(e.enc_frames(lens[1:2])[0])
@@ -581,7 +629,10 @@ def test_squeezeformer_odd_lengths_against_oracle(sq512, oracle_mods):
     with torch.no_grad():
         ref = osq.encoder_full(sd, feats, lens)
     enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
-    assert ref.shape == enc.shape and (ref - enc).abs().max() < 1e-3
+    assert ref.shape == enc.shape and np.abs(valid_frames(ref, lens) - valid_frames(enc, lens)).max() < 1e-3
+    with computing_padded_frames(e):
+        enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1).cpu()
+    assert (ref - enc).abs().max() < 1e-3
 
 
 # ---------------------------------------------------------------------------------------------------
