@@ -808,14 +808,18 @@ def extra_squeezeformer_greedy(args, rank, world, local):
                                     'all passes); half-rate layers below 192 row blocks run the separate d_ff-split launches instead'})
     eng.profile_select(0)
     total = float(lens.sum()) / 16000.0
-    dt = out['balanced']
+    best = min(out, key=out.get)          # both policies are measured in this run; the line is the faster one and says which
+    dt = out[best]
     eng.close()
     roof = workload_roofline(GFLOP_SQUEEZEFORMER_B64, dt * 1e3, 'SURVEY 8(d): 1.43 TFLOP of useful (unpadded) encoder work in the 64 utterances')
     roof['kernels'] = kernels
     return {'workload': f'configs[2] with ctc_greedy: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s) -> text, '
-                        'length-sorted passes of equal padded size (16 / 19 / 29 utterances); encoder-bound line of the Squeezeformer',
+                        + ('length-sorted passes of equal padded size (16 / 19 / 29 utterances)' if best == 'balanced' else
+                           'two length-sorted passes of 32 (the row blocks of padded frames are not computed: masr_debug_set key 38)')
+                        + '; encoder-bound line of the Squeezeformer',
             'value': round(total / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps, 'ms_per_step': round(dt * 1e3, 3),
-            'fixed_passes_of_32_ms_per_step': round(out[32] * 1e3, 3), 'fused_layer_ab_ms_per_step': ab, 'transcripts': len(res),
+            'fixed_passes_of_32_ms_per_step': round(out[32] * 1e3, 3), 'balanced_passes_ms_per_step': round(out['balanced'] * 1e3, 3),
+            'fused_layer_ab_ms_per_step': ab, 'transcripts': len(res),
             'roofline': roof}
 
 
@@ -1008,39 +1012,17 @@ class ExtrasWatchdog:
         os._exit(0)
 
 
-def extra_in_fresh_process(workload):
-    """Run ``bench.py --workload <workload>`` in a process of its own and hand back its JSON line.  For the configs[2] lines with
-    the prefix search on the GPU: the search of a pass runs on a side stream NEXT to the encoder of the following pass, and ROCm
-    maps streams onto GPU_MAX_HW_QUEUES hardware queues round-robin in creation order -- in a process that has already created
-    the streams of the contract step, the pools and the facades, a side stream lands on the main stream's queue and the search
-    runs BEHIND the encoder instead of next to it (round 5: 63.4 ms per call inside the bench process, 45.8 ms in a process that
-    starts with the workload -- same box, same code, tools/beam_batch_profile.py).  A user's server creates its predictor
-    first; the measurement does the same."""
-    def run(args, rank, world, local):
-        cmd = [sys.executable, os.path.abspath(__file__), '--workload', workload, '--no-cpu-baseline', '--steps', str(args.steps)]
-        env = dict(os.environ)                     # (world == 1: the child takes device 0 of the same visible set)
-        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'MASR_FORCE_DIST'):
-            env.pop(k, None)
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
-        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
-        if p.returncode != 0 or not lines:
-            raise RuntimeError(f'bench.py --workload {workload} failed ({p.returncode}): {p.stderr[-400:]}')
-        res = json.loads(lines[-1])
-        res['measured_in'] = 'a process of its own (python bench.py --workload %s): see bench.extra_in_fresh_process' % workload
-        return res
-    return run
-
-
 def run_extras(args, rank, world, local, out=None):
     out = {} if out is None else out
     jobs = [('efficient_b256', extra_efficient_b256), ('stream128', extra_stream128)]
     if world == 1:
         # the per-GPU share of configs[4] on an 8-GPU node (128 streams / 8), measured on this one GPU
         jobs.append(('stream16', lambda a, r, w, l: extra_stream128(a, r, w, l, n_streams=16)))
-        fresh = not os.environ.get('MASR_BENCH_ENGINE_FACTORY') and os.environ.get('MASR_BENCH_BEAM_INPROCESS') != '1'
-        jobs.append(('squeezeformer_b64_beam', extra_in_fresh_process('squeezeformer_b64_beam') if fresh else extra_squeezeformer_beam))
-        jobs.append(('squeezeformer_b64_beam_sharp', extra_in_fresh_process('squeezeformer_b64_beam_sharp') if fresh else
-                     (lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True))))
+        # (rounds 3-5 measured these two lines in a process of their own: the prefix search ran on torch side streams whose hardware
+        #  queue depended on what the process had created before.  The library owns its side streams now -- masr_side_stream, a
+        #  queue pool of their own -- and the lines are measured here, in the long bench process, like everything else.)
+        jobs.append(('squeezeformer_b64_beam', extra_squeezeformer_beam))
+        jobs.append(('squeezeformer_b64_beam_sharp', lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True)))
         jobs.append(('squeezeformer_b64_beam_wordlm_host', lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True, word_lm=True)))
         jobs.append(('squeezeformer_b64_greedy', extra_squeezeformer_greedy))
         jobs.append(('facade', extra_facade))

@@ -386,6 +386,27 @@ const float* packed_rows_of(masr_engine* e, const float* W, int N, hipStream_t s
     return it->second.first.as<float>();
 }
 
+// fragment-order copies of an FFN's two weight matrices (ffn_pc.hip layout), cached per W1 pointer
+int packed_ffn_of(masr_engine* e, const float* w1, const float* w2, hipStream_t s, const float** p1, const float** p2) {
+    const int d = e->cfg.d_model;
+    auto it = e->ffn_packed.find(w1);
+    if (it == e->ffn_packed.end()) {
+        std::pair<DevBuf, DevBuf> pk;
+        CHK(pk.first.ensure((size_t)e->cfg.d_ff * d * sizeof(float)));
+        CHK(pk.second.ensure((size_t)e->cfg.d_ff * d * sizeof(float)));
+        launch_pack_ffn_pc(w1, w2, pk.first.as<float>(), pk.second.as<float>(), e->cfg.d_ff, s);
+        it = e->ffn_packed.emplace(w1, pk).first;
+    }
+    *p1 = it->second.first.as<float>();
+    *p2 = it->second.second.as<float>();
+    return 0;
+}
+// the fused Squeezeformer stages cover these sizes (launch_sqz_stage's own checks, sqz_layer.hip): anything else takes the separate launches
+static bool sqz_stage_supported(const masr_engine* e) {
+    const int K = e->cfg.cnn_kernel;
+    return e->cfg.d_model == 256 && e->cfg.d_ff % 128 == 0 && e->cfg.d_ff >= 256 && (K == 31 || K == 15);
+}
+
 void rowgemm(masr_engine* e, hipStream_t s, int pro, int epi, const float* A, int lda, const float* lnw,
              const float* lnb, const float* W, const float* bias, float* C, int ldc, int M, int N, const float* R,
              int ldr, float alpha, const int* lens, int mask_tp, int seq_t, int pad, int* out_idx, float* out_maxp,
@@ -1325,6 +1346,20 @@ static int finalize_squeezeformer(masr_engine* e, hipStream_t s) {
     }
     CHK(up(e, "ctc.ctc_lo.weight", {V, d}, &e->ctc_w));
     CHK(up(e, "ctc.ctc_lo.bias", {V}, &e->ctc_b));
+    if (sqz_stage_supported(e)) {
+        // the fused stages' fragment-order weight copies are made HERE, once, behind this call's synchronisation: a forward pass on
+        // any stream then only reads the caches (they used to be filled by whichever stream ran the first pass, with nothing
+        // ordering a second stream's reads behind that pack kernel)
+        for (int i = 0; i < L; ++i) {
+            const SqLayerW& w = e->sq_layers[i];
+            const float *p1, *p2;
+            CHK(packed_ffn_of(e, w.f1_w1, w.f1_w2, s, &p1, &p2));
+            CHK(packed_ffn_of(e, w.f2_w1, w.f2_w2, s, &p1, &p2));
+            if (!packed_rows_of(e, w.wo, d, s) || !packed_rows_of(e, w.pw1_w, 2 * d, s) || !packed_rows_of(e, w.pw2_w, d, s) ||
+                !packed_rows_of(e, w.wqkv, 3 * d, s))
+                return fail("squeezeformer: packing the layer's weights failed");
+        }
+    }
     HIPCHK(hipStreamSynchronize(s));
     e->host.clear();
     e->finalized = true;
@@ -1384,7 +1419,7 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
         const int M = B * Tq;
         // Fused layer (sqz_layer.hip): attention + two row-block kernels.  Taken when the row blocks fill the chip (below that the
         // d_ff-split FFN and the K-split projections of the unfused sequence are the faster launches); bit-identical either way.
-        const bool fused = g_sqz_fused_blocks > 0 && (M + 31) / 32 >= g_sqz_fused_blocks && d == 256 && (K == 31 || K == 15);
+        const bool fused = g_sqz_fused_blocks > 0 && (M + 31) / 32 >= g_sqz_fused_blocks && sqz_stage_supported(e);
         // x = LN1(x + MHSA(ada(x)))
         if (!qkv_ready)
             rowgemm(e, s, RG_PRO_AFFINE, RG_EPI_STORE, x, d, w.att_s, w.att_b, w.wqkv, w.bqkv, e->qkv.as<float>(), 3 * d, M,
@@ -1398,25 +1433,12 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
         if (fused) {
             // the next layer's QKV projection rides on this layer's last launch unless the frame rate changes in between
             const bool next_same = i + 1 < L && i + 1 != e->reduce_idx && !(i + 1 == e->recover_idx && e->reduce_idx >= 0);
-            auto packed_ffn = [&](const float* w1, const float* w2, const float** p1, const float** p2) -> int {
-                auto it = e->ffn_packed.find(w1);
-                if (it == e->ffn_packed.end()) {
-                    std::pair<DevBuf, DevBuf> pk;
-                    CHK(pk.first.ensure((size_t)e->cfg.d_ff * d * sizeof(float)));
-                    CHK(pk.second.ensure((size_t)e->cfg.d_ff * d * sizeof(float)));
-                    launch_pack_ffn_pc(w1, w2, pk.first.as<float>(), pk.second.as<float>(), e->cfg.d_ff, s);
-                    it = e->ffn_packed.emplace(w1, pk).first;
-                }
-                *p1 = it->second.first.as<float>();
-                *p2 = it->second.second.as<float>();
-                return 0;
-            };
             SqzStageArgs a{};
             a.x = x; a.out = x; a.att = e->att.as<float>();
             a.head_w = packed_rows_of(e, w.wo, d, s); a.head_b = w.bo;
             a.ln_a_w = w.ln1_w; a.ln_a_b = w.ln1_b; a.ln_b_w = w.ln2_w; a.ln_b_b = w.ln2_b;
             a.ffn_s = w.f1_s; a.ffn_b = w.f1_b; a.b1 = w.f1_b1; a.b2 = w.f1_b2;
-            CHK(packed_ffn(w.f1_w1, w.f1_w2, &a.w1, &a.w2));
+            CHK(packed_ffn_of(e, w.f1_w1, w.f1_w2, s, &a.w1, &a.w2));
             a.tail_w = packed_rows_of(e, w.pw1_w, 2 * d, s); a.tail_b = w.pw1_b; a.tail_s = w.cv_s; a.tail_sb = w.cv_b; a.tail_n = 2 * d;
             a.glu_out = e->glu.as<float>(); a.glu_pad_l = pad_l; a.glu_pad_tot = 2 * half;
             a.lens = lens; a.M = M; a.dff = e->cfg.d_ff; a.seq_t = Tq; a.mstride = mstride; a.ktaps = K; a.eps = 1e-5f; a.skip_pad = skm & 1;
@@ -1432,7 +1454,7 @@ static int encode_full_squeezeformer(masr_engine* e, hipStream_t s, const float*
             b.gpad = causal ? nullptr : w.gconst; b.glu_pad_l = pad_l;
             b.ln_a_w = w.ln3_w; b.ln_a_b = w.ln3_b; b.ln_b_w = w.ln4_w; b.ln_b_b = w.ln4_b;
             b.ffn_s = w.f2_s; b.ffn_b = w.f2_b; b.b1 = w.f2_b1; b.b2 = w.f2_b2;
-            CHK(packed_ffn(w.f2_w1, w.f2_w2, &b.w1, &b.w2));
+            CHK(packed_ffn_of(e, w.f2_w1, w.f2_w2, s, &b.w1, &b.w2));
             if (next_same) {
                 const SqLayerW& nx = e->sq_layers[i + 1];
                 b.tail_w = packed_rows_of(e, nx.wqkv, 3 * d, s); b.tail_b = nx.bqkv; b.tail_s = nx.att_s; b.tail_sb = nx.att_b;
@@ -2352,7 +2374,10 @@ int masr_stream_room(masr_engine* e, int32_t stream_id, int32_t* frames_left) {
     if (!frames_left) return fail("null argument");
     Stream* st;
     CHK(stream_of(e, stream_id, &st));
-    *frames_left = st->cap - st->offset;
+    // (the Efficient-Conformer's grouped layers pad a chunk to a multiple of the group size before the room check of
+    //  masr_encode_chunk: that slack is taken off HERE, for that family only, so that a caller compares plain frame counts)
+    const int slack = e->cfg.model_kind == 2 ? std::max(0, e->group_size) : 0;
+    *frames_left = std::max(0, st->cap - st->offset - slack);
     return 0;
 }
 

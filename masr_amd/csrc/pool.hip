@@ -339,7 +339,7 @@ int masr_pool_step(masr_pool* p, int32_t n_feeds, const int32_t* feed_handle, co
             }
             int32_t room = 0;
             PCHK(masr_stream_room(p->e, sess[i]->sid, &room));
-            if (emit > 0 && emit + 3 > room) {           // (+ 3: the Efficient-Conformer's grouped layers pad a chunk to a multiple of 3)
+            if (emit > 0 && emit > room) {               // (masr_stream_room already holds back the Efficient-Conformer's group padding)
                 refused.push_back(sess[i]->sid);
                 continue;
             }

@@ -384,7 +384,8 @@ class MASRPredictor:
             rate = int(self.configs.preprocess_conf.get('sample_rate', 16000))
             if pass_padded is None:
                 if lengths is not None:
-                    raise ValueError("batch_size='balanced' with caller-supplied lengths needs pass_padded in the same unit")
+                    raise ValueError("batch_size='balanced' with caller-supplied lengths needs pass_padded in the same unit "
+                                     "(evaluate() passes manifest durations and derives it: pass_size() x 10 seconds)")
                 pass_padded = self.pass_size() * 10 * rate
             batch_size = ('balanced', float(pass_padded))
         rank, world = parallel.world_info()
@@ -414,6 +415,8 @@ class MASRPredictor:
         if isinstance(batch_size, tuple):             # ('balanced', budget): count x longest <= budget per pass
             cuts = balanced_cuts([hints[i] for i in order], batch_size[1])
         elif isinstance(batch_size, list):            # explicit pass sizes, counted from the LONGEST utterance down (the last size repeats)
+            if not batch_size:
+                raise ValueError('batch_size: an empty list of pass sizes')
             cuts, hi, k = [], len(order), 0
             while hi > 0:
                 step = max(1, int(batch_size[min(k, len(batch_size) - 1)]))
@@ -497,7 +500,7 @@ class MASRPredictor:
                 torch.cuda.current_stream(self.predictor.engine.device).wait_stream(side)
         return [got[i] for i in which]
 
-    def evaluate(self, manifest, batch_size='auto', display_result=False, decode_all_frames=False):
+    def evaluate(self, manifest, batch_size='auto', display_result=False, decode_all_frames=False, pass_padded=None):
         """Batched offline evaluation on the engine (the reference's batch > 1 consumer: MASRTrainer.evaluate,
         trainer.py:592-651): ``manifest`` is the reference's txt manifest (one JSON object per line with ``audio_filepath``
         and ``text``, data_utils/reader.py:32-40,55), utterances are sorted by duration, padded per batch and decoded with
@@ -517,8 +520,11 @@ class MASRPredictor:
         metric = wer if self.configs.metrics_type == 'wer' else cer
         # manifest durations sort and shard the work: a rank opens only the files of its own shard, one pass at a time
         known = [it[2] for it in items] if all(it[2] > 0 for it in items) else None
+        # batch_size='balanced': the pass budget in the unit of the lengths -- manifest durations are seconds
+        if batch_size == 'balanced' and known is not None and pass_padded is None:
+            pass_padded = self.pass_size() * 10.0
         results = self.predict_batch([it[0] for it in items], decode_all_frames=decode_all_frames, batch_size=batch_size,
-                                     lengths=known)
+                                     lengths=known, pass_padded=pass_padded)
         errors = []
         for (path, label, _), res in zip(items, results):
             err = metric(res['text'], label)

@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from masr_amd import _lib
+from masr_amd._lib import MasrError
 from masr_amd.data_utils.audio import AudioSegment
 from masr_amd.engine import reference_gains
 
@@ -188,6 +189,7 @@ class StreamPool:
         """destroy the C pool (closes its streams on the engine, synchronises the engine's device).  Idempotent; called by
         ``HipEngine.close()`` for every pool still alive on it, so a pool never touches a destroyed engine."""
         c, self._c = getattr(self, '_c', None), None
+        self._closed = True
         if c is not None and getattr(self.engine, 'h', None):
             with torch.cuda.device(self.engine.device):
                 self._lib.masr_pool_destroy(c)
@@ -210,7 +212,12 @@ class StreamPool:
             self._gain_error = exc
             return 1
 
+    def _alive(self):
+        if getattr(self, '_closed', False):
+            raise MasrError('this StreamPool is shut down (its engine was closed): open a new pool on a live engine')
+
     def open(self):
+        self._alive()
         if self._c is not None:
             h = C.c_int32()
             _lib.check(self._lib.masr_pool_open(self._c, C.byref(h)))
@@ -224,6 +231,7 @@ class StreamPool:
         return sid
 
     def close(self, handle):
+        self._alive()
         if self._c is not None:
             _lib.check(self._lib.masr_pool_close(self._c, int(handle)))
             self.sessions.pop(handle)
@@ -239,6 +247,7 @@ class StreamPool:
 
     def reset(self, handle):
         """start a new utterance on an open session (MASRPredictor.reset_stream, predict.py:346-353)"""
+        self._alive()
         if self._c is not None:
             _lib.check(self._lib.masr_pool_reset(self._c, int(handle)))
             self.sessions[handle] = _Session(handle, 0, None)
@@ -255,6 +264,7 @@ class StreamPool:
     def feed(self, handle, audio_data, is_end=False, channels=1, samp_width=2, sample_rate=16000):
         """queue raw PCM bytes (or a float / int numpy array) for a session (predict.py:260-272); processed by the next
         ``step()``"""
+        self._alive()
         s = self.sessions[handle]
         wire = isinstance(audio_data, (bytes, bytearray, memoryview)) and samp_width == 2 and channels == 1 and \
             sample_rate == self.sample_rate
@@ -417,6 +427,7 @@ class StreamPool:
         return out
 
     def step(self):
+        self._alive()
         if self._c is not None:
             return self._step_c()
         self.last_packed = None
