@@ -358,7 +358,9 @@ void launch_recover_add(const float* saved, const float* y, float* x, int B, int
 // (ctc_greedy_decoder.py:20-21).  One workgroup per frame; the row lives in registers.
 // argmax is taken on the logits with first-index tie breaking (numpy argmax semantics).
 // ------------------------------------------------------------------------------------------
-static constexpr int SM_MAXPT = 32;  // supports V <= 8192
+// per-thread row slice of the vocabulary kernels below (256 threads): 32 values cover V <= 8192 (the shipped vocabularies), 64
+// cover V <= 16384 (the template argument; launch_* pick by V)
+template <int SM_MAXPT>
 __global__ __launch_bounds__(256) void softmax_argmax_kernel(float* logits, int V, int ldv, int write_probs,
                                                              int* __restrict__ idx, float* __restrict__ maxp) {
     __shared__ float red_v[4];
@@ -416,7 +418,8 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(float* logits, int 
 void launch_softmax_argmax(float* logits, int M, int V, int ldv, int write_probs, int* idx, float* maxp,
                            hipStream_t s) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(M), dim3(256), 0, s, logits, V, ldv, write_probs, idx, maxp);
+    if (V <= 8192) hipLaunchKernelGGL(softmax_argmax_kernel<32>, dim3(M), dim3(256), 0, s, logits, V, ldv, write_probs, idx, maxp);
+    else hipLaunchKernelGGL(softmax_argmax_kernel<64>, dim3(M), dim3(256), 0, s, logits, V, ldv, write_probs, idx, maxp);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -612,6 +615,7 @@ void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hi
 // cutoff_prob, at most top_n entries; log(p + FLT_MIN)).  One workgroup per frame, top_n rounds of a
 // block-wide arg-max over the register-resident row (ties -> smaller index).
 // ------------------------------------------------------------------------------------------
+template <int SM_MAXPT>
 __global__ __launch_bounds__(256) void topk_prune_kernel(const float* __restrict__ probs, int V, int top_n,
                                                          float cutoff_prob, int* __restrict__ out_idx,
                                                          float* __restrict__ out_logp, int* __restrict__ out_cnt, int blank,
@@ -670,8 +674,12 @@ __global__ __launch_bounds__(256) void topk_prune_kernel(const float* __restrict
 void launch_topk_prune(const float* probs, int M, int V, int top_n, float cutoff_prob, int* out_idx, float* out_logp,
                        int* out_cnt, int blank, float* out_blank_lp, hipStream_t s) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(topk_prune_kernel, dim3(M), dim3(256), 0, s, probs, V, top_n, cutoff_prob, out_idx, out_logp, out_cnt,
-                       blank, out_blank_lp);
+    if (V <= 8192)
+        hipLaunchKernelGGL(topk_prune_kernel<32>, dim3(M), dim3(256), 0, s, probs, V, top_n, cutoff_prob, out_idx, out_logp, out_cnt,
+                           blank, out_blank_lp);
+    else
+        hipLaunchKernelGGL(topk_prune_kernel<64>, dim3(M), dim3(256), 0, s, probs, V, top_n, cutoff_prob, out_idx, out_logp, out_cnt,
+                           blank, out_blank_lp);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1847,7 +1847,7 @@ int masr_ctc_probs(masr_engine* e, const float* enc_dev, int32_t M, float* probs
     if (!e || !e->finalized) return fail("engine not finalized");
     ENTER(e);
     if (!probs_dev) return fail("probs_dev is null");
-    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+    if (e->cfg.vocab_size > 16384) return fail("vocab_size > 16384 is not supported by the softmax / pruning kernels (one 256-thread workgroup holds a row in registers)");
     return ctc_head(e, enc_dev, M, probs_dev, 1, argmax_dev, maxprob_dev, (hipStream_t)stream);
 }
 
@@ -1883,7 +1883,7 @@ int masr_argmax_rows(masr_engine* e, const float* probs_dev, int32_t M, int32_t 
                      float* maxprob_dev, void* stream) {
     if (!e) return fail("null engine");
     ENTER(e);
-    if (V > 8192) return fail("V > 8192 not supported");
+    if (V > 16384) return fail("V > 16384 not supported (one 256-thread workgroup holds a row in registers)");
     launch_argmax_rows(probs_dev, M, V, argmax_dev, maxprob_dev, (hipStream_t)stream);
     LAUNCHCHK();
     return 0;
@@ -1893,7 +1893,7 @@ int masr_ctc_topk(masr_engine* e, const float* probs_dev, int32_t M, int32_t V, 
                   int32_t* idx_dev, float* logp_dev, int32_t* count_dev, void* stream) {
     if (!e) return fail("null engine");
     ENTER(e);
-    if (V > 8192) return fail("V > 8192 not supported");
+    if (V > 16384) return fail("V > 16384 not supported (one 256-thread workgroup holds a row in registers)");
     if (top_n <= 0) return fail("top_n must be positive");
     launch_topk_prune(probs_dev, M, V, top_n, cutoff_prob, idx_dev, logp_dev, count_dev, -1, nullptr, (hipStream_t)stream);
     LAUNCHCHK();
@@ -1905,7 +1905,7 @@ int masr_ctc_topk_blank(masr_engine* e, const float* probs_dev, int32_t M, int32
                         void* stream) {
     if (!e) return fail("null engine");
     ENTER(e);
-    if (V > 8192) return fail("V > 8192 not supported");
+    if (V > 16384) return fail("V > 16384 not supported (one 256-thread workgroup holds a row in registers)");
     if (top_n <= 0) return fail("top_n must be positive");
     if (blank < 0 || blank >= V || !blank_logp_dev) return fail("masr_ctc_topk_blank: blank id out of range or null output");
     launch_topk_prune(probs_dev, M, V, top_n, cutoff_prob, idx_dev, logp_dev, count_dev, blank, blank_logp_dev,
@@ -1942,7 +1942,7 @@ int masr_beam_search_gpu_lm(masr_engine* e, const int32_t* idx_dev, const float*
     if (!e) return fail("null engine");
     ENTER(e);
     if (B <= 0 || T_stride <= 0) return fail("empty batch");
-    if (e->cfg.vocab_size > 8192 && e->finalized) return fail("vocab_size > 8192 not supported");
+    if (e->cfg.vocab_size > 16384 && e->finalized) return fail("vocab_size > 16384 not supported");
     BeamGpuArgs a{};
     a.cidx = idx_dev; a.clp = logp_dev; a.ccount = count_dev; a.frames = frames_dev;
     a.blank_lp = lm ? blank_logp_dev : nullptr;
@@ -2524,7 +2524,7 @@ static int encode_chunk_squeezeformer(masr_engine* e, hipStream_t s, std::vector
         CHK(ffn(e, s, M, w.f2_s, w.f2_b, w.f2_w1, w.f2_b1, w.f2_w2, w.f2_b2, 1.0f, 1, w.ln4_w, w.ln4_b,
                 l == L - 1 ? e->enc.as<float>() : x));
     }
-    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+    if (e->cfg.vocab_size > 16384) return fail("vocab_size > 16384 is not supported by the softmax / pruning kernels (one 256-thread workgroup holds a row in registers)");
     CHK(ctc_head(e, e->enc.as<float>(), n * T0, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
     for (int i = 0; i < n; ++i) {
         st[i]->offset += T0;
@@ -2661,7 +2661,7 @@ static int encode_chunk_efficient(masr_engine* e, hipStream_t s, std::vector<Str
     }
     CHK(e->enc.ensure((size_t)n * T2 * d * sizeof(float)));
     launch_layernorm(x, e->after_w, e->after_b, e->enc.as<float>(), n * T2, 1e-5f, 0, 0, nullptr, s);
-    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+    if (e->cfg.vocab_size > 16384) return fail("vocab_size > 16384 is not supported by the softmax / pruning kernels (one 256-thread workgroup holds a row in registers)");
     CHK(ctc_head(e, e->enc.as<float>(), n * T2, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
     for (int i = 0; i < n; ++i) {
         st[i]->offset += T0;
@@ -2700,7 +2700,7 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
         if (Tq3 <= 0) return fail("chunk too short");
         CHK(e->enc.ensure((size_t)n * Tq3 * enc_dim(e) * sizeof(float)));
         CHK(ds2_forward(e, s, feats_dev, nullptr, n, Tc, e->enc.as<float>(), st.data(), &Tq));
-        if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+        if (e->cfg.vocab_size > 16384) return fail("vocab_size > 16384 is not supported by the softmax / pruning kernels (one 256-thread workgroup holds a row in registers)");
         CHK(ctc_head(e, e->enc.as<float>(), n * Tq, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
         for (int i = 0; i < n; ++i) st[i]->offset += Tq;
         return 0;
@@ -2764,7 +2764,7 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
     }
     CHK(e->enc.ensure((size_t)M * d * sizeof(float)));
     launch_layernorm(x, e->after_w, e->after_b, e->enc.as<float>(), M, 1e-5f, 0, 0, nullptr, s);
-    if (e->cfg.vocab_size > 8192) return fail("vocab_size > 8192 not supported by the softmax kernel");
+    if (e->cfg.vocab_size > 16384) return fail("vocab_size > 16384 is not supported by the softmax / pruning kernels (one 256-thread workgroup holds a row in registers)");
     CHK(ctc_head(e, e->enc.as<float>(), M, probs_dev, probs_dev ? 1 : 0, argmax_dev, maxprob_dev, s));
     for (int i = 0; i < n; ++i) {
         st[i]->cache_t1 = chunk_window(*st[i], Tq).next_cache_t1;

@@ -221,6 +221,52 @@ def test_v4233_top4_against_reference_fixture(eng4233, oracle_mods):
     assert torch.equal(idx2.reshape(-1), idx) and torch.allclose(mp2.reshape(-1), mp, atol=1e-6)
 
 
+def test_vocabulary_of_12000_against_oracle(oracle_mods):
+    """V = 12 000 (beyond the 8 192 one 256-thread workgroup held in registers until round 6; limit now 16 384): softmax
+    probabilities, fused greedy head (argmax / max probability without materialising the probabilities) and vocabulary pruning
+    against the oracle's CTC head (loss/ctc.py:62-70) on the reference's golden inputs; V = 16 385 is refused with a message"""
+    import ctypes as C
+    from masr_amd.engine import HipEngine
+    from masr_amd.decoders.beam_search_decoder import BeamSearchDecoder
+    oc, weights, golden_inputs = oracle_mods[0], oracle_mods[3], oracle_mods[4]
+    V = 12000
+    sd = weights.conformer_state_dict(0, V)
+    e = HipEngine(sd, vocab_size=V)
+    try:
+        feats, lens = golden_inputs()
+        with torch.no_grad():
+            ref_enc = oc.encoder_full(sd, torch.as_tensor(feats), torch.as_tensor(lens))
+            ref = oc.ctc_probs(sd, ref_enc).numpy()
+        enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1)
+        probs, idx, mp = e.ctc_probs(enc, want_argmax=True)
+        got = probs.cpu().numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-3
+        srt = np.sort(ref, axis=-1)
+        safe = (srt[..., -1] - srt[..., -2]) > 2e-3
+        assert (idx.cpu().numpy().reshape(ref.shape[:2])[safe] == ref.argmax(-1)[safe]).all()
+        assert np.abs(mp.cpu().numpy().reshape(ref.shape[:2]) - ref.max(-1)).max() < 1e-3
+        idx2, mp2 = e.ctc_greedy_frames(enc)                       # fused head: the probabilities are never written
+        assert torch.equal(idx2.reshape(-1), idx) and torch.allclose(mp2.reshape(-1), mp, atol=1e-6)
+        # vocabulary pruning (cutoff_prob 0.99, top 40) of the same rows against numpy on the engine's own probabilities
+        vocab = ['<blank>'] + [chr(0x4e00 + i) for i in range(V - 1)]
+        dec = BeamSearchDecoder(0, 0, 20, 0.99, 40, vocab, language_model_path=None)
+        ci, cl, cc, _, K = dec._candidates(probs[0])
+        for t in range(0, got.shape[1], 7):
+            order = np.argsort(-got[0, t], kind='stable')[:K]
+            cum = np.cumsum(got[0, t][order])
+            n = int(min(K, np.searchsorted(cum, 0.99) + 1))
+            assert cc[t] == n and list(ci[t, :n]) == list(order[:n])
+            assert np.abs(cl[t, :n] - np.log(got[0, t][order[:n]] + np.finfo(np.float32).tiny)).max() < 1e-5
+    finally:
+        e.close()
+    big = HipEngine(weights.conformer_state_dict(0, 16385), vocab_size=16385)
+    try:
+        with pytest.raises(Exception, match='16384'):
+            big.ctc_probs(big.encode_full(dev(feats), dev(lens, torch.int32), -1))
+    finally:
+        big.close()
+
+
 def test_streaming_chunks_against_reference_fixture(eng512, oracle_mods):
     e, sd = eng512
     _, _, _, _, golden_inputs = oracle_mods
