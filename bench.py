@@ -706,7 +706,7 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
     # per pass: 16 / 19 / 29 utterances in three rounds where 2 x 32 take four, the second half empty).  MASR_BENCH_BEAM_PASS
     # overrides (a number, or 'balanced').
     per_pass = os.environ.get('MASR_BENCH_BEAM_PASS', 'balanced' if (lm and word_lm) else '32')
-    per_pass = per_pass if per_pass == 'balanced' else int(per_pass)
+    per_pass = per_pass if per_pass == 'balanced' else ([int(v) for v in per_pass.split(',')] if ',' in per_pass else int(per_pass))
     pass_padded = float(os.environ['MASR_BENCH_BEAM_PADDED']) * 160000 if os.environ.get('MASR_BENCH_BEAM_PADDED') else None      # (x 10 s of audio)
     # three untimed calls: the caching allocator's per-stream pools (probabilities of a pass: 134 MB, allocated on the main
     # stream, restacked on a side stream) reach their steady state only with the third call -- with one warm-up call the first
@@ -739,6 +739,7 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
     pred.predictor.engine.close()
     return {'workload': f'configs[2]: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s), '
                         + ('length-sorted passes of equal padded size (16 / 19 / 29 utterances)' if per_pass == 'balanced' else
+                           f'length-sorted passes of {per_pass} utterances (longest first)' if isinstance(per_pass, list) else
                            f'{-(-64 // per_pass)} length buckets of {per_pass}') + ', ctc_beam_search beam 300 / top-n 40, '
                         + ('alpha 2.2 beta 4.3 with a synthetic 3-gram WORD LM: prefix search on %d host threads' % conf['num_processes']
                            if lm and word_lm else

@@ -140,6 +140,25 @@ def test_length_balanced_shards_and_gather_world2():
         assert sc[i] == 0.25 * i
 
 
+def test_length_balanced_shards_and_gather_world4_uneven():
+    """30 utterances over FOUR gloo ranks (shards of 8 / 8 / 7 / 7: an uneven deal, the gather pads the short shards): every rank
+    ends with all 30 hypotheses in input order -- the 4-GPU point of the scaling sweep, on CPU"""
+    rng = __import__('numpy').random.default_rng(5)
+    lengths = [int(v) for v in rng.integers(32000, 320001, 30)]
+    shards = parallel.length_balanced_shards(lengths, 4)
+    assert sorted(i for s in shards for i in s) == list(range(30))
+    assert sorted(len(s) for s in shards) == [7, 7, 8, 8]
+    tot = [sum(lengths[i] for i in s) for s in shards]
+    assert max(tot) - min(tot) <= max(lengths)               # length-balanced, not just count-balanced
+    res = _spawn(_sharded_worker, 4, lengths)
+    assert res[0] == res[1] == res[2] == res[3]
+    toks, n, sc = res[0]
+    for i, L in enumerate(lengths):
+        want = _fake_tokens(i, L)
+        assert n[i] == len(want) and toks[i][:n[i]] == want and all(v == -1 for v in toks[i][n[i]:])
+        assert sc[i] == 0.25 * i
+
+
 class _Pool:
     """StreamPool interface stand-in: a session's tokens are the byte counts of the chunks it has been fed"""
     vocab = [str(i) for i in range(100)]

@@ -4,7 +4,8 @@
 #     bash tools/scale_sweep.sh [steps] [warmup]        ->  gpurun_out/scale/scale_N.json + scale_summary.json
 # Every N is launched exactly as the driver launches it (python -m torch.distributed.run, one rank per GPU over RCCL).  Checks:
 # the N = 1 value equals the plain `python bench.py` line within 3 %, every line saw all its ranks in the timed region's
-# all-gather (config.rccl_ranks_seen), and the per-rank step times are reported next to the max-over-ranks value.
+# all-gather (config.rccl_ranks_seen), and the per-rank step times (reported next to the max-over-ranks value) lie within 5 % of
+# each other.  Exit code 2 when a check fails; gpurun_out/scale/scale_summary.json holds the SCALE-shaped rows either way.
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 STEPS=${1:-20}; WARM=${2:-5}
@@ -37,6 +38,10 @@ for p in sorted(glob.glob(os.path.join(out, 'scale_*.json')), key=lambda p: int(
     if seen != list(range(n)):
         ok = False
         print(f'N={n}: the timed all-gather saw ranks {seen}, expected {list(range(n))}')
+    per = r['config'].get('ms_per_step_per_rank') or []
+    if len(per) == n and n > 1 and (max(per) - min(per)) > 0.05 * max(per):
+        ok = False
+        print(f'N={n}: per-rank step times spread by more than 5 %: {per}')
 base = next((r['value'] for r in rows if r['n_gpus'] == 1), None)
 for r in rows:
     if base:
