@@ -3,6 +3,7 @@
 // .hip files and is launched on the caller's stream.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -496,16 +497,18 @@ int build_fbank_tables(masr_engine* e) {
 
 // ---- side streams (masr_side_stream) ------------------------------------------------------------------------------------------
 // The library owns the streams its callers run beside the main stream: two for the prefix searches of consecutive passes, one for
-// the per-pass preparation, one for copies.  ONE SET PER DEVICE, created with the first engine on that device and shared by every
-// engine there.  They are created non-blocking at the device's HIGHEST stream priority: the HIP runtime keeps one pool of hardware
-// queues per priority and deals the streams of a pool onto at most GPU_MAX_HW_QUEUES (default 4) queues, so these four have
-// hardware queues of their own whatever else the process has created or will create at normal priority (torch's pools, a server's
-// copy streams, other engines) -- rounds 3-5 borrowed torch.cuda.Stream()s of normal priority, and a search stream that shared a
-// queue with the main stream ran BEHIND the next encoder pass (BASELINE configs[2]: 63 vs 46 ms per call by process history).  The
-// priority also lets a search's 32-64 long-running workgroups take the first compute units that drain instead of queueing behind
-// the rest of an encoder launch.  (hipExtStreamCreateWithCUMask would give a dedicated queue AND a CU reservation, but it can
-// only create streams that synchronise with the NULL stream, which is torch's default stream: every search would serialise with
-// the encoder it is meant to run beside.)
+// the per-pass preparation, one for copies.  ONE SET PER DEVICE, created with the FIRST engine on that device -- a fixed, early place
+// in the process's history -- and shared by every engine there; non-blocking, default priority.  Rounds 3-5 borrowed
+// torch.cuda.Stream()s created wherever a predictor first needed one: the HIP runtime deals streams onto a small pool of hardware
+// queues (GPU_MAX_HW_QUEUES, default 4) at creation, and in a process that had already created its share a search stream landed on
+// the main stream's queue and ran BEHIND the next encoder pass (BASELINE configs[2]: 63 vs 46 ms per call by process history,
+// repaired then by raising GPU_MAX_HW_QUEUES from masr_amd/__init__.py).  Created here they take their queues before anything a
+// server creates later; bench.py measures the configs[2] lines inside its long process and in a fresh one: same numbers.
+// Measured and rejected (round 6, configs[2] sharpened head, passes of 32, ms per call): highest priority 28.9, lowest 28.8,
+// default 24.0 -- a queue of another priority class has a hardware-queue pool of its own (never aliased), but every launch beside
+// it pays for it (the same call WITHOUT its search kernels: 22.3 against 19.7 ms).  MASR_SIDE_PRIORITY=high|low for the A/B.
+// hipExtStreamCreateWithCUMask (a dedicated queue and a CU reservation) can only create streams that synchronise with the NULL
+// stream, which is torch's default stream: every search would serialise with the encoder it is meant to run beside.
 struct SideStreams {
     hipStream_t s[MASR_SIDE_STREAMS] = {};
     bool made = false;
@@ -518,7 +521,10 @@ static int side_streams_of(int dev, SideStreams** out) {
     if (!ss.made) {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (int k = 0; k < MASR_SIDE_STREAMS; ++k) HIPCHK(hipStreamCreateWithPriority(&ss.s[k], hipStreamNonBlocking, greatest));
+        const char* pe = getenv("MASR_SIDE_PRIORITY");          // A/B only
+        const int prio = (pe && pe[0] == 'h') ? greatest : (pe && pe[0] == 'l') ? least : 0;
+        if (pe) fprintf(stderr, "masr side streams: priority %d (device range: least %d .. greatest %d)\n", prio, least, greatest);
+        for (int k = 0; k < MASR_SIDE_STREAMS; ++k) HIPCHK(hipStreamCreateWithPriority(&ss.s[k], hipStreamNonBlocking, prio));
         ss.made = true;
     }
     *out = &ss;

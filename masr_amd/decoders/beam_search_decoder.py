@@ -232,9 +232,8 @@ class BeamSearchDecoder:
             toks = torch.zeros(B, max_len, dtype=torch.int32, device=eng.device)
             lens = torch.zeros(B, dtype=torch.int32, device=eng.device)
             scores = torch.zeros(B, dtype=torch.float32, device=eng.device)
-            if os.environ.get('MASR_DEBUG_SKIP_SEARCH') != '1':      # (timing experiment: everything but the search kernel)
-              check(self._lib.masr_beam_search_gpu_lm(eng.h, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
-                                                      C.c_void_p(cnt.data_ptr()), C.c_void_p(fr.data_ptr()), B, Ts, K,
+            check(self._lib.masr_beam_search_gpu_lm(eng.h, C.c_void_p(idx.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                                    C.c_void_p(cnt.data_ptr()), C.c_void_p(fr.data_ptr()), B, Ts, K,
                                                     self.beam_size, self.blank_id, *self._lm_args(), self._ptr(blp),
                                                     C.c_void_p(toks.data_ptr()), max_len,
                                                     C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),

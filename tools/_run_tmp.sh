@@ -1,7 +1,5 @@
-mkdir -p gpurun_out/r06m
-run() { python bench.py --workload $1 --no-cpu-baseline 2>gpurun_out/r06m/err.txt | tail -1 > gpurun_out/r06m/o.json; python -c "
-import json,sys; d=json.load(open('gpurun_out/r06m/o.json')); print('$1', '$2', d['value'], d['ms_per_step'])"; }
-export MASR_DEBUG_SKIP_SEARCH=1
-for pp in 32 balanced 64 32,24,8 16; do
-MASR_BENCH_BEAM_PASS=$pp run squeezeformer_b64_beam_sharp "no-search $pp"
-done
+mkdir -p gpurun_out/r06n
+for w in squeezeformer_b64_beam squeezeformer_b64_beam_sharp; do python bench.py --workload $w --no-cpu-baseline 2>gpurun_out/r06n/$w.err | tail -1 > gpurun_out/r06n/$w.json; python -c "
+import json,sys; d=json.load(open('gpurun_out/r06n/$w.json')); print('fresh process $w', d['value'], d['ms_per_step'])"; done
+python bench.py > gpurun_out/r06n/bench.json 2> gpurun_out/r06n/bench.err; python -c "
+import json; d=json.loads(open('gpurun_out/r06n/bench.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac']); e=d['extra']; print({k:(e[k].get('ms_per_step'), e[k].get('value')) if isinstance(e[k],dict) else e[k] for k in e})"
