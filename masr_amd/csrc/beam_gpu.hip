@@ -357,10 +357,46 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         const int o = cur * beam, o2 = (cur ^ 1) * beam;
         if (a.narrow && n * cnt <= NW_ENT) {
             // ================= narrow frame: waves 0 .. NW_WAVES-1 work, the others wait ======================================
+            // scorer-state table of the frame: next to ln P_LM(c | context) the table fill records m and the backoffs of the context
+            // EXTENDED by c (lm_cond_next: they come out of the same probes), so a surviving extension takes its scorer state from
+            // LDS instead of probing the model again (lm_state_of: 2 - 4 more dependent loads per new prefix, at the end of the
+            // frame's critical path).  STW words per (context, candidate) in the wide step's entry-key area, idle in narrow frames.
+            // ALL sixteen waves fill it (the waiting ones wake up between barriers 2 and 3): one probe round trip for up to 1024
+            // (context, candidate) pairs.
+            constexpr int STW = ORD > 1 ? ORD - 1 : 1;
+            float* lmst = reinterpret_cast<float*>(ekeys);
+            const int ucap_n = min(ucap, (beam * K) / (STW * max(cnt, 1)));
+            auto fill_scorer_table = [&]() {
+                const int nu = min(misc[5], ucap_n);
+                for (int e = tid; e < nu * cnt; e += BS_THREADS) {
+                    const int uq = e / cnt, k = e - uq * cnt;
+                    const int craw = c_idx[k];
+                    float v = LM_OOV_SCORE;
+                    if (!(craw >> 30)) {
+                        const int p = urep[uq];
+                        LmState sp;
+                        sp.ctx = lv_ctx[o + p];
+                        sp.m = lv_m[o + p] & 255;
+                        sp.oov = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sp.bo[q] = lv_bo[4 * (o + p) + q];
+                        int m2;
+                        float bo2[STW];
+                        v = lm_cond_next<(ORD > 0 ? ORD : 1)>(a.lm, sp, craw, c_uni[k], c_ubo[k], &m2, bo2);
+                        lmst[e * STW] = __int_as_float(m2);
+#pragma unroll
+                        for (int q = 1; q < STW; ++q) lmst[e * STW + q] = bo2[q];
+                    }
+                    lmtab[e] = v;
+                }
+            };
             if (wave >= NW_WAVES) {
                 nx_cnt = nx2_cnt;
                 if (t + 2 < T) nx2_cnt = min(a.ccount[row0 + t + 2 + vz], K);
-                for (int b = 0; b < NW_BARRIERS; ++b) __syncthreads();
+                __syncthreads();
+                __syncthreads();
+                if (lm_cache) fill_scorer_table();
+                for (int b = 2; b < NW_BARRIERS; ++b) __syncthreads();
                 n = misc[6];
                 pool_count = misc[7];
                 cur ^= 1;
@@ -377,15 +413,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             BS_TICK(6);
             // ---- N1. string identities -> hash, scorer contexts -> rows, worst live score ------------------------------------
             const int blank_k = misc[0];
-            // scorer-state table of the frame: next to ln P_LM(c | context) the table fill records m and the backoffs of the context
-            // EXTENDED by c (lm_cond_next: they come out of the same probes), so a surviving extension takes its scorer state from
-            // LDS instead of probing the model again (lm_state_of: 2 - 4 more dependent loads per new prefix, at the end of the
-            // frame's critical path).  STW words per (context, candidate) in the wide step's entry-key area, idle in narrow frames.
-            constexpr int STW = ORD > 1 ? ORD - 1 : 1;
-            float* lmst = reinterpret_cast<float*>(ekeys);
-            const int ucap_n = min(ucap, (beam * K) / (STW * max(cnt, 1)));
             const int i0 = NW_PPT * tid;                  // this thread's live prefixes: i0 .. i0 + NW_PPT - 1
             unsigned long long my_ek[NW_PPT];
+            bool owner[NW_PPT];
+            int own_slot[NW_PPT];
+#pragma unroll
+            for (int j = 0; j < NW_PPT; ++j) { owner[j] = false; own_slot[j] = 0; }
             unsigned kmin = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 0; j < NW_PPT; ++j) {
@@ -410,15 +443,33 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                             unsigned hc = (unsigned)((ek * 0x9E3779B97F4A7C15ull) >> 55);        // 9 bits
                             while (true) {
                                 const unsigned long long old = atomicCAS(&ckey[hc], 0ull, ek);
-                                if (old == 0ull) {
-                                    const int uid = atomicAdd(&misc[5], 1);
-                                    cuid[hc] = uid < ucap_n ? uid : -1;
-                                    if (uid < ucap_n) urep[uid] = i;
+                                if (old == 0ull) {       // first prefix with this context: it owns the table row
+                                    owner[j] = true;
+                                    own_slot[j] = (int)hc;
                                     break;
                                 }
                                 if (old == ek) break;
                                 hc = (hc + 1) & 511;
                             }
+                        }
+                    }
+                }
+            }
+            if (lm_cache) {
+                // table rows of the new contexts: ONE counter update per wave (the owners' ranks come from the ballot) instead of one
+                // returning atomic per context on a single LDS word
+#pragma unroll
+                for (int j = 0; j < NW_PPT; ++j) {
+                    const unsigned long long om = __ballot(owner[j]);
+                    if (om) {
+                        const int leader = __ffsll((long long)om) - 1;
+                        int base = 0;
+                        if (lane == leader) base = atomicAdd(&misc[5], __popcll(om));
+                        base = __builtin_amdgcn_readlane(base, leader);
+                        if (owner[j]) {
+                            const int uid = base + __popcll(om & ((1ull << lane) - 1ull));
+                            cuid[own_slot[j]] = uid < ucap_n ? uid : -1;
+                            if (uid < ucap_n) urep[uid] = i0 + j;
                         }
                     }
                 }
@@ -464,30 +515,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                     }
                 }
             }
-            if (lm_cache) {
-                const int nu = min(misc[5], ucap_n);
-                for (int e = tid; e < nu * cnt; e += NW_T) {
-                    const int uq = e / cnt, k = e - uq * cnt;
-                    const int craw = c_idx[k];
-                    float v = LM_OOV_SCORE;
-                    if (!(craw >> 30)) {
-                        const int p = urep[uq];
-                        LmState sp;
-                        sp.ctx = lv_ctx[o + p];
-                        sp.m = lv_m[o + p] & 255;
-                        sp.oov = 0;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) sp.bo[q] = lv_bo[4 * (o + p) + q];
-                        int m2;
-                        float bo2[STW];
-                        v = lm_cond_next<(ORD > 0 ? ORD : 1)>(a.lm, sp, craw, c_uni[k], c_ubo[k], &m2, bo2);
-                        lmst[e * STW] = __int_as_float(m2);
-#pragma unroll
-                        for (int q = 1; q < STW; ++q) lmst[e * STW + q] = bo2[q];
-                    }
-                    lmtab[e] = v;
-                }
-            }
+            if (lm_cache) fill_scorer_table();
             __syncthreads();                                                                                  // (3)
             BS_TICK(8);
             // ---- N3. extensions: NW_EPT consecutive entries e = p * cnt + k per thread, keys stay in registers ---------------
@@ -901,11 +929,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 int* hp = hist + pass * 256;
                 hist_add(hp, (tmax & mask) == prefix, (tmax >> shift) & 255);
                 __syncthreads();
-                int bin, rem;
-                pick_bin(hp, need, bin, rem);
+                int bin, rem, total, binc;
+                pick_bin_tot(hp, need, bin, rem, total, binc);
                 prefix |= (unsigned)bin << shift;
                 mask |= 255u << shift;
                 need = rem;
+                if (rem == binc) break;          // the picked bin is needed whole: exactly `beam` maxima are >= prefix already
             }
             low = max(prefix, NEG + 1);                                 // >= beam entries are >= low
         }
@@ -943,11 +972,16 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 for (int i = 0; i < NPT; ++i)
                     if (i * BS_THREADS < nsurv) hist_add(hp, ke[i] != 0 && (ke[i] & mask) == prefix, (ke[i] >> shift) & 255);
                 __syncthreads();
-                int bin, rem;
-                pick_bin(hp, need, bin, rem);
+                int bin, rem, total, binc;
+                pick_bin_tot(hp, need, bin, rem, total, binc);
                 prefix |= (unsigned)bin << shift;
                 mask |= 255u << shift;
                 need = rem;
+                if (rem == binc && pass < 3) {   // the picked bin is needed whole: every key at or above it stays, no tie to break
+                    prefix -= 1u;
+                    need = 0;
+                    break;
+                }
             }
             thr = prefix;
             need_eq = need;
