@@ -215,12 +215,13 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     int* lv_m = reinterpret_cast<int*>(lv_bo + 8 * beam);                // [2][beam] m | oov << 8
     // (the scorer's 14 words per live prefix exist only when a language model is bound: an LM-free beam 500 x 40 fits without them)
     int* pu = lv_m + 2 * beam;                                           // [beam] row of the per-frame scorer table of the prefix's context, or -1
-    int* c_idx = use_lm ? pu + beam + (beam & 1) : reinterpret_cast<int*>(lv_ctx);   // [BS_KMAX]; bit 30 set = unknown to the language model
+    // candidate arrays of a frame, TWO sets: a narrow frame stages the candidates of the next narrow frame while its own are still in use
+    int* c_idx0 = use_lm ? pu + beam + (beam & 1) : reinterpret_cast<int*>(lv_ctx);   // [2][BS_KMAX]; bit 30 set = unknown to the language model
                                                                          // (+ beam & 1: the histogram area behind it holds 64-bit keys)
-    float* c_lp = reinterpret_cast<float*>(c_idx + BS_KMAX);             // [BS_KMAX]
-    float* c_uni = c_lp + BS_KMAX;                                       // [BS_KMAX] ln P_LM(candidate) (unigram), per frame
-    float* c_ubo = c_uni + BS_KMAX;                                      // [BS_KMAX] ln backoff of the candidate's unigram
-    int* hist = reinterpret_cast<int*>(c_ubo + BS_KMAX);                 // [7][256]: one per radix pass of a step
+    float* c_lp0 = reinterpret_cast<float*>(c_idx0 + 2 * BS_KMAX);       // [2][BS_KMAX]
+    float* c_uni0 = c_lp0 + 2 * BS_KMAX;                                 // [2][BS_KMAX] ln P_LM(candidate) (unigram), per frame
+    float* c_ubo0 = c_uni0 + 2 * BS_KMAX;                                // [2][BS_KMAX] ln backoff of the candidate's unigram
+    int* hist = reinterpret_cast<int*>(c_ubo0 + 2 * BS_KMAX);            // [7][256]: one per radix pass of a step
     int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
     int* misc = wsum + (6 + NPT) * BS_WAVES;                                         // [8]: 0 blank_k, 1 sel_bin, 2 need
     unsigned short* slist = reinterpret_cast<unsigned short*>(misc + 8 + 32);  // [beam * K] surviving extension entries
@@ -300,16 +301,17 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         }                                                                                                        \
     } while (0)
     // stage the frame in nx_* (wave 0): candidates, blank index, scorer flags / unigrams -> LDS; then advance the pipeline
-#define BS_STAGE_FRAME() do {                                                                                    \
+#define BS_STAGE_FRAME(ci_, cl_, cu_, cb_, cntv_, tt_) do {                                                      \
+        const int cnt_ = (cntv_);                                                                                \
         if (wave == 0) {                                                                                         \
-            const bool isb = lane < cnt && nx_c == a.blank;                                                      \
+            const bool isb = lane < cnt_ && nx_c == a.blank;                                                     \
             const unsigned long long bm = __ballot(isb);                                                         \
-            if (lane < cnt) {                                                                                    \
+            if (lane < cnt_) {                                                                                   \
                 /* the scorer's known-word flag of this candidate rides in bit 30 of its index: one lookup per frame and */ \
                 /* candidate instead of one per (prefix, candidate) pair */                                      \
                 const bool unk = use_lm && !(nx_c >= 0 && nx_c < a.lm.n_words && nx_kn);                         \
-                c_idx[lane] = nx_c | (unk ? (1 << 30) : 0);                                                      \
-                c_lp[lane] = nx_lp;                                                                              \
+                (ci_)[lane] = nx_c | (unk ? (1 << 30) : 0);                                                      \
+                (cl_)[lane] = nx_lp;                                                                             \
                 if (use_lm) {                             /* the candidate's unigram: one lookup per frame and candidate */ \
                     float up = LM_OOV_SCORE, ub = 0.f;                                                           \
                     if (!unk) {                                                                                  \
@@ -317,8 +319,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                         if (nx_uk0 == key) { up = nx_up0; ub = nx_ub0; }                                         \
                         else if (nx_uk0 != 0ull) lm_find(a.lm, key, &up, &ub);                                   \
                     }                                                                                            \
-                    c_uni[lane] = up;                                                                            \
-                    c_ubo[lane] = ub;                                                                            \
+                    (cu_)[lane] = up;                                                                            \
+                    (cb_)[lane] = ub;                                                                            \
                 }                                                                                                \
             }                                                                                                    \
             if (lane == 0) {                                                                                     \
@@ -329,8 +331,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             }                                                                                                    \
         }                                                                                                        \
         nx_cnt = nx2_cnt; nx_c = nx2_c; nx_lp = nx2_lp; nx_blp = nx2_blp;                                        \
-        if (t + 1 < T) BS_PROBE_UNIGRAM();                                                                       \
-        if (t + 2 < T) BS_LOAD_FRAME(t + 2, nx2_cnt, nx2_c, nx2_lp, nx2_blp);                                    \
+        if ((tt_) + 1 < T) BS_PROBE_UNIGRAM();                                                                   \
+        if ((tt_) + 2 < T) BS_LOAD_FRAME((tt_) + 2, nx2_cnt, nx2_c, nx2_lp, nx2_blp);                            \
     } while (0)
     if (T > 0) {
         BS_LOAD_FRAME(0, nx_cnt, nx_c, nx_lp, nx_blp);
@@ -345,6 +347,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     long long tick_ = prof ? clock64() : 0;
     __syncthreads();
 
+    bool prepared = false;
+    int staged_cnt = 0, cpar = 0;
     for (int t = 0; t < T; ++t) {
         // The thread's indices are made opaque once per frame: every LDS address of the step is then recomputed from them (one or
         // two VALU instructions) instead of being hoisted out of the frame loop, kept alive across all its phases and SPILLED -- a
@@ -353,7 +357,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         asm volatile("" : "+v"(tid_), "+v"(my_p_), "+v"(my_g_));
         const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int my_p = my_p_, my_g = my_g_;
-        const int cnt = nx_cnt;
+        // `prepared`: the previous (narrow) frame already cleared this frame's tables and staged its candidates into the other set
+        const int cnt = prepared ? staged_cnt : nx_cnt;
+        int* c_idx = c_idx0 + cpar * BS_KMAX;
+        float* c_lp = c_lp0 + cpar * BS_KMAX;
+        float* c_uni = c_uni0 + cpar * BS_KMAX;
+        float* c_ubo = c_ubo0 + cpar * BS_KMAX;
         const int o = cur * beam, o2 = (cur ^ 1) * beam;
         if (a.narrow && n * cnt <= NW_ENT) {
             // ================= narrow frame: waves 0 .. NW_WAVES-1 work, the others wait ======================================
@@ -391,25 +400,37 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 }
             };
             if (wave >= NW_WAVES) {
-                nx_cnt = nx2_cnt;
-                if (t + 2 < T) nx2_cnt = min(a.ccount[row0 + t + 2 + vz], K);
-                __syncthreads();
-                __syncthreads();
+                // (the waiting waves mirror the working waves' count pipeline: a frame is staged once, by THIS frame's N0 or by the
+                //  tail of the previous narrow frame)
+                if (!prepared) {
+                    nx_cnt = nx2_cnt;
+                    if (t + 2 < T) nx2_cnt = min(a.ccount[row0 + t + 2 + vz], K);
+                    __syncthreads();                                                                          // (1)
+                }
+                __syncthreads();                                                                              // (2)
                 if (lm_cache) fill_scorer_table();
                 for (int b = 2; b < NW_BARRIERS; ++b) __syncthreads();
                 n = misc[6];
                 pool_count = misc[7];
                 cur ^= 1;
+                prepared = t + 1 < T && n * nx_cnt <= NW_ENT;
+                if (prepared) {
+                    staged_cnt = nx_cnt;
+                    nx_cnt = nx2_cnt;
+                    if (t + 3 < T) nx2_cnt = min(a.ccount[row0 + t + 3 + vz], K);
+                    cpar ^= 1;
+                }
                 continue;
             }
             if (prof) ++pcl[5];
             // ---- N0. tables, candidates, prefetch ------------------------------------------------------------------------
-            for (int i = tid; i < BS_HASH; i += NW_T) hkey[i] = 0ull;
-            if (lm_cache)
-                for (int i = tid; i < 512; i += NW_T) ckey[i] = 0ull;
-            for (int i = tid; i < n; i += NW_T) { rep[i] = -INFINITY; ext[i] = -INFINITY; head[i] = -1; }
-            BS_STAGE_FRAME();
-            __syncthreads();                                                                                  // (1)
+            if (!prepared) {
+                for (int i = tid; i < BS_HASH; i += NW_T) hkey[i] = 0ull;
+                if (lm_cache)
+                    for (int i = tid; i < 512; i += NW_T) ckey[i] = 0ull;
+                BS_STAGE_FRAME(c_idx, c_lp, c_uni, c_ubo, cnt, t);
+                __syncthreads();                                                                              // (1)
+            }
             BS_TICK(6);
             // ---- N1. string identities -> hash, scorer contexts -> rows, worst live score ------------------------------------
             const int blank_k = misc[0];
@@ -425,6 +446,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 const int i = i0 + j;
                 my_ek[j] = 0ull;
                 if (i < n) {
+                    rep[i] = -INFINITY; ext[i] = -INFINITY; head[i] = -1;       // (first touched behind barrier 2)
                     const unsigned long long key = lv_hid[o + i];
                     unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
                     while (atomicCAS(&hkey[h], 0ull, key) != 0ull) h = (h + 1) & (BS_HASH - 1);
@@ -687,10 +709,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 }
             }
             {
-                // the selected extensions, in entry order, as a dense list (the select's histogram area is free behind the scan's
-                // barrier): the new prefixes are then built one per thread instead of one divergent pass per block position
-                int* sel_pe = hist;
-                unsigned* sel_key = reinterpret_cast<unsigned*>(hist + 512);
+                // the selected extensions, in entry order, as a dense list: the new prefixes are then built one per thread instead of
+                // one divergent pass per block position
+                int* sel_pe = head;                                     // (the children lists are dead behind the extension phase;
+                unsigned* sel_key = reinterpret_cast<unsigned*>(next);  //  the select's histogram area is cleared for the next frame below)
                 int gb = exE & 0xffff, eb = exE >> 16;
 #pragma unroll
                 for (int j = 0; j < NW_EPT; ++j) {
@@ -744,6 +766,19 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             n = n_exist + n_new;
             cur ^= 1;
             if (tid == 0) { misc[6] = n; misc[7] = pool_count; }
+            // the next frame is narrow too: its tables are cleared and its candidates staged HERE (into the other candidate set;
+            // the string hash, the context hash and the select's tables are dead by now), so it starts at N1 -- one barrier and
+            // the staging's latency less per frame
+            prepared = t + 1 < T && n * nx_cnt <= NW_ENT;
+            if (prepared) {
+                for (int i = tid; i < BS_HASH; i += NW_T) hkey[i] = 0ull;
+                if (lm_cache)
+                    for (int i = tid; i < 512; i += NW_T) ckey[i] = 0ull;
+                staged_cnt = nx_cnt;
+                cpar ^= 1;
+                BS_STAGE_FRAME(c_idx0 + cpar * BS_KMAX, c_lp0 + cpar * BS_KMAX, c_uni0 + cpar * BS_KMAX, c_ubo0 + cpar * BS_KMAX,
+                               staged_cnt, t + 1);
+            }
             __syncthreads();                                                                                  // (11)
             BS_TICK(13);
             continue;
@@ -752,7 +787,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         for (int i = tid; i < 7 * 256; i += BS_THREADS) hist[i] = 0;
         if (tid < n) { rep[tid] = -INFINITY; ext[tid] = -INFINITY; head[tid] = -1; }
         if (tid < BS_HASH) hkey[tid] = 0ull;
-        BS_STAGE_FRAME();
+        BS_STAGE_FRAME(c_idx, c_lp, c_uni, c_ubo, cnt, t);
+        prepared = false;
         __syncthreads();
         // ---- 1. live children lists; blank term ------------------------------------------------------------------
         const int blank_k = misc[0];
@@ -1124,7 +1160,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 }
 
 size_t beam_gpu_lds_bytes(int beam, int K, bool use_lm) {
-    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 15 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 4 * BS_KMAX * 4 + 7 * 256 * 4 +
+    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 15 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 8 * BS_KMAX * 4 + 7 * 256 * 4 +
            (6 + 32) * BS_WAVES * 4 + (8 + 32) * 4 + 128;
 }
 

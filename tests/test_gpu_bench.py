@@ -77,33 +77,6 @@ def test_contract_step_texts_are_the_steps_own(force_dist, monkeypatch):
             torch.distributed.destroy_process_group()
 
 
-_HISTORY_PROBE = r'''
-import json, os, sys, types
-sys.path.insert(0, %(root)r)
-import torch
-pre = int(sys.argv[1])
-keep = []
-if pre:                                 # a server that touched the GPU first: torch streams with work on them, then two engines + a pool
-    keep = [torch.cuda.Stream() for _ in range(pre)]
-    x = torch.ones(1 << 20, device='cuda')
-    for s in keep:
-        with torch.cuda.stream(s):
-            x = x * 1.0
-    torch.cuda.synchronize()
-import bench
-if pre:
-    from masr_amd.serving import StreamPool
-    e1 = bench.make_engine('conformer', 0)
-    e2 = bench.make_engine('efficient_conformer', 0)
-    p1 = bench.facade('conformer', 'ctc_greedy', 0)
-    pool = StreamPool(p1)
-    keep += [e1, e2, p1, pool]
-args = types.SimpleNamespace(steps=10, warmup=3)
-r = bench.extra_squeezeformer_beam(args, 0, 1, 0, sharp=True)
-print('RESULT ' + json.dumps({'ms': r['ms_per_step']}))
-'''
-
-
 def test_beam_call_time_does_not_depend_on_what_the_process_created_before():
     """BASELINE configs[2] (sharpened head) through predict_batch with the GPU prefix search: in a process that starts with it, and
     in a process that first created twelve busy torch streams, two engines, a predictor and a stream pool (a server's history).
@@ -115,8 +88,8 @@ def test_beam_call_time_does_not_depend_on_what_the_process_created_before():
     env.pop('GPU_MAX_HW_QUEUES', None)
     ms = {}
     for pre in (0, 12):
-        p = subprocess.run([sys.executable, '-c', _HISTORY_PROBE % {'root': ROOT}, str(pre)], env=env, capture_output=True, text=True,
-                           timeout=900)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'beam_history_probe.py'), str(pre)], env=env,
+                           capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [ln for ln in p.stdout.splitlines() if ln.startswith('RESULT ')]
         ms[pre] = json.loads(line[-1][7:])['ms']

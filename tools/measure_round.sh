@@ -1,5 +1,5 @@
 #!/bin/bash
-# One measurement pass of a build on the GPU box (rounds 4, 5): GPU test suite, the default bench line, rocprofv3 kernel traces of
+# One measurement pass of a build on the GPU box (rounds 4 - 6): GPU test suite, the default bench line, rocprofv3 kernel traces of
 # EVERY BASELINE config's workload (+ the B = 1 pass), PMC passes (FETCH_SIZE / WRITE_SIZE for the contract step; matrix-pipe busy
 # for the contract step, the Efficient-Conformer passes, the Squeezeformer + beam search call and the 128-stream pool), summaries
 # next to them.      usage (from the repo root, through gpurun):  bash tools/measure_round.sh gpurun_out/r05m
@@ -31,7 +31,21 @@ rocprofv3 --pmc $MF --kernel-trace -d $R/$D/pmS -o m -- python $R/bench.py --wor
 rocprofv3 --kernel-trace --stats -d $R/$D/ktb -o b -- python $R/tools/b1_ab.py trace > $R/$D/ktb.log 2>&1
 cd $R
 python tools/serve_bench.py > $D/serving.json 2> $D/serving.err
-for o in 0 3 5; do python tools/beam_profile.py 498 4233 300 $o 2>&1 | tail -2; done > $D/beam_profile.txt 2>&1
+# the prefix search alone: flat posteriors (40 candidates per frame: the wide step) and a sharpened head (3.7: the narrow step),
+# without / with the scorer; the narrow step off (masr_debug_set key 37 through BEAM_PROFILE_NARROW=0); 64 searches side by side
+{ for sc in 1 14; do for o in 0 3 5; do python tools/beam_profile.py 498 4233 300 $o 1 1 $sc 2>&1 | grep -v amdgpu | tail -4; done; done
+  echo "== narrow step off (every frame on the wide step), sharpened head"
+  for o in 0 3; do BEAM_PROFILE_NARROW=0 python tools/beam_profile.py 498 4233 300 $o 1 1 14 2>&1 | grep -v amdgpu | tail -2; done
+  echo "== 64 utterances side by side, sharpened head, 3-gram"
+  BEAM_PROFILE_B=64 python tools/beam_profile.py 498 4233 300 3 1 1 14 2>&1 | grep -v amdgpu | tail -1; } > $D/beam_profile.txt 2>&1
+# the beam call after a server-like process history against a cold process (tests/test_gpu_bench.py asserts within 10 %)
+{ python tools/beam_history_probe.py 0 2>/dev/null | grep RESULT; python tools/beam_history_probe.py 12 2>/dev/null | grep RESULT; } > $D/beam_history.txt
+# GPU-side time lines of one configs[2] call (rocprofv3 kernel trace): searches against the encoder passes
+for w in squeezeformer_b64_beam_sharp squeezeformer_b64_beam; do
+  ( cd /tmp; rocprofv3 --kernel-trace -d $R/$D/ktl -o t -- python $R/bench.py --workload $w --no-cpu-baseline --steps 4 > $R/$D/ktl_$w.log 2>&1 )
+  python tools/beam_gpu_timeline.py $(find $D/ktl -name "*.db") 2 2 > $D/beam_timeline_$w.txt 2>&1; rm -rf $D/ktl
+done
+python tools/sqz_skip_ab.py 2>&1 | grep -v amdgpu | grep "skip padded" > $D/sqz_skip_ab.txt
 python tools/chunk_lat.py build 2>&1 | tail -1 > $D/chunk_lat.txt
 python tools/stream_host_profile.py 128 3 2>&1 | grep -E "streams:|masr_pool_step" > $D/pool_host.txt
 python tools/stream_host_profile.py 16 3 2>&1 | grep -E "streams:|masr_pool_step" >> $D/pool_host.txt

@@ -22,7 +22,7 @@ ref = None
 ONLY = os.environ.get('SQZ_AB_ONLY')          # e.g. '1:64' -> one configuration (for a rocprofv3 trace)
 for skip in ((int(ONLY.split(":")[0]),) if ONLY else (7, 0)):
     eng.lib.masr_debug_set(eng.h, 38, skip)
-    for mode in ((int(ONLY.split(':')[1]),) if ONLY else ('balanced', 32, 64, [24, 40])):
+    for mode in ((int(ONLY.split(':')[1]),) if ONLY else ('balanced', 32, 64)):
         for _ in range(2):
             res = pred.predict_batch(audio, batch_size=mode)
         torch.cuda.synchronize()
