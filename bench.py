@@ -62,7 +62,7 @@ def conformer_gflop(T, t2=None, vocab=VOCAB, d=256, dff=2048, layers=12, k=15, p
 
 def workload_roofline(gflop, ms, note):
     """whole-workload roofline block of a secondary config: algorithmic GFLOP of one step / its wall time, against the fp32 MFMA
-    peak (the per-kernel evidence of these workloads is under profiles/r05_*_kernel_stats.txt)"""
+    peak (the per-kernel evidence of these workloads is under profiles/r06_*_kernel_stats.txt)"""
     ach = gflop / ms                                               # GFLOP / ms = TFLOP/s
     return {'bound': 'mfma', 'scope': 'whole step (wall time, host framing included)', 'achieved': round(ach, 2),
             'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
@@ -148,7 +148,7 @@ ROOFLINE_KERNELS = [
 def committed_traffic(fragment):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this build (profiles/rNN_hbm_traffic.json:
     FETCH_SIZE with the gfx950 correction + WRITE_SIZE); (bytes, file) or (None, None)."""
-    for name in ('r05_hbm_traffic.json', 'r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+    for name in ('r06_hbm_traffic.json', 'r05_hbm_traffic.json', 'r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
         try:
             k = json.load(open(os.path.join(ROOT, 'profiles', name)))['kernels']
             for key, v in k.items():
@@ -754,8 +754,8 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
             'call_ms': {'p50': round(float(np.percentile(calls, 50)) * 1e3, 3), 'min': round(min(calls) * 1e3, 3),
                         'max': round(max(calls) * 1e3, 3)},
             'roofline': workload_roofline(GFLOP_SQUEEZEFORMER_B64, dt * 1e3 / steps,
-                                          'SURVEY 8(d): 1.43 TFLOP of useful encoder work in the 64 utterances; the call is bound by '
-                                          'the prefix search of its longest utterance, not by the encoder (DESIGN 9)')}
+                                          'SURVEY 8(d): 1.43 TFLOP of useful encoder work in the 64 utterances; with a sharpened head the call is its two '
+                                          'encoder passes + the second search (3.5 ms); with flat posteriors the first search (DESIGN 5, 9)')}
 
 
 def extra_squeezeformer_greedy(args, rank, world, local):
