@@ -609,6 +609,24 @@ void launch_export_cnn(const float* cache, float* out, int L, int pad, int d, hi
     hipLaunchKernelGGL(export_cnn_kernel, dim3(L), dim3(256), 0, s, cache, out, pad, d);
 }
 
+// wave-wide max / min with the result in every lane: an inclusive DPP scan (row shifts + row broadcasts, lanes without a source keep
+// their own value) whose last lane holds the reduction
+__device__ __forceinline__ float wave_max_f32_dpp(float v) {
+#define MASR_DPP_MAXF(ctrl, rows) \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), (ctrl), (rows), 0xf, false)))
+    MASR_DPP_MAXF(0x111, 0xf); MASR_DPP_MAXF(0x112, 0xf); MASR_DPP_MAXF(0x114, 0xf); MASR_DPP_MAXF(0x118, 0xf);
+    MASR_DPP_MAXF(0x142, 0xa); MASR_DPP_MAXF(0x143, 0xc);
+#undef MASR_DPP_MAXF
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_min_i32_dpp(int v) {
+#define MASR_DPP_MINI(ctrl, rows) v = min(v, __builtin_amdgcn_update_dpp(v, v, (ctrl), (rows), 0xf, false))
+    MASR_DPP_MINI(0x111, 0xf); MASR_DPP_MINI(0x112, 0xf); MASR_DPP_MINI(0x114, 0xf); MASR_DPP_MINI(0x118, 0xf);
+    MASR_DPP_MINI(0x142, 0xa); MASR_DPP_MINI(0x143, 0xc);
+#undef MASR_DPP_MINI
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // ------------------------------------------------------------------------------------------
 // Vocabulary pruning for the CTC prefix beam search (get_pruned_log_probs of the third-party
 // ctc_beam_search_decoder: sort descending, keep the shortest prefix whose cumulative probability reaches
@@ -642,11 +660,11 @@ __global__ __launch_bounds__(256) void topk_prune_kernel(const float* __restrict
             const int j = threadIdx.x + i * 256;
             if (v[i] > m) { m = v[i]; mi = j; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float om = __shfl_xor(m, o, 64);
-            const int oi = __shfl_xor(mi, o, 64);
-            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        {   // wave arg-max (value desc, index asc) on DPP row shifts / broadcasts: twelve VALU instructions where the shuffle form was
+            // twelve ds_bpermute round trips per round -- this kernel sits between a pass's CTC head and its prefix search
+            const float wm = wave_max_f32_dpp(m);
+            mi = wave_min_i32_dpp(m == wm ? mi : 0x7fffffff);
+            m = wm;
         }
         __syncthreads();
         if (lane == 0) { red_v[wave] = m; red_i[wave] = mi; }
