@@ -37,7 +37,8 @@ typedef struct masr_config {
     int32_t causal;          /* `streaming: True` => causal conv + dynamic-chunk masks (model.py:37-42) */
     int32_t max_pos;         /* positional table length (reference max_len = 5000, embedding.py:14)  */
     int32_t device_id;
-    int32_t reserved[5];
+    int32_t reserved[5];     /* squeezeformer: [0] reduce_idx, [1] recover_idx; efficient_conformer: [0] stride layer, [1] grouped layers,
+                                [2] group size; conformer: [0] = 1 -> cnn_module_norm: batch_norm (convolution.py:60-67; full-context only) */
 } masr_config;
 
 const char* masr_last_error(void);

@@ -275,6 +275,7 @@ struct masr_engine {
           *tr_pw_b = nullptr, *rec_w = nullptr, *rec_b = nullptr;
     int reduce_idx = -1, recover_idx = -1;
     int stride_idx = -1, n_group_layers = 0, group_size = 3;   // Efficient-Conformer (model_kind 2)
+    bool conv_bn = false;            // Conformer with cnn_module_norm: batch_norm (cfg.reserved[0] = 1): LayerW::cln_w / cln_b hold the folded scale / shift
     PinnedStage stage;
     DevBuf qplanes, attp, cnnptrs, ffpart;                                      // planar q|k|v and attention output, [B][Tpad][256]
     // fbank tables
@@ -568,6 +569,7 @@ int masr_create(const masr_config* cfg, masr_engine** out) {
     e->cfg = *cfg;
     if (e->cfg.max_pos <= 0) e->cfg.max_pos = 5000;
     e->reduce_idx = cfg->model_kind == 1 ? cfg->reserved[0] : -1;
+    e->conv_bn = cfg->model_kind == 0 && cfg->reserved[0] == 1;
     e->recover_idx = cfg->model_kind == 1 ? cfg->reserved[1] : -1;
     if (cfg->model_kind == 2) {
         e->stride_idx = cfg->reserved[0];
@@ -740,7 +742,23 @@ int masr_finalize(masr_engine* e, void* stream) {
         CHK(ln("norm_conv", &w.ln_conv_w, &w.ln_conv_b));
         CHK(ln("norm_ff", &w.ln_ff_w, &w.ln_ff_b));
         CHK(ln("norm_final", &w.ln_fin_w, &w.ln_fin_b));
-        CHK(ln("conv_module.norm", &w.cln_w, &w.cln_b));
+        if (e->conv_bn) {
+            // cnn_module_norm: batch_norm (conformer/convolution.py:60-67): eval-mode BatchNorm1d folded into y = x * scale + shift
+            const HostTensor *tw, *tb, *tm, *tv;
+            CHK(get(e, p + "conv_module.norm.weight", {d}, &tw));
+            CHK(get(e, p + "conv_module.norm.bias", {d}, &tb));
+            CHK(get(e, p + "conv_module.norm.running_mean", {d}, &tm));
+            CHK(get(e, p + "conv_module.norm.running_var", {d}, &tv));
+            std::vector<float> sc(d), sh(d);
+            for (int c = 0; c < d; ++c) {
+                sc[c] = tw->v[c] / sqrtf(tv->v[c] + 1e-5f);
+                sh[c] = tb->v[c] - tm->v[c] * sc[c];
+            }
+            CHK(upload(e, sc, &w.cln_w));
+            CHK(upload(e, sh, &w.cln_b));
+        } else {
+            CHK(ln("conv_module.norm", &w.cln_w, &w.cln_b));
+        }
         CHK(up(e, p + "feed_forward_macaron.w_1.weight", {dff, d}, &w.ffm_w1));
         CHK(up(e, p + "feed_forward_macaron.w_1.bias", {dff}, &w.ffm_b1));
         CHK(up(e, p + "feed_forward_macaron.w_2.weight", {d, dff}, &w.ffm_w2));
@@ -1114,10 +1132,13 @@ int conv_module(masr_engine* e, hipStream_t s, const LayerW& w, const EncodeCtx&
         a.W = w.pw2_w; a.bias = w.pw2_b; a.C = x; a.ldc = d; a.R = x; a.ldr = d; a.M = M; a.N = d; a.alpha = 1.f; a.eps = 1e-5f;
         a.mstride = mstride; a.seq_t = c.Tq; a.pad = pad; a.lens = c.lens; a.mask_tp = c.lens ? c.Tq : 0;
         ProfScope ps(e, s, PROF_GEMM, 2.0 * M * (double)d * d);
-        if (g_few_rows_path && launch_rowgemm(a, RG_PRO_DWCONV, RG_EPI_RESID, s)) return 0;
+        if (!e->conv_bn && g_few_rows_path && launch_rowgemm(a, RG_PRO_DWCONV, RG_EPI_RESID, s)) return 0;
     }
-    launch_dwconv_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), c.nseq, c.Tq, K,
-                          1e-5f, s, gconst);
+    if (e->conv_bn)        // BatchNorm build: the depthwise kernel's BN variant (the Squeezeformer's), then pointwise_conv2
+        launch_dwconv_bn_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), c.nseq, c.Tq, K, s, gconst);
+    else
+        launch_dwconv_ln_silu(e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->dwo.as<float>(), c.nseq, c.Tq, K,
+                              1e-5f, s, gconst);
     rowgemm(e, s, RG_PRO_PLAIN, RG_EPI_RESID, e->dwo.as<float>(), d, nullptr, nullptr, w.pw2_w, w.pw2_b, x, d, M, d, x, d,
             1.f, c.lens, c.lens ? c.Tq : 0, 0, 0, nullptr, nullptr, PROF_GEMM, mstride);
     return 0;
@@ -1782,7 +1803,7 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
                 &qkv_done));
         if (!qkv_done) mhsa(e, s, w, M);
         // attention and the chain kernel behind it as ONE launch (32 queries x all four heads per workgroup; key 34 = 0: two launches)
-        const bool fuse_ac = g_attn_chain && !few_rows && !g_no_chain && H == 4 && d == 256 && g_rowgemm_packed;
+        const bool fuse_ac = g_attn_chain && !few_rows && !g_no_chain && !e->conv_bn && H == 4 && d == 256 && g_rowgemm_packed;
         if (fuse_ac) {
             AttnChainArgs a{};
             a.seqs = e->attseq.as<AttSeq>(); a.nseq = B; a.q_stride = 3 * d; a.kv_stride = 3 * d;
@@ -1805,14 +1826,14 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
             // 7.4 + 7.7 us for the two K-split launches whose columns spread over the chip); norm_final rides on the split
             // FFN's reduction
             mhsa_out(e, s, w, M);
-            const bool fuse = g_split_head && e->cfg.cnn_kernel == 15 && g_ffn_packed >= 2 && !g_no_ffn_head;
+            const bool fuse = g_split_head && e->cfg.cnn_kernel == 15 && g_ffn_packed >= 2 && !g_no_ffn_head && !e->conv_bn;
             CHK(conv_module(e, s, w, ctx, false, 0, 4, false, fuse));
             const FfnHead head{e->glu.as<float>(), w.dw_w, w.dw_b, w.cln_w, w.cln_b, e->cfg.causal ? w.gconst : nullptr,
                                w.pw2_w, w.pw2_b, feat_lens_dev, Tq, e->cfg.cnn_kernel, 4, nullptr};
             CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2, 0.5f, 0, w.ln_fin_w, w.ln_fin_b, x, nullptr,
                     nullptr, fuse ? &head : nullptr));
             continue;                              // (prev stays null: nothing deferred)
-        } else if (g_no_chain) {
+        } else if (g_no_chain || e->conv_bn) {      // (BatchNorm build: the fused head stage carries the LayerNorm variant only)
             mhsa_out(e, s, w, M);
             CHK(conv_module(e, s, w, ctx, false));
             CHK(ffn(e, s, M, w.ln_ff_w, w.ln_ff_b, w.ff_w1, w.ff_b1, w.ff_w2, w.ff_b2));
@@ -2273,6 +2294,7 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     } else if (!e->cfg.causal) {
         return fail("chunked streaming needs the streaming-trained (causal conv) build");
     }
+    if (e->conv_bn) return fail("cnn_module_norm=batch_norm: only the full-context forward is implemented (the chunk-step kernels carry the LayerNorm variant)");
     if (max_frames_out <= 0 || max_frames_out > e->cfg.max_pos) max_frames_out = e->cfg.max_pos;
     int id = -1;
     for (size_t i = 0; i < e->streams.size(); ++i)

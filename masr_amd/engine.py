@@ -84,16 +84,19 @@ def _validate_encoder_conf(use_model, enc, state_dict):
         if v not in allowed:
             raise _lib.MasrError(f'{use_model}: encoder_conf.{key}={v!r} is not implemented (supported: {allowed})')
     if use_model in ('conformer', 'efficient_conformer'):
-        want('cnn_module_norm', ('layer_norm',), 'layer_norm')
+        # batch_norm (conformer/convolution.py:60-67): Conformer only, full-context forward only (eval-mode statistics folded)
+        want('cnn_module_norm', ('layer_norm', 'batch_norm') if use_model == 'conformer' else ('layer_norm',), 'layer_norm')
         want('activation_type', ('swish',), 'swish')
         want('normalize_before', (True,), True)
         want('use_cnn_module', (True,), True)
         want('macaron_style', (True,), True)
         want('input_layer', ('conv2d',), 'conv2d')
         want('pos_enc_layer_type', ('rel_pos',), 'rel_pos')
-        if state_dict is not None and any(k.endswith('conv_module.norm.running_mean') for k in state_dict):
-            raise _lib.MasrError(f'{use_model}: the checkpoint holds BatchNorm statistics (conv_module.norm.running_mean): '
-                                 f'cnn_module_norm=batch_norm is not implemented on this path')
+        has_bn = state_dict is not None and any(k.endswith('conv_module.norm.running_mean') for k in state_dict)
+        is_bn = enc.get('cnn_module_norm', 'layer_norm') == 'batch_norm'
+        if has_bn != is_bn and state_dict is not None:
+            raise _lib.MasrError(f'{use_model}: encoder_conf.cnn_module_norm={enc.get("cnn_module_norm", "layer_norm")!r} but the checkpoint '
+                                 f'{"holds" if has_bn else "has no"} BatchNorm statistics (conv_module.norm.running_mean)')
     elif use_model == 'squeezeformer':
         want('cnn_norm_type', ('batch_norm',), 'batch_norm')
         want('activation_type', ('swish',), 'swish')
@@ -130,6 +133,7 @@ class HipEngine:
                              cnn_kernel=int(enc.get('cnn_module_kernel', 15)), n_mels=n_mels,
                              vocab_size=int(vocab_size), causal=1 if streaming else 0, max_pos=max_pos,
                              device_id=device)
+            cfg.reserved[0] = 1 if enc.get('cnn_module_norm', 'layer_norm') == 'batch_norm' else 0
         elif use_model == 'squeezeformer':
             # configs/squeezeformer.yml: encoder_dim, feed_forward_expansion_factor, reduce_idx / recover_idx
             dim = int(enc.get('encoder_dim', 256))

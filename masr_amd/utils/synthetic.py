@@ -22,9 +22,10 @@ def _uniform(seed, name, shape, bound):
 
 
 def conformer_state_dict(seed=0, vocab_size=4233, d=256, heads=4, d_ff=2048, num_blocks=12,
-                         kernel=15, n_mels=80, ctc_gain=6.0):
+                         kernel=15, n_mels=80, ctc_gain=6.0, cnn_module_norm='layer_norm'):
     """Keys/shapes == reference ``encoder.*`` + ``ctc.*`` entries (attention-decoder
-    ``decoder.*`` entries are never used by get_encoder_out*, model.py:152-190)."""
+    ``decoder.*`` entries are never used by get_encoder_out*, model.py:152-190).  ``cnn_module_norm='batch_norm'``
+    (conformer/convolution.py:60-67): the conv module's norm carries running statistics (same weight / bias shapes)."""
     sd = {}
     f2 = ((n_mels - 1) // 2 - 1) // 2
 
@@ -60,6 +61,9 @@ def conformer_state_dict(seed=0, vocab_size=4233, d=256, heads=4, d_ff=2048, num
         sd[p + 'conv_module.depthwise_conv.weight'] = _uniform(seed, p + 'dw.w', (d, 1, kernel), math.sqrt(3.0 / kernel))
         sd[p + 'conv_module.depthwise_conv.bias'] = _uniform(seed, p + 'dw.b', (d,), 0.1)
         ln(p + 'conv_module.norm')
+        if cnn_module_norm == 'batch_norm':
+            sd[p + 'conv_module.norm.running_mean'] = _uniform(seed, p + 'cnorm.mean', (d,), 0.3)
+            sd[p + 'conv_module.norm.running_var'] = 1.0 + _uniform(seed, p + 'cnorm.var', (d,), 0.5)
         sd[p + 'conv_module.pointwise_conv2.weight'] = _uniform(seed, p + 'pw2.w', (d, d, 1), math.sqrt(3.0 / d))
         sd[p + 'conv_module.pointwise_conv2.bias'] = _uniform(seed, p + 'pw2.b', (d,), 0.1)
         for n in ('norm_ff', 'norm_mha', 'norm_ff_macaron', 'norm_conv', 'norm_final'):

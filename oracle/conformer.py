@@ -80,7 +80,7 @@ def _attention(sd, p, x, pos_emb, key_mask, heads, cache=None):
 
 
 def _conv_module(sd, p, x, pad_mask, kernel, cache=None, causal=True):
-    """ConvolutionModule.forward, layer_norm variant (conformer/convolution.py:76-132).  x [B,T,d]; pad_mask bool [B,T]
+    """ConvolutionModule.forward, layer_norm and batch_norm variants (conformer/convolution.py:76-132).  x [B,T,d]; pad_mask bool [B,T]
     (True=valid) or None; cache [B,d,kernel-1] or None.  causal (streaming-trained model): NB the left zero padding (or
     cache) is concatenated BEFORE pointwise_conv1, so padded frames carry glu(bias).  Non-causal (streaming: False):
     symmetric zero padding inside the depthwise Conv1d (:53-61)."""
@@ -99,7 +99,11 @@ def _conv_module(sd, p, x, pad_mask, kernel, cache=None, causal=True):
     x = F.glu(x, dim=1)
     x = F.conv1d(x, sd[p + '.depthwise_conv.weight'], sd[p + '.depthwise_conv.bias'], groups=x.shape[1],
                  padding=0 if causal else lorder // 2)
-    x = F.silu(_ln(sd, p + '.norm', x.transpose(1, 2))).transpose(1, 2)
+    if p + '.norm.running_mean' in sd:    # cnn_module_norm: batch_norm (convolution.py:60-63,122-125): eval-mode BatchNorm1d on [B, C, T]
+        x = F.silu(F.batch_norm(x, sd[p + '.norm.running_mean'], sd[p + '.norm.running_var'], sd[p + '.norm.weight'],
+                                sd[p + '.norm.bias'], False, 0.0, 1e-5))
+    else:
+        x = F.silu(_ln(sd, p + '.norm', x.transpose(1, 2))).transpose(1, 2)
     x = F.conv1d(x, sd[p + '.pointwise_conv2.weight'], sd[p + '.pointwise_conv2.bias'])
     if pad_mask is not None:
         x = x.masked_fill(~pad_mask.unsqueeze(1), 0.0)

@@ -548,6 +548,46 @@ def test_conformer_nonstreaming_build_against_reference_fixture(oracle_mods):
     e.close()
 
 
+@pytest.mark.parametrize('streaming', [False, True])
+def test_conformer_batch_norm_conv_module_against_oracle(oracle_mods, streaming):
+    """conformer.yml with encoder_conf.cnn_module_norm: batch_norm (conformer/convolution.py:60-67): eval-mode BatchNorm folded
+    into the depthwise kernel's scale / shift variant; full-context forward of both builds against the oracle (which
+    tests/test_oracle_golden.py pins to the live reference model with that option), one long and one ragged batch; chunked
+    streaming is refused with a message; a checkpoint / config mismatch is refused at construction"""
+    from masr_amd.engine import HipEngine
+    oc, weights, golden_inputs = oracle_mods[0], oracle_mods[3], oracle_mods[4]
+    sd = weights.conformer_state_dict(0, 512, cnn_module_norm='batch_norm')
+    e = HipEngine(sd, vocab_size=512, streaming=streaming, encoder_conf={'cnn_module_norm': 'batch_norm'})
+    try:
+        feats, lens = golden_inputs()
+        with torch.no_grad():
+            ref = oc.encoder_full(sd, torch.as_tensor(feats), torch.as_tensor(lens), streaming=streaming)
+            ref_p = oc.ctc_probs(sd, ref).numpy()
+        enc = e.encode_full(dev(feats), dev(lens, torch.int32), -1)
+        assert np.abs(enc.cpu().numpy() - ref.numpy()).max() < 1e-3
+        assert np.abs(e.ctc_probs(enc).cpu().numpy() - ref_p).max() < 1e-3
+        g = torch.Generator().manual_seed(3)                 # 32 x <= 10 s: the row-block kernels' regime
+        x = torch.randn(32, 998, 80, generator=g) * 3 + 13
+        l2 = torch.randint(300, 999, (32,), generator=g)
+        l2[0] = 998
+        x = x * (torch.arange(998)[None, :, None] < l2[:, None, None])
+        with torch.no_grad():
+            ref2 = oc.encoder_full(sd, x[:3], l2[:3], streaming=streaming).numpy()
+        got2 = e.encode_full(dev(x), dev(l2, torch.int32), -1).cpu().numpy()
+        for b in range(3):                                   # (the oracle runs three utterances as their own padded batch)
+            v = int(e.enc_frames(l2[b:b + 1])[0])
+            assert np.abs(got2[b, :v] - ref2[b, :v]).max() < 1e-3
+        if streaming:
+            with pytest.raises(Exception, match='batch_norm'):
+                e.stream_open(0)
+    finally:
+        e.close()
+    with pytest.raises(Exception, match='cnn_module_norm'):   # LayerNorm config on a BatchNorm checkpoint
+        HipEngine(sd, vocab_size=512, streaming=streaming)
+    with pytest.raises(Exception, match='cnn_module_norm'):
+        HipEngine(weights.conformer_state_dict(0, 512), vocab_size=512, encoder_conf={'cnn_module_norm': 'batch_norm'})
+
+
 def test_squeezeformer_streaming_build_against_reference_fixture(oracle_mods):
     """squeezeformer.yml as shipped (streaming: True): causal conv module (history rows = glu(bias)) + stream time reduction"""
     from masr_amd.engine import HipEngine

@@ -128,6 +128,34 @@ def test_flop_model_matches_survey():
 
 
 @pytest.mark.skipif(not shims.reference_available(), reason='/root/reference not present')
+@pytest.mark.parametrize('streaming', [False, True])
+def test_oracle_batch_norm_conv_module_against_live_reference(streaming):
+    """encoder_conf.cnn_module_norm: batch_norm (conformer/convolution.py:60-67,122-125) -- the oracle's conv module against the
+    reference ConformerModel built with that option, full-context forward, symmetric and causal conv"""
+    import json
+    import tempfile
+    import yaml
+    shims.install()
+    from masr.model_utils.conformer.model import ConformerModel
+    cfg = yaml.safe_load(open(os.path.join(shims.REFERENCE_ROOT, 'configs', 'conformer.yml'), encoding='utf-8'))
+    enc_conf = dict(cfg['encoder_conf'], cnn_module_norm='batch_norm')
+    sd = weights.conformer_state_dict(4, 300, cnn_module_norm='batch_norm')
+    p = os.path.join(tempfile.mkdtemp(), 'm.json')
+    json.dump({'mean': [0.0] * 80, 'istd': [1.0] * 80}, open(p, 'w'))
+    m = ConformerModel(input_dim=80, vocab_size=300, mean_istd_path=p, streaming=streaming,
+                       encoder_conf=enc_conf, decoder_conf=cfg['decoder_conf'], **cfg['model_conf']).eval()
+    missing = m.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if 'conv_module.norm' in k]
+    torch.manual_seed(6)
+    x = torch.randn(2, 150, 80) * 3 + 13
+    lens = torch.tensor([150, 99])
+    with torch.no_grad():
+        ref = m.get_encoder_out(x, lens)
+        got = oc.ctc_probs(sd, oc.encoder_full(sd, x, lens, streaming=streaming))
+        assert (ref - got).abs().max() < 1e-6
+
+
+@pytest.mark.skipif(not shims.reference_available(), reason='/root/reference not present')
 def test_oracle_against_live_reference():
     import json
     import tempfile
