@@ -73,6 +73,16 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
     return v;
 }
 
+// wave-wide unsigned max / min, result in every lane (the scan's DPP pattern; lanes without a source keep their own value)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define BS_DPP_MAXU(ctrl, rows) v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, (ctrl), (rows), 0xf, false))
+    BS_DPP_MAXU(0x111, 0xf); BS_DPP_MAXU(0x112, 0xf); BS_DPP_MAXU(0x114, 0xf); BS_DPP_MAXU(0x118, 0xf);
+    BS_DPP_MAXU(0x142, 0xa); BS_DPP_MAXU(0x143, 0xc);
+#undef BS_DPP_MAXU
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
+
 // exclusive block scan of one int per thread (packed counters); `wsum` must be a scratch row [BS_WAVES] that nobody
 // else touches during this step (one barrier per scan); returns the exclusive prefix, total in `total`
 __device__ __forceinline__ int block_scan(int v, int* wsum, int& total) {
@@ -325,6 +335,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             }                                                                                                    \
             if (lane == 0) {                                                                                     \
                 misc[0] = bm ? __ffsll((long long)bm) - 1 : -1;                                                  \
+                misc[1] = 0; misc[2] = (int)0xFFFFFFFFu;      /* wide step: max / min over the frame's finite keys */ \
                 misc[3] = (int)0xFFFFFFFFu;                  /* min over the live prefixes' score keys */         \
                 misc[4] = __float_as_int(nx_blp);                                                                \
                 misc[5] = 0;                                 /* distinct effective scorer contexts of this frame */ \
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         float* c_uni = c_uni0 + cpar * BS_KMAX;
         float* c_ubo = c_ubo0 + cpar * BS_KMAX;
         const int o = cur * beam, o2 = (cur ^ 1) * beam;
-        if (a.narrow && n * cnt <= NW_ENT) {
+        if ((a.narrow & 1) && n * cnt <= NW_ENT) {
             // ================= narrow frame: waves 0 .. NW_WAVES-1 work, the others wait ======================================
             // scorer-state table of the frame: next to ln P_LM(c | context) the table fill records m and the backoffs of the context
             // EXTENDED by c (lm_cond_next: they come out of the same probes), so a surviving extension takes its scorer state from
@@ -939,17 +950,32 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             kex = okey(my_sc);
         }
         unsigned keys[NPT];
-        unsigned tmax = kex;
-        int fin = kex > NEG;
+        unsigned tmax = kex, tminw = kex - (NEG + 1u);                  // (tminw: min over the FINITE keys, as key - (NEG + 1): "no entry" and
+        int fin = kex > NEG;                                            //  -inf keys wrap around to huge values and drop out of the minimum)
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int e = tid + i * BS_THREADS;
             keys[i] = e < nq ? ekeys[e] : 0u;                           // 0 = no entry
             tmax = max(tmax, keys[i]);
+            tminw = min(tminw, keys[i] - (NEG + 1u));
             fin += keys[i] > NEG;
+        }
+        // The finite keys of a frame share their leading bytes (scores of one frame lie within a factor of two or so: sign,
+        // exponent and often more are common): the workgroup's max and min ride on the count's barrier, and the radix passes over
+        // the bytes in which they agree are skipped -- one of three bound passes and one of four select passes, nearly always
+        {   // (one LDS atomic pair per wave into misc[1] / misc[2], reset by the frame's staging; two reads behind the barrier)
+            const unsigned wmax = wave_max_u32(tmax), wminw = wave_min_u32(tminw);
+            if (lane == 0) {
+                atomicMax(reinterpret_cast<unsigned*>(&misc[1]), wmax);
+                atomicMin(reinterpret_cast<unsigned*>(&misc[2]), wminw);
+            }
         }
         int tot;
         block_scan(fin, wsum + 0 * BS_WAVES, tot);
+        const unsigned kmaxb = (unsigned)misc[1] > NEG ? (unsigned)misc[1] : 0u;
+        const unsigned kminb = (unsigned)misc[2] < 0u - (NEG + 1u) ? (unsigned)misc[2] + NEG + 1u : 0xFFFFFFFFu;      // (wrapped: no finite key)
+        const int skip = (a.narrow & 2) ? 0 : kmaxb >= kminb ? ((kmaxb ^ kminb) == 0u ? 4 : (__clz((int)(kmaxb ^ kminb)) >> 3)) : 0;     // common leading bytes
+        const unsigned cmask = skip == 0 ? 0u : skip >= 4 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (32 - 8 * skip);
         BS_TICK(2);
         // ---- 4a. lower bound of the beam-th best key: the beam-th best of the per-thread maxima, to 24 bits ---------------
         unsigned low = NEG + 1;                                         // every finite entry
@@ -958,9 +984,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         //  no gain / slower, 19.6 -> 19.6 / 21.0 us per frame at 3.7 candidates: the survivors' rows cost the compaction what the
         //  three bound passes cost the selection)
         if (overflow) {
-            unsigned prefix = 0, mask = 0;
+            unsigned prefix = kmaxb & cmask, mask = cmask;
             int need = beam;
-            for (int pass = 0; pass < 3; ++pass) {
+            for (int pass = min(skip, 3); pass < 3; ++pass) {
                 const int shift = 24 - 8 * pass;
                 int* hp = hist + pass * 256;
                 hist_add(hp, (tmax & mask) == prefix, (tmax >> shift) & 255);
@@ -972,7 +998,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 need = rem;
                 if (rem == binc) break;          // the picked bin is needed whole: exactly `beam` maxima are >= prefix already
             }
-            low = max(prefix, NEG + 1);                                 // >= beam entries are >= low
+            low = max(prefix & 0xFFFFFF00u, NEG + 1);                   // >= beam entries are >= low (24 bits, as before)
         }
         // ---- 4b. survivors (extension entries >= low) -> ordered list, re-dealt one per thread ----------------------------
         int ns = 0;
@@ -998,9 +1024,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         unsigned thr = NEG;        // select key > thr, plus `need_eq` of the keys == thr
         int need_eq = 0;
         if (overflow) {
-            unsigned prefix = 0, mask = 0;
+            unsigned prefix = kmaxb & cmask, mask = cmask;
             int need = beam;
-            for (int pass = 0; pass < 4; ++pass) {
+            for (int pass = skip; pass < 4; ++pass) {
                 const int shift = 24 - 8 * pass;
                 int* hp = hist + (3 + pass) * 256;
                 hist_add(hp, kx != 0 && (kx & mask) == prefix, (kx >> shift) & 255);

@@ -35,7 +35,7 @@ dec.prune_min_cutoff = bool(prune)
 eng = runtime.aux_engine()
 cache = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 eng.lib.masr_debug_set(eng.h, 32, cache)
-eng.lib.masr_debug_set(eng.h, 37, int(os.environ.get('BEAM_PROFILE_NARROW', '1')))      # 0: every frame on the wide step
+eng.lib.masr_debug_set(eng.h, 37, int(os.environ.get('BEAM_PROFILE_NARROW', '1')))      # 0: every frame on the wide step; 3: narrow step on, the wide step's pass skipping off
 cand = dec._candidates(probs[0], to_host=False)[2].float().mean().item()
 print(f'logit scale {scale}: {cand:.1f} candidates per frame')
 ref = dec._batch([probs[i] for i in range(NB)])
