@@ -52,12 +52,11 @@ __device__ __forceinline__ float ikey(unsigned k) {       // inverse of okey
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// identity of the prefix string: hash chain over its characters (64 bits; never 0)
+// identity of the prefix string: hash chain over its characters (64 bits; never 0).  The chain step is the scorer's lm_mix (two
+// 32-bit multiplies; for a fixed character a bijection of the parent's identity): the step is also taken once per (prefix,
+// candidate) pair of a parent with many live children (live_child below), where three 64-bit multiplies were the pair's cost
 __device__ __forceinline__ unsigned long long str_hash(unsigned long long parent, int ch) {
-    unsigned long long z = parent * 0x9E3779B97F4A7C15ull + (unsigned long long)(ch + 2) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
+    const unsigned long long z = lm_mix(parent, (unsigned long long)(ch + 2));
     return z ? z : 1ull;
 }
 static constexpr int BS_HASH = 1024;
@@ -194,6 +193,28 @@ static constexpr int NW_ENT = NW_EPT * NW_T;
 static constexpr int NW_PPT = (512 + NW_T - 1) / NW_T;              // live prefixes per thread, consecutive (beam <= 512)
 static constexpr int NW_BARRIERS = 11;
 
+// Is the child (p, c) itself a live prefix?  Its index, or -1.  A prefix with few live children is asked through its children
+// list; one with many (flat posteriors fill the beam with the siblings of a few parents: every one of the parent's candidates
+// would walk all of them -- BASELINE configs[2] on a random-init model spent 85 000 of its 130 000 cycles per frame there) through
+// the frame's hash of the live prefixes' string identities: the child's identity is str_hash(identity of p, c) by construction.
+static constexpr int BS_WALK_MAX = 4;
+__device__ __forceinline__ int live_child(int hd, int nchild, const int* next, const int* lv_ch_o, unsigned long long hid_p, int c,
+                                          const unsigned long long* hkey, const int* hval) {
+    if (nchild <= BS_WALK_MAX) {
+        for (int j = hd; j >= 0; j = next[j])
+            if (lv_ch_o[j] == c) return j;
+        return -1;
+    }
+    const unsigned long long key = str_hash(hid_p, c);
+    unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
+    while (true) {
+        const unsigned long long hk = hkey[h];
+        if (hk == key) return hval[h];
+        if (hk == 0ull) return -1;
+        h = (h + 1) & (BS_HASH - 1);
+    }
+}
+
 // NPT = extension entries per thread in the selection phase, strided (beam * K <= 1024 * NPT)
 // ORD = 0: no external scorer; 3 | 5: a language model of order <= ORD is bound (bounds the probes per scored extension, which
 //       live in registers while a batch of extensions is in flight)
@@ -220,7 +241,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     float* ext = rep + beam;                                            // [beam] parent-extension term of nb_cur
     int* head = reinterpret_cast<int*>(ext + beam);                      // [beam] first live child
     int* next = head + beam;                                             // [beam] next live child of the same parent
-    unsigned long long* lv_ctx = reinterpret_cast<unsigned long long*>(next + beam + (beam & 1));   // [2][beam] packed LM context
+    int* nch = next + beam;                                              // [beam] number of live children
+    unsigned long long* lv_ctx = reinterpret_cast<unsigned long long*>(nch + beam);   // [2][beam] packed LM context (1024 + 16 beam words behind hkey: 8-byte aligned)
     float* lv_bo = reinterpret_cast<float*>(lv_ctx + 2 * beam);          // [2][beam][4] backoffs of the context's suffixes
     int* lv_m = reinterpret_cast<int*>(lv_bo + 8 * beam);                // [2][beam] m | oov << 8
     // (the scorer's 14 words per live prefix exist only when a language model is bound: an LM-free beam 500 x 40 fits without them)
@@ -457,7 +479,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 const int i = i0 + j;
                 my_ek[j] = 0ull;
                 if (i < n) {
-                    rep[i] = -INFINITY; ext[i] = -INFINITY; head[i] = -1;       // (first touched behind barrier 2)
+                    rep[i] = -INFINITY; ext[i] = -INFINITY; head[i] = -1; nch[i] = 0;       // (first touched behind barrier 2)
                     const unsigned long long key = lv_hid[o + i];
                     unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
                     while (atomicCAS(&hkey[h], 0ull, key) != 0ull) h = (h + 1) & (BS_HASH - 1);
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                         if (hk == 0ull) break;
                         h = (h + 1) & (BS_HASH - 1);
                     }
-                    if (par >= 0) next[i] = atomicExch(&head[par], i);
+                    if (par >= 0) { next[i] = atomicExch(&head[par], i); atomicAdd(&nch[par], 1); }
                     if (lm_cache) {
                         int row = -1;
                         if (my_ek[j] != 0ull) {
@@ -597,11 +619,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                                 }
                                 val += a.alpha * lmp + a.beta;
                             }
-                            for (int q = head[p]; q >= 0; q = next[q])
-                                if (lv_ch[o + q] == c) {
-                                    ext[q] = val;
-                                    val = -INFINITY;
-                                }
+                            const int q = live_child(head[p], nch[p], next, lv_ch + o, lv_hid[o + p], c, hkey, hval);
+                            if (q >= 0) {           // the child (p, c) is a live prefix: merge into it
+                                ext[q] = val;
+                                val = -INFINITY;
+                            }
                         }
                         const unsigned kk = okey(val);
                         keyE[j] = kk > NEG ? kk : 0u;             // 0: no entry / -inf
@@ -796,7 +818,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         }
         // ---- 0. candidates -> LDS, clear tables; prefetch the next frame -------------------------------------
         for (int i = tid; i < 7 * 256; i += BS_THREADS) hist[i] = 0;
-        if (tid < n) { rep[tid] = -INFINITY; ext[tid] = -INFINITY; head[tid] = -1; }
+        if (tid < n) { rep[tid] = -INFINITY; ext[tid] = -INFINITY; head[tid] = -1; nch[tid] = 0; }
         if (tid < BS_HASH) hkey[tid] = 0ull;
         BS_STAGE_FRAME(c_idx, c_lp, c_uni, c_ubo, cnt, t);
         prepared = false;
@@ -858,7 +880,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 if (hk == 0ull) break;
                 h = (h + 1) & (BS_HASH - 1);
             }
-            if (par >= 0) next[tid] = atomicExch(&head[par], tid);
+            if (par >= 0) { next[tid] = atomicExch(&head[par], tid); atomicAdd(&nch[par], 1); }
         }
         if (lm_cache) {
             if (tid < n) {                               // my context's table row
@@ -871,6 +893,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 pu[tid] = row;
             }
             const int nu = min(misc[5], ucap);
+            if (prof) { pcl[14] += (unsigned long long)misc[5]; pcl[15] += 1ull; }      // distinct scorer contexts of the wide frames / wide frames
             for (int e = tid; e < nu * cnt; e += BS_THREADS) {
                 const int uq = e / cnt, k = e - uq * cnt;
                 const int craw = c_idx[k];
@@ -898,7 +921,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         const int nq = n * cnt;
         if (my_p < n) {
             const float sc = lv_sc[o + my_p], pb = lv_b[o + my_p], pnb = lv_nb[o + my_p];
-            const int ch = lv_ch[o + my_p], hd = head[my_p];
+            const int ch = lv_ch[o + my_p], hd = head[my_p], nkid = nch[my_p];
+            const unsigned long long hid_p = lv_hid[o + my_p];
             LmState sp;
             if (use_lm) {
                 sp.ctx = lv_ctx[o + my_p];
@@ -927,11 +951,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                                                                    : lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, sp, c, c_uni[k]);
                         val += a.alpha * lmp + a.beta;
                     }
-                    for (int j = hd; j >= 0; j = next[j])
-                        if (lv_ch[o + j] == c) {                    // the child (p, c) is a live prefix: merge into it
-                            ext[j] = val;
-                            val = -INFINITY;
-                        }
+                    const int j = live_child(hd, nkid, next, lv_ch + o, hid_p, c, hkey, hval);
+                    if (j >= 0) {                                   // the child (p, c) is a live prefix: merge into it
+                        ext[j] = val;
+                        val = -INFINITY;
+                    }
                 }
                 ekeys[my_p * cnt + k] = okey(val);
             }
@@ -1186,7 +1210,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 }
 
 size_t beam_gpu_lds_bytes(int beam, int K, bool use_lm) {
-    return (size_t)beam * K * 6 + (size_t)(26 + (use_lm ? 15 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 8 * BS_KMAX * 4 + 7 * 256 * 4 +
+    return (size_t)beam * K * 6 + (size_t)(27 + (use_lm ? 15 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 8 * BS_KMAX * 4 + 7 * 256 * 4 +
            (6 + 32) * BS_WAVES * 4 + (8 + 32) * 4 + 128;
 }
 

@@ -2939,6 +2939,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
                     h[0], h[1], h[2], h[3], h[4]);
             fprintf(stderr, "  narrow step (%lld frames): tables+candidates %lld  hash+contexts %lld  children+scorer table %lld  extensions %lld  "
                     "prefixes+select %lld  scan %lld  survivors %lld  new prefixes %lld\n", h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13]);
+            if (h[15] > 0) fprintf(stderr, "  wide step (%lld frames): %.1f distinct scorer contexts per frame\n", h[15], (double)h[14] / (double)h[15]);
             e->beam_prof = nullptr;
         }
     }
