@@ -215,6 +215,17 @@ __device__ __forceinline__ int live_child(int hd, int nchild, const int* next, c
     }
 }
 
+// candidate index of character c in the frame's map (-1: not a candidate of this frame)
+__device__ __forceinline__ int cand_of(const int* ckmap, int c) {
+    unsigned h = ((unsigned)c * 0x9E3779B1u) >> 25;
+    while (true) {
+        const int v = ckmap[h];
+        if (v == 0) return -1;
+        if (((v - 1) >> 8) == c) return (v - 1) & 255;
+        h = (h + 1) & 127;
+    }
+}
+
 // NPT = extension entries per thread in the selection phase, strided (beam * K <= 1024 * NPT)
 // ORD = 0: no external scorer; 3 | 5: a language model of order <= ORD is bound (bounds the probes per scored extension, which
 //       live in registers while a batch of extensions is in flight)
@@ -257,6 +268,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     int* wsum = hist + 7 * 256;                                          // [6 + NPT][BS_WAVES]: one scan row per scan of a step
     int* misc = wsum + (6 + NPT) * BS_WAVES;                                         // [8]: 0 blank_k, 1 sel_bin, 2 need
     unsigned short* slist = reinterpret_cast<unsigned short*>(misc + 8 + 32);  // [beam * K] surviving extension entries
+    // wide step: which candidates of a prefix are live children (bit k of kidmask[p]: the child computes that extension term itself,
+    // the (p, k) pair is skipped) and the frame's map character -> candidate index (open addressing, 128 slots, entry (c << 8 | k) + 1)
+    unsigned long long* kidmask = reinterpret_cast<unsigned long long*>(
+        reinterpret_cast<unsigned char*>(slist) + (((size_t)beam * K * 2 + 7) & ~(size_t)7));     // [beam]
+    int* ckmap = reinterpret_cast<int*>(kidmask + beam);                                           // [128]
     // Scorer table of the frame (use_lm): ln P_LM(c | context) depends on the prefix only through its EFFECTIVE context -- the m most
     // recent words, m = length of the longest suffix that exists in the model -- so the live prefixes' contexts are deduplicated
     // (LDS hash in the histogram area, which the selection phases only need later and which is cleared again behind the extension
@@ -338,6 +354,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         if (wave == 0) {                                                                                         \
             const bool isb = lane < cnt_ && nx_c == a.blank;                                                     \
             const unsigned long long bm = __ballot(isb);                                                         \
+            ckmap[lane] = 0; ckmap[64 + lane] = 0;        /* character -> candidate index (one wave: LDS operations in order) */ \
+            if (lane < cnt_) {                                                                                   \
+                unsigned hq = ((unsigned)nx_c * 0x9E3779B1u) >> 25;                                              \
+                while (atomicCAS(&ckmap[hq], 0, ((nx_c << 8) | lane) + 1) != 0) hq = (hq + 1) & 127;             \
+            }                                                                                                    \
             if (lane < cnt_) {                                                                                   \
                 /* the scorer's known-word flag of this candidate rides in bit 30 of its index: one lookup per frame and */ \
                 /* candidate instead of one per (prefix, candidate) pair */                                      \
@@ -818,7 +839,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         }
         // ---- 0. candidates -> LDS, clear tables; prefetch the next frame -------------------------------------
         for (int i = tid; i < 7 * 256; i += BS_THREADS) hist[i] = 0;
-        if (tid < n) { rep[tid] = -INFINITY; ext[tid] = -INFINITY; head[tid] = -1; nch[tid] = 0; }
+        if (tid < n) { rep[tid] = -INFINITY; ext[tid] = -INFINITY; kidmask[tid] = 0ull; }
         if (tid < BS_HASH) hkey[tid] = 0ull;
         BS_STAGE_FRAME(c_idx, c_lp, c_uni, c_ubo, cnt, t);
         prepared = false;
@@ -866,7 +887,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         const float min_cut = full_beam ? (float)((double)ikey((unsigned)misc[3]) + (double)__int_as_float(misc[4]) -
                                                   fmax(0.0, (double)a.beta))
                                         : -INFINITY;
-        if (tid < n) {                                  // is my parent prefix live?  then I am on its children list
+        int my_par = -1, my_kq = -1;                    // this live prefix as the child (my_par, candidate my_kq) of a live parent
+        if (tid < n) {                                  // is my parent prefix live, and am I one of its candidates in this frame?
             {
                 const float lpb = blank_k >= 0 ? c_lp[blank_k] : -INFINITY, scb = lv_sc[o + tid];
                 bcur[tid] = blank_k >= 0 && !(lpb + scb < min_cut) ? lpb + scb : -INFINITY;
@@ -880,7 +902,14 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 if (hk == 0ull) break;
                 h = (h + 1) & (BS_HASH - 1);
             }
-            if (par >= 0) { next[tid] = atomicExch(&head[par], tid); atomicAdd(&nch[par], 1); }
+            if (par >= 0) {                              // my parent is live: am I one of its candidates in this frame?
+                const int kq = cand_of(ckmap, lv_ch[o + tid]);
+                if (kq >= 0) {
+                    atomicOr(&kidmask[par], 1ull << kq);
+                    my_par = par;
+                    my_kq = kq;
+                }
+            }
         }
         if (lm_cache) {
             if (tid < n) {                               // my context's table row
@@ -919,10 +948,42 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         BS_TICK(0);
         // ---- 2. extensions (p, c): G threads per prefix, each a strided set of candidates ------------------------
         const int nq = n * cnt;
+        if (my_kq >= 0) {
+            // A live prefix whose parent is live takes the parent's extension by its own last character ITSELF (the arithmetic of the
+            // (parent, candidate) pair below, on the parent's state): the pair is then skipped through the parent's kidmask bit.
+            // Rounds 3-5 let every pair search the parent's children list -- hundreds of siblings under flat posteriors.
+            const int p = my_par, k = my_kq;
+            const float scp = lv_sc[o + p], pbp = lv_b[o + p];
+            const int craw = c_idx[k];
+            const int c = craw & ~(1 << 30);
+            const float lp = c_lp[k];
+            float val = -INFINITY;
+            if (c != a.blank && !(lp + scp < min_cut)) {
+                if (c == lv_ch[o + p]) val = pbp > -INFINITY ? lp + pbp : -INFINITY;
+                else val = lp + scp;
+                if (use_lm && val > -INFINITY) {
+                    const int mo = lv_m[o + p];
+                    const int rowp = lm_cache ? pu[p] : -1;
+                    float lmp;
+                    if ((mo >> 8) || (craw >> 30)) lmp = LM_OOV_SCORE;
+                    else if (rowp >= 0) lmp = lmtab[rowp * cnt + k];
+                    else {
+                        LmState spp;
+                        spp.ctx = lv_ctx[o + p];
+                        spp.m = mo & 255; spp.oov = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) spp.bo[j] = lv_bo[4 * (o + p) + j];
+                        lmp = lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, spp, c, c_uni[k]);
+                    }
+                    val += a.alpha * lmp + a.beta;
+                }
+            }
+            ext[tid] = val;
+        }
         if (my_p < n) {
             const float sc = lv_sc[o + my_p], pb = lv_b[o + my_p], pnb = lv_nb[o + my_p];
-            const int ch = lv_ch[o + my_p], hd = head[my_p], nkid = nch[my_p];
-            const unsigned long long hid_p = lv_hid[o + my_p];
+            const int ch = lv_ch[o + my_p];
+            const unsigned long long kids = kidmask[my_p];
             LmState sp;
             if (use_lm) {
                 sp.ctx = lv_ctx[o + my_p];
@@ -944,17 +1005,14 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                     } else {
                         val = lp + sc;
                     }
-                    // the external scorer: every way into the prefix p + c carries the same alpha * ln P_LM + beta
-                    if (use_lm && val > -INFINITY) {
+                    if ((kids >> k) & 1ull) {
+                        val = -INFINITY;                            // the child (p, c) is a live prefix: it took this term itself (above)
+                    } else if (use_lm && val > -INFINITY) {
+                        // the external scorer: every way into the prefix p + c carries the same alpha * ln P_LM + beta
                         const float lmp = (sp.oov || (craw >> 30)) ? LM_OOV_SCORE
                                           : my_row >= 0            ? lmtab[my_row * cnt + k]
                                                                    : lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, sp, c, c_uni[k]);
                         val += a.alpha * lmp + a.beta;
-                    }
-                    const int j = live_child(hd, nkid, next, lv_ch + o, hid_p, c, hkey, hval);
-                    if (j >= 0) {                                   // the child (p, c) is a live prefix: merge into it
-                        ext[j] = val;
-                        val = -INFINITY;
                     }
                 }
                 ekeys[my_p * cnt + k] = okey(val);
@@ -1211,7 +1269,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
 
 size_t beam_gpu_lds_bytes(int beam, int K, bool use_lm) {
     return (size_t)beam * K * 6 + (size_t)(27 + (use_lm ? 15 : 0)) * beam * 4 + 8 + BS_HASH * 12 + 8 * BS_KMAX * 4 + 7 * 256 * 4 +
-           (6 + 32) * BS_WAVES * 4 + (8 + 32) * 4 + 128;
+           (6 + 32) * BS_WAVES * 4 + (8 + 32) * 4 + 128 + (size_t)beam * 8 + 128 * 4 + 8;
 }
 
 template <int NPT, int ORD>

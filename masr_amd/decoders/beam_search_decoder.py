@@ -149,10 +149,10 @@ class BeamSearchDecoder:
         lm = self._ext_scorer is not None
         if lm and not self._ext_scorer.is_character_based:
             return False
-        # beam_gpu_lds_bytes (beam_gpu.hip): extension keys + survivor list, 27 (+ 15 with a scorer) words of live-prefix state,
+        # beam_gpu_lds_bytes (beam_gpu.hip): extension keys + survivor list, 29 (+ 15 with a scorer) words of live-prefix state,
         # fixed tables
         return (K <= 64 and 2 <= self.beam_size <= 512 and
-                self.beam_size * K * 6 + (168 if lm else 108) * self.beam_size + 24232 <= 160 * 1024)
+                self.beam_size * K * 6 + (176 if lm else 116) * self.beam_size + 24752 <= 160 * 1024)
 
     def _text(self, toks):
         return ''.join(self.vocab_list[t] for t in toks).replace('<space>', ' ')
