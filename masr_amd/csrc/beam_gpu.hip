@@ -54,7 +54,7 @@ __device__ __forceinline__ float ikey(unsigned k) {       // inverse of okey
 
 // identity of the prefix string: hash chain over its characters (64 bits; never 0).  The chain step is the scorer's lm_mix (two
 // 32-bit multiplies; for a fixed character a bijection of the parent's identity): the step is also taken once per (prefix,
-// candidate) pair of a parent with many live children (live_child below), where three 64-bit multiplies were the pair's cost
+// candidate) pair of a parent with many live children in one version of round 6, where three 64-bit multiplies were the pair's cost
 __device__ __forceinline__ unsigned long long str_hash(unsigned long long parent, int ch) {
     const unsigned long long z = lm_mix(parent, (unsigned long long)(ch + 2));
     return z ? z : 1ull;
@@ -193,28 +193,6 @@ static constexpr int NW_ENT = NW_EPT * NW_T;
 static constexpr int NW_PPT = (512 + NW_T - 1) / NW_T;              // live prefixes per thread, consecutive (beam <= 512)
 static constexpr int NW_BARRIERS = 11;
 
-// Is the child (p, c) itself a live prefix?  Its index, or -1.  A prefix with few live children is asked through its children
-// list; one with many (flat posteriors fill the beam with the siblings of a few parents: every one of the parent's candidates
-// would walk all of them -- BASELINE configs[2] on a random-init model spent 85 000 of its 130 000 cycles per frame there) through
-// the frame's hash of the live prefixes' string identities: the child's identity is str_hash(identity of p, c) by construction.
-static constexpr int BS_WALK_MAX = 4;
-__device__ __forceinline__ int live_child(int hd, int nchild, const int* next, const int* lv_ch_o, unsigned long long hid_p, int c,
-                                          const unsigned long long* hkey, const int* hval) {
-    if (nchild <= BS_WALK_MAX) {
-        for (int j = hd; j >= 0; j = next[j])
-            if (lv_ch_o[j] == c) return j;
-        return -1;
-    }
-    const unsigned long long key = str_hash(hid_p, c);
-    unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
-    while (true) {
-        const unsigned long long hk = hkey[h];
-        if (hk == key) return hval[h];
-        if (hk == 0ull) return -1;
-        h = (h + 1) & (BS_HASH - 1);
-    }
-}
-
 // candidate index of character c in the frame's map (-1: not a candidate of this frame)
 __device__ __forceinline__ int cand_of(const int* ckmap, int c) {
     unsigned h = ((unsigned)c * 0x9E3779B1u) >> 25;
@@ -250,9 +228,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
     float* bcur = lv_sc + 2 * beam;                                     // [beam]
     float* rep = bcur + beam;                                           // [beam] repeat term of nb_cur
     float* ext = rep + beam;                                            // [beam] parent-extension term of nb_cur
-    int* head = reinterpret_cast<int*>(ext + beam);                      // [beam] first live child
-    int* next = head + beam;                                             // [beam] next live child of the same parent
-    int* nch = next + beam;                                              // [beam] number of live children
+    int* head = reinterpret_cast<int*>(ext + beam);                      // [beam] narrow step: selected extensions (prefix | candidate << 16), dense
+    int* next = head + beam;                                             // [beam] ... and their keys (rounds 3-5: children lists)
+    int* nch = next + beam;                                              // [beam] (spare)
     unsigned long long* lv_ctx = reinterpret_cast<unsigned long long*>(nch + beam);   // [2][beam] packed LM context (1024 + 16 beam words behind hkey: 8-byte aligned)
     float* lv_bo = reinterpret_cast<float*>(lv_ctx + 2 * beam);          // [2][beam][4] backoffs of the context's suffixes
     int* lv_m = reinterpret_cast<int*>(lv_bo + 8 * beam);                // [2][beam] m | oov << 8
@@ -393,7 +371,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
         BS_PROBE_UNIGRAM();
         if (T > 1) BS_LOAD_FRAME(1, nx2_cnt, nx2_c, nx2_lp, nx2_blp);
     }
-    const bool prof = a.prof && u == 0 && tid == 0;
+    const bool prof = a.prof && u == (int)gridDim.x - 1 && tid == 0;      // (the LAST workgroup: the longest utterance of a length-sorted pass)
     // phase counters of workgroup 0 live in LDS (16 x 64 bit behind misc): 0-4 wide step, 5 narrow frames, 6-13 narrow step
     unsigned long long* pcl = reinterpret_cast<unsigned long long*>(misc + 8);
     if (tid < 16) pcl[tid] = 0ull;
@@ -500,7 +478,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                 const int i = i0 + j;
                 my_ek[j] = 0ull;
                 if (i < n) {
-                    rep[i] = -INFINITY; ext[i] = -INFINITY; head[i] = -1; nch[i] = 0;       // (first touched behind barrier 2)
+                    rep[i] = -INFINITY; ext[i] = -INFINITY; kidmask[i] = 0ull;       // (first touched behind barrier 2)
                     const unsigned long long key = lv_hid[o + i];
                     unsigned h = (unsigned)(key >> 40) & (BS_HASH - 1);
                     while (atomicCAS(&hkey[h], 0ull, key) != 0ull) h = (h + 1) & (BS_HASH - 1);
@@ -558,7 +536,10 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             }
             __syncthreads();                                                                                  // (2)
             BS_TICK(7);
-            // ---- N2. blank term, children lists, scorer table ------------------------------------------------------------------
+            // ---- N2. blank term, live children of live parents, scorer table ------------------------------------------------
+            int parP[NW_PPT], kqP[NW_PPT];
+#pragma unroll
+            for (int j = 0; j < NW_PPT; ++j) { parP[j] = -1; kqP[j] = -1; }
             const float min_cut = full_beam ? (float)((double)ikey((unsigned)misc[3]) + (double)__int_as_float(misc[4]) -
                                                       fmax(0.0, (double)a.beta))
                                             : -INFINITY;
@@ -579,7 +560,14 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                         if (hk == 0ull) break;
                         h = (h + 1) & (BS_HASH - 1);
                     }
-                    if (par >= 0) { next[i] = atomicExch(&head[par], i); atomicAdd(&nch[par], 1); }
+                    if (par >= 0) {                      // my parent is live: am I one of its candidates in this frame?
+                        const int kq = cand_of(ckmap, lv_ch[o + i]);
+                        if (kq >= 0) {
+                            atomicOr(&kidmask[par], 1ull << kq);
+                            parP[j] = par;
+                            kqP[j] = kq;
+                        }
+                    }
                     if (lm_cache) {
                         int row = -1;
                         if (my_ek[j] != 0ull) {
@@ -597,6 +585,37 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
             // ---- N3. extensions: NW_EPT consecutive entries e = p * cnt + k per thread, keys stay in registers ---------------
             const int nq = n * cnt;
             const int eptf = (nq + NW_T - 1) / NW_T;      // block of consecutive entries per thread in THIS frame: 1 .. NW_EPT
+#pragma unroll
+            for (int j = 0; j < NW_PPT; ++j)
+                if (kqP[j] >= 0) {                        // a live child of a live parent takes the parent's extension term itself
+                    const int p = parP[j], k = kqP[j];
+                    const float scp = lv_sc[o + p], pbp = lv_b[o + p];
+                    const int craw = c_idx[k];
+                    const int c = craw & ~(1 << 30);
+                    const float lp = c_lp[k];
+                    float val = -INFINITY;
+                    if (c != a.blank && !(lp + scp < min_cut)) {
+                        if (c == lv_ch[o + p]) val = pbp > -INFINITY ? lp + pbp : -INFINITY;
+                        else val = lp + scp;
+                        if (use_lm && val > -INFINITY) {
+                            const int mo = lv_m[o + p];
+                            const int rowp = lm_cache ? pu[p] : -1;
+                            float lmp;
+                            if ((mo >> 8) || (craw >> 30)) lmp = LM_OOV_SCORE;
+                            else if (rowp >= 0) lmp = lmtab[rowp * cnt + k];
+                            else {
+                                LmState spp;
+                                spp.ctx = lv_ctx[o + p];
+                                spp.m = mo & 255; spp.oov = 0;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) spp.bo[q] = lv_bo[4 * (o + p) + q];
+                                lmp = lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, spp, c, c_uni[k]);
+                            }
+                            val += a.alpha * lmp + a.beta;
+                        }
+                    }
+                    ext[i0 + j] = val;
+                }
             unsigned keyE[NW_EPT];
             int peE[NW_EPT];                              // p | k << 16 of the entry
             {
@@ -624,7 +643,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                             } else {
                                 val = lp + sc;
                             }
-                            if (use_lm && val > -INFINITY) {
+                            if ((kidmask[p] >> k) & 1ull) {
+                                val = -INFINITY;       // the child (p, c) is a live prefix: it took this term itself (above)
+                            } else if (use_lm && val > -INFINITY) {
                                 const int mo = lv_m[o + p];
                                 const int my_row = lm_cache ? pu[p] : -1;
                                 float lmp;
@@ -639,11 +660,6 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamGpuArgs a) 
                                     lmp = lm_cond_desc<(ORD > 0 ? ORD : 1)>(a.lm, sp, c, c_uni[k]);
                                 }
                                 val += a.alpha * lmp + a.beta;
-                            }
-                            const int q = live_child(head[p], nch[p], next, lv_ch + o, lv_hid[o + p], c, hkey, hval);
-                            if (q >= 0) {           // the child (p, c) is a live prefix: merge into it
-                                ext[q] = val;
-                                val = -INFINITY;
                             }
                         }
                         const unsigned kk = okey(val);

@@ -2935,7 +2935,7 @@ int masr_debug_set(masr_engine* e, int32_t key, int32_t value) {
         } else if (e->beam_prof) {
             long long h[16];
             HIPCHK(hipMemcpy(h, e->beam_prof, sizeof(h), hipMemcpyDeviceToHost));
-            fprintf(stderr, "beam phases (cycles, wg 0): setup+hash %lld  extensions %lld  prefixes+count %lld  select %lld  compact %lld\n",
+            fprintf(stderr, "beam phases (cycles, last workgroup): setup+hash %lld  extensions %lld  prefixes+count %lld  select %lld  compact %lld\n",
                     h[0], h[1], h[2], h[3], h[4]);
             fprintf(stderr, "  narrow step (%lld frames): tables+candidates %lld  hash+contexts %lld  children+scorer table %lld  extensions %lld  "
                     "prefixes+select %lld  scan %lld  survivors %lld  new prefixes %lld\n", h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13]);
