@@ -415,7 +415,21 @@ class ContractStep:
         return [r for r in range(len(sums)) if int(got[r * BATCH:(r + 1) * BATCH].sum()) == int(sums[r])]
 
     def step(self, i, mode='full', next_pcm=None):
-        """``next_pcm``: the HBM-resident batch of the following step when it is not ``self.pcm`` again (tests)"""
+        """``next_pcm``: the HBM-resident batch of the following step when it is not ``self.pcm`` again (tests).
+        ``mode='lanes'``: the 'full' step with consecutive steps on the engine's two lanes (masr_select_lane: two workspace sets,
+        two streams), so the kernels of step k + 1 fill what step k's leave idle -- reported beside the contract line, whose
+        timed region stays on one lane (a kernel bracketed by HIP events must not share the CUs with another step's kernels)."""
+        if mode == 'lanes':
+            lane = i & 1
+            if getattr(self, 'lane_streams', None) is None:
+                self.lane_streams = [torch.cuda.current_stream(self.dev), self.eng.side_stream(4)]
+                self.lane_streams[1].wait_stream(self.lane_streams[0])
+            self.eng.select_lane(lane)
+            try:
+                with torch.cuda.stream(self.lane_streams[lane]):
+                    return self.step(i, 'full', next_pcm)
+            finally:
+                self.eng.select_lane(0)
         slot = i & 1
         pcm = self.pcm
         if mode == 'host':
@@ -479,6 +493,7 @@ def run_contract(args, rank, world, local):
     #  warm-up step ~4 ms of one-time work sat in its 20 timed steps: 6.70 against 6.45-6.47 ms per step, tools/h2h_ab.py)
     dt_dev = parallel.timed_region(lambda i: cs.step(i, 'device'), args.steps, 3)
     dt_host = parallel.timed_region(lambda i: cs.step(i, 'host'), args.steps, 3, flush=cs.flush)
+    dt_lanes = parallel.timed_region(lambda i: cs.step(i, 'lanes'), args.steps, 4, flush=cs.flush) if hasattr(eng, 'side_stream') and torch.cuda.is_available() else None
     others = []
     # the other heavy kernels, each timed the same way over a few more steps (every rank runs the steps -- they contain the
     # all-gather -- rank 0 keeps the numbers)
@@ -540,6 +555,9 @@ def run_contract(args, rank, world, local):
                'roofline': roofline,
                'timing': {'device_only': dict(per(dt_dev), note='PCM in HBM -> packed hypothesis rows in HBM; the host waits only for the (earlier) mean squares'),
                           'host_to_host': dict(per(dt_host), note='pinned host int16 PCM -> H2D (copy stream, under the previous step) -> ... -> D2H -> text on host')}}
+        if dt_lanes is not None:
+            res['timing']['two_lanes'] = dict(per(dt_lanes), note='the contract step with consecutive steps on the two lanes of the engine (two streams, two '
+                                                                   'workspace sets): HBM-resident PCM -> text on host, steps k and k + 1 side by side')
     return eng, res
 
 
@@ -595,12 +613,29 @@ def extra_efficient_b256(args, rank, world, local):
     vocab = np.array(synthetic.synthetic_vocab(VOCAB), dtype=object)
     texts = []
 
+    # consecutive passes on the engine's two lanes (masr_select_lane: two workspace sets, two streams): the kernels of one pass
+    # fill the CUs the other's leave idle (MASR_BENCH_EFFICIENT_LANES=1: one after the other, rounds 1-5)
+    lanes = max(1, min(2, int(os.environ.get('MASR_BENCH_EFFICIENT_LANES', '2')))) if len(passes) > 1 and hasattr(eng, 'side_stream') and torch.cuda.is_available() else 1
+    main = torch.cuda.current_stream(eng.device) if torch.cuda.is_available() else None
+    lane_streams = [main] + ([eng.side_stream(4)] if lanes > 1 else [])
+
     def step(i):
         k = 0
-        for pcm, n in passes:
+        for st in lane_streams[1:]:
+            st.wait_stream(main)                      # (the previous step's gather has read the outputs)
+        for j, (pcm, n) in enumerate(passes):
             b = pcm.shape[0]
-            eng.transcribe_batch(pcm, n, out=(tok[k:k + b], nt[k:k + b], sc[k:k + b]))
+            if lanes > 1:
+                eng.select_lane(j % lanes)
+                with torch.cuda.stream(lane_streams[j % lanes]):
+                    eng.transcribe_batch(pcm, n, out=(tok[k:k + b], nt[k:k + b], sc[k:k + b]))
+            else:
+                eng.transcribe_batch(pcm, n, out=(tok[k:k + b], nt[k:k + b], sc[k:k + b]))
             k += b
+        if lanes > 1:
+            eng.select_lane(0)
+            for st in lane_streams[1:]:
+                main.wait_stream(st)
         t, c, _ = parallel.gather_hypotheses(tok, nt, sc)
         if rank == 0:
             texts[:] = parallel.tokens_to_text(t.cpu().numpy(), c.cpu().numpy(), vocab)
@@ -608,7 +643,8 @@ def extra_efficient_b256(args, rank, world, local):
     dt = parallel.timed_region(step, steps, 1)
     eng.close()
     return {'workload': f'configs[3]: efficient_conformer.yml streaming fbank, 256 x 10 s utterances sharded over {world} GPU(s) '
-                        f'({hi - lo} on rank 0, device passes of {min(per_pass, hi - lo)}), ctc_greedy, all-gather of hypotheses, text on host',
+                        f'({hi - lo} on rank 0, device passes of {min(per_pass, hi - lo)}' + (', consecutive passes on the two lanes of the engine' if lanes > 1 else '')
+                        + '), ctc_greedy, all-gather of hypotheses, text on host',
             'value': round(total * 10.0 * steps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world, 'steps': steps,
             'ms_per_step': round(dt * 1e3 / steps, 3), 'scaling': 'strong', 'transcripts': len(texts),
             'roofline': workload_roofline(GFLOP_PER_UTT_EFFICIENT * (hi - lo), dt * 1e3 / steps,

@@ -340,13 +340,24 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
                  float* c_dev, int32_t M, int32_t N, int32_t K, int32_t act, float alpha, void* stream);
 
 /* Side streams owned by the library: kind 0 / 1 = prefix searches of consecutive device passes, 2 = per-pass preparation (upload,
- * mean squares, gains), 3 = copies.  One set per DEVICE, created with the first masr_create on it (before anything the process
+ * mean squares, gains), 3 = copies, 4 = the encoder passes of lane 1 (masr_select_lane).  One set per DEVICE, created with the first masr_create on it (before anything the process
  * creates later: their hardware-queue assignment does not depend on what a server does afterwards, see engine.hip) and shared by
  * every engine there; non-blocking, default priority.  The caller borrows them (torch.cuda.ExternalStream) and never destroys
  * them.  They take the place of the worker processes of the reference's batch decoder (masr/decoders/beam_search_decoder.py:59-73:
  * num_processes search workers beside the model's forward). */
-#define MASR_SIDE_STREAMS 4
+#define MASR_SIDE_STREAMS 5
 int masr_side_stream(masr_engine* e, int32_t kind, void** stream_out);
+
+/* Lanes: an engine holds MASR_LANES sets of forward workspaces (activations, descriptor tables; ONE set of weights).  The calls
+ * that follow masr_select_lane(e, k) use set k, so two offline passes of one engine can be in flight on two streams -- the
+ * length-sorted device passes of a batch (the reference forms them one after the other: trainer.py:592-651 evaluates batch by
+ * batch, predict.py:194-234 utterance by utterance) side by side: a pass whose row blocks do not fill the last round of a launch
+ * leaves CUs to the other pass's kernels (BASELINE configs[2], two passes of 32: 17.0 -> 14.9 ms of encoder time).  Launches that
+ * share a lane must be ordered by their stream, exactly as all launches of an engine had to be before; a set is allocated on its
+ * lane's first use and sized by the largest pass it has seen.  Results do not depend on the lane.  Lane 0 is active after
+ * masr_create; streaming sessions (masr_stream_*) keep their caches outside the lanes.  Not thread-safe, like every call. */
+#define MASR_LANES 2
+int masr_select_lane(masr_engine* e, int32_t lane);
 
 /* Diagnostics: A/B switches of the kernels, for in-process measurements (tools/ *_ab.py); production = the defaults.
  *   1  fused-FFN variant (0 production, 1 without weight loads)      2  beam-search phase profile of workgroup 0

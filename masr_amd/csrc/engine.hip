@@ -125,6 +125,9 @@ struct DevBuf {
         // zero once: kernels that skip the padded row blocks of a batch (masr_debug_set key 38) leave those rows as they are, and
         // what is there must at least be finite -- a later 0 * stale product must not see the NaN patterns of fresh memory
         HIPCHK(hipMemset(p, 0, want));
+        // (the fill runs on the NULL stream, which a non-blocking stream does not wait for: without this a lane's first launches
+        // could write the buffer BEFORE it is cleared -- the first two-lane call lost its second pass that way)
+        HIPCHK(hipStreamSynchronize(nullptr));
         bytes = want;
         return 0;
     }
@@ -242,8 +245,40 @@ enum ProfKind { PROF_NONE = 0, PROF_GEMM = 1, PROF_FFN1 = 2, PROF_CONV2 = 3, PRO
 
 }  // namespace
 
-struct masr_engine {
+// Everything a forward call WRITES on the device (and the pinned descriptor staging of the chunk step): one set per LANE.
+// masr_select_lane parks the active set and brings another one in, so two offline passes can be in flight on two streams of one
+// engine (one set of weights) -- launches that share a lane must be ordered by their stream, as before.
+struct EngineWs {
+    DevBuf gx, rnn_out, hstate, cstate, ds2_lens;                               // DeepSpeech2 workspaces
+    PinnedStage stage;
+    DevBuf qplanes, attp, cnnptrs, ffpart;                                      // planar q|k|v and attention output, [B][Tpad][256]
+    DevBuf fb_scratch;
+    DevBuf x1, x2, x, ln, hid, qkv, att, lnpad, glu, dwo, logits, feats, enc, idx, maxp, attseq, gain, nframes, lens, xsave,
+        xred, xh;      // xh: rows updated by the head stage of a d_ff-split FFN launch (few rows)
+    void release_all() {
+        for (DevBuf* b : {&gx, &rnn_out, &hstate, &cstate, &ds2_lens, &qplanes, &attp, &cnnptrs, &ffpart, &fb_scratch, &x1, &x2, &x,
+                          &ln, &hid, &qkv, &att, &lnpad, &glu, &dwo, &logits, &feats, &enc, &idx, &maxp, &attseq, &gain, &nframes,
+                          &lens, &xsave, &xred, &xh})
+            b->release();
+        stage.release();
+    }
+};
+
+// hipMemset runs on the NULL stream, which a non-blocking stream (every torch side stream, the library's own) does not wait for:
+// the host waits for the fill, so that whatever is launched next on any stream sees the cleared memory
+static int clear_sync(void* p, int value, size_t n) {
+    HIPCHK(hipMemset(p, value, n));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+struct masr_engine : EngineWs {
     masr_config cfg;
+    EngineWs parked[MASR_LANES];     // the workspace sets of the lanes that are not active (parked[lane] is unused)
+    int lane = 0;
+    hipEvent_t pack_ev = nullptr;    // recorded behind the last call that built a packed weight copy on first use ...
+    void* pack_stream = nullptr;     // ... on this stream: calls on OTHER streams wait for it before they read the copies
+    bool pack_pending = false;
     bool finalized = false;
     std::map<std::string, HostTensor> host;
     std::vector<void*> owned;   // device weight allocations
@@ -254,7 +289,6 @@ struct masr_engine {
     std::vector<LayerW> layers;
     std::vector<SqLayerW> sq_layers;
     std::vector<Ds2LayerW> ds2_layers;
-    DevBuf gx, rnn_out, hstate, cstate, ds2_lens;
     std::vector<GBeam> gbeams;
     DevBuf beam_pool, beam_state;
     // whole-utterance prefix searches launched on OTHER streams than the first one get workspaces of their own: two searches may
@@ -276,8 +310,6 @@ struct masr_engine {
     int reduce_idx = -1, recover_idx = -1;
     int stride_idx = -1, n_group_layers = 0, group_size = 3;   // Efficient-Conformer (model_kind 2)
     bool conv_bn = false;            // Conformer with cnn_module_norm: batch_norm (cfg.reserved[0] = 1): LayerW::cln_w / cln_b hold the folded scale / shift
-    PinnedStage stage;
-    DevBuf qplanes, attp, cnnptrs, ffpart;                                      // planar q|k|v and attention output, [B][Tpad][256]
     // fbank tables
     float *window = nullptr, *melwt = nullptr, *tw512 = nullptr, *twr4 = nullptr;
     FbankTables fbank_tables() const { return FbankTables{window, melwt, tw512, twr4, mel_lo}; }
@@ -287,10 +319,6 @@ struct masr_engine {
     int dct_ceps = 0;
     double *lin_win = nullptr, *lin_tw = nullptr;
     double lin_scale = 0.0;
-    DevBuf fb_scratch;
-    // workspace
-    DevBuf x1, x2, x, ln, hid, qkv, att, lnpad, glu, dwo, logits, feats, enc, idx, maxp, attseq, gain, nframes, lens, xsave,
-        xred, xh;      // xh: rows updated by the head stage of a d_ff-split FFN launch (few rows)
     // streams
     std::vector<Stream> streams;
     // profiling
@@ -353,6 +381,34 @@ struct ProfScope {
         if (!on) return;
         hipEventRecord(e->prof_events[e->prof_used].second, s);
         e->prof_used++;
+    }
+};
+
+// Packed weight copies are built on first use by whatever call needs them first, on that call's stream.  With two lanes a call
+// on ANOTHER stream may find the copy in the map while the packing launch is still queued: the call that packed records an event
+// behind itself, and calls on other streams wait for that event until it has completed.
+struct CallGuard {
+    masr_engine* e;
+    hipStream_t s;
+    size_t n0;
+    static size_t packed_count(const masr_engine* e) { return e->ffn_packed.size() + e->ffn_dual_packed.size() + e->x3_packed.size(); }
+    CallGuard(masr_engine* e_, hipStream_t s_) : e(e_), s(s_), n0(packed_count(e_)) {
+        if (!e->pack_pending) return;
+        if (hipEventQuery(e->pack_ev) == hipSuccess) {
+            e->pack_pending = false;
+        } else {
+            (void)hipGetLastError();          // (hipErrorNotReady is not an error of ours)
+            if ((void*)s != e->pack_stream) (void)hipStreamWaitEvent(s, e->pack_ev, 0);
+        }
+    }
+    ~CallGuard() {
+        if (packed_count(e) == n0) return;
+        if (!e->pack_ev && hipEventCreateWithFlags(&e->pack_ev, hipEventDisableTiming) != hipSuccess) return;
+        // (a pending event of another stream: this call waited for it at its start, so the new record covers it)
+        if (hipEventRecord(e->pack_ev, s) == hipSuccess) {
+            e->pack_stream = (void*)s;
+            e->pack_pending = true;
+        }
     }
 };
 
@@ -588,12 +644,11 @@ int masr_create(const masr_config* cfg, masr_engine** out) {
 void masr_destroy(masr_engine* e) {
     if (!e) return;
     for (void* p : e->owned) (void)hipFree(p);
-    DevBuf* bufs[] = {&e->x1, &e->x2, &e->x, &e->ln, &e->hid, &e->qkv, &e->att, &e->lnpad, &e->glu, &e->dwo,
-                      &e->logits, &e->feats, &e->enc, &e->idx, &e->maxp, &e->attseq, &e->gain, &e->nframes, &e->lens, &e->xsave, &e->xh,
-                      &e->xred, &e->qplanes, &e->attp, &e->cnnptrs, &e->ffpart, &e->gx, &e->rnn_out, &e->hstate, &e->cstate,
-                      &e->ds2_lens, &e->beam_pool, &e->beam_state};
-    for (DevBuf* b : bufs) b->release();
-    e->stage.release();
+    e->release_all();
+    for (auto& w : e->parked) w.release_all();
+    e->beam_pool.release();
+    e->beam_state.release();
+    if (e->pack_ev) (void)hipEventDestroy(e->pack_ev);
     for (auto& s : e->streams) {
         s.att.release();
         s.cnn.release();
@@ -1772,6 +1827,7 @@ int masr_encode_full(masr_engine* e, const float* feats_dev, const int32_t* feat
                      int32_t decoding_chunk_size, float* enc_out_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
     ENTER(e);
+    CallGuard call_guard(e, (hipStream_t)stream);
     if (B <= 0) return fail("empty batch");
     hipStream_t s = (hipStream_t)stream;
     if (e->cfg.model_kind == 3) return ds2_forward(e, s, feats_dev, feat_lens_dev, B, T, enc_out_dev, nullptr, nullptr);
@@ -1873,6 +1929,7 @@ int masr_ctc_probs(masr_engine* e, const float* enc_dev, int32_t M, float* probs
                    float* maxprob_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
     ENTER(e);
+    CallGuard call_guard(e, (hipStream_t)stream);
     if (!probs_dev) return fail("probs_dev is null");
     if (e->cfg.vocab_size > 16384) return fail("vocab_size > 16384 is not supported by the softmax / pruning kernels (one 256-thread workgroup holds a row in registers)");
     return ctc_head(e, enc_dev, M, probs_dev, 1, argmax_dev, maxprob_dev, (hipStream_t)stream);
@@ -1882,6 +1939,7 @@ int masr_ctc_greedy_frames(masr_engine* e, const float* enc_dev, int32_t M, int3
                            void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
     ENTER(e);
+    CallGuard call_guard(e, (hipStream_t)stream);
     if (e->cfg.model_kind == 3)      // K = 1024 / 2048 rows: generic GEMM + softmax statistics (logits stay in a workspace)
         return ctc_head(e, enc_dev, M, nullptr, 0, argmax_dev, maxprob_dev, (hipStream_t)stream);
     // few row blocks (one utterance: 7; the Efficient Conformer's half-rate output at 32 x 10 s: 124): the fused head gives a
@@ -2227,6 +2285,7 @@ static int transcribe_impl(masr_engine* e, const void* samples_dev, int32_t fmt,
                            int32_t* rows_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
     ENTER(e);
+    CallGuard call_guard(e, (hipStream_t)stream);
     if (n_max < 400) return fail("n_max < 400 samples: no frame");
     hipStream_t s = (hipStream_t)stream;
     const int d = enc_dim(e), F = e->cfg.n_mels;
@@ -2309,7 +2368,7 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     if (e->cfg.model_kind == 3) {      // LSTM state (h, c) per layer; no attention cache, no frame limit
         st.cap = 1 << 30;
         CHK(st.cnn.ensure((size_t)L * 2 * d * sizeof(float)));
-        HIPCHK(hipMemset(st.cnn.p, 0, (size_t)L * 2 * d * sizeof(float)));
+        CHK(clear_sync(st.cnn.p, 0, (size_t)L * 2 * d * sizeof(float)));
         st.offset = 0;
         st.open = true;
         *stream_id = id;
@@ -2317,11 +2376,11 @@ int masr_stream_open(masr_engine* e, int32_t max_frames_out, int32_t* stream_id)
     }
     CHK(st.att.ensure((size_t)L * st.cap * 2 * d * sizeof(float)));
     CHK(st.cnn.ensure((size_t)L * pad * d * sizeof(float)));
-    HIPCHK(hipMemset(st.cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
+    CHK(clear_sync(st.cnn.p, 0, (size_t)L * pad * d * sizeof(float)));
     CHK(st.cnn2.ensure((size_t)L * pad * d * sizeof(float)));
-    HIPCHK(hipMemset(st.cnn2.p, 0, (size_t)L * pad * d * sizeof(float)));
+    CHK(clear_sync(st.cnn2.p, 0, (size_t)L * pad * d * sizeof(float)));
     if (e->cfg.model_kind == 2)     // planar caches of the grouped layers: rows behind the last key must read as zero
-        HIPCHK(hipMemset(st.att.p, 0, (size_t)L * st.cap * 2 * d * sizeof(float)));
+        CHK(clear_sync(st.att.p, 0, (size_t)L * st.cap * 2 * d * sizeof(float)));
     st.offset = 0;
     st.offset_r = 0;
     st.history = -1;
@@ -2345,8 +2404,8 @@ int masr_stream_reset(masr_engine* e, int32_t stream_id) {
     ENTER(e);
     const int d = e->cfg.d_model, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(st->cnn.p, 0, (e->cfg.model_kind == 3 ? (size_t)L * 2 * d : (size_t)L * pad * d) * sizeof(float)));
-    if (e->cfg.model_kind == 2) HIPCHK(hipMemset(st->att.p, 0, (size_t)L * st->cap * 2 * d * sizeof(float)));
+    CHK(clear_sync(st->cnn.p, 0, (e->cfg.model_kind == 3 ? (size_t)L * 2 * d : (size_t)L * pad * d) * sizeof(float)));
+    if (e->cfg.model_kind == 2) CHK(clear_sync(st->att.p, 0, (size_t)L * st->cap * 2 * d * sizeof(float)));
     st->offset = 0;
     st->offset_r = 0;
     st->cache_t1 = 0;
@@ -2707,6 +2766,7 @@ int masr_encode_chunk(masr_engine* e, const int32_t* stream_ids, int32_t n, cons
                       float* probs_dev, int32_t* argmax_dev, float* maxprob_dev, void* stream) {
     if (!e || !e->finalized) return fail("engine not finalized");
     ENTER(e);
+    CallGuard call_guard(e, (hipStream_t)stream);
     if (n <= 0) return fail("no streams");
     hipStream_t s = (hipStream_t)stream;
     const int d = e->cfg.d_model, H = e->cfg.heads, L = e->cfg.num_blocks, pad = e->cfg.cnn_kernel - 1;
@@ -2870,15 +2930,29 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
                  float* c_dev, int32_t M, int32_t N, int32_t K, int32_t act, float alpha, void* stream) {
     if (!e) return fail("null engine");
     ENTER(e);
+    CallGuard call_guard(e, (hipStream_t)stream);
     if (K % 32) return fail("K must be a multiple of 32");
     gemm(e, (hipStream_t)stream, a_dev, K, w_dev, bias_dev, c_dev, N, M, N, K, act, alpha, res_dev, N);
     LAUNCHCHK();
     return 0;
 }
 
+int masr_select_lane(masr_engine* e, int32_t lane) {
+    if (!e) return fail("null engine");
+    if (lane < 0 || lane >= MASR_LANES) return fail("masr_select_lane: lane must be in [0, " + std::to_string(MASR_LANES) + ")");
+    if (lane == e->lane) return 0;
+    EngineWs& active = *e;                   // park the active set, bring the lane's own in (pointers and sizes only)
+    e->parked[e->lane] = active;
+    active = e->parked[lane];
+    e->parked[lane] = EngineWs();
+    e->lane = lane;
+    return 0;
+}
+
 int masr_side_stream(masr_engine* e, int32_t kind, void** stream_out) {
     if (!e || !stream_out) return fail("null argument");
-    if (kind < 0 || kind >= MASR_SIDE_STREAMS) return fail("masr_side_stream: kind must be 0 / 1 (prefix search), 2 (preparation) or 3 (copy)");
+    if (kind < 0 || kind >= MASR_SIDE_STREAMS)
+        return fail("masr_side_stream: kind must be 0 / 1 (prefix search), 2 (preparation), 3 (copy) or 4 (second encoder lane)");
     SideStreams* ss = nullptr;
     if (side_streams_of(e->cfg.device_id, &ss)) return 1;
     *stream_out = (void*)ss->s[kind];

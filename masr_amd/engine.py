@@ -228,9 +228,9 @@ class HipEngine:
 
     def side_stream(self, kind):
         """a side stream of THIS DEVICE owned by libmasr_hip.so (masr_side_stream; kind 0 / 1: prefix searches of consecutive
-        passes, 2: per-pass preparation, 3: copies), as a torch stream.  One set per device, created with the device's first
-        engine at the highest stream priority -- hardware queues of their own, whatever streams the process creates before or
-        after (include/masr_hip.h); borrowed, never destroyed."""
+        passes, 2: per-pass preparation, 3: copies, 4: encoder passes of lane 1), as a torch stream.  One set per device, created
+        with the device's first engine at default priority -- hardware queues of their own, whatever streams the process creates
+        before or after (include/masr_hip.h); borrowed, never destroyed."""
         cache = self.__dict__.setdefault('_side', {})
         st = cache.get(kind)
         if st is None:
@@ -238,6 +238,12 @@ class HipEngine:
             check(self.lib.masr_side_stream(self.h, int(kind), C.byref(ptr)))
             st = cache[kind] = torch.cuda.ExternalStream(ptr.value, device=self.device)
         return st
+
+    def select_lane(self, lane):
+        """masr_select_lane: the calls that follow use workspace set ``lane`` (0 / 1) of this engine, so two offline passes can be
+        in flight on two streams; launches sharing a lane must be ordered by their stream (include/masr_hip.h)."""
+        check(self.lib.masr_select_lane(self.h, int(lane)))
+        self.lane = int(lane)
 
     def to_host(self, t):
         """small device tensor -> numpy through a pinned buffer, waiting for THIS stream only.  (``tensor.cpu()`` copies to

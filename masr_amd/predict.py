@@ -191,10 +191,20 @@ class MASRPredictor:
             ring['lens'][k] = torch.zeros(max(len(segs), 64), dtype=torch.int32, pin_memory=True)
         stage = ring['bufs'][k][:need].view(len(segs), n_max)
         buf = stage.numpy()
-        for i, s in enumerate(segs):
-            m = int(n[i])
-            buf[i, :m] = s._pcm16 if as_pcm else s._samples
-            buf[i, m:] = 0
+
+        def fill(rows):
+            for i in rows:
+                m = int(n[i])
+                buf[i, :m] = segs[i]._pcm16 if as_pcm else segs[i]._samples
+                buf[i, m:] = 0
+        # 20 MB per pass of 32 x 20 s: row copies release the GIL, four host threads take rows in turn (0.66 -> 0.3 ms per pass)
+        if need >= (1 << 20) and len(segs) >= 8:
+            if getattr(self, '_fill_pool', None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._fill_pool = ThreadPoolExecutor(4, thread_name_prefix='masr_stage')
+            list(self._fill_pool.map(fill, [range(j, len(segs), 4) for j in range(4)]))
+        else:
+            fill(range(len(segs)))
         lens = ring['lens'][k][:len(segs)]
         lens.numpy()[:] = n
         xs = stage.to(eng.device, non_blocking=True)
@@ -204,22 +214,45 @@ class MASRPredictor:
         ring['events'][k] = ev
         return xs, ns
 
-    def _prepare(self, live, n, use_db, target_db):
-        """upload + (bit-exact normalisation route) the reference's gains: the mean squares come back from the device, the
-        scalar float32 expressions of audio.py:287-304,519-529 run in this host's numpy, the gains go up again -- all on the
-        preparation stream; the main stream then waits for that stream's event, the host for nothing else."""
+    def _prepare_begin(self, live, n, use_db):
+        """first half of a pass's preparation, nothing waited for: staging + upload + (bit-exact normalisation route) the mean
+        squares on their way back to a pinned slot, all on the preparation stream.  Issued for pass k + 1 BEFORE the encoder of
+        pass k is launched: a launch on another queue waits for free CUs once an encoder pass is running (3.5 ms, round 6)."""
         eng = self.predictor.engine
-        main = torch.cuda.current_stream(eng.device)
-        prep = self._prep_stream()
-        with torch.cuda.stream(prep):
+        with torch.cuda.stream(self._prep_stream()):
             xs, ns = self._stage_batch(live, n)
-            gain = eng.host_gains(xs, ns, target_db) if use_db else None          # (waits for the preparation stream only)
-            done = torch.cuda.Event()
-            done.record()
-        main.wait_event(done)
-        for t in (xs, ns, gain):
-            if t is not None:
-                t.record_stream(main)
+            ms_host = None
+            if use_db:
+                ring = self.__dict__.setdefault('_ms_ring', {'bufs': [None] * 4, 'turn': 0})
+                k = ring['turn']
+                ring['turn'] = (k + 1) % 4
+                if ring['bufs'][k] is None or ring['bufs'][k].numel() < len(live):
+                    ring['bufs'][k] = torch.empty(max(len(live), 64), dtype=torch.float32, pin_memory=True)
+                ms_host = ring['bufs'][k][:len(live)]
+                ms_host.copy_(eng.mean_square(xs, ns), non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+        return xs, ns, ms_host, ready
+
+    def _prepare(self, live, n, use_db, target_db):
+        """both halves at once (a pass prepared right before its encoder)"""
+        return self._prepare_finish(self._prepare_begin(live, n, use_db), target_db)
+
+    def _prepare_finish(self, began, target_db):
+        """second half: the reference's gains -- the scalar float32 expressions of audio.py:287-304,519-529 in this host's numpy on
+        the mean squares the device computed -- uploaded on the CURRENT stream (the pass's encoder stream), which then waits for
+        the upload of the samples; the host has waited for the preparation stream's event only."""
+        from masr_amd.engine import reference_gains
+        eng = self.predictor.engine
+        xs, ns, ms_host, ready = began
+        main = torch.cuda.current_stream(eng.device)
+        gain = None
+        if ms_host is not None:
+            ready.synchronize()
+            gain = eng.to_device(reference_gains(ms_host.numpy().copy(), target_db))
+        main.wait_event(ready)
+        for t in (xs, ns):
+            t.record_stream(main)
         return xs, ns, gain
 
     def _rows_slot(self, B, width):
@@ -231,7 +264,23 @@ class MASRPredictor:
             ring['bufs'][k] = torch.empty(max(B * width, 1 << 14), dtype=torch.int32, pin_memory=True)
         return ring['bufs'][k][:B * width].view(B, width)
 
-    def _predict_local(self, segs, decode_all_frames=False, as_tokens=False, defer=False, hold_search=False):
+    def _begin_pass(self, segs):
+        """host side of a device pass + the asynchronous half of its preparation (``_prepare_begin``); ``_predict_local`` takes
+        the result as ``began``.  Utterances too short for one feature frame are set aside here."""
+        pc = self.configs.preprocess_conf
+        rate = int(pc.get('sample_rate', 16000))
+        min_samples = 320 if pc.get('feature_method', 'fbank') == 'linear' else 400
+        for s in segs:
+            if s.sample_rate != rate:
+                s.resample(rate)
+        # 7 feature frames is the least Conv2dSubsampling4 accepts (subsampling.py:65-112)
+        ok = [i for i, s in enumerate(segs) if s.num_samples >= min_samples + 6 * 160]
+        live = [segs[i] for i in ok]
+        n = np.array([s.num_samples for s in live], np.int32)
+        return {'count': len(segs), 'ok': ok, 'n': n, 'min_samples': min_samples,
+                'prep': self._prepare_begin(live, n, pc.use_dB_normalization) if ok else None}
+
+    def _predict_local(self, segs, decode_all_frames=False, as_tokens=False, defer=False, hold_search=False, began=None):
         """AudioSegments -> [{'text','score'}] on THIS rank's engine.  Utterances too short for one feature frame decode to
         the empty transcript (the reference's encoder cannot take them either); a digitally silent utterance (mean square 0) is
         normalised with gain = target_dB like the reference (audio.py:519-529), only a gain above max_gain_db raises (:300-303).
@@ -240,23 +289,18 @@ class MASRPredictor:
         copy behind an event; beam search on the GPU: the prefix search runs on a side stream)."""
         eng = self.predictor.engine
         pc = self.configs.preprocess_conf
-        rate = int(pc.get('sample_rate', 16000))
         method = pc.get('feature_method', 'fbank')
-        min_samples = 320 if method == 'linear' else 400
-        for s in segs:
-            if s.sample_rate != rate:
-                s.resample(rate)
-        out = [None] * len(segs)
-        # 7 feature frames is the least Conv2dSubsampling4 accepts (subsampling.py:65-112)
-        ok = [i for i, s in enumerate(segs) if s.num_samples >= min_samples + 6 * 160]
-        if len(ok) != len(segs):
-            for i in set(range(len(segs))) - set(ok):
+        if began is None:
+            began = self._begin_pass(segs)
+        ok, n, min_samples = began['ok'], began['n'], began['min_samples']
+        out = [None] * began['count']
+        if len(ok) != began['count']:
+            for i in set(range(began['count'])) - set(ok):
                 out[i] = ([], 0) if as_tokens else {'text': '', 'score': 0}
         if not ok:
             return (lambda: out) if defer else out
-        live = [segs[i] for i in ok]
-        n = np.array([s.num_samples for s in live], np.int32)
-        xs, ns, gain = self._prepare(live, n, pc.use_dB_normalization, pc.target_dB)
+        live = ok                # (only its length is used below)
+        xs, ns, gain = self._prepare_finish(began['prep'], pc.target_dB)
         greedy = self.configs.decoder != 'ctc_beam_search'
         if greedy and method == 'fbank':
             # the whole pass is ONE C-ABI call and ONE copy back: rows [B, T' + 2] = tokens | count | score bits
@@ -476,11 +520,43 @@ class MASRPredictor:
                     lo += part['B']
                 return []
             pending.append(([], fetch))
-        for lo, hi in cuts:
+        # Two LANES (masr_select_lane): consecutive passes run on two streams and two workspace sets of the one engine, so the
+        # kernels of one pass fill the CUs the other leaves idle -- a fused Squeezeformer stage holds one 32-row block per CU,
+        # the 429 / 179 valid row blocks of BASELINE configs[2]'s two passes are 2 + 1 rounds of 256 CUs one after the other
+        # and 2.4 side by side (encoders alone: 17.0 -> 14.8 ms; the greedy call 18.5 -> 17.2 ms).  The preparation of pass
+        # k + 1 (upload, mean squares) is queued BEFORE the encoder of pass k.  NOT with the prefix search on the GPU: a search
+        # is a chain of dependent memory round trips and slows down with everything that runs beside it -- its pass's encoder
+        # must finish EARLY, not share the chip (sharpened head 23.5 -> 24.7 ms, flat 28.0 -> 30.8 ms per call with two lanes;
+        # passes of 16 or uneven passes on two lanes: 23.4 - 31 / 33 - 38 ms).  MASR_LANES=1 | 2 overrides (A/B).
+        eng = self.predictor.engine
+        lanes = int(os.environ.get('MASR_LANES', '1' if gpu_search else '2'))
+        lanes = max(1, min(2, lanes)) if len(cuts) > 1 and not group_utts else 1
+        main = torch.cuda.current_stream(eng.device)
+        lane_streams = [main] + ([eng.side_stream(4)] if lanes > 1 else [])
+        for st in lane_streams[1:]:
+            st.wait_stream(main)             # (once, before the first pass: whatever the caller queued comes first)
+        began = {}
+
+        def begin(k):
+            lo, hi = cuts[k]
+            segs = [self._load_audio(audio_list[i], sample_rate) for i in order[lo:hi]]
+            began[k] = self._begin_pass(segs)
+        for k, (lo, hi) in enumerate(cuts):
             idx = order[lo:hi]
-            segs = [self._load_audio(audio_list[i], sample_rate) for i in idx]
-            res = self._predict_local(segs, decode_all_frames, as_tokens, defer=True, hold_search=group_utts > 0)
-            del segs
+            if k not in began:
+                begin(k)
+            if lanes > 1 and k + 1 < len(cuts):
+                begin(k + 1)
+            lane = k % lanes
+            if lane:
+                eng.select_lane(lane)
+            try:
+                with torch.cuda.stream(lane_streams[lane]):
+                    res = self._predict_local(None, decode_all_frames, as_tokens, defer=True, hold_search=group_utts > 0,
+                                              began=began.pop(k))
+            finally:
+                if lane:
+                    eng.select_lane(0)
             if isinstance(res, tuple) and res[0] == 'held':
                 held.append((idx, res[1], res[2]))
                 if sum(part['B'] for _, part, _ in held) >= group_utts:
@@ -496,8 +572,8 @@ class MASRPredictor:
         if pending:
             for item in pending:
                 collect(item)
-            for side in getattr(self, '_sides', None) or []:
-                torch.cuda.current_stream(self.predictor.engine.device).wait_stream(side)
+            for side in (getattr(self, '_sides', None) or []) + lane_streams[1:]:
+                main.wait_stream(side)
         return [got[i] for i in which]
 
     def evaluate(self, manifest, batch_size='auto', display_result=False, decode_all_frames=False, pass_padded=None):

@@ -878,3 +878,63 @@ def test_two_gpu_server_with_beam_search_predictors(tmp_path):
     want = [preds[0].predict(c) for c in clips for _ in range(2)]
     for g_, w_ in zip(got, want):
         assert g_['text'] == w_['text'] and abs(g_['score'] - w_['score']) < 1e-2
+
+
+def test_two_lanes_of_one_engine_equal_one_lane(tmp_path, monkeypatch):
+    """masr_select_lane: two passes in flight on two streams of ONE engine (two workspace sets, one set of weights) give the rows
+    each pass gives alone on lane 0 -- bit-identical -- whichever lane runs which pass; then the facade: predict_batch in three
+    length-sorted passes with MASR_LANES=2 (the default without a GPU prefix search) and =1 returns the same transcripts and scores, greedy and GPU prefix search."""
+    from masr_amd.decoders.lm_scorer import write_synthetic_arpa
+    from masr_amd.engine import HipEngine
+    from masr_amd.predict import MASRPredictor
+    from masr_amd.utils import synthetic
+    V = 4233
+    sd = synthetic.squeezeformer_state_dict(0, V)
+    eng = HipEngine(sd, {}, streaming=False, use_model='squeezeformer')
+    rng = np.random.default_rng(7)
+    lens = np.sort(rng.integers(32000, 200001, 24).astype(np.int32))[::-1].copy()
+    pcm = synthetic.synthetic_pcm(24, int(lens.max()), seed=7)
+    passes = []
+    for lo in (0, 12):
+        sel = lens[lo:lo + 12]
+        x = torch.from_numpy(np.ascontiguousarray(pcm[lo:lo + 12, :int(sel.max())])).to(eng.device)
+        for i in range(12):
+            x[i, int(sel[i]):] = 0
+        n = torch.from_numpy(sel.copy()).to(eng.device)
+        passes.append((x, n, eng.host_gains(x, n, -20.0)))
+    def valid(rows):          # tokens | count | score bits: what lies behind a row's count is not written
+        r = rows.cpu().numpy()
+        return [(r[i, :r[i, -2]].tolist(), int(r[i, -2]), int(r[i, -1])) for i in range(r.shape[0])]
+    alone = [valid(eng.transcribe_rows(x, n, True, -20.0, gain_in=g)) for x, n, g in passes]
+    assert sum(c for rows in alone for _, c, _ in rows) > 0
+    streams = [torch.cuda.current_stream(eng.device), eng.side_stream(4)]
+    streams[1].wait_stream(streams[0])
+    for order in ((0, 1), (1, 0), (0, 1)):
+        outs = {}
+        for k, lane in enumerate(order):
+            x, n, g = passes[k]
+            eng.select_lane(lane)
+            with torch.cuda.stream(streams[lane]):
+                outs[k] = eng.transcribe_rows(x, n, True, -20.0, gain_in=g)
+        eng.select_lane(0)
+        torch.cuda.synchronize()
+        for k in (0, 1):
+            assert valid(outs[k]) == alone[k], (order, k)
+    with pytest.raises(Exception):
+        eng.select_lane(2)
+    eng.close()
+
+    audio = [pcm[i, :lens[i]].copy() for i in range(24)]
+    vocab = synthetic.synthetic_vocab(V)
+    lm_path = write_synthetic_arpa(os.path.join(tmp_path, 'lm3.arpa'), vocab, order=3, seed=5)
+    cfg, _ = _squeezeformer_beam_cfg(tmp_path, V, 100, lm_path)
+    for decoder in ('ctc_greedy', 'ctc_beam_search'):
+        cfg['decoder'] = decoder
+        pred = MASRPredictor(configs=cfg, use_gpu=True, state_dict=sd)
+        got = {}
+        for lanes in ('2', '1', '2'):
+            monkeypatch.setenv('MASR_LANES', lanes)
+            got.setdefault(lanes, []).append(pred.predict_batch(audio, batch_size=8))
+        assert got['2'][0] == got['1'][0] == got['2'][1], decoder
+        assert sum(len(r['text']) for r in got['2'][0]) > 0
+        pred.predictor.engine.close()
