@@ -493,7 +493,14 @@ def run_contract(args, rank, world, local):
     #  warm-up step ~4 ms of one-time work sat in its 20 timed steps: 6.70 against 6.45-6.47 ms per step, tools/h2h_ab.py)
     dt_dev = parallel.timed_region(lambda i: cs.step(i, 'device'), args.steps, 3)
     dt_host = parallel.timed_region(lambda i: cs.step(i, 'host'), args.steps, 3, flush=cs.flush)
-    dt_lanes = parallel.timed_region(lambda i: cs.step(i, 'lanes'), args.steps, 4, flush=cs.flush) if hasattr(eng, 'side_stream') and torch.cuda.is_available() else None
+    dt_lanes, lanes_kernel = None, None
+    if hasattr(eng, 'side_stream') and torch.cuda.is_available():
+        # consecutive steps on the engine's two lanes; the roofline kernel bracketed the same way (its duration then includes what
+        # the other step's kernels take from the CUs it shares with them)
+        dt_lanes = parallel.timed_region(lambda i: cs.step(i, 'lanes'), args.steps, 4, flush=cs.flush, after_warmup=prof_on)
+        lanes_kernel = eng.profile_read(reset=True)
+        eng.profile_select(0)
+        eng.lib.masr_debug_set(eng.h, 16, 1)
     others = []
     # the other heavy kernels, each timed the same way over a few more steps (every rank runs the steps -- they contain the
     # all-gather -- rank 0 keeps the numbers)
@@ -558,6 +565,11 @@ def run_contract(args, rank, world, local):
         if dt_lanes is not None:
             res['timing']['two_lanes'] = dict(per(dt_lanes), note='the contract step with consecutive steps on the two lanes of the engine (two streams, two '
                                                                    'workspace sets): HBM-resident PCM -> text on host, steps k and k + 1 side by side')
+            res['timing']['two_lanes']['whole_step_mfma_frac'] = round(GFLOP_PER_STEP / (dt_lanes * 1e3 / args.steps) / PEAK_F32_MFMA_TFLOPS, 4)
+            if lanes_kernel and lanes_kernel[1] > 0:
+                res['timing']['two_lanes']['roofline_kernel_avg_us'] = round(lanes_kernel[0] * 1e3 / lanes_kernel[1], 2)
+                res['timing']['two_lanes']['roofline_kernel_note'] = ('the roofline kernel bracketed by HIP events while the other lane\'s '
+                                                                      'kernels share the CUs with it')
     return eng, res
 
 
@@ -819,7 +831,7 @@ def extra_squeezeformer_greedy(args, rank, world, local):
     # 0 = the twelve separate launches of round 4) on the same call
     ab = {}
     if os.environ.get('MASR_BENCH_SQZ_AB', '1') == '1' and hasattr(eng, 'lib'):
-        for blocks in (0, 96, 192):
+        for blocks in (0, 96, 128, 192):
             eng.lib.masr_debug_set(eng.h, 36, blocks)
             pred.predict_batch(audio, batch_size='balanced')
             torch.cuda.synchronize()
@@ -828,7 +840,7 @@ def extra_squeezeformer_greedy(args, rank, world, local):
                 pred.predict_batch(audio, batch_size='balanced')
             torch.cuda.synchronize()
             ab[f'fused_from_{blocks}_row_blocks' if blocks else 'separate_launches'] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
-        eng.lib.masr_debug_set(eng.h, 36, 192)
+        eng.lib.masr_debug_set(eng.h, 36, 128)
     kernels = []
     for kind, name in ((6, 'sqz_stage_kernel<0, 1>: [out-proj + LN1] + FFN1 + LN2 + [pw1 + GLU]'),
                        (7, 'sqz_stage_kernel<1, 31>: [dwconv + BN + SiLU + pw2 + LN3] + FFN2 + LN4 + [next QKV]')):
@@ -842,7 +854,7 @@ def extra_squeezeformer_greedy(args, rank, world, local):
             kernels.append({'kernel': name, 'launches': int(n), 'avg_us': round(ms * 1e3 / n, 2), 'achieved': round(ach, 2),
                             'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'unit': 'TFLOP/s',
                             'note': 'HIP events around every launch of one predict_batch call (launches of full-rate and half-rate layers, '
-                                    'all passes); half-rate layers below 192 row blocks run the separate d_ff-split launches instead'})
+                                    'all passes); half-rate layers below 128 row blocks run the separate d_ff-split launches instead'})
     eng.profile_select(0)
     total = float(lens.sum()) / 16000.0
     best = min(out, key=out.get)          # both policies are measured in this run; the line is the faster one and says which

@@ -106,8 +106,11 @@ static int g_attn_chain = 0;
 static int g_ffn_coop = 0;
 static int g_few_rows_path = 1;   // masr_debug_set key 29: 0 = offline Conformer layers of few row blocks keep the row-block chain kernel (A/B)
 // masr_debug_set key 36: row blocks from which a full-context Squeezeformer layer runs as attention + the two fused stage kernels of
-// sqz_layer.hip (0 = never: the twelve separate launches, kept for A/B and the bit-identity test)
-static int g_sqz_fused_blocks = 192;
+// sqz_layer.hip (0 = never: the twelve separate launches, kept for A/B and the bit-identity test).  128 since round 6: the half-rate
+// layers of BASELINE configs[2]'s second pass (144 row blocks, 100 of them valid) are 0.4 ms per call faster fused, on one lane
+// and on two (17.5 -> 17.0 / 19.2 -> 18.8 ms); passes of ~120 half-rate row blocks (32 x 10 s) stay on the d_ff-split launches
+// (fused from 96: 21.2 against 18.9 ms per call of three such passes, round 5)
+static int g_sqz_fused_blocks = 128;
 static int g_no_chain = 0;   // masr_debug_set key 5: 1 = separate out-projection and pointwise_conv1 kernels (A/B)
 
 namespace {

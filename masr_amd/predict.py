@@ -175,7 +175,11 @@ class MASRPredictor:
         loaded from: half the bytes over PCIe, x / 2^15 happens in the kernel), on the CURRENT stream.  Staging buffers take
         turns; each carries the event of its last upload, so filling one never waits for the device unless that very
         buffer's previous copy (two passes ago) is still in flight."""
-        eng = self.predictor.engine
+        return self._stage_upload(self._stage_fill(segs, n))
+
+    def _stage_fill(self, segs, n):
+        """host half of ``_stage_batch``: the rows on their way into the pinned buffer (four pool threads; not waited for --
+        the fills of two passes run next to each other), -> what ``_stage_upload`` needs"""
         as_pcm = all(s._pcm16 is not None for s in segs)
         dt = torch.int16 if as_pcm else torch.float32
         n_max = int(n.max())
@@ -197,16 +201,25 @@ class MASRPredictor:
                 m = int(n[i])
                 buf[i, :m] = segs[i]._pcm16 if as_pcm else segs[i]._samples
                 buf[i, m:] = 0
-        # 20 MB per pass of 32 x 20 s: row copies release the GIL, four host threads take rows in turn (0.66 -> 0.3 ms per pass)
+        # 20 MB per pass of 32 x 20 s: row copies release the GIL, four host threads take rows in turn (0.66 -> 0.45 ms per pass)
+        futures = []
         if need >= (1 << 20) and len(segs) >= 8:
             if getattr(self, '_fill_pool', None) is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._fill_pool = ThreadPoolExecutor(4, thread_name_prefix='masr_stage')
-            list(self._fill_pool.map(fill, [range(j, len(segs), 4) for j in range(4)]))
+            futures = [self._fill_pool.submit(fill, range(j, len(segs), 4)) for j in range(4)]
         else:
             fill(range(len(segs)))
         lens = ring['lens'][k][:len(segs)]
         lens.numpy()[:] = n
+        return ring, k, stage, lens, futures
+
+    def _stage_upload(self, filled):
+        """device half of ``_stage_batch``: waits for the fill, queues the two copies on the current stream"""
+        eng = self.predictor.engine
+        ring, k, stage, lens, futures = filled
+        for f in futures:
+            f.result()
         xs = stage.to(eng.device, non_blocking=True)
         ns = lens.to(eng.device, non_blocking=True)
         ev = torch.cuda.Event()
@@ -214,13 +227,14 @@ class MASRPredictor:
         ring['events'][k] = ev
         return xs, ns
 
-    def _prepare_begin(self, live, n, use_db):
+    def _prepare_begin(self, live, n, use_db, filled=None):
         """first half of a pass's preparation, nothing waited for: staging + upload + (bit-exact normalisation route) the mean
         squares on their way back to a pinned slot, all on the preparation stream.  Issued for pass k + 1 BEFORE the encoder of
-        pass k is launched: a launch on another queue waits for free CUs once an encoder pass is running (3.5 ms, round 6)."""
+        pass k is launched: a launch on another queue waits for free CUs once an encoder pass is running (6 ms, round 6).
+        ``filled``: the pass's ``_stage_fill``, started earlier."""
         eng = self.predictor.engine
         with torch.cuda.stream(self._prep_stream()):
-            xs, ns = self._stage_batch(live, n)
+            xs, ns = self._stage_upload(filled if filled is not None else self._stage_fill(live, n))
             ms_host = None
             if use_db:
                 ring = self.__dict__.setdefault('_ms_ring', {'bufs': [None] * 4, 'turn': 0})
@@ -264,9 +278,10 @@ class MASRPredictor:
             ring['bufs'][k] = torch.empty(max(B * width, 1 << 14), dtype=torch.int32, pin_memory=True)
         return ring['bufs'][k][:B * width].view(B, width)
 
-    def _begin_pass(self, segs):
+    def _begin_pass(self, segs, fill_only=False):
         """host side of a device pass + the asynchronous half of its preparation (``_prepare_begin``); ``_predict_local`` takes
-        the result as ``began``.  Utterances too short for one feature frame are set aside here."""
+        the result as ``began``.  Utterances too short for one feature frame are set aside here.  ``fill_only``: only the
+        staging fill is started (pool threads); ``_issue_pass`` queues the device half later."""
         pc = self.configs.preprocess_conf
         rate = int(pc.get('sample_rate', 16000))
         min_samples = 320 if pc.get('feature_method', 'fbank') == 'linear' else 400
@@ -277,8 +292,16 @@ class MASRPredictor:
         ok = [i for i, s in enumerate(segs) if s.num_samples >= min_samples + 6 * 160]
         live = [segs[i] for i in ok]
         n = np.array([s.num_samples for s in live], np.int32)
-        return {'count': len(segs), 'ok': ok, 'n': n, 'min_samples': min_samples,
-                'prep': self._prepare_begin(live, n, pc.use_dB_normalization) if ok else None}
+        began = {'count': len(segs), 'ok': ok, 'n': n, 'min_samples': min_samples, 'prep': None,
+                 'filled': (live, self._stage_fill(live, n)) if ok else None}
+        return began if fill_only else self._issue_pass(began)
+
+    def _issue_pass(self, began):
+        if began['filled'] is not None:
+            live, filled = began['filled']
+            began['prep'] = self._prepare_begin(live, began['n'], self.configs.preprocess_conf.use_dB_normalization, filled)
+            began['filled'] = None
+        return began
 
     def _predict_local(self, segs, decode_all_frames=False, as_tokens=False, defer=False, hold_search=False, began=None):
         """AudioSegments -> [{'text','score'}] on THIS rank's engine.  Utterances too short for one feature frame decode to
@@ -537,15 +560,20 @@ class MASRPredictor:
             st.wait_stream(main)             # (once, before the first pass: whatever the caller queued comes first)
         began = {}
 
-        def begin(k):
+        def begin(k, fill_only=False):
             lo, hi = cuts[k]
             segs = [self._load_audio(audio_list[i], sample_rate) for i in order[lo:hi]]
-            began[k] = self._begin_pass(segs)
+            began[k] = self._begin_pass(segs, fill_only)
         for k, (lo, hi) in enumerate(cuts):
             idx = order[lo:hi]
+            # (MASR_PREP_AHEAD=0, A/B: the next pass prepared AFTER this pass's encoder is launched -- its upload and mean squares
+            #  then wait 6 ms for CUs and the second lane starts late: 18.6 against 17.0 ms per configs[2] greedy call)
+            ahead = lanes > 1 and k + 1 < len(cuts) and os.environ.get('MASR_PREP_AHEAD', '1') == '1'
             if k not in began:
                 begin(k)
-            if lanes > 1 and k + 1 < len(cuts):
+            if ahead:
+                # (the fills of the two passes started TOGETHER -- begin(k, fill_only=True), begin(k + 1, fill_only=True), then
+                #  _issue_pass of both -- measured slower: first encoder kernel at 1.4 instead of 1.15 ms, 17.5 vs 17.0 ms per call)
                 begin(k + 1)
             lane = k % lanes
             if lane:

@@ -647,7 +647,7 @@ def test_squeezeformer_fused_layer_is_bit_identical_to_the_separate_launches(ora
             fused = e.encode_full(xd, ld).cpu()
             assert e.lib.masr_debug_set(e.h, 36, 0) == 0
             plain = e.encode_full(xd, ld).cpu()
-            assert e.lib.masr_debug_set(e.h, 36, 192) == 0
+            assert e.lib.masr_debug_set(e.h, 36, 128) == 0
         assert torch.isfinite(fused).all() and torch.isfinite(skipping).all()
         assert torch.equal(fused, plain), f'max |fused - separate| = {(fused - plain).abs().max().item():.3e}'
         # skipping the padded row blocks changes no bit of a valid frame, and the padded frames of the output read zero
