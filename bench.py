@@ -493,14 +493,6 @@ def run_contract(args, rank, world, local):
     #  warm-up step ~4 ms of one-time work sat in its 20 timed steps: 6.70 against 6.45-6.47 ms per step, tools/h2h_ab.py)
     dt_dev = parallel.timed_region(lambda i: cs.step(i, 'device'), args.steps, 3)
     dt_host = parallel.timed_region(lambda i: cs.step(i, 'host'), args.steps, 3, flush=cs.flush)
-    dt_lanes, lanes_kernel = None, None
-    if hasattr(eng, 'side_stream') and torch.cuda.is_available():
-        # consecutive steps on the engine's two lanes; the roofline kernel bracketed the same way (its duration then includes what
-        # the other step's kernels take from the CUs it shares with them)
-        dt_lanes = parallel.timed_region(lambda i: cs.step(i, 'lanes'), args.steps, 4, flush=cs.flush, after_warmup=prof_on)
-        lanes_kernel = eng.profile_read(reset=True)
-        eng.profile_select(0)
-        eng.lib.masr_debug_set(eng.h, 16, 1)
     others = []
     # the other heavy kernels, each timed the same way over a few more steps (every rank runs the steps -- they contain the
     # all-gather -- rank 0 keeps the numbers)
@@ -562,19 +554,45 @@ def run_contract(args, rank, world, local):
                'roofline': roofline,
                'timing': {'device_only': dict(per(dt_dev), note='PCM in HBM -> packed hypothesis rows in HBM; the host waits only for the (earlier) mean squares'),
                           'host_to_host': dict(per(dt_host), note='pinned host int16 PCM -> H2D (copy stream, under the previous step) -> ... -> D2H -> text on host')}}
-        if dt_lanes is not None:
-            res['timing']['two_lanes'] = dict(per(dt_lanes), note='the contract step with consecutive steps on the two lanes of the engine (two streams, two '
-                                                                   'workspace sets): HBM-resident PCM -> text on host, steps k and k + 1 side by side')
-            res['timing']['two_lanes']['whole_step_mfma_frac'] = round(GFLOP_PER_STEP / (dt_lanes * 1e3 / args.steps) / PEAK_F32_MFMA_TFLOPS, 4)
-            if lanes_kernel and lanes_kernel[1] > 0:
-                res['timing']['two_lanes']['roofline_kernel_avg_us'] = round(lanes_kernel[0] * 1e3 / lanes_kernel[1], 2)
-                res['timing']['two_lanes']['roofline_kernel_note'] = ('the roofline kernel bracketed by HIP events while the other lane\'s '
-                                                                      'kernels share the CUs with it')
     return eng, res
 
 
 # ---- secondary workloads (BASELINE configs[2,3,4]) ----------------------------------------------------------------------
 SHARP_HEAD_GAIN = 4.0
+
+
+def extra_contract_two_lanes(args, rank, world, local):
+    """configs[1], the contract step ('full': HBM-resident PCM -> text on host) with CONSECUTIVE STEPS ON THE ENGINE'S TWO LANES
+    (masr_select_lane: two workspace sets over one set of weights, two streams): the kernels of step k + 1 fill the CUs that
+    step k's leave idle.  A line of its own, not the contract line: a kernel bracketed by HIP events shares its CUs with the
+    other step's kernels here (reported: what the roofline kernel then reads), so ``value`` / ``roofline`` of the contract line
+    and the committed rocprofv3 trace of its command stay on one lane."""
+    from masr_amd import parallel
+    from masr_amd.utils import synthetic
+    eng = make_engine('conformer', local)
+    if not (hasattr(eng, 'side_stream') and torch.cuda.is_available()):
+        eng.close()
+        return {'workload': 'configs[1] on two lanes: needs the GPU engine', 'value': None}
+    cs = ContractStep(eng, rank, world, synthetic.synthetic_vocab(VOCAB))
+
+    def prof_on():
+        eng.lib.masr_debug_set(eng.h, 16, PROF_STRIDE)
+        eng.profile_select(args.profile_kind)
+        eng.profile_read(reset=True)
+    steps = max(args.steps, 10)
+    dt = parallel.timed_region(lambda i: cs.step(i, 'lanes'), steps, 4, flush=cs.flush, after_warmup=prof_on)
+    ms, n, _ = eng.profile_read(reset=True)
+    eng.profile_select(0)
+    eng.lib.masr_debug_set(eng.h, 16, 1)
+    dt1 = parallel.timed_region(lambda i: cs.step(i, 'full'), steps, 3, flush=cs.flush)
+    eng.close()
+    audio_step = world * BATCH * (N_SAMPLES / 16000.0)
+    return {'workload': 'configs[1]: conformer.yml streaming fbank, batch=32 x 10 s per GPU per step, HBM-resident PCM -> text on host, '
+                        'consecutive steps on the two lanes of the engine (steps k and k + 1 side by side)',
+            'value': round(audio_step * steps / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': world, 'steps': steps,
+            'ms_per_step': round(dt * 1e3 / steps, 3), 'one_lane_ms_per_step_same_process': round(dt1 * 1e3 / steps, 3),
+            'roofline_kernel_avg_us_beside_the_other_lane': round(ms * 1e3 / n, 2) if n else None,
+            'roofline': workload_roofline(GFLOP_PER_STEP, dt * 1e3 / steps, 'SURVEY 8(d): 742 GFLOP per batch-32 step')}
 
 
 def facade(use_model, decoder, device, streaming=True, vocab=VOCAB, beam_conf=None, head_gain=None):
@@ -1063,7 +1081,7 @@ class ExtrasWatchdog:
 
 def run_extras(args, rank, world, local, out=None):
     out = {} if out is None else out
-    jobs = [('efficient_b256', extra_efficient_b256), ('stream128', extra_stream128)]
+    jobs = [('conformer_b32_two_lanes', extra_contract_two_lanes), ('efficient_b256', extra_efficient_b256), ('stream128', extra_stream128)]
     if world == 1:
         # the per-GPU share of configs[4] on an 8-GPU node (128 streams / 8), measured on this one GPU
         jobs.append(('stream16', lambda a, r, w, l: extra_stream128(a, r, w, l, n_streams=16)))
@@ -1124,6 +1142,7 @@ def main():
     line = None
     if args.workload != 'conformer_b32':
         fn = {'efficient_b256': extra_efficient_b256, 'stream128': extra_stream128, 'bf16x3': extra_bf16x3,
+              'conformer_b32_two_lanes': extra_contract_two_lanes,
               'squeezeformer_b64_beam': extra_squeezeformer_beam,
               'squeezeformer_b64_beam_nolm': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, lm=False),
               'squeezeformer_b64_beam_sharp': lambda a, r, w, l: extra_squeezeformer_beam(a, r, w, l, sharp=True),

@@ -58,6 +58,17 @@ def test_contract_step_texts_are_the_steps_own(force_dist, monkeypatch):
             assert got == want
             assert all(np.array_equal(g, w) for g, w in zip(gains, want_gains))     # every step ran on ITS batch's gains
             assert cs.n_texts == 5 * bench.BATCH
+        # consecutive steps on the engine's two lanes (two workspace sets, two streams): the same texts from the same batches
+        got = []
+        for k, b in enumerate(batches):
+            cs.pcm = b
+            cs.step(k, 'lanes', next_pcm=batches[k + 1] if k + 1 < len(batches) else None)
+            if k:
+                got.append(list(cs.texts))
+        cs.flush()
+        got.append(list(cs.texts))
+        assert got == want
+        torch.cuda.synchronize()
         # 'host' mode: the PCM comes over PCIe on a copy stream, one step ahead; every step must still transcribe that batch
         host_want, _ = direct(cs.pcm_host.to(eng.device))
         for k in range(4):
