@@ -860,6 +860,8 @@ def extra_squeezeformer_greedy(args, rank, world, local):
             ab[f'fused_from_{blocks}_row_blocks' if blocks else 'separate_launches'] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
         eng.lib.masr_debug_set(eng.h, 36, 128)
     kernels = []
+    lanes_env = os.environ.get('MASR_LANES')
+    os.environ['MASR_LANES'] = '1'          # a kernel bracketed by HIP events must not share the CUs with the other lane's pass
     for kind, name in ((6, 'sqz_stage_kernel<0, 1>: [out-proj + LN1] + FFN1 + LN2 + [pw1 + GLU]'),
                        (7, 'sqz_stage_kernel<1, 31>: [dwconv + BN + SiLU + pw2 + LN3] + FFN2 + LN4 + [next QKV]')):
         eng.profile_select(kind)
@@ -871,9 +873,13 @@ def extra_squeezeformer_greedy(args, rank, world, local):
             ach = fl / (ms * 1e-3) / 1e12
             kernels.append({'kernel': name, 'launches': int(n), 'avg_us': round(ms * 1e3 / n, 2), 'achieved': round(ach, 2),
                             'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'unit': 'TFLOP/s',
-                            'note': 'HIP events around every launch of one predict_batch call (launches of full-rate and half-rate layers, '
-                                    'all passes); half-rate layers below 128 row blocks run the separate d_ff-split launches instead'})
+                            'note': 'HIP events around every launch of one predict_batch call on ONE lane (launches of full-rate and half-rate '
+                                    'layers, all passes); half-rate layers below 128 row blocks run the separate d_ff-split launches instead'})
     eng.profile_select(0)
+    if lanes_env is None:
+        os.environ.pop('MASR_LANES', None)
+    else:
+        os.environ['MASR_LANES'] = lanes_env
     total = float(lens.sum()) / 16000.0
     best = min(out, key=out.get)          # both policies are measured in this run; the line is the faster one and says which
     dt = out[best]
@@ -882,7 +888,8 @@ def extra_squeezeformer_greedy(args, rank, world, local):
     roof['kernels'] = kernels
     return {'workload': f'configs[2] with ctc_greedy: squeezeformer.yml non-streaming fbank, 64 utterances 2-20 s ({total:.1f} audio-s) -> text, '
                         + ('length-sorted passes of equal padded size (16 / 19 / 29 utterances)' if best == 'balanced' else
-                           'two length-sorted passes of 32 (the row blocks of padded frames are not computed: masr_debug_set key 38)')
+                           'two length-sorted passes of 32 side by side on the two lanes of the engine (masr_select_lane; the row blocks of padded '
+                           'frames are not computed: masr_debug_set key 38)')
                         + '; encoder-bound line of the Squeezeformer',
             'value': round(total / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps, 'ms_per_step': round(dt * 1e3, 3),
             'fixed_passes_of_32_ms_per_step': round(out[32] * 1e3, 3), 'balanced_passes_ms_per_step': round(out['balanced'] * 1e3, 3),
