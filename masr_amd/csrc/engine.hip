@@ -1804,6 +1804,9 @@ static int ds2_forward(masr_engine* e, hipStream_t s, const float* feats, const 
             HIPCHK(hipMemsetAsync(hbuf, 0, sizeof(float) * hsz, s));
             HIPCHK(hipMemsetAsync(cbuf, 0, sizeof(float) * hsz, s));
         }
+        // (the whole sequence of a layer as one cooperative launch with W_hh resident in registers and a barrier in global memory
+        //  per step was built and measured in round 6: 10.0 against 6.0 ms at B = 1, 26.4 against 25.7 ms at B = 32 --
+        //  tools/studies/lstm_seq_study.hip)
         for (int step = 0; step < Tq; ++step)
             launch_lstm_step(e->gx.as<float>(), w.whh, hbuf + (size_t)(step & 1) * hsz, hbuf + (size_t)((step + 1) & 1) * hsz,
                              cbuf, e->rnn_out.as<float>(), xl, nseq, Tq, H, step, ndir, s);
