@@ -923,6 +923,31 @@ def test_two_lanes_of_one_engine_equal_one_lane(tmp_path, monkeypatch):
     with pytest.raises(Exception):
         eng.select_lane(2)
     eng.close()
+    # a FRESH Conformer engine builds its packed weight copies on first use, on the calling stream: the first call ever runs on
+    # lane 1 / the side stream, the second one right behind it on lane 0 / the main stream must wait for the packing launches
+    csd = synthetic.conformer_state_dict(0, V)
+    want = None
+    for first_lane in (None, 1):
+        ce = HipEngine(csd, {}, vocab_size=V, streaming=True, use_model='conformer')
+        x, n, _ = passes[1]
+        g = ce.host_gains(x, n, -20.0)
+        main, side = torch.cuda.current_stream(ce.device), ce.side_stream(4)
+        torch.cuda.synchronize()
+        if first_lane is None:
+            rows = [valid(ce.transcribe_rows(x, n, True, -20.0, gain_in=g)) for _ in range(2)]
+        else:
+            side.wait_stream(main)
+            ce.select_lane(1)
+            with torch.cuda.stream(side):
+                r1 = ce.transcribe_rows(x, n, True, -20.0, gain_in=g)
+            ce.select_lane(0)
+            r0 = ce.transcribe_rows(x, n, True, -20.0, gain_in=g)
+            torch.cuda.synchronize()
+            rows = [valid(r1), valid(r0)]
+        if want is None:
+            want = rows[0]
+        assert rows[0] == want and rows[1] == want, first_lane
+        ce.close()
 
     audio = [pcm[i, :lens[i]].copy() for i in range(24)]
     vocab = synthetic.synthetic_vocab(V)
