@@ -178,8 +178,8 @@ class MASRPredictor:
         return self._stage_upload(self._stage_fill(segs, n))
 
     def _stage_fill(self, segs, n):
-        """host half of ``_stage_batch``: the rows on their way into the pinned buffer (four pool threads; not waited for --
-        the fills of two passes run next to each other), -> what ``_stage_upload`` needs"""
+        """host half of ``_stage_batch``: the rows on their way into the pinned buffer (four pool threads, not waited for here),
+        -> what ``_stage_upload`` needs"""
         as_pcm = all(s._pcm16 is not None for s in segs)
         dt = torch.int16 if as_pcm else torch.float32
         n_max = int(n.max())
@@ -227,14 +227,14 @@ class MASRPredictor:
         ring['events'][k] = ev
         return xs, ns
 
-    def _prepare_begin(self, live, n, use_db, filled=None):
+    def _prepare_begin(self, live, n, use_db):
         """first half of a pass's preparation, nothing waited for: staging + upload + (bit-exact normalisation route) the mean
-        squares on their way back to a pinned slot, all on the preparation stream.  Issued for pass k + 1 BEFORE the encoder of
-        pass k is launched: a launch on another queue waits for free CUs once an encoder pass is running (6 ms, round 6).
-        ``filled``: the pass's ``_stage_fill``, started earlier."""
+        squares on their way back to a pinned slot, all on the preparation stream.  With two lanes it is issued for pass k + 1
+        BEFORE the encoder of pass k is launched: issued beside a running encoder pass, the upload and the mean squares start
+        4 - 6 ms late (round 6; whichever side stream, 4 or 8 hardware queues)."""
         eng = self.predictor.engine
         with torch.cuda.stream(self._prep_stream()):
-            xs, ns = self._stage_upload(filled if filled is not None else self._stage_fill(live, n))
+            xs, ns = self._stage_upload(self._stage_fill(live, n))
             ms_host = None
             if use_db:
                 ring = self.__dict__.setdefault('_ms_ring', {'bufs': [None] * 4, 'turn': 0})
@@ -278,10 +278,9 @@ class MASRPredictor:
             ring['bufs'][k] = torch.empty(max(B * width, 1 << 14), dtype=torch.int32, pin_memory=True)
         return ring['bufs'][k][:B * width].view(B, width)
 
-    def _begin_pass(self, segs, fill_only=False):
+    def _begin_pass(self, segs):
         """host side of a device pass + the asynchronous half of its preparation (``_prepare_begin``); ``_predict_local`` takes
-        the result as ``began``.  Utterances too short for one feature frame are set aside here.  ``fill_only``: only the
-        staging fill is started (pool threads); ``_issue_pass`` queues the device half later."""
+        the result as ``began``.  Utterances too short for one feature frame are set aside here."""
         pc = self.configs.preprocess_conf
         rate = int(pc.get('sample_rate', 16000))
         min_samples = 320 if pc.get('feature_method', 'fbank') == 'linear' else 400
@@ -292,16 +291,8 @@ class MASRPredictor:
         ok = [i for i, s in enumerate(segs) if s.num_samples >= min_samples + 6 * 160]
         live = [segs[i] for i in ok]
         n = np.array([s.num_samples for s in live], np.int32)
-        began = {'count': len(segs), 'ok': ok, 'n': n, 'min_samples': min_samples, 'prep': None,
-                 'filled': (live, self._stage_fill(live, n)) if ok else None}
-        return began if fill_only else self._issue_pass(began)
-
-    def _issue_pass(self, began):
-        if began['filled'] is not None:
-            live, filled = began['filled']
-            began['prep'] = self._prepare_begin(live, began['n'], self.configs.preprocess_conf.use_dB_normalization, filled)
-            began['filled'] = None
-        return began
+        return {'count': len(segs), 'ok': ok, 'n': n, 'min_samples': min_samples,
+                'prep': self._prepare_begin(live, n, pc.use_dB_normalization) if ok else None}
 
     def _predict_local(self, segs, decode_all_frames=False, as_tokens=False, defer=False, hold_search=False, began=None):
         """AudioSegments -> [{'text','score'}] on THIS rank's engine.  Utterances too short for one feature frame decode to
@@ -560,10 +551,10 @@ class MASRPredictor:
             st.wait_stream(main)             # (once, before the first pass: whatever the caller queued comes first)
         began = {}
 
-        def begin(k, fill_only=False):
+        def begin(k):
             lo, hi = cuts[k]
             segs = [self._load_audio(audio_list[i], sample_rate) for i in order[lo:hi]]
-            began[k] = self._begin_pass(segs, fill_only)
+            began[k] = self._begin_pass(segs)
         for k, (lo, hi) in enumerate(cuts):
             idx = order[lo:hi]
             # (MASR_PREP_AHEAD=0, A/B: the next pass prepared AFTER this pass's encoder is launched -- its upload and mean squares
@@ -572,8 +563,8 @@ class MASRPredictor:
             if k not in began:
                 begin(k)
             if ahead:
-                # (the fills of the two passes started TOGETHER -- begin(k, fill_only=True), begin(k + 1, fill_only=True), then
-                #  _issue_pass of both -- measured slower: first encoder kernel at 1.4 instead of 1.15 ms, 17.5 vs 17.0 ms per call)
+                # (the staging fills of the two passes started TOGETHER on eight threads, uploads behind them: measured slower --
+                #  first encoder kernel at 1.4 instead of 1.15 ms, 17.5 vs 17.0 ms per call)
                 begin(k + 1)
             lane = k % lanes
             if lane:
