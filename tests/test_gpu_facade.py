@@ -979,3 +979,56 @@ def test_conformer_passes_on_two_lanes_equal_one_lane(predictor, monkeypatch):
     assert got['2'][0] == got['1'][0] == got['2'][1]
     assert got['2'][0][4] == {'text': '', 'score': 0} and sum(len(r['text']) for r in got['2'][0]) > 0
     assert predictor.predictor.engine.lane == 0
+
+
+@pytest.mark.parametrize('family', ['conformer', 'efficient_conformer', 'squeezeformer', 'deepspeech2'])
+def test_lanes_with_growing_ragged_passes_every_family(family):
+    """eight ragged passes of growing and shrinking size alternate over the two lanes of one engine (every workspace of both sets
+    is reallocated at least once while the other lane has work in flight); each pass must give the rows it gives on a fresh
+    engine's lane 0, for every model family (the DeepSpeech2 workspaces are part of the sets too)"""
+    from masr_amd.engine import HipEngine
+    from masr_amd.utils import synthetic
+    V = 300
+    make = {'conformer': lambda: HipEngine(synthetic.conformer_state_dict(0, V), {}, vocab_size=V, streaming=True, use_model='conformer'),
+            'efficient_conformer': lambda: HipEngine(synthetic.efficient_conformer_state_dict(0, V), {}, vocab_size=V, streaming=True,
+                                                     use_model='efficient_conformer'),
+            'squeezeformer': lambda: HipEngine(synthetic.squeezeformer_state_dict(0, V), {}, vocab_size=V, streaming=False,
+                                               use_model='squeezeformer'),
+            'deepspeech2': lambda: HipEngine(synthetic.deepspeech2_state_dict(0, V, bidirectional=True), vocab_size=V, streaming=False,
+                                             use_model='deepspeech2')}[family]
+    rng = np.random.default_rng(11)
+    sizes = [(2, 30000), (5, 60000), (3, 20000), (9, 90000), (1, 120000), (12, 40000), (4, 150000), (6, 50000)]
+    pcm = synthetic.synthetic_pcm(12, 150000, seed=11)
+
+    def valid(rows):
+        r = rows.cpu().numpy()
+        return [(r[i, :r[i, -2]].tolist(), int(r[i, -2]), int(r[i, -1])) for i in range(r.shape[0])]
+    ref_eng, eng = make(), make()
+    try:
+        passes = []
+        for B, n_max in sizes:
+            lens = np.sort(rng.integers(n_max // 3, n_max + 1, B).astype(np.int32))[::-1].copy()
+            lens[0] = n_max
+            x = torch.from_numpy(np.ascontiguousarray(pcm[:B, :n_max])).to(eng.device)
+            for i in range(B):
+                x[i, int(lens[i]):] = 0
+            n = torch.from_numpy(lens).to(eng.device)
+            g = ref_eng.host_gains(x, n, -20.0)
+            passes.append((x, n, g, valid(ref_eng.transcribe_rows(x, n, True, -20.0, gain_in=g))))
+        assert sum(c for p in passes for _, c, _ in p[3]) > 0
+        streams = [torch.cuda.current_stream(eng.device), eng.side_stream(4)]
+        streams[1].wait_stream(streams[0])
+        for rep in range(2):
+            outs = []
+            for k, (x, n, g, _) in enumerate(passes):
+                lane = (k + rep) & 1
+                eng.select_lane(lane)
+                with torch.cuda.stream(streams[lane]):
+                    outs.append(eng.transcribe_rows(x, n, True, -20.0, gain_in=g))
+            eng.select_lane(0)
+            torch.cuda.synchronize()
+            for k, (_, _, _, want) in enumerate(passes):
+                assert valid(outs[k]) == want, (family, rep, k)
+    finally:
+        ref_eng.close()
+        eng.close()
