@@ -202,7 +202,8 @@ class MASRPredictor:
                 buf[i, :m] = segs[i]._pcm16 if as_pcm else segs[i]._samples
                 buf[i, m:] = 0
         # 20 MB per pass of 32 x 20 s: row copies release the GIL, four host threads take rows in turn (0.66 -> 0.45 ms per pass;
-        # 2 / 8 / 12 threads: 17.0 / 17.4 / 18.5 ms per configs[2] greedy call against 16.9 with four)
+        # 2 / 8 / 12 threads: 17.0 / 17.4 / 18.5 ms per configs[2] greedy call against 16.9 with four; 16 contiguous row groups
+        # uploaded block by block under the fill of the next block: 18.6 ms -- the staging of a pass 0.27 -> 0.80 ms)
         futures = []
         if need >= (1 << 20) and len(segs) >= 8:
             if getattr(self, '_fill_pool', None) is None:
