@@ -323,6 +323,58 @@ class BeamSearchDecoder:
         done.record()
         return ('gpu', Bt, max_len, packed, (idx, logp, cnt, blp, fr, toks, lens, scores, parts), done)
 
+    # ---- host-thread search of a device pass, deferred ---------------------------------------------------------------------------
+    def search_host_deferred(self, probs, frames, want_tokens=False):
+        """The host-thread prefix search (word-based scorers, sizes beyond the GPU kernel) of ONE device pass without stalling the
+        device: the vocabulary pruning is queued on the current stream right behind the pass's CTC head, and a function is
+        returned that -- when called -- waits for the pruning, brings the candidates to the host on the library's copy stream
+        (5 MB for 32 x 494 frames x 40; NOT queued behind the encoder, see ``_batch_collect``) and runs the search on
+        ``num_processes`` host threads.  The caller launches the encoders of the next passes first and collects afterwards: host
+        searches run under device passes instead of between them."""
+        part = self.prune_padded(probs, frames)
+        done = torch.cuda.Event()
+        done.record()
+        if self._ext_scorer is not None and not self._ext_scorer.is_character_based and not getattr(self, '_said_host', False):
+            self._said_host = True
+            logger.info('masr_amd BeamSearchDecoder: word-based language model -> prefix search on host threads')
+
+        def collect():
+            B, Ts, K = part['B'], part['Ts'], part['K']
+            dev = [part['idx'].view(-1), part['logp'].view(-1).view(torch.int32), part['cnt'].view(-1)]
+            if part['blp'] is not None:
+                dev.append(part['blp'].view(-1).view(torch.int32))
+            total = sum(t.numel() for t in dev)
+            host = self._pinned_out(total)
+            done.synchronize()
+            with torch.cuda.stream(runtime.aux_engine(part['idx'].device).side_stream(3)):
+                at, views = 0, []
+                for t in dev:
+                    host[at:at + t.numel()].copy_(t, non_blocking=True)
+                    views.append(host[at:at + t.numel()].numpy())
+                    at += t.numel()
+                ev = torch.cuda.Event()
+                ev.record()
+            ev.synchronize()
+            idx, logp, cnt = views[0], views[1].view(np.float32), views[2]
+            blp = views[3].view(np.float32) if part['blp'] is not None else None
+            max_len = max(Ts, 1)
+            toks = np.zeros((B, max_len), np.int32)
+            lens = np.zeros(B, np.int32)
+            scores = np.zeros(B, np.float32)
+            fr = np.ascontiguousarray(part['frames'], np.int32)
+            rc = self._lib.masr_beam_search_batch_lm(idx.ctypes.data_as(C.c_void_p), logp.ctypes.data_as(C.c_void_p),
+                                                     cnt.ctypes.data_as(C.c_void_p), fr.ctypes.data_as(C.c_void_p), B, Ts, K,
+                                                     self.beam_size, self.blank_id, self.num_processes, *self._lm_args(),
+                                                     self._ptr(blp), toks.ctypes.data_as(C.c_void_p), max_len,
+                                                     lens.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p))
+            self._pin_free.append(host)
+            if rc != 0:
+                raise _lib.MasrError('masr_beam_search_batch failed')
+            if want_tokens:
+                return [(toks[i, :lens[i]].tolist(), float(scores[i])) for i in range(B)]
+            return [(float(scores[i]), self._text(toks[i, :lens[i]])) for i in range(B)]
+        return collect
+
     def decode_chunk(self, probs, logits_lens):
         """streaming: feed a chunk probs [1, T, V]; returns (score, text) of the best prefix so far
         (beam_search_decoder.py:75-91)."""

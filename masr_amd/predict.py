@@ -385,6 +385,11 @@ class MASRPredictor:
                     # probabilities are then dead); the search itself is launched ONCE for the passes of a group (_run_sorted)
                     return ('held', dec.prune_padded(seqs, n_host), fill)
                 return launch_search()
+            if defer and torch.is_tensor(seqs) and seqs.is_cuda and os.environ.get('MASR_HOST_SEARCH_DEFER', '1') == '1':
+                # host-thread search (word-based scorer, sizes beyond the GPU kernel): pruning queued now, candidates fetched and
+                # searched when the results are collected -- under the encoders of the passes launched in between
+                handle = dec.search_host_deferred(seqs, n_host, want_tokens=as_tokens)
+                return lambda: fill(handle())
             res = fill(dec._batch(seqs, want_tokens=as_tokens, frames=n_host))
             return (lambda: res) if defer else res
         idx, mp = eng.ctc_greedy_frames(enc)
@@ -498,7 +503,16 @@ class MASRPredictor:
         # the longest utterance is the critical path of the call) then starts right after the first encoder pass and the
         # shorter passes' encoders and searches run underneath it
         depth = 2
-        gpu_search = self.configs.decoder == 'ctc_beam_search' and getattr(self.beam_search_decoder, 'use_gpu_search', False)
+        dec = self.beam_search_decoder if self.configs.decoder == 'ctc_beam_search' else None
+        # (a word-based scorer, or beam x top-n beyond the kernel's LDS: the search runs on host threads whatever use_gpu_search says)
+        gpu_search = dec is not None and getattr(dec, 'use_gpu_search', False) and \
+            dec.gpu_search_supported(1, len(self._text_featurizer.vocab_list))
+        if dec is not None and not gpu_search and os.environ.get('MASR_HOST_SEARCH_DEFER', '1') == '1':
+            # host-thread search: pruning is queued behind each pass, the search itself runs when the pass is collected -- two
+            # passes behind the launches, so the device always has a pass queued; the pass of the shortest utterances (the
+            # quickest search) comes last: nothing runs under the last search
+            cuts.reverse()
+            depth = 3
         if gpu_search:
             cuts.reverse()
             # a prefix search is a long serial kernel on a few CUs (one workgroup per utterance, frames in sequence): the encoders
