@@ -759,7 +759,7 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
         conf['language_model_path'] = None           # explicit scorer-free search (not a reference configuration)
     pred = facade('squeezeformer', 'ctc_beam_search', local, streaming=False, beam_conf=conf,
                   head_gain=SHARP_HEAD_GAIN if sharp else None)
-    steps = 3 if word_lm else 10
+    steps = 6 if word_lm else 10
     # device passes of 32 utterances, longest first: the prefix search of a pass (one workgroup per utterance, frames in sequence --
     # the longest utterance is the call's critical path) runs on a side stream under the encoder of the next pass.  Measured with
     # MASR_BENCH_BEAM_PASS: passes of 16 are faster with the sharpened head (27.2 vs 30.7 ms per call: the longest utterance's search
@@ -807,7 +807,8 @@ def extra_squeezeformer_beam(args, rank, world, local, lm=True, sharp=False, wor
                         + ('length-sorted passes of equal padded size (16 / 19 / 29 utterances)' if per_pass == 'balanced' else
                            f'length-sorted passes of {per_pass} utterances (longest first)' if isinstance(per_pass, list) else
                            f'{-(-64 // per_pass)} length buckets of {per_pass}') + ', ctc_beam_search beam 300 / top-n 40, '
-                        + ('alpha 2.2 beta 4.3 with a synthetic 3-gram WORD LM: prefix search on %d host threads' % conf['num_processes']
+                        + ('alpha 2.2 beta 4.3 with a synthetic 3-gram WORD LM: prefix search on %d host threads, each pass searched when it is '
+                           'collected, under the encoders (two lanes) of the passes launched behind it' % conf['num_processes']
                            if lm and word_lm else
                            'alpha 2.2 beta 4.3 with a synthetic 3-gram character LM scored on the GPU' if lm else 'LM-free'),
             'posteriors': ('SHARPENED CTC head (random-init logits x %g: 1-3 candidates survive cutoff_prob 0.99 per frame, what a '
