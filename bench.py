@@ -282,12 +282,16 @@ class ContractStep:
         self.out = [torch.empty(BATCH, self.Tp + 2, dtype=torch.int32, device=self.dev) for _ in range(2)]
         rows = world * BATCH
         self.host = [torch.empty(rows, self.Tp + 2, dtype=torch.int32, pin_memory=gpu) for _ in range(2)]
-        self.side = torch.cuda.Stream(device=self.dev) if gpu else None
+        # the step's helper streams are the library's (masr_side_stream: chosen by probing so that none shares the compute stream's
+        # hardware queue, whatever the process created before -- on a rank of a multi-GPU job RCCL comes first and shifts the
+        # runtime's round-robin deal of queues); the stand-in engine of the CPU tests has none
+        lib_streams = gpu and hasattr(eng, 'side_stream')
+        self.side = (eng.side_stream(1) if lib_streams else torch.cuda.Stream(device=self.dev)) if gpu else None
         self.computed = [torch.cuda.Event() if gpu else None for _ in range(2)]      # compute stream: outputs of the slot written
         self.events = [torch.cuda.Event() if gpu else None for _ in range(2)]        # side stream: slot gathered (and on the host)
         self.used = [False, False]
         # the gain round trip: mean squares (device) -> pinned host -> reference_gains -> pinned host -> device, two slots
-        self.prep_stream = torch.cuda.Stream(device=self.dev) if gpu else None
+        self.prep_stream = (eng.side_stream(2) if lib_streams else torch.cuda.Stream(device=self.dev)) if gpu else None
         self.ms_dev = [torch.empty(BATCH, dtype=torch.float32, device=self.dev) for _ in range(2)]
         self.ms_host = [torch.empty(BATCH, dtype=torch.float32, pin_memory=gpu) for _ in range(2)]
         self.ms_ready = [torch.cuda.Event() if gpu else None for _ in range(2)]
@@ -380,7 +384,8 @@ class ContractStep:
         if self.side is None:
             return self.pcm_host.to(self.dev)
         if self.h2d is None:
-            self.h2d = {'stream': torch.cuda.Stream(device=self.dev), 'buf': [torch.empty_like(self.pcm) for _ in range(2)],
+            self.h2d = {'stream': self.eng.side_stream(0) if hasattr(self.eng, 'side_stream') else torch.cuda.Stream(device=self.dev),
+                        'buf': [torch.empty_like(self.pcm) for _ in range(2)],
                         'ready': [torch.cuda.Event() for _ in range(2)], 'issued': None}
         if self.h2d['issued'] != i:
             self._copy_pcm(i)

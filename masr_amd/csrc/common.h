@@ -126,6 +126,8 @@ void launch_dwconv_ln_silu(const float* g, const float* wkc, const float* bias, 
                            float* out, int nseq, int Tq, int ktaps, float eps, hipStream_t s, const float* gconst = nullptr);
 // same with an eval-mode BatchNorm folded into a per-channel scale/shift instead of the LayerNorm
 void launch_glu_const(const float* bias512, float* out256, hipStream_t s);
+void launch_queue_spin(long long ticks, hipStream_t s);      // holds the stream's hardware queue for `ticks` x 10 ns
+void launch_queue_nop(hipStream_t s);
 void launch_dwconv_bn_silu(const float* g, const float* wkc, const float* bias, const float* scale, const float* shift,
                            float* out, int nseq, int Tq, int ktaps, hipStream_t s, const float* gconst = nullptr);
 // Efficient-Conformer stride layer: depthwise causal conv with stride 2 (+ LayerNorm + SiLU) on the padded layout

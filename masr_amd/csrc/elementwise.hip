@@ -812,4 +812,14 @@ void launch_conv_hist(const float* x, const float* w, const float* b, float* con
                            pad, eps);
 }
 
+// ---- probes of engine.hip's side-stream selection: a kernel that holds its queue for `ticks` of the 100 MHz wall clock, and one
+// that does nothing (which of two streams share a hardware queue: the empty kernel on one waits for the spin on the other)
+__global__ void queue_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void queue_nop_kernel() {}
+void launch_queue_spin(long long ticks, hipStream_t s) { hipLaunchKernelGGL(queue_spin_kernel, dim3(1), dim3(1), 0, s, ticks); }
+void launch_queue_nop(hipStream_t s) { hipLaunchKernelGGL(queue_nop_kernel, dim3(1), dim3(1), 0, s); }
+
 }  // namespace masr

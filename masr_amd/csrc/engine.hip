@@ -562,8 +562,16 @@ int build_fbank_tables(masr_engine* e) {
 // torch.cuda.Stream()s created wherever a predictor first needed one: the HIP runtime deals streams onto a small pool of hardware
 // queues (GPU_MAX_HW_QUEUES, default 4) at creation, and in a process that had already created its share a search stream landed on
 // the main stream's queue and ran BEHIND the next encoder pass (BASELINE configs[2]: 63 vs 46 ms per call by process history,
-// repaired then by raising GPU_MAX_HW_QUEUES from masr_amd/__init__.py).  Created here they take their queues before anything a
-// server creates later; bench.py measures the configs[2] lines inside its long process and in a fresh one: same numbers.
+// repaired then by raising GPU_MAX_HW_QUEUES from masr_amd/__init__.py).  Creating them early (the first half of round 6) only moved
+// the dependence: the runtime deals queues round-robin in creation order, whatever was created BEFORE the first engine shifts the
+// deal -- after torch.distributed had initialised RCCL (one stream) search stream 0 and the second lane's stream shared the
+// NULL stream's queue (configs[2] sharpened 30.0 instead of 23.2 ms per call), and in a cold process the preparation stream did
+// (every upload of a pass issued beside a running encoder started 4 - 6 ms late).  So the set is CHOSEN BY PROBING: candidate
+// streams are created until three hardware queues other than the NULL stream's have been seen (two streams share a queue when an
+// empty kernel on one waits for a spinning kernel on the other; ~0.3 ms per probe, at most 16 candidates, once per device):
+//   queue B: search stream 0 and the second lane (never used together)     queue C: search stream 1
+//   queue D: preparation and copies (short work only)                      the NULL stream's queue: nobody
+// With fewer queues than that (GPU_MAX_HW_QUEUES < 4) the roles double up in that order.  MASR_SIDE_DEBUG=1 prints the choice.
 // Measured and rejected (round 6, configs[2] sharpened head, passes of 32, ms per call): highest priority 28.9, lowest 28.8,
 // default 24.0 -- a queue of another priority class has a hardware-queue pool of its own (never aliased), but every launch beside
 // it pays for it (the same call WITHOUT its search kernels: 22.3 against 19.7 ms).  MASR_SIDE_PRIORITY=high|low for the A/B.
@@ -584,7 +592,53 @@ static int side_streams_of(int dev, SideStreams** out) {
         const char* pe = getenv("MASR_SIDE_PRIORITY");          // A/B only
         const int prio = (pe && pe[0] == 'h') ? greatest : (pe && pe[0] == 'l') ? least : 0;
         if (pe) fprintf(stderr, "masr side streams: priority %d (device range: least %d .. greatest %d)\n", prio, least, greatest);
-        for (int k = 0; k < MASR_SIDE_STREAMS; ++k) HIPCHK(hipStreamCreateWithPriority(&ss.s[k], hipStreamNonBlocking, prio));
+        // true when an empty kernel on `b` waits for a kernel that spins on `a`: the two streams share a hardware queue
+        auto aliased = [](hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb, bool* out) -> int {
+            launch_queue_spin(30000, a);                       // 300 us
+            HIPCHK(hipEventRecord(ea, a));
+            launch_queue_nop(b);
+            HIPCHK(hipEventRecord(eb, b));
+            HIPCHK(hipEventSynchronize(eb));
+            *out = hipEventQuery(ea) == hipSuccess;            // the spin was over before the empty kernel got through
+            (void)hipGetLastError();
+            HIPCHK(hipEventSynchronize(ea));
+            return 0;
+        };
+        hipEvent_t ea = nullptr, eb = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<hipStream_t> cls;                          // one stream per hardware queue seen so far (not the NULL stream's)
+        std::vector<hipStream_t> spare;                        // candidates on a queue already represented (kept: destroying a
+        const bool dbg = getenv("MASR_SIDE_DEBUG") != nullptr; // stream would hand its slot of the deal to the next one created)
+        for (int c = 0; c < 16 && cls.size() < 3; ++c) {
+            hipStream_t st = nullptr;
+            HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
+            bool same = false;
+            if (aliased(nullptr, st, ea, eb, &same)) return 1;
+            for (size_t k = 0; k < cls.size() && !same; ++k)
+                if (aliased(cls[k], st, ea, eb, &same)) return 1;
+            (same ? spare : cls).push_back(st);
+        }
+        (void)hipEventDestroy(ea);
+        (void)hipEventDestroy(eb);
+        if (cls.empty()) {                                     // one hardware queue in all: everything shares it
+            hipStream_t st = nullptr;
+            if (!spare.empty()) st = spare.back();
+            else HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
+            cls.push_back(st);
+        }
+        hipStream_t qB = cls[0], qC = cls[cls.size() > 1 ? 1 : 0], qD = cls[cls.size() > 2 ? 2 : cls.size() - 1];
+        // roles that share a queue still get streams of their own where a spare on that queue exists (ordering stays per role)
+        ss.s[0] = qB;
+        ss.s[1] = qC;
+        ss.s[2] = qD;
+        ss.s[3] = qD;
+        ss.s[4] = qB;
+        if (dbg)
+            fprintf(stderr, "masr side streams (device %d): %zu hardware queues besides the NULL stream's after %zu candidates; search 0 / "
+                    "lane 1 = %p, search 1 = %p, preparation / copy = %p\n", dev, cls.size(), cls.size() + spare.size(), (void*)qB,
+                    (void*)qC, (void*)qD);
         ss.made = true;
     }
     *out = &ss;

@@ -98,10 +98,14 @@ def test_beam_call_time_does_not_depend_on_what_the_process_created_before():
     env = dict(os.environ, PYTHONPATH=ROOT)
     env.pop('GPU_MAX_HW_QUEUES', None)
     ms = {}
-    for pre in (0, 12):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'beam_history_probe.py'), str(pre)], env=env,
+    # the runtime deals hardware queues round-robin in creation order: 12, 13 and 14 earlier streams and an RCCL communicator
+    # shift the deal by 0, 1, 2 and 1 of 4 -- the first half of round 6 passed with 12 and lost 30 % behind RCCL (search stream 0
+    # on the NULL stream's queue); the side streams are now chosen by probing which queue a candidate landed on (engine.hip)
+    for pre in ((0,), (12,), (13,), (14,), (0, 'rccl')):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'beam_history_probe.py')] + [str(v) for v in pre], env=env,
                            capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [ln for ln in p.stdout.splitlines() if ln.startswith('RESULT ')]
         ms[pre] = json.loads(line[-1][7:])['ms']
-    assert ms[12] <= 1.10 * ms[0], f'cold process {ms[0]} ms per call, after a server-like history {ms[12]} ms'
+    for pre, v in ms.items():
+        assert v <= 1.10 * ms[(0,)], f'cold process {ms[(0,)]} ms per call, after the history {pre}: {v} ms ({ms})'
