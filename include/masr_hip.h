@@ -340,9 +340,11 @@ int masr_op_gemm(masr_engine* e, const float* a_dev, const float* w_dev, const f
                  float* c_dev, int32_t M, int32_t N, int32_t K, int32_t act, float alpha, void* stream);
 
 /* Side streams owned by the library: kind 0 / 1 = prefix searches of consecutive device passes, 2 = per-pass preparation (upload,
- * mean squares, gains), 3 = copies, 4 = the encoder passes of lane 1 (masr_select_lane).  One set per DEVICE, created with the first masr_create on it (before anything the process
- * creates later: their hardware-queue assignment does not depend on what a server does afterwards, see engine.hip) and shared by
- * every engine there; non-blocking, default priority.  The caller borrows them (torch.cuda.ExternalStream) and never destroys
+ * mean squares, gains), 3 = copies, 4 = the encoder passes of lane 1 (masr_select_lane).  One set per DEVICE, made with the first
+ * masr_create on it and shared by every engine there; non-blocking, default priority.  The streams are CHOSEN BY PROBING which
+ * hardware queue a candidate landed on (the runtime deals queues round-robin in creation order, so that depends on everything
+ * the process created before): none of them shares the NULL stream's queue, kinds 0 and 1 are on different queues; kinds 0 and 4
+ * are one stream (never used together), kinds 2 and 3 are one stream (short work only) -- see engine.hip.  The caller borrows them (torch.cuda.ExternalStream) and never destroys
  * them.  They take the place of the worker processes of the reference's batch decoder (masr/decoders/beam_search_decoder.py:59-73:
  * num_processes search workers beside the model's forward). */
 #define MASR_SIDE_STREAMS 5
