@@ -1,6 +1,12 @@
 """Study (round 6): which of the library's side streams share a hardware queue with each other or with torch's default stream --
 in a cold process and after torch.distributed (RCCL) was initialised first.  Two streams alias when a short kernel on one waits
-for a long spin kernel on the other.  usage: [MASR_FORCE_DIST=1] python tools/studies/stream_alias_probe.py"""
+for a long spin kernel on the other.  usage: [MASR_FORCE_DIST=1] python tools/studies/stream_alias_probe.py
+
+Found with the side streams simply created at the first masr_create (one box, GPU_MAX_HW_QUEUES unset = 4 queues, streams dealt
+round-robin in creation order):   cold process: {main, side2 (preparation), torch3} {side0, torch1, torch5} {side1, torch0, torch4}
+{side3, side4, torch2};   after torch.distributed / RCCL: {main, side0 (search 0), side4 (lane 1), torch3} {side1, ...} {side2, ...}
+{side3, ...} -- the configs[2] sharpened call 30.0 instead of 23.2 ms.  With the set chosen by probing (engine.hip, final):
+{main, ...} {side0, side4} {side1} {side2, side3} in both."""
 import os
 import sys
 import time
