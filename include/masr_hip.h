@@ -320,6 +320,14 @@ int masr_stream_cache_len(masr_engine* e, int32_t stream_id, int32_t* cache_len)
  * failing the call. */
 int masr_stream_room(masr_engine* e, int32_t stream_id, int32_t* frames_left);
 
+/* Host side of the boundary: the utterances of one device pass -- B separate host arrays src[i] of n_samples[i] samples of
+ * sample_bytes (2: int16 PCM, 4: float32) -- into ONE padded staging buffer dst [B rows of row_bytes], the rest of every row
+ * zeroed: the padded batch the reference's collate_fn forms (masr/data_utils/collate_fn.py:6-34), built on the audio so that a
+ * single transfer brings the pass to the device.  `threads` (1..16) library-owned worker threads take rows in turn; dst is
+ * normally pinned memory.  No engine, no GPU. */
+int masr_stage_rows(void* dst, int64_t row_bytes, const void* const* src, const int32_t* n_samples, int32_t B, int32_t sample_bytes,
+                    int32_t threads);
+
 /* Host-side resampling of one utterance to the model's rate.  Replaces resampy.resample(samples, sr, target, filter) behind
  * AudioSegment.resample (masr/data_utils/audio.py:306-317; resampy is third-party: its published band-limited sinc interpolation
  * is restated, parity unpinned).  x [n_orig] float32 host, ratio = sr_new / sr_orig, win / dwin [nwin] the right wing of the

@@ -102,6 +102,7 @@ SIGNATURES = {
     'masr_op_gemm': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     'masr_side_stream': [_P, _I, C.POINTER(_P)],
     'masr_select_lane': [_P, _I],
+    'masr_stage_rows': [_P, C.c_int64, _P, _P, _I, _I, _I],
     'masr_debug_set': [_P, _I, _I],
     'masr_profile_select': [_P, _I],
     'masr_profile_read': [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _I],

@@ -12,7 +12,7 @@ LIB_DIR = os.path.join(ROOT, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libmasr_hip.so')
 SOURCES = ['gemm_f32.hip', 'ffn_reduce.hip', 'ffn_pc.hip', 'sqz_layer.hip', 'rowgemm.hip', 'rowgemm_small.hip', 'elementwise.hip',
            'attention.hip', 'lstm.hip', 'beam_gpu.hip', 'lm_scorer.cpp', 'fbank.hip', 'silero.hip', 'engine.hip', 'pool.hip',
-           'beam_search.cpp', 'resample.cpp']
+           'beam_search.cpp', 'stage.cpp', 'resample.cpp']
 # MASR_BUILD_EXPERIMENTS=1: the measured-and-rejected kernels of earlier rounds (A/B material behind masr_debug_set keys 20 / 24 /
 # 30 / 34 / 35) are compiled in as well; the default library holds the product kernels only
 EXPERIMENTS = os.environ.get('MASR_BUILD_EXPERIMENTS') == '1'

@@ -11,6 +11,7 @@ How the calls map onto the engine:
   * ``predict_batch`` / ``evaluate`` shard their utterances over the ranks of an initialised ``torch.distributed`` process
     group (one process per GPU, ``parallel.py``) and all-gather the hypotheses.
 """
+import ctypes as C
 import json
 import logging
 import os
@@ -178,8 +179,7 @@ class MASRPredictor:
         return self._stage_upload(self._stage_fill(segs, n))
 
     def _stage_fill(self, segs, n):
-        """host half of ``_stage_batch``: the rows on their way into the pinned buffer (four pool threads, not waited for here),
-        -> what ``_stage_upload`` needs"""
+        """host half of ``_stage_batch``: the rows into the pinned buffer -> what ``_stage_upload`` needs"""
         as_pcm = all(s._pcm16 is not None for s in segs)
         dt = torch.int16 if as_pcm else torch.float32
         n_max = int(n.max())
@@ -194,34 +194,24 @@ class MASRPredictor:
         if ring['lens'][k] is None or ring['lens'][k].numel() < len(segs):
             ring['lens'][k] = torch.zeros(max(len(segs), 64), dtype=torch.int32, pin_memory=True)
         stage = ring['bufs'][k][:need].view(len(segs), n_max)
-        buf = stage.numpy()
-
-        def fill(rows):
-            for i in rows:
-                m = int(n[i])
-                buf[i, :m] = segs[i]._pcm16 if as_pcm else segs[i]._samples
-                buf[i, m:] = 0
-        # 20 MB per pass of 32 x 20 s: row copies release the GIL, four host threads take rows in turn (0.66 -> 0.45 ms per pass;
-        # 2 / 8 / 12 threads: 17.0 / 17.4 / 18.5 ms per configs[2] greedy call against 16.9 with four; 16 contiguous row groups
-        # uploaded block by block under the fill of the next block: 18.6 ms -- the staging of a pass 0.27 -> 0.80 ms)
-        futures = []
-        if need >= (1 << 20) and len(segs) >= 8:
-            if getattr(self, '_fill_pool', None) is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._fill_pool = ThreadPoolExecutor(4, thread_name_prefix='masr_stage')
-            futures = [self._fill_pool.submit(fill, range(j, len(segs), 4)) for j in range(4)]
-        else:
-            fill(range(len(segs)))
+        # masr_stage_rows (csrc/stage.cpp): the rows of the pass into the pinned buffer, zero-padded, on four library threads --
+        # 20 MB per pass of 32 x 20 s.  (Python threads over numpy row assignments: 0.45 ms per pass, one thread 0.66 ms; 2 / 8 / 12
+        # python threads 17.0 / 17.4 / 18.5 ms per configs[2] greedy call against 16.9 with four; 16 row groups uploaded block by
+        # block under the fill of the next block: 18.6 ms.)
+        rows = [np.ascontiguousarray(s._pcm16 if as_pcm else s._samples, np.int16 if as_pcm else np.float32) for s in segs]
+        ptrs = (C.c_void_p * len(rows))(*[r.ctypes.data for r in rows])
+        n32 = np.ascontiguousarray(n, np.int32)
+        assert all(r.shape[0] >= int(m) for r, m in zip(rows, n32))
+        check(self.predictor.engine.lib.masr_stage_rows(C.c_void_p(stage.data_ptr()), n_max * stage.element_size(), ptrs,
+                                                       n32.ctypes.data_as(C.c_void_p), len(rows), stage.element_size(), 4))
         lens = ring['lens'][k][:len(segs)]
-        lens.numpy()[:] = n
-        return ring, k, stage, lens, futures
+        lens.numpy()[:] = n32
+        return ring, k, stage, lens
 
     def _stage_upload(self, filled):
-        """device half of ``_stage_batch``: waits for the fill, queues the two copies on the current stream"""
+        """device half of ``_stage_batch``: queues the two copies on the current stream"""
         eng = self.predictor.engine
-        ring, k, stage, lens, futures = filled
-        for f in futures:
-            f.result()
+        ring, k, stage, lens = filled
         xs = stage.to(eng.device, non_blocking=True)
         ns = lens.to(eng.device, non_blocking=True)
         ev = torch.cuda.Event()

@@ -289,3 +289,25 @@ def test_balanced_pass_cuts_cover_every_utterance_within_the_budget():
     assert lens.sum() < padded < fixed
     assert balanced_cuts([5, 50, 500], 100) == [(0, 2), (2, 3)]                  # 500 > budget: its own pass; 2 x 50 fits
     assert balanced_cuts([], 10) == [] and balanced_cuts([3, 3, 3, 3], 12) == [(0, 4)]
+
+
+def test_stage_rows_pads_like_the_reference_collate():
+    """masr_stage_rows (csrc/stage.cpp): ragged int16 / float32 utterances -> one zero-padded [B, n_max] buffer, any thread count,
+    small and large batches (the worker pool only takes over above 1 MB), repeated calls; bad arguments are refused"""
+    import ctypes as C
+    from masr_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(5)
+    for dtype, sb in ((np.int16, 2), (np.float32, 4)):
+        for B, n_max in ((1, 5), (7, 1000), (13, 150000), (32, 40000)):
+            n = rng.integers(0, n_max + 1, B).astype(np.int32)
+            n[0] = n_max
+            rows = [(rng.standard_normal(int(m)) * 1000).astype(dtype) for m in n]
+            ptrs = (C.c_void_p * B)(*[r.ctypes.data for r in rows])
+            for threads in (1, 4, 16, 4):
+                dst = np.full((B, n_max), 7, dtype)
+                assert lib.masr_stage_rows(C.c_void_p(dst.ctypes.data), n_max * sb, ptrs, n.ctypes.data_as(C.c_void_p), B, sb,
+                                           threads) == 0
+                for i in range(B):
+                    assert np.array_equal(dst[i, :n[i]], rows[i]) and not dst[i, n[i]:].any(), (dtype, B, threads, i)
+    assert lib.masr_stage_rows(None, 8, None, None, 1, 2, 1) != 0
