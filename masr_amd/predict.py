@@ -462,6 +462,37 @@ class MASRPredictor:
         tok, nt, sc = parallel.gather_sharded_results(tok, nt, sc, shards, len(audio_list))
         return [{'text': self._text(tok[i, :nt[i]]), 'score': float(sc[i])} for i in range(len(audio_list))]
 
+    def predict_batch_deferred(self, audio_list, sample_rate=16000):
+        """ONE device pass over ``audio_list`` launched, nothing waited for: returns a function that -- when called -- waits for the
+        pass and returns [{'text', 'score'}] in input order.  What a serving loop calls for the batch it has formed BEFORE it
+        collects the previous one: staging, upload and launches of batch k + 1 then run under the device work of batch k, and
+        consecutive calls alternate over the engine's two lanes (not with the prefix search on the GPU, whose launches already
+        run beside the next pass).  The reference serves one request at a time (infer_server.py:48-71)."""
+        eng = self.predictor.engine
+        dec = self.beam_search_decoder if self.configs.decoder == 'ctc_beam_search' else None
+        gpu_search = dec is not None and getattr(dec, 'use_gpu_search', False) and \
+            dec.gpu_search_supported(1, len(self._text_featurizer.vocab_list))
+        lanes = max(1, min(2, int(os.environ.get('MASR_LANES', '1' if gpu_search else '2'))))
+        turn = self.__dict__.get('_deferred_turn', 0)
+        self._deferred_turn = turn + 1
+        lane = turn % lanes
+        main = torch.cuda.current_stream(eng.device)
+        stream = main
+        if lane:
+            stream = eng.side_stream(4)
+            if not self.__dict__.get('_lane1_ordered'):
+                stream.wait_stream(main)             # (once: whatever the caller had queued before the first pass on lane 1)
+                self._lane1_ordered = True
+        began = self._begin_pass([self._load_audio(a, sample_rate) for a in audio_list])
+        if lane:
+            eng.select_lane(lane)
+        try:
+            with torch.cuda.stream(stream):
+                return self._predict_local(None, defer=True, began=began)
+        finally:
+            if lane:
+                eng.select_lane(0)
+
     def _run_sorted(self, audio_list, sample_rate, hints, which, decode_all_frames, batch_size, as_tokens):
         """decode ``audio_list[i] for i in which`` in length-sorted device passes (cut shortest first, ties in input order -- the
         batches ``evaluate`` forms from a duration-sorted manifest); results in the order of ``which``.  Pipeline depth 2:

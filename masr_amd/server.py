@@ -29,6 +29,7 @@ No static pages, templates or upload archive: the web UI is outside the hot path
 """
 import asyncio
 import logging
+import os
 import threading
 import time
 from concurrent.futures import Future
@@ -103,8 +104,8 @@ class EngineWorker(object):
         self._thread.join()
 
     # ---- worker side --------------------------------------------------------------------------------------------------
-    def _take(self):
-        """block until there is something to do; returns (calls, offline batch, feeds)"""
+    def _take(self, block=True):
+        """block until there is something to do (``block=False``: look once); returns (calls, offline batch, feeds)"""
         with self._cv:
             while True:
                 if self._stop:
@@ -120,10 +121,17 @@ class EngineWorker(object):
                         batch, self._offline = self._offline[:self.max_batch], self._offline[self.max_batch:]
                     self._busy = len(calls) + len(batch) + len(feeds)
                     return calls, batch, feeds
+                if not block:
+                    return [], [], []
                 timeout = None
                 if self._offline:
                     timeout = max(0.0, self.max_wait - (now - self._offline[0][0]))
                 self._cv.wait(timeout)
+
+    def _batch_ready(self):
+        with self._cv:
+            return bool(self._offline) and (len(self._offline) >= self.max_batch or
+                                            time.monotonic() - self._offline[0][0] >= self.max_wait)
 
     def _enter_device(self):
         """this thread works for ONE engine: make its GPU torch's current device here (allocations, current stream)"""
@@ -137,9 +145,15 @@ class EngineWorker(object):
 
     def _run(self):
         self._enter_device()
+        # offline batches are LAUNCHED (MASRPredictor.predict_batch_deferred) and collected afterwards: while one is on the device
+        # the next one that is ready is staged, uploaded and launched (on the engine's other lane) before the first is waited for --
+        # at most two in flight, and nothing is held back when no further batch is ready
+        inflight = []
         while True:
-            work = self._take()
+            work = self._take(block=not inflight)
             if work is None:
+                for entry in inflight:
+                    self._finish_batch(entry)
                 return
             calls, batch, feeds = work
             for fn, args, kwargs, fut in calls:
@@ -147,7 +161,17 @@ class EngineWorker(object):
             if feeds:
                 self._step_streams(feeds)
             if batch:
-                self._run_batch(batch)
+                if len(inflight) >= 2:
+                    self._finish_batch(inflight.pop(0))
+                entry = self._start_batch(batch)
+                if entry is not None:
+                    inflight.append(entry)
+                    if self._batch_ready():
+                        with self._cv:
+                            self._busy = sum(len(e[0]) for e in inflight)
+                        continue
+            while inflight:
+                self._finish_batch(inflight.pop(0))
             with self._cv:
                 self._busy = 0
 
@@ -160,13 +184,19 @@ class EngineWorker(object):
         except BaseException as e:          # the client gets the exception, the worker lives on
             fut.set_exception(e)
 
-    def _run_batch(self, batch):
+    def _start_batch(self, batch):
+        """launch one offline batch; -> (live requests, function that returns their results) or None when nothing is left to wait
+        for (cancelled requests, a predictor without deferred passes, a batch that failed at launch and was redone one by one)"""
         live = [(a, f) for _, a, f in batch if f.set_running_or_notify_cancel()]
         if not live:
-            return
+            return None
         self.stats['batches'] += 1
         self.stats['utterances'] += len(live)
+        # (MASR_SERVE_PIPELINE=0, A/B: every batch recognised and waited for before the next one is looked at, rounds 3-5)
+        deferred = getattr(self.predictor, 'predict_batch_deferred', None) if os.environ.get('MASR_SERVE_PIPELINE', '1') == '1' else None
         try:
+            if deferred is not None and len(live) > 1:
+                return live, deferred([a for a, _ in live])
             if len(live) == 1:
                 results = [self.predictor.predict(audio_data=live[0][0])]
             else:
@@ -174,12 +204,26 @@ class EngineWorker(object):
             for (_, fut), res in zip(live, results):
                 fut.set_result(res)
         except BaseException:
-            # one unreadable upload must not fail its neighbours: fall back to one call per request
-            for audio, fut in live:
-                try:
-                    fut.set_result(self.predictor.predict(audio_data=audio))
-                except BaseException as e:
-                    fut.set_exception(e)
+            self._one_by_one(live)
+        return None
+
+    def _finish_batch(self, entry):
+        live, fetch = entry
+        try:
+            for (_, fut), res in zip(live, fetch()):
+                fut.set_result(res)
+        except BaseException:
+            self._one_by_one(live)
+
+    def _one_by_one(self, live):
+        # one unreadable upload must not fail its neighbours: fall back to one call per request
+        for audio, fut in live:
+            if fut.done():
+                continue
+            try:
+                fut.set_result(self.predictor.predict(audio_data=audio))
+            except BaseException as e:
+                fut.set_exception(e)
 
     def _step_streams(self, feeds):
         # a session may have queued several chunks since the last tick: they are stepped in arrival order, one chunk per

@@ -311,3 +311,48 @@ def test_stage_rows_pads_like_the_reference_collate():
                 for i in range(B):
                     assert np.array_equal(dst[i, :n[i]], rows[i]) and not dst[i, n[i]:].any(), (dtype, B, threads, i)
     assert lib.masr_stage_rows(None, 8, None, None, 1, 2, 1) != 0
+
+
+def test_engine_worker_launches_the_next_batch_before_it_collects_the_previous_one():
+    """EngineWorker with a predictor that has deferred passes (MASRPredictor.predict_batch_deferred): with two batches' worth of
+    requests waiting, both are LAUNCHED before the first is collected (at most two in flight); every request gets its own result;
+    a batch that fails at launch or at collection is redone one request at a time (the bad one fails alone)"""
+    from masr_amd.server import EngineWorker
+    import time as _time
+
+    class Deferred(_FakePredictor):
+        def __init__(self):
+            super().__init__()
+            self.events = []
+
+        def predict(self, audio_data, **kw):
+            if audio_data.startswith(b'bad'):
+                raise ValueError('unreadable')
+            return super().predict(audio_data, **kw)
+
+        def predict_batch_deferred(self, audio_list, **kw):
+            if any(a == b'bad-at-launch' for a in audio_list):
+                raise ValueError('unreadable')
+            self.events.append(('launch', len(audio_list)))
+
+            def fetch():
+                self.events.append(('collect', len(audio_list)))
+                if any(a == b'bad-at-collect' for a in audio_list):
+                    raise ValueError('unreadable')
+                return [{'text': f'n{len(a)}', 'score': 50.0} for a in audio_list]
+            return fetch
+    p = Deferred()
+    w = EngineWorker(p, None, max_batch=4, max_wait_ms=50.0)
+    gate = w.call(_time.sleep, 0.3)                       # the worker is busy while twelve requests queue up
+    futs = [w.recognize(b'x' * (i + 1)) for i in range(12)]
+    gate.result(timeout=10)
+    assert [f.result(timeout=10)['text'] for f in futs] == [f'n{i + 1}' for i in range(12)]
+    assert [e for e in p.events if e[0] == 'launch'] == [('launch', 4)] * 3
+    assert p.events[:3] == [('launch', 4), ('launch', 4), ('collect', 4)], p.events      # two in flight, then the oldest comes back
+    assert p.events.count(('collect', 4)) == 3
+    for bad in (b'bad-at-launch', b'bad-at-collect'):
+        futs = [w.recognize(b) for b in (b'aa', bad, b'cccc')]
+        assert futs[0].result(timeout=10)['text'] == 'n2' and futs[2].result(timeout=10)['text'] == 'n4'
+        with pytest.raises(Exception):
+            futs[1].result(timeout=10)
+    w.shutdown()

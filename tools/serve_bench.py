@@ -42,10 +42,14 @@ out['offline_one_by_one_audio_s_per_s'] = round(audio_s / (time.perf_counter() -
 
 w = EngineWorker(p, StreamPool(p, max_frames_out=300), max_batch=32, max_wait_ms=5.0)
 [f.result() for f in [w.recognize(c) for c in clips]]          # warm-up: both staging buffers of the facade exist afterwards
-t0 = time.perf_counter()
-futs = [w.recognize(c) for c in clips]
-[f.result() for f in futs]
-out['offline_engine_worker_audio_s_per_s'] = round(audio_s / (time.perf_counter() - t0), 1)
+bursts = []
+for _ in range(7):                                              # a burst of 64 requests is ~15 ms: seven of them, the median reported
+    t0 = time.perf_counter()
+    futs = [w.recognize(c) for c in clips]
+    [f.result() for f in futs]
+    bursts.append(round(audio_s / (time.perf_counter() - t0), 1))
+out['offline_engine_worker_audio_s_per_s'] = float(np.median(bursts))
+out['offline_engine_worker_bursts'] = bursts
 out['worker_batches'] = dict(w.stats)
 
 # streaming: 16 sessions, 0.5 s chunks (8000 samples), 10 s each
