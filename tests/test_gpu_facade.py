@@ -1032,3 +1032,18 @@ def test_lanes_with_growing_ragged_passes_every_family(family):
     finally:
         ref_eng.close()
         eng.close()
+
+
+def test_deferred_passes_return_what_predict_batch_returns(predictor):
+    """MASRPredictor.predict_batch_deferred: three passes launched back to back (they alternate over the engine's two lanes), then
+    collected in order and out of order -- each returns exactly what predict_batch returns for its list"""
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    rng = np.random.default_rng(9)
+    lists = [[pcm[o:o + n].copy() for o, n in zip(rng.integers(0, 40000, k), rng.integers(9000, 90000, k))] for k in (5, 3, 7)]
+    lists[1].append(pcm[:100].copy())                      # no frame: the empty transcript
+    want = [predictor.predict_batch(a) for a in lists]
+    for order in ((0, 1, 2), (2, 0, 1)):
+        fetch = [predictor.predict_batch_deferred(a) for a in lists]
+        got = {k: fetch[k]() for k in order}
+        assert [got[k] for k in range(3)] == want, order
+    assert predictor.predictor.engine.lane == 0
