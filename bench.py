@@ -991,6 +991,29 @@ def extra_facade(args, rank, world, local):
         'value': round(BATCH * 10.0 / dt, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps,
         'ms_per_step': round(dt * 1e3, 3), 'transcripts': len(res),
         'roofline': workload_roofline(GFLOP_PER_STEP, dt * 1e3, 'SURVEY 8(d): 742 GFLOP per 32 x 10 s')}}
+    # the same batches through predict_batch_deferred, as the server worker issues them: batch k + 1 staged, uploaded and launched (on
+    # the engine's other lane) before batch k is collected -- host numpy arrays in, text out, everything inside the timed region
+    if hasattr(pred, 'predict_batch_deferred'):
+        def pipelined(n):
+            prev, last = None, None
+            for _ in range(n):
+                cur = pred.predict_batch_deferred(audio)
+                if prev is not None:
+                    last = prev()
+                prev = cur
+            return prev()
+        pipelined(4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res2 = pipelined(steps)
+        dt2 = (time.perf_counter() - t0) / steps
+        out['facade_b32_pipelined'] = {
+            'workload': 'configs[1] through the facade, pipelined: MASRPredictor.predict_batch_deferred(32 host int16 ndarrays of 10 s) for '
+                        'batch k + 1 before the results of batch k are fetched (two in flight, consecutive batches on the two lanes of the '
+                        'engine) -- what server.EngineWorker does with the batches it forms; host arrays in, text out, bit-exact gain route',
+            'value': round(BATCH * 10.0 / dt2, 1), 'unit': 'audio-seconds/sec', 'n_gpus': 1, 'steps': steps,
+            'ms_per_step': round(dt2 * 1e3, 3), 'transcripts': len(res2), 'same_transcripts_as_facade_b32': res2 == res,
+            'roofline': workload_roofline(GFLOP_PER_STEP, dt2 * 1e3, 'SURVEY 8(d): 742 GFLOP per 32 x 10 s')}
     golden = os.path.join(ROOT, 'tests', 'golden', 'testwav.npz')
     wav = np.load(golden)['pcm'] if os.path.exists(golden) else synthetic.synthetic_pcm(1, 134240, seed=7)[0]
     for _ in range(5):
