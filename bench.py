@@ -1200,6 +1200,11 @@ def main():
         if rank == 0:
             if extra is not None:
                 res['extra'] = extra
+                two = extra.get('conformer_b32_two_lanes') or {}
+                if two.get('value'):
+                    # the same step with consecutive steps side by side on the engine's two lanes: beside `value`, never instead of it
+                    # (`value` / `roofline` are measured on ONE lane: a kernel bracketed by HIP events must have the CUs to itself)
+                    res['value_two_lanes'] = two['value']
             if world == 1 and not args.no_cpu_baseline:
                 try:
                     res['cpu_baseline'] = cpu_baseline()
