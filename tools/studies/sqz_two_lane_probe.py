@@ -33,6 +33,8 @@ for c in passes:
     gain = eng.host_gains(x, n, -20.0)
     batches.append((x, n, gain))
     lo += c
+if os.environ.get('PROBE_SHORT_FIRST') == '1':          # the pass of the SHORT utterances launched first (lane 0), the long one second
+    batches.reverse()
 streams = [torch.cuda.current_stream(dev), eng.side_stream(4)]
 torch.cuda.synchronize()
 
