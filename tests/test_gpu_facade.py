@@ -1047,3 +1047,38 @@ def test_deferred_passes_return_what_predict_batch_returns(predictor):
         got = {k: fetch[k]() for k in order}
         assert [got[k] for k in range(3)] == want, order
     assert predictor.predictor.engine.lane == 0
+
+
+def test_stream_sessions_step_between_deferred_passes(predictor):
+    """a server's mixed load on one engine: offline batches launched as deferred passes (alternating over the two lanes) with
+    stream-pool steps in between, nothing waited for until the end -- the partial results of the sessions and the batches' results
+    equal what each gives alone"""
+    from masr_amd.serving import StreamPool
+    pcm = np.load(os.path.join(GOLDEN, 'testwav.npz'))['pcm']
+    rng = np.random.default_rng(21)
+    batches = [[pcm[o:o + n].copy() for o, n in zip(rng.integers(0, 30000, 6), rng.integers(20000, 100000, 6))] for _ in range(4)]
+    chunks = [[pcm[10000 * k + lo:10000 * k + lo + 8000].tobytes() for lo in range(0, 48000, 8000)] for k in range(3)]
+
+    def stream_run(pool, between=None):
+        hs = [pool.open() for _ in chunks]
+        outs = []
+        for c in range(6):
+            for k, h in enumerate(hs):
+                pool.feed(h, chunks[k][c], is_end=c == 5)
+            if between is not None:
+                between(c)
+            step = pool.step()
+            outs.append([step[h] for h in hs])
+        for h in hs:
+            pool.close(h)
+        return outs
+    want_batches = [predictor.predict_batch(b) for b in batches]
+    pool = StreamPool(predictor)
+    want_stream = stream_run(pool)
+    fetches = []
+    got_stream = stream_run(pool, between=lambda c: fetches.append(predictor.predict_batch_deferred(batches[c])) if c < 4 else None)
+    got_batches = [f() for f in fetches]
+    pool.shutdown()
+    assert got_stream == want_stream
+    assert got_batches == want_batches
+    assert any(r is not None and r['text'] for step in got_stream for r in step)
